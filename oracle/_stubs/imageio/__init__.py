@@ -1,0 +1,1 @@
+"""Empty import-only stand-in (plotting / CMA-ES are outside the hot path).  TEST INFRASTRUCTURE."""

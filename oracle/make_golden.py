@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by RUNNING THE ACTUAL REFERENCE.  TEST INFRASTRUCTURE.
+
+Runs only in the build container (needs /root/reference).  It imports the
+reference's hot-path modules -- with oracle/_stubs/ standing in for the
+third-party packages that are not installed (gpyreg, corner, cma, imageio) --
+evaluates them on the seeded inputs of pyvbmc_amd/synthetic.py and stores
+inputs + reference outputs as small .npz fixtures.  It also re-packs the
+MATLAB-derived known-answer DATA files the reference's own tests hold
+(pyvbmc/testing/**.mat/.txt) into npz; no reference source text is copied.
+
+    python oracle/make_golden.py        # rewrites tests/golden/
+"""
+import itertools
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+REF = Path("/root/reference")
+sys.path.insert(0, str(ROOT / "oracle" / "_stubs"))
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(REF))
+
+import gpyreg as gpr  # noqa: E402  (the stand-in)
+import scipy.io  # noqa: E402
+from pyvbmc.entropy import entlb_vbmc, entmc_vbmc  # noqa: E402
+from pyvbmc.variational_posterior import VariationalPosterior  # noqa: E402
+from pyvbmc.vbmc.variational_optimization import (  # noqa: E402
+    _gp_log_joint,
+    _neg_elcbo,
+    _soft_bound_loss,
+    _vp_bound_loss,
+)
+
+from pyvbmc_amd import synthetic  # noqa: E402
+
+OUT = ROOT / "tests" / "golden"
+
+
+def ref_vp(wl):
+    vp = VariationalPosterior(wl.D, wl.K)
+    vp.mu = wl.mu.copy()
+    vp.sigma = wl.sigma.reshape(1, -1).copy()
+    vp.lambd = wl.lambd.reshape(-1, 1).copy()
+    vp.w = wl.w.reshape(1, -1).copy()
+    vp.eta = wl.eta.reshape(1, -1).copy()
+    return vp
+
+
+def ref_gp(wl, hyp):
+    noise = gpr.noise_functions.GaussianNoise(
+        constant_add=True, user_provided_add=wl.s2 is not None
+    )
+    gp = gpr.GP(
+        D=wl.D,
+        covariance=gpr.covariance_functions.SquaredExponential(),
+        mean=gpr.mean_functions.NegativeQuadratic(),
+        noise=noise,
+    )
+    gp.update(X_new=wl.X, y_new=wl.y, s2_new=wl.s2, hyp=hyp)
+    return gp
+
+
+def flagname(f):
+    return "".join("1" if b else "0" for b in f)
+
+
+def case(name, cfg, S_multi, seed, all_flag_combos=False, **shrink):
+    wl = synthetic.make_workload(cfg, S=S_multi, **shrink)
+    NsK = wl.NsK
+    out = dict(
+        cfg=cfg, D=wl.D, K=wl.K, N=wl.N, Ns_total=wl.Ns_total, NsK=NsK, seed=seed,
+        mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta,
+        X=wl.X, y=wl.y, hyp=wl.hyp, theta=wl.theta,
+        s2=np.zeros(0) if wl.s2 is None else wl.s2,
+    )
+    combos = (
+        list(itertools.product([False, True], repeat=4))
+        if all_flag_combos
+        else [(False,) * 4, (True,) * 4]
+    )
+    # --- entropy ------------------------------------------------------------
+    for gf in combos:
+        for jac in (True, False):
+            vp = ref_vp(wl)
+            np.random.seed(seed)
+            H, dH = entmc_vbmc(vp, NsK, gf, jac)
+            out[f"entmc_H_{flagname(gf)}_{int(jac)}"] = H
+            out[f"entmc_dH_{flagname(gf)}_{int(jac)}"] = dH
+            H, dH = entlb_vbmc(ref_vp(wl), gf, jac)
+            out[f"entlb_H_{flagname(gf)}_{int(jac)}"] = H
+            out[f"entlb_dH_{flagname(gf)}_{int(jac)}"] = dH
+    # --- GP expected log joint ------------------------------------------------
+    for tag, hyp in (("S1", wl.hyp[:1]), ("SM", wl.hyp)):
+        gp = ref_gp(wl, hyp)
+        vp = ref_vp(wl)
+        G, dG, _, _, _ = _gp_log_joint(vp, gp, True, True, True, False, False)
+        out[f"glj_{tag}_G"], out[f"glj_{tag}_dG"] = G, dG
+        G, _, varG, _, var_ss, I_sk, J_sjk = _gp_log_joint(vp, gp, False, True, True, True, True)
+        out[f"glj_{tag}_var_G"] = G
+        out[f"glj_{tag}_varG"] = np.asarray(varG)
+        out[f"glj_{tag}_var_ss"] = var_ss
+        out[f"glj_{tag}_I_sk"] = I_sk
+        out[f"glj_{tag}_J_sjk"] = J_sjk
+    # --- negative ELBO ----------------------------------------------------------
+    gp = ref_gp(wl, wl.hyp[:1])
+    bnd = synthetic.default_theta_bnd(wl)
+    # push a few parameters outside the soft bounds so the penalty is exercised
+    theta_out = wl.theta.copy()
+    theta_out[0] = bnd["ub"][0] + 0.3
+    theta_out[wl.D * wl.K] = bnd["ub"][wl.D * wl.K] + 0.2 - np.log(wl.lambd[0])
+    theta_out[-1] += 0.7
+    out["theta_out"] = theta_out
+    for tag, th, tb in (("nobnd", wl.theta, None), ("bnd", wl.theta, bnd), ("bndout", theta_out, bnd)):
+        for ns_tag, Ns in (("mc", NsK), ("lb", 0)):
+            vp = ref_vp(wl)
+            np.random.seed(seed)
+            th_in = th.copy()
+            F, dF, G, H, varF = _neg_elcbo(th_in, gp, vp, 0.0, Ns, True, False, tb, 0.0, False)
+            out[f"elbo_{tag}_{ns_tag}_F"] = F
+            out[f"elbo_{tag}_{ns_tag}_dF"] = dF
+            out[f"elbo_{tag}_{ns_tag}_G"] = G
+            out[f"elbo_{tag}_{ns_tag}_H"] = H
+            out[f"elbo_{tag}_{ns_tag}_theta_after"] = th_in
+    vp = ref_vp(wl)
+    np.random.seed(seed)
+    r = _neg_elcbo(wl.theta.copy(), gp, vp, 0.0, NsK, False, True, None, 0.0, True)
+    out["elbo_full_F"], out["elbo_full_G"], out["elbo_full_H"] = r[0], r[2], r[3]
+    out["elbo_full_varF"] = np.asarray(r[4])
+    out["elbo_full_I_sk"], out["elbo_full_J_sjk"] = r[9], r[10]
+    # --- mixture pdf --------------------------------------------------------------
+    rng = np.random.default_rng(77 + cfg)
+    comp = rng.integers(0, wl.K, size=48)
+    xq = wl.mu.T[comp] + wl.lambd * wl.sigma[comp, None] * rng.standard_normal((48, wl.D))
+    xq = np.vstack([xq, 3.0 * rng.standard_normal((12, wl.D)), 60.0 * np.ones((4, wl.D))])
+    out["pdf_x"] = xq
+    vp = ref_vp(wl)
+    out["pdf_y"] = vp.pdf(xq, orig_flag=False)
+    out["pdf_logy"] = vp.pdf(xq, orig_flag=False, log_flag=True)
+    yy, dy = vp.pdf(xq, orig_flag=False, grad_flag=True)
+    out["pdf_dy"] = dy
+    with np.errstate(all="ignore"):
+        yy, dy = vp.pdf(xq, orig_flag=False, log_flag=True, grad_flag=True)
+    out["pdf_dlogy"] = dy
+    for df in (10.0, -2.0, 3.5, -7.0):
+        out[f"pdf_y_df{df}"] = vp.pdf(xq, orig_flag=False, df=df)
+        out[f"pdf_logy_df{df}"] = vp.pdf(xq, orig_flag=False, log_flag=True, df=df)
+    out["pdf_1d"] = vp.pdf(xq[0], orig_flag=False)  # 1-D input -> raveled output
+    # --- moments / parameter round trip ---------------------------------------------
+    m, c = ref_vp(wl).moments(orig_flag=False, cov_flag=True)
+    out["mom_mean"], out["mom_cov"] = m, c
+    vp = ref_vp(wl)
+    th_raw = wl.theta + 0.1 * np.random.default_rng(5).standard_normal(wl.theta.size)
+    vp.set_parameters(th_raw)
+    out["rt_theta_in"] = th_raw
+    out["rt_mu"], out["rt_sigma"], out["rt_lambd"], out["rt_w"] = (
+        vp.mu, vp.sigma.ravel(), vp.lambd.ravel(), vp.w.ravel())
+    out["rt_theta_out"] = vp.get_parameters()
+    out["rt_theta_out_noraw"] = vp.get_parameters(raw_flag=False)
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print(f"wrote {name}: D={wl.D} K={wl.K} N={wl.N} NsK={NsK} keys={len(out)}")
+
+
+def matlab_known():
+    """Known-answer DATA held by the reference's own tests, re-packed as npz."""
+    out = {}
+    m = scipy.io.loadmat(
+        REF / "pyvbmc/testing/entropy/entropy-test.mat", struct_as_record=False, squeeze_me=True
+    )
+    vp = m["vp"]
+    out.update(
+        ent_D=int(m["D"]), ent_K=int(m["K"]), ent_Ns=int(m["Ns"]), ent_H=float(m["H"]),
+        ent_Hl=float(m["Hl"]), ent_dH=np.asarray(m["dH"]).ravel(), ent_dHl=np.asarray(m["dHl"]).ravel(),
+        ent_jacobian_flag=int(m["jacobian_flag"]),
+        ent_mu=np.asarray(vp.mu, dtype=float), ent_sigma=np.asarray(vp.sigma, dtype=float).ravel(),
+        ent_lambd=np.asarray(getattr(vp, "lambda"), dtype=float).ravel(),
+        ent_w=np.asarray(vp.w, dtype=float).ravel(), ent_eta=np.asarray(vp.eta, dtype=float).ravel(),
+    )
+    m = scipy.io.loadmat(
+        REF / "pyvbmc/testing/variational_posterior/test_moments_no_orig_flag_2_MATLAB.mat",
+        struct_as_record=False, squeeze_me=True,
+    )
+    for k, v in m.items():
+        if not k.startswith("__"):
+            out[f"mom_{k}"] = np.asarray(v, dtype=float)
+    vb = REF / "pyvbmc/testing/vbmc"
+    for f in ("X", "y", "hyp", "mu", "dG_gp_log_joint", "dF"):
+        out[f"vbmc_{f}"] = np.loadtxt(vb / f"{f}.txt", delimiter=",")
+    # constants asserted at test_variational_optimization.py:143-147,192-198
+    out.update(
+        vbmc_G=-0.461812484952867, vbmc_varG=6.598768992700180e-05,
+        vbmc_var_ss=1.031705745662353e-04, vbmc_F=11.746298071422430,
+        vbmc_H=-11.284485586469563,
+    )
+    for f in ("fess", "activesample_proposalpdf"):
+        m = scipy.io.loadmat(vb / "compare_MATLAB" / f"{f}.mat")
+        for k, v in m.items():
+            if not k.startswith("__"):
+                out[f"{f}_{k}"] = np.asarray(v, dtype=float)
+    vpdir = REF / "pyvbmc/testing/variational_posterior"
+    for f in ("X", "mu", "bnd_lb", "bnd_ub"):
+        out[f"vp_{f}"] = np.loadtxt(vpdir / f"{f}.txt", delimiter=",")
+    np.savez_compressed(OUT / "matlab_known.npz", **out)
+    print("wrote matlab_known:", sorted(out))
+
+
+def misc():
+    """Small direct calls: soft-bound loss and vp-bound loss known inputs."""
+    out = {}
+    x = np.zeros(3)
+    x[0], x[1] = 15.0, -20.0
+    L, dL = _soft_bound_loss(x, np.full(3, -10.0), np.full(3, 10.0), compute_grad=True)
+    out["sbl_x"], out["sbl_L"], out["sbl_dL"] = x, L, dL
+    np.savez_compressed(OUT / "misc.npz", **out)
+
+
+if __name__ == "__main__":
+    OUT.mkdir(parents=True, exist_ok=True)
+    case("c1", 1, S_multi=2, seed=1, all_flag_combos=True)
+    case("c2s", 2, S_multi=3, seed=2, Ns_total=20 * 200)
+    case("c3s", 3, S_multi=8, seed=3, Ns_total=50 * 200)
+    case("c5s", 5, S_multi=2, seed=5, Ns_total=100 * 100)
+    matlab_known()
+    misc()
