@@ -1,0 +1,242 @@
+/*
+ * vbmc_hip.h -- C ABI of libvbmc_hip.so: the MI355X (gfx950) implementation of
+ * PyVBMC's ELBO-evaluation hot path.
+ *
+ * The reference (acerbilab/pyvbmc) is pure Python and has no FFI; the boundary
+ * it offers for this path is a set of Python callables.  Each entry point below
+ * names the reference callable whose arithmetic it replaces (paths relative to
+ * /root/reference/pyvbmc).  The Python mirror of those callables lives in
+ * pyvbmc_amd/ and reaches this library through ctypes only.
+ *
+ * Conventions
+ *   - every pointer argument is CALLER-OWNED HOST memory, contiguous, float64 /
+ *     int32 / int64 as typed; the library copies in and out.  No torch types.
+ *   - matrices are row-major.  `mu_KxD` is K rows of D means, i.e. exactly
+ *     theta[:D*K] / mu.ravel(order="F") of the reference's (D,K) array
+ *     (variational_posterior/variational_posterior.py:653-676).
+ *   - return value: 0 = ok, <0 = error (VBMC_E_*); text via vbmc_last_error().
+ *     No C++ exception crosses the boundary.
+ *   - a vbmc_ctx owns one device, its HIP streams, device scratch and (optionally)
+ *     one RCCL communicator.  A ctx is not thread-safe; distinct ctxs are
+ *     independent.
+ *   - grad_flags bit0..3 = gradients wrt (mu, sigma, lambda, w), the reference's
+ *     4-tuple `grad_flags` (entropy/entmc_vbmc.py:9, entlb_vbmc.py:8).
+ *   - all arithmetic is float64.
+ */
+#ifndef VBMC_HIP_H
+#define VBMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vbmc_ctx vbmc_ctx;
+
+enum {
+  VBMC_OK = 0,
+  VBMC_E_ARG = -1,     /* bad argument / state (e.g. mixture not set)      */
+  VBMC_E_HIP = -2,     /* HIP runtime error                                 */
+  VBMC_E_RCCL = -3,    /* RCCL error                                        */
+  VBMC_E_NODEV = -4,   /* no usable gfx950 device                           */
+  VBMC_E_UNSUP = -5,   /* combination the reference raises NotImplemented on */
+  VBMC_E_NONFINITE = -6 /* non-finite input where the path needs finite     */
+};
+
+/* GP mean functions understood by the path
+ * (vbmc/variational_optimization.py:1383-1392). */
+enum { VBMC_MEAN_ZERO = 0, VBMC_MEAN_CONST = 1, VBMC_MEAN_NEGQUAD = 2 };
+
+/* Source of the standard-normal draws of the Monte-Carlo entropy. */
+enum {
+  VBMC_EPS_RESIDENT = 0, /* draws uploaded with vbmc_set_eps (parity mode: the
+                            reference's np.random.randn stream, entmc_vbmc.py:67) */
+  VBMC_EPS_PHILOX = 1    /* Philox4x32-10 + Box-Muller generated in-kernel,
+                            fresh per call from `seed` (throughput mode)        */
+};
+
+/* ---- library / context ------------------------------------------------- */
+
+/* ABI version of this header (bumped on any signature change). */
+int vbmc_abi_version(void);
+
+/* Number of visible HIP devices (0 on a box without a GPU; never fails hard). */
+int vbmc_device_count(int* n_out);
+
+/* Create a context on HIP device `device_id`.  Fails with VBMC_E_NODEV when no
+ * GPU is present -- there is no CPU fallback behind this ABI.
+ * device_id == -1 creates a HOST-ONLY context: it can hold the mixture
+ * (vbmc_set_mixture / vbmc_theta_to_mixture) and run the host finalisation
+ * (vbmc_entmc_finalize); every entry point that would launch a kernel returns
+ * VBMC_E_NODEV on it.  It exists so the sharded reduce->finalise path can be
+ * exercised by multi-process CPU tests. */
+int vbmc_ctx_create(int device_id, vbmc_ctx** out);
+void vbmc_ctx_destroy(vbmc_ctx* ctx);
+
+/* Last error text of `ctx` (or of the failed vbmc_ctx_create when ctx==NULL). */
+const char* vbmc_last_error(const vbmc_ctx* ctx);
+
+/* Device facts for the bench harness: name (NUL-terminated, truncated to
+ * name_len), compute units, max clock kHz, global memory bytes. */
+int vbmc_device_info(const vbmc_ctx* ctx, char* name, int name_len, int* cu_count,
+                     int* clock_khz, uint64_t* hbm_bytes);
+
+/* Block until everything queued on the ctx has finished (bench bracketing). */
+int vbmc_synchronize(vbmc_ctx* ctx);
+
+/* Duration in milliseconds of the most recent launch of the dominant kernel of
+ * the given entry point, measured with HIP events on the ctx's own stream.
+ * which: 0 = entmc main kernel, 1 = gp_log_joint, 2 = mixture pdf,
+ *        3 = gp_predict, 4 = whole last vbmc_neg_elcbo device section. */
+int vbmc_last_kernel_ms(vbmc_ctx* ctx, int which, double* ms_out);
+
+/* ---- mixture state: VariationalPosterior attributes --------------------- */
+
+/* Upload the mixture (variational_posterior.py:106-138: mu (D,K), sigma (1,K),
+ * lambd (D,1), w (1,K), eta (1,K)).  Values are taken as given (no
+ * renormalisation: that is set_parameters' job, see vbmc_theta_to_mixture). */
+int vbmc_set_mixture(vbmc_ctx* ctx, int D, int K, const double* mu_KxD,
+                     const double* sigma_K, const double* lambd_D, const double* w_K,
+                     const double* eta_K);
+
+/* Host-side restatement of VariationalPosterior.set_parameters (raw_flag=True)
+ * (variational_posterior.py:680-759) for the fused objective: theta ->
+ * (mu, sigma, lambd, w) with exp, softmax (max-shifted), lambda renormalised to
+ * unit RMS, plus eta = theta[-K:] - max (variational_optimization.py:1082-1085).
+ * optimize_mask bit0..3 = optimize_{mu,sigma,lambd,weights}; blocks whose bit is
+ * clear are absent from theta and the current ctx mixture values are kept.
+ * Outputs (each nullable) receive the new attribute values. */
+int vbmc_theta_to_mixture(vbmc_ctx* ctx, const double* theta, int n_theta,
+                          int optimize_mask, double* mu_KxD, double* sigma_K,
+                          double* lambd_D, double* w_K, double* eta_K);
+
+/* ---- a3: VariationalPosterior.pdf / log_pdf in the transformed space ---- */
+
+/* y[n] = sum_k w_k N(x_n; mu_k, sigma_k^2 diag(lambda^2))  (df = +/-inf or 0),
+ * multivariate-t (df > 0) or product-of-univariate-t (df < 0) tails
+ * (variational_posterior.py:441-529); log_flag: log with 0 -> -inf (:531-541);
+ * grad_flag: dy (n x D), for log_flag dy/y (:464-469,532-533).  grad with finite
+ * non-zero df -> VBMC_E_UNSUP (the reference raises NotImplementedError :499,527).
+ * Bounds masking / Jacobian of orig_flag=True stay on the host (parameter
+ * transformer), as in the reference they are separate pre/post steps. */
+int vbmc_mixture_pdf(vbmc_ctx* ctx, int64_t n, const double* x_nxD, int log_flag,
+                     int grad_flag, double df, double* y_n, double* dy_nxD);
+
+/* ---- a6: entropy/entmc_vbmc.py:6-134 ------------------------------------ */
+
+/* Make the antithetic half-draws resident in HBM: eps_half is [K][n_half][D]
+ * (for component j the rows the reference draws with randn(Ns//2, D),
+ * entmc_vbmc.py:64-68).  `row_begin,row_count` select the slice of each
+ * component's rows this ctx will process (sharding); pass 0,n_half
+ * for the whole job. */
+int vbmc_set_eps(vbmc_ctx* ctx, int K, int64_t n_half, int D, const double* eps_half,
+                 int64_t row_begin, int64_t row_count);
+
+/* Monte-Carlo entropy and its reparameterisation gradient.
+ *   ns_per_comp : the reference's (even-rounded) Ns = 2*n_half.
+ *   eps_mode    : VBMC_EPS_RESIDENT or VBMC_EPS_PHILOX (`seed` used by the latter).
+ *   row_begin,row_count : the antithetic-pair rows of every component this ctx
+ *                 evaluates (0,n_half = all); the normaliser stays ns_per_comp.
+ *   H, dH       : as the reference returns them -- dH packs only the enabled
+ *                 blocks [mu 'F' | sigma | lambda | w] (entmc_vbmc.py:48-51,132),
+ *                 Jacobians applied when jacobian_flag (entmc_vbmc.py:114-130).
+ *   raw_out     : nullable; receives the un-Jacobianed accumulator vector
+ *                 [H | mu (K blocks of D) | sigma (K) | lambda (D) | w (K)]
+ *                 (length 1+D*K+2K+D) -- the vector the all-reduce sums.
+ * If the ctx has a communicator (vbmc_comm_init) the raw vector is summed over
+ * ranks with ONE ncclAllReduce before finalisation. */
+int vbmc_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed,
+               int64_t row_begin, int64_t row_count, int grad_flags, int jacobian_flag,
+               double* H, double* dH, double* raw_out);
+
+/* Finalise a raw accumulator vector on the host (Jacobians + packing,
+ * entmc_vbmc.py:114-132) with the ctx's current mixture: what every rank does
+ * after the all-reduce.  Exposed so the sharded path can be tested without a GPU
+ * collective. */
+int vbmc_entmc_finalize(vbmc_ctx* ctx, const double* raw, int grad_flags,
+                        int jacobian_flag, double* H, double* dH);
+
+/* ---- a7: entropy/entlb_vbmc.py:6-180 ------------------------------------- */
+int vbmc_entlb(vbmc_ctx* ctx, int grad_flags, int jacobian_flag, double* H, double* dH);
+
+/* ---- GP posterior state: what gpyreg hands the path (a11) --------------- */
+
+/* X (N x D); per GP sample s: hyp (P doubles: [log ell (D), log sf, noise (1),
+ * mean (0 | 1 | 1+2D)]), alpha (N), L (N x N), L_chol, sn2_eff = 1/sW[0]^2
+ * (variational_optimization.py:1394-1398), sW (N) and sn2_mult for predict. */
+int vbmc_set_gp(vbmc_ctx* ctx, int N, int D, int S, int P, int mean_kind,
+                const double* X_NxD, const double* hyp_SxP, const double* alpha_SxN,
+                const double* L_SxNxN, const int32_t* L_chol_S, const double* sW_SxN,
+                const double* sn2_mult_S);
+
+/* ---- a8: vbmc/variational_optimization.py:1238-1606 _gp_log_joint ------- */
+
+/* G, dG (enabled blocks; sigma/lambda/w blocks only under jacobian_flag,
+ * :1528-1546), and when compute_var: varG, var_ss (:1578-1596), I_sk (S x K),
+ * J_sjk (S x K x K).  avg_flag as the reference (:1578).  Outputs nullable.
+ * With avg_flag=0 or S==1 semantics: G_out/dG_out hold per-sample values laid
+ * out [S] and [n_dG][S] like the reference's arrays.  compute_var with any
+ * gradient -> VBMC_E_UNSUP (reference raises :1303-1307); compute_var==2 too. */
+int vbmc_gp_log_joint(vbmc_ctx* ctx, int grad_flags, int avg_flag, int jacobian_flag,
+                      int compute_var, double* G, double* dG, double* varG,
+                      double* var_ss, double* I_SxK, double* J_SxKxK);
+
+/* ---- a12: gpyreg GP.predict (third party) ------------ */
+
+/* Per sample: fmu = m(x*) + K*^T alpha; fs2 = max(0, sf^2 - ||L^-T (sW o K*)||^2)
+ * (L_chol) or max(0, sf^2 + diag(K*^T L K*)).  separate_samples: outputs (M x S)
+ * row-major; else (M): mean over s and mean_s fs2 + var_s(fmu, ddof=1)
+ * (the law restated at acquisition_functions/abstract_acq_fcn.py:82-97).
+ * add_noise: adds exp(2 hyp_noise)*sn2_mult to the variance. */
+int vbmc_gp_predict(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int add_noise,
+                    int separate_samples, double* fmu, double* fs2);
+
+/* ---- a9: the fused objective _neg_elcbo (:991-1235) ---------------------- */
+
+typedef struct {
+  /* inputs */
+  int64_t ns_per_comp;  /* reference `Ns` (per component); 0 -> entlb           */
+  int eps_mode;         /* VBMC_EPS_*                                            */
+  uint64_t seed;        /* Philox seed                                           */
+  int compute_grad;     /* reference compute_grad                                */
+  int optimize_mask;    /* bit0..3 = vp.optimize_{mu,sigma,lambd,weights}        */
+  int64_t row_begin;    /* antithetic-pair rows of every component evaluated by  */
+  int64_t row_count;    /* this ctx; row_count < 0 -> the rank's even share       */
+  /* soft bounds (theta_bnd), all nullable together (:1195-1229)                 */
+  const double* bnd_lb; /* length n_bnd                                          */
+  const double* bnd_ub;
+  int n_bnd;
+  double tol_con;
+  double weight_threshold;
+  double weight_penalty;
+} vbmc_elbo_opts;
+
+/* One evaluation of F = -G - H (+ bound / weight penalties) and dF with a single
+ * device round trip: theta -> mixture (vbmc_theta_to_mixture), G/dG kernel,
+ * entropy kernels, optional all-reduce, host finalisation.  theta's eta tail is
+ * max-shifted IN PLACE like the reference does to its caller (:1082-1085).
+ * Outputs: F, dF (n_theta; untouched if !compute_grad), G, H; mixture outputs as
+ * in vbmc_theta_to_mixture (nullable). */
+int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta, const vbmc_elbo_opts* opts,
+                   double* F, double* dF, double* G, double* H, double* mu_KxD,
+                   double* sigma_K, double* lambd_D, double* w_K, double* eta_K);
+
+/* ---- multi-GPU: one process per GPU, one collective ---------- */
+
+/* 128-byte RCCL unique id, created on rank 0 and shipped to the other ranks by
+ * the host launcher (file / env / any side channel). */
+int vbmc_comm_unique_id(uint8_t id_out[128]);
+/* Join the communicator: after this, vbmc_entmc / vbmc_neg_elcbo all-reduce the
+ * raw entropy accumulator over `world` ranks. */
+int vbmc_comm_init(vbmc_ctx* ctx, const uint8_t id[128], int rank, int world);
+int vbmc_comm_destroy(vbmc_ctx* ctx);
+/* Device-side barrier + max over ranks of a host double (bench timing). */
+int vbmc_comm_allreduce_max(vbmc_ctx* ctx, double* value_inout);
+int vbmc_comm_barrier(vbmc_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VBMC_HIP_H */

@@ -1,0 +1,59 @@
+"""Oracle: the device RNG, restated.  TEST INFRASTRUCTURE.
+
+NumPy restatement of pyvbmc_amd/csrc/philox.h (Philox4x32-10, Salmon et al.
+SC'11, + float64 Box-Muller) so that the Monte-Carlo entropy of the HIP kernel in
+VBMC_EPS_PHILOX mode can be checked against the oracle on the SAME draws.  There
+is no reference counterpart (the reference draws from NumPy's MT19937 stream).
+Integer side is bit-exact; the float side (log, sqrt, cos/sin) agrees to ~1 ulp.
+"""
+import numpy as np
+
+M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+W0, W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised over equal-shaped uint32 arrays c0..c3; scalar keys."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint32).copy() for c in (c0, c1, c2, c3))
+    k0, k1 = np.uint32(k0), np.uint32(k1)
+    with np.errstate(over="ignore"):
+        for _ in range(10):
+            p0 = M0 * c0.astype(np.uint64)
+            p1 = M1 * c2.astype(np.uint64)
+            n0 = (p1 >> np.uint64(32)).astype(np.uint32) ^ c1 ^ k0
+            n1 = (p1 & MASK).astype(np.uint32)
+            n2 = (p0 >> np.uint64(32)).astype(np.uint32) ^ c3 ^ k1
+            n3 = (p0 & MASK).astype(np.uint32)
+            c0, c1, c2, c3 = n0, n1, n2, n3
+            k0 = np.uint32((int(k0) + int(W0)) & 0xFFFFFFFF)
+            k1 = np.uint32((int(k1) + int(W1)) & 0xFFFFFFFF)
+    return c0, c1, c2, c3
+
+
+def eps_half(K, n_half, D, seed, row_begin=0, row_count=None):
+    """[K][row_count][D] standard normals exactly as the kernel generates them:
+    counter = (row_lo, row_hi, pair, 0), key = (seed_lo, seed_hi),
+    row = j * n_half + i (global antithetic-pair row index)."""
+    if row_count is None:
+        row_count = n_half - row_begin
+    seed = int(seed)
+    out = np.empty((K, row_count, D))
+    j = np.arange(K, dtype=np.uint64)[:, None]
+    i = np.arange(row_begin, row_begin + row_count, dtype=np.uint64)[None, :]
+    row = j * np.uint64(n_half) + i
+    lo = (row & MASK).astype(np.uint32)
+    hi = (row >> np.uint64(32)).astype(np.uint32)
+    for p in range((D + 1) // 2):
+        x0, x1, x2, x3 = philox4x32_10(
+            lo, hi, np.full_like(lo, p), np.zeros_like(lo), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+        )
+        a = ((x0.astype(np.uint64) << np.uint64(32)) | x1.astype(np.uint64)) >> np.uint64(11)
+        b = ((x2.astype(np.uint64) << np.uint64(32)) | x3.astype(np.uint64)) >> np.uint64(11)
+        u1 = (a + np.uint64(1)).astype(np.float64) * 2.0**-53
+        u2 = b.astype(np.float64) * 2.0**-53
+        rad = np.sqrt(-2.0 * np.log(u1))
+        out[:, :, 2 * p] = rad * np.cos(2.0 * np.pi * u2)
+        if 2 * p + 1 < D:
+            out[:, :, 2 * p + 1] = rad * np.sin(2.0 * np.pi * u2)
+    return out

@@ -1,0 +1,256 @@
+"""ctypes binding of libvbmc_hip.so (the C ABI declared in include/vbmc_hip.h).
+
+This is the only route from Python to the GPU: no PyTorch, no CPU fallback.  If
+the shared library is missing, or no gfx950 device is visible when a context is
+requested, the import / call raises -- it never silently computes elsewhere.
+"""
+import ctypes as C
+import os
+import threading
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("VBMC_HIP_LIB", _HERE / "libvbmc_hip.so"))
+
+EPS_RESIDENT, EPS_PHILOX = 0, 1
+MEAN_ZERO, MEAN_CONST, MEAN_NEGQUAD = 0, 1, 2
+E_ARG, E_HIP, E_RCCL, E_NODEV, E_UNSUP, E_NONFINITE = -1, -2, -3, -4, -5, -6
+
+
+class VbmcHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libvbmc_hip error {code}: {msg}")
+        self.code = code
+
+
+class NoDeviceError(VbmcHipError):
+    pass
+
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+
+class ElboOpts(C.Structure):
+    _fields_ = [
+        ("ns_per_comp", C.c_int64),
+        ("eps_mode", C.c_int),
+        ("seed", C.c_uint64),
+        ("compute_grad", C.c_int),
+        ("optimize_mask", C.c_int),
+        ("row_begin", C.c_int64),
+        ("row_count", C.c_int64),
+        ("bnd_lb", _dp),
+        ("bnd_ub", _dp),
+        ("n_bnd", C.c_int),
+        ("tol_con", C.c_double),
+        ("weight_threshold", C.c_double),
+        ("weight_penalty", C.c_double),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/vbmc_hip.h declares
+SIGNATURES = {
+    "vbmc_abi_version": (C.c_int, []),
+    "vbmc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "vbmc_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "vbmc_ctx_destroy": (None, [_vp]),
+    "vbmc_last_error": (C.c_char_p, [_vp]),
+    "vbmc_device_info": (
+        C.c_int,
+        [_vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)],
+    ),
+    "vbmc_synchronize": (C.c_int, [_vp]),
+    "vbmc_last_kernel_ms": (C.c_int, [_vp, C.c_int, _dp]),
+    "vbmc_set_mixture": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "vbmc_theta_to_mixture": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "vbmc_mixture_pdf": (C.c_int, [_vp, C.c_int64, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp]),
+    "vbmc_set_eps": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, _dp, C.c_int64, C.c_int64]),
+    "vbmc_entmc": (
+        C.c_int,
+        [_vp, C.c_int64, C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_int, _dp, _dp, _dp],
+    ),
+    "vbmc_entmc_finalize": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, _dp]),
+    "vbmc_entlb": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp]),
+    "vbmc_set_gp": (
+        C.c_int,
+        [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp,
+         C.POINTER(C.c_int32), _dp, _dp],
+    ),
+    "vbmc_gp_log_joint": (
+        C.c_int,
+        [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp],
+    ),
+    "vbmc_gp_predict": (C.c_int, [_vp, C.c_int64, _dp, C.c_int, C.c_int, _dp, _dp]),
+    "vbmc_neg_elcbo": (
+        C.c_int,
+        [_vp, _dp, C.c_int, C.POINTER(ElboOpts), _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
+    ),
+    "vbmc_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "vbmc_comm_init": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
+    "vbmc_comm_destroy": (C.c_int, [_vp]),
+    "vbmc_comm_allreduce_max": (C.c_int, [_vp, _dp]),
+    "vbmc_comm_barrier": (C.c_int, [_vp]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load():
+    """Load (once) and return the shared library; raises if it is missing."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not LIB_PATH.exists():
+                raise ImportError(
+                    f"{LIB_PATH} not found: build it with `python -m pyvbmc_amd.build` "
+                    "(hipcc, gfx950).  pyvbmc_amd has no CPU fallback."
+                )
+            lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)  # AttributeError if the symbol is missing
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def device_count():
+    n = C.c_int(0)
+    load().vbmc_device_count(C.byref(n))
+    return n.value
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a):
+    """float64 pointer of a C-contiguous array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_dp)
+
+
+def flags_to_bits(flags):
+    if np.isscalar(flags):
+        return 15 if flags else 0
+    return sum((1 << i) for i, f in enumerate(flags) if f)
+
+
+class Context:
+    """One vbmc_ctx: a device, its stream/scratch and optional RCCL communicator.
+    Not thread-safe; create one per host thread."""
+
+    def __init__(self, device=None):
+        lib = load()
+        if device is None:
+            device = int(os.environ.get("VBMC_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        # device == -1: host-only context (mixture bookkeeping + host finalisation; every
+        # kernel-launching call raises NoDeviceError) -- used by the CPU tests only
+        h = _vp()
+        rc = lib.vbmc_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            msg = (lib.vbmc_last_error(None) or b"").decode()
+            raise (NoDeviceError if rc == E_NODEV else VbmcHipError)(rc, msg)
+        self._h = h
+        self._lib = lib
+        self.device = int(device)
+        self.rank, self.world = 0, 1
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vbmc_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            msg = (self._lib.vbmc_last_error(self._h) or b"").decode()
+            if rc == E_UNSUP:
+                raise NotImplementedError(msg)
+            if rc == E_ARG:
+                raise ValueError(msg)
+            if rc == E_NODEV:
+                raise NoDeviceError(rc, msg)
+            raise VbmcHipError(rc, msg)
+
+    # -- thin typed wrappers --------------------------------------------------
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu, clk, mem = C.c_int(), C.c_int(), C.c_uint64()
+        self.check(self._lib.vbmc_device_info(self._h, name, 256, C.byref(cu), C.byref(clk), C.byref(mem)))
+        return {"name": name.value.decode(), "cu_count": cu.value, "clock_khz": clk.value,
+                "hbm_bytes": mem.value}
+
+    def synchronize(self):
+        self.check(self._lib.vbmc_synchronize(self._h))
+
+    def last_kernel_ms(self, which=0):
+        v = C.c_double()
+        self.check(self._lib.vbmc_last_kernel_ms(self._h, which, C.byref(v)))
+        return v.value
+
+    def set_mixture(self, mu_DK, sigma, lambd, w, eta):
+        mu_DK = np.asarray(mu_DK, dtype=np.float64)
+        D, K = mu_DK.shape
+        mu_kd = f64(mu_DK.T)
+        s, l, ww = f64(np.ravel(sigma)), f64(np.ravel(lambd)), f64(np.ravel(w))
+        e = f64(np.ravel(eta)) if eta is not None and np.size(eta) == K else None
+        if s.size != K or l.size != D or ww.size != K:
+            raise ValueError("mixture attribute shapes do not match (D, K)")
+        self.check(self._lib.vbmc_set_mixture(self._h, D, K, ptr(mu_kd), ptr(s), ptr(l), ptr(ww), ptr(e)))
+        self.D, self.K = D, K
+
+    def set_eps(self, eps_half, row_begin=0, row_count=None):
+        eps_half = f64(eps_half)
+        K, h, D = eps_half.shape
+        if row_count is None:
+            row_count = h - row_begin
+        self.check(self._lib.vbmc_set_eps(self._h, K, h, D, ptr(eps_half), row_begin, row_count))
+
+    def comm_init(self, uid_bytes, rank, world):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid_bytes)
+        self.check(self._lib.vbmc_comm_init(self._h, buf, rank, world))
+        self.rank, self.world = rank, world
+
+    def comm_barrier(self):
+        self.check(self._lib.vbmc_comm_barrier(self._h))
+
+    def comm_max(self, value):
+        v = C.c_double(value)
+        self.check(self._lib.vbmc_comm_allreduce_max(self._h, C.byref(v)))
+        return v.value
+
+
+def comm_unique_id():
+    buf = (C.c_uint8 * 128)()
+    rc = load().vbmc_comm_unique_id(buf)
+    if rc != 0:
+        raise VbmcHipError(rc, (load().vbmc_last_error(None) or b"").decode())
+    return bytes(buf)
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context used when a call is not given one explicitly."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+def set_default_context(ctx):
+    global _default_ctx
+    _default_ctx = ctx

@@ -1,0 +1,87 @@
+// Multi-GPU: one process per GPU, ONE collective per evaluation -- an
+// ncclAllReduce(sum, float64) of the raw entropy accumulator over xGMI
+// (SURVEY.md 8e).  The reference has no communication layer; this is new.
+// The message is <= 1+D*K+2K+D doubles (611 at config 3/4, 2221 at config 5):
+// latency-bound, so no bucketing and no overlap games -- it is enqueued on the
+// ctx stream right behind the reduce kernels and in front of the D2H copy.
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "common.h"
+
+#define NCCL_TRY(ctx, call)                                                                 \
+  do {                                                                                      \
+    ncclResult_t r_ = (call);                                                               \
+    if (r_ != ncclSuccess)                                                                  \
+      return vbmc_fail((ctx), VBMC_E_RCCL, "%s failed: %s", #call, ncclGetErrorString(r_)); \
+  } while (0)
+
+int comm_allreduce_sum(vbmc_ctx* ctx, double* d_buf, int n) {
+  if (!ctx->comm || ctx->world <= 1) return 0;
+  NCCL_TRY(ctx, ncclAllReduce(d_buf, d_buf, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm,
+                              ctx->stream));
+  return 0;
+}
+
+extern "C" {
+
+int vbmc_comm_unique_id(uint8_t id_out[128]) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess)
+    return vbmc_fail(nullptr, VBMC_E_RCCL, "ncclGetUniqueId failed: %s", ncclGetErrorString(r));
+  memcpy(id_out, &id, 128);
+  return VBMC_OK;
+}
+
+int vbmc_comm_init(vbmc_ctx* ctx, const uint8_t id[128], int rank, int world) {
+  if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return VBMC_E_ARG;
+  NEED_DEVICE(ctx);
+  if (ctx->comm) return vbmc_fail(ctx, VBMC_E_ARG, "comm_init: communicator already initialised");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId uid;
+  memcpy(&uid, id, 128);
+  ncclComm_t c;
+  NCCL_TRY(ctx, ncclCommInitRank(&c, world, uid, rank));
+  ctx->comm = (ncclComm*)c;
+  ctx->rank = rank;
+  ctx->world = world;
+  return VBMC_OK;
+}
+
+int vbmc_comm_destroy(vbmc_ctx* ctx) {
+  if (!ctx) return VBMC_E_ARG;
+  if (ctx->comm) {
+    (void)ncclCommDestroy((ncclComm_t)ctx->comm);
+    ctx->comm = nullptr;
+    ctx->world = 1;
+    ctx->rank = 0;
+  }
+  return VBMC_OK;
+}
+
+int vbmc_comm_allreduce_max(vbmc_ctx* ctx, double* value_inout) {
+  if (!ctx || !value_inout) return VBMC_E_ARG;
+  if (!ctx->comm || ctx->world <= 1) return VBMC_OK;
+  NEED_DEVICE(ctx);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_dev(ctx, &ctx->d_out, &ctx->d_out_cap, 8);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_out, value_inout, sizeof(double), hipMemcpyHostToDevice,
+                              ctx->stream));
+  NCCL_TRY(ctx, ncclAllReduce(ctx->d_out, ctx->d_out, 1, ncclDouble, ncclMax,
+                              (ncclComm_t)ctx->comm, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(value_inout, ctx->d_out, sizeof(double), hipMemcpyDeviceToHost,
+                              ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return VBMC_OK;
+}
+
+int vbmc_comm_barrier(vbmc_ctx* ctx) {
+  double v = 0.0;
+  return vbmc_comm_allreduce_max(ctx, &v);
+}
+
+}  // extern "C"

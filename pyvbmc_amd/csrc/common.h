@@ -1,0 +1,164 @@
+// Internal declarations shared by the translation units of libvbmc_hip.so.
+// Not part of the ABI (that is include/vbmc_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/vbmc_hip.h"
+
+struct ncclComm;
+
+// Device-resident copy of the mixture, laid out for the kernels.
+// One contiguous allocation of doubles; offsets below in units of double.
+struct MixLayout {
+  int D = 0, K = 0;
+  int o_mup = 0;    // [K][D]  mu_dk / lambda_d   (means in lambda-scaled coordinates)
+  int o_mu = 0;     // [K][D]  mu_dk
+  int o_is2 = 0;    // [K]     1 / sigma_k^2
+  int o_wc = 0;     // [K]     w_k * nconst / sigma_k^D   (nconst = (2pi)^(-D/2) / prod lambda)
+  int o_rc = 0;     // [K]     nconst / sigma_k^D
+  int o_sig = 0;    // [K]     sigma_k
+  int o_w = 0;      // [K]     w_k
+  int o_lam = 0;    // [D]     lambda_d
+  int o_ilam = 0;   // [D]     1 / lambda_d
+  int total = 0;
+  void plan(int D_, int K_) {
+    D = D_;
+    K = K_;
+    int o = 0;
+    o_mup = o; o += K * D;
+    o_mu = o; o += K * D;
+    o_is2 = o; o += K;
+    o_wc = o; o += K;
+    o_rc = o; o += K;
+    o_sig = o; o += K;
+    o_w = o; o += K;
+    o_lam = o; o += D;
+    o_ilam = o; o += D;
+    total = o;
+  }
+};
+
+struct GpState {
+  bool set = false;
+  int N = 0, D = 0, S = 0, P = 0, mean_kind = 0;
+  std::vector<double> hyp;       // S x P (host copy)
+  std::vector<int32_t> L_chol;   // S
+  std::vector<double> sn2_eff;   // S  (1 / sW[0]^2)
+  std::vector<double> sn2_mult;  // S
+  double* d_X = nullptr;      // N x D
+  double* d_alpha = nullptr;  // S x N
+  double* d_L = nullptr;      // S x N x N
+  double* d_Linv = nullptr;   // S x N x N : inverse of the upper Cholesky factor (L_chol samples)
+  double* d_sW = nullptr;     // S x N
+  double* d_hyp = nullptr;    // S x P
+};
+
+struct vbmc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[10] = {};  // pairs: (0,1) entmc, (2,3) glj, (4,5) pdf, (6,7) predict, (8,9) elbo
+  bool ev_valid[5] = {false, false, false, false, false};
+  std::string err;
+  hipDeviceProp_t prop;
+
+  // mixture (host copies are authoritative for finalisation arithmetic)
+  bool mix_set = false;
+  int D = 0, K = 0;
+  std::vector<double> mu, sigma, lambd, w, eta;  // mu is K x D
+  MixLayout ml;
+  double* d_mix = nullptr;
+  size_t d_mix_cap = 0;
+  std::vector<double> h_mixpack;
+
+  // resident antithetic half draws: [K][eps_rows][D]
+  double* d_eps = nullptr;
+  size_t d_eps_cap = 0;
+  int eps_K = 0, eps_D = 0;
+  int64_t eps_rows = 0, eps_row_begin = 0, eps_n_half = 0;
+
+  // scratch (grown on demand)
+  double* d_scratch = nullptr;
+  size_t d_scratch_cap = 0;
+  double* d_out = nullptr;  // small result vectors
+  size_t d_out_cap = 0;
+  double* h_pinned = nullptr;  // pinned host staging for results
+  size_t h_pinned_cap = 0;
+
+  GpState gp;
+
+  ncclComm* comm = nullptr;
+  int rank = 0, world = 1;
+};
+
+// error helpers -----------------------------------------------------------
+int vbmc_fail(vbmc_ctx* ctx, int code, const char* fmt, ...);
+extern thread_local std::string g_create_err;
+
+#define HIP_TRY(ctx, call)                                                            \
+  do {                                                                                \
+    hipError_t e_ = (call);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      return vbmc_fail((ctx), VBMC_E_HIP, "%s failed: %s (%s:%d)", #call,             \
+                       hipGetErrorString(e_), __FILE__, __LINE__);                    \
+  } while (0)
+
+// Entry points that launch kernels refuse a host-only context (device_id -1).
+#define NEED_DEVICE(ctx)                                                                     \
+  do {                                                                                       \
+    if ((ctx)->device < 0)                                                                   \
+      return vbmc_fail((ctx), VBMC_E_NODEV,                                                  \
+                       "host-only context: this entry point needs a gfx950 device "          \
+                       "(libvbmc_hip has no CPU fallback)");                                 \
+  } while (0)
+
+int set_mixture_host(vbmc_ctx* ctx, int D, int K, const double* mu_KxD, const double* sigma_K,
+                     const double* lambd_D, const double* w_K, const double* eta_K);
+
+// buffer helpers (ctx.hip) --------------------------------------------------
+int ensure_dev(vbmc_ctx* ctx, double** p, size_t* cap, size_t n_doubles);
+int ensure_pinned(vbmc_ctx* ctx, size_t n_doubles);
+
+// raw-vector length of the entropy accumulator
+static inline int raw_len(int D, int K) { return 1 + D * K + 2 * K + D; }
+
+// kernels' host launchers (one per .hip file) -------------------------------
+// entropy
+int launch_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed,
+                 int64_t row_begin, int64_t row_count, int want_grad, double* d_raw);
+int launch_entlb(vbmc_ctx* ctx, double* d_res);  // writes raw entlb terms
+// mixture pdf
+int launch_mixture_pdf(vbmc_ctx* ctx, int64_t n, const double* d_x, int log_flag,
+                       int grad_flag, double df, double* d_y, double* d_dy);
+// gp
+int launch_gp_log_joint(vbmc_ctx* ctx, int want_grad, double* d_res, double* d_Z);
+int launch_gp_var(vbmc_ctx* ctx, const double* d_Z, double* d_V, double* d_Q);
+int launch_trinv(vbmc_ctx* ctx);
+int launch_gp_predict_sample(vbmc_ctx* ctx, int s, int64_t M, const double* d_xs, double* d_Ks,
+                             double* d_part, int add_noise, double* d_fmu, double* d_fs2);
+
+// host finalisation of the GP expected log joint (api_gp.hip)
+struct GljHost {
+  std::vector<double> G;        // S
+  std::vector<double> I_sk;     // S x K
+  std::vector<double> mu;       // S x (K*D)   d/dmu, 'F' order (K blocks of D)
+  std::vector<double> sigma;    // S x K       pre-Jacobian
+  std::vector<double> lambd;    // S x D
+  std::vector<double> w;        // S x K  (= I_sk)
+};
+void glj_finalize(const vbmc_ctx* ctx, const double* res, int want_grad, GljHost& o);
+// packs dG for one sample (or the average) into out; returns its length
+int glj_pack(const vbmc_ctx* ctx, const double* mu, const double* sg, const double* lm,
+             const double* wg, int grad_flags, int jacobian_flag, double* out);
+// comm
+int comm_allreduce_sum(vbmc_ctx* ctx, double* d_buf, int n);
+
+// host finalisation (finalize.cpp) -----------------------------------------
+void softmax_jacobian_apply(const std::vector<double>& eta, const double* g, double* out);
+int entropy_pack(const vbmc_ctx* ctx, double H, const double* mu, const double* sg,
+                 const double* lm, const double* wg, int grad_flags, int jacobian_flag,
+                 double* H_out, double* dH_out);

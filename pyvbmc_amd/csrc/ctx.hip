@@ -1,0 +1,323 @@
+// Context, device memory and mixture/eps/GP state upload for libvbmc_hip.so.
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+
+#include "common.h"
+
+thread_local std::string g_create_err;
+
+int vbmc_fail(vbmc_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx)
+    ctx->err = buf;
+  else
+    g_create_err = buf;
+  return code;
+}
+
+int ensure_dev(vbmc_ctx* ctx, double** p, size_t* cap, size_t n) {
+  if (*cap >= n && *p) return 0;
+  // never free under a running kernel: the stream is in-order, sync first
+  if (*p) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+  }
+  size_t want = n + n / 4 + 64;
+  HIP_TRY(ctx, hipMalloc((void**)p, want * sizeof(double)));
+  *cap = want;
+  return 0;
+}
+
+int ensure_pinned(vbmc_ctx* ctx, size_t n) {
+  if (ctx->h_pinned_cap >= n && ctx->h_pinned) return 0;
+  if (ctx->h_pinned) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipHostFree(ctx->h_pinned));
+    ctx->h_pinned = nullptr;
+    ctx->h_pinned_cap = 0;
+  }
+  size_t want = n + n / 4 + 64;
+  HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_pinned, want * sizeof(double), hipHostMallocDefault));
+  ctx->h_pinned_cap = want;
+  return 0;
+}
+
+extern "C" {
+
+int vbmc_abi_version(void) { return 1; }
+
+int vbmc_device_count(int* n_out) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    n = 0;
+    (void)hipGetLastError();
+  }
+  if (n_out) *n_out = n;
+  return VBMC_OK;
+}
+
+int vbmc_ctx_create(int device_id, vbmc_ctx** out) {
+  if (!out) return vbmc_fail(nullptr, VBMC_E_ARG, "vbmc_ctx_create: out is NULL");
+  *out = nullptr;
+  if (device_id == -1) {
+    // host-only context: mixture bookkeeping and host finalisation only (used by the
+    // CPU tests of the sharded path); every kernel-launching entry point refuses it.
+    vbmc_ctx* h = new vbmc_ctx();
+    h->device = -1;
+    *out = h;
+    return VBMC_OK;
+  }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return vbmc_fail(nullptr, VBMC_E_NODEV,
+                     "no HIP device visible (%s); libvbmc_hip has no CPU fallback",
+                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  }
+  if (device_id < 0 || device_id >= n)
+    return vbmc_fail(nullptr, VBMC_E_ARG, "device_id %d out of range [0,%d)", device_id, n);
+  vbmc_ctx* ctx = new vbmc_ctx();
+  ctx->device = device_id;
+  e = hipSetDevice(device_id);
+  if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_id);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  for (int i = 0; i < 10 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
+  if (e != hipSuccess) {
+    int rc = vbmc_fail(nullptr, VBMC_E_HIP, "context setup failed: %s", hipGetErrorString(e));
+    delete ctx;
+    return rc;
+  }
+  if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+    int rc = vbmc_fail(nullptr, VBMC_E_NODEV, "device %d is %s; this library is built for gfx950 only",
+                       device_id, ctx->prop.gcnArchName);
+    vbmc_ctx_destroy(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return VBMC_OK;
+}
+
+void vbmc_ctx_destroy(vbmc_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->device < 0) {
+    delete ctx;
+    return;
+  }
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  vbmc_comm_destroy(ctx);
+  double* bufs[] = {ctx->d_mix, ctx->d_eps, ctx->d_scratch, ctx->d_out, ctx->gp.d_X,
+                    ctx->gp.d_alpha, ctx->gp.d_L, ctx->gp.d_Linv, ctx->gp.d_sW, ctx->gp.d_hyp};
+  for (double* b : bufs)
+    if (b) (void)hipFree(b);
+  if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  for (int i = 0; i < 10; ++i)
+    if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* vbmc_last_error(const vbmc_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+int vbmc_device_info(const vbmc_ctx* ctx, char* name, int name_len, int* cu_count,
+                     int* clock_khz, uint64_t* hbm_bytes) {
+  if (!ctx) return VBMC_E_ARG;
+  if (ctx->device < 0) return vbmc_fail(const_cast<vbmc_ctx*>(ctx), VBMC_E_NODEV, "host-only context");
+  if (name && name_len > 0) {
+    snprintf(name, (size_t)name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+  }
+  if (cu_count) *cu_count = ctx->prop.multiProcessorCount;
+  if (clock_khz) *clock_khz = ctx->prop.clockRate;
+  if (hbm_bytes) *hbm_bytes = (uint64_t)ctx->prop.totalGlobalMem;
+  return VBMC_OK;
+}
+
+int vbmc_synchronize(vbmc_ctx* ctx) {
+  if (!ctx) return VBMC_E_ARG;
+  if (ctx->device < 0) return VBMC_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return VBMC_OK;
+}
+
+int vbmc_last_kernel_ms(vbmc_ctx* ctx, int which, double* ms_out) {
+  if (!ctx || which < 0 || which > 4 || !ms_out) return VBMC_E_ARG;
+  NEED_DEVICE(ctx);
+  if (!ctx->ev_valid[which]) return vbmc_fail(ctx, VBMC_E_ARG, "no timed launch recorded for %d", which);
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2 * which + 1]));
+  float ms = 0.f;
+  HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[2 * which], ctx->ev[2 * which + 1]));
+  *ms_out = (double)ms;
+  return VBMC_OK;
+}
+
+}  // extern "C"
+
+// Host-side derivation of the kernel-friendly mixture pack + upload.
+static int upload_mixture(vbmc_ctx* ctx) {
+  const int D = ctx->D, K = ctx->K;
+  ctx->ml.plan(D, K);
+  const MixLayout& ml = ctx->ml;
+  if (ctx->device < 0) return 0;  // host-only context keeps just the host copies
+  ctx->h_mixpack.assign((size_t)ml.total, 0.0);
+  double* p = ctx->h_mixpack.data();
+  double prod_lam = 1.0;
+  for (int d = 0; d < D; ++d) prod_lam *= ctx->lambd[d];
+  // nconst = 1 / (2 pi)^(D/2) / prod(lambda)   (entmc_vbmc.py:54-56)
+  const double nconst = 1.0 / std::pow(2.0 * M_PI, 0.5 * D) / prod_lam;
+  for (int k = 0; k < K; ++k) {
+    for (int d = 0; d < D; ++d) {
+      p[ml.o_mu + k * D + d] = ctx->mu[(size_t)k * D + d];
+      p[ml.o_mup + k * D + d] = ctx->mu[(size_t)k * D + d] / ctx->lambd[d];
+    }
+    const double s = ctx->sigma[k];
+    const double sD = std::pow(s, (double)D);
+    p[ml.o_is2 + k] = 1.0 / (s * s);
+    p[ml.o_rc + k] = nconst / sD;
+    p[ml.o_wc + k] = ctx->w[k] * nconst / sD;
+    p[ml.o_sig + k] = s;
+    p[ml.o_w + k] = ctx->w[k];
+  }
+  for (int d = 0; d < D; ++d) {
+    p[ml.o_lam + d] = ctx->lambd[d];
+    p[ml.o_ilam + d] = 1.0 / ctx->lambd[d];
+  }
+  int rc = ensure_dev(ctx, &ctx->d_mix, &ctx->d_mix_cap, (size_t)ml.total);
+  if (rc) return rc;
+  // pageable source: hipMemcpyAsync from pageable memory stages synchronously,
+  // so h_mixpack may be rewritten right after this returns.
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mix, p, sizeof(double) * ml.total, hipMemcpyHostToDevice,
+                              ctx->stream));
+  return 0;
+}
+
+int set_mixture_host(vbmc_ctx* ctx, int D, int K, const double* mu_KxD, const double* sigma_K,
+                     const double* lambd_D, const double* w_K, const double* eta_K) {
+  if (D < 1 || K < 1) return vbmc_fail(ctx, VBMC_E_ARG, "set_mixture: bad D=%d K=%d", D, K);
+  ctx->D = D;
+  ctx->K = K;
+  ctx->mu.assign(mu_KxD, mu_KxD + (size_t)K * D);
+  ctx->sigma.assign(sigma_K, sigma_K + K);
+  ctx->lambd.assign(lambd_D, lambd_D + D);
+  ctx->w.assign(w_K, w_K + K);
+  if (eta_K)
+    ctx->eta.assign(eta_K, eta_K + K);
+  else
+    ctx->eta.assign((size_t)K, 0.0);
+  for (int k = 0; k < K; ++k)
+    if (!(ctx->sigma[k] > 0.0) || !std::isfinite(ctx->sigma[k]))
+      return vbmc_fail(ctx, VBMC_E_NONFINITE, "set_mixture: sigma[%d]=%g must be finite and > 0", k,
+                       ctx->sigma[k]);
+  for (int d = 0; d < D; ++d)
+    if (!(ctx->lambd[d] > 0.0) || !std::isfinite(ctx->lambd[d]))
+      return vbmc_fail(ctx, VBMC_E_NONFINITE, "set_mixture: lambd[%d]=%g must be finite and > 0", d,
+                       ctx->lambd[d]);
+  ctx->mix_set = true;
+  return upload_mixture(ctx);
+}
+
+extern "C" {
+
+int vbmc_set_mixture(vbmc_ctx* ctx, int D, int K, const double* mu_KxD, const double* sigma_K,
+                     const double* lambd_D, const double* w_K, const double* eta_K) {
+  if (!ctx || !mu_KxD || !sigma_K || !lambd_D || !w_K) return VBMC_E_ARG;
+  if (ctx->device >= 0) HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return set_mixture_host(ctx, D, K, mu_KxD, sigma_K, lambd_D, w_K, eta_K);
+}
+
+int vbmc_theta_to_mixture(vbmc_ctx* ctx, const double* theta, int n_theta, int optimize_mask,
+                          double* mu_KxD, double* sigma_K, double* lambd_D, double* w_K,
+                          double* eta_K) {
+  if (!ctx || !theta) return VBMC_E_ARG;
+  if (!ctx->mix_set) return vbmc_fail(ctx, VBMC_E_ARG, "theta_to_mixture: mixture (D,K) not set");
+  if (ctx->device >= 0) HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int D = ctx->D, K = ctx->K;
+  const bool o_mu = optimize_mask & 1, o_sg = optimize_mask & 2, o_lm = optimize_mask & 4,
+             o_w = optimize_mask & 8;
+  const int need = (o_mu ? D * K : 0) + (o_sg ? K : 0) + (o_lm ? D : 0) + (o_w ? K : 0);
+  if (n_theta != need)
+    return vbmc_fail(ctx, VBMC_E_ARG, "theta length %d != %d for D=%d K=%d mask=%d", n_theta, need, D,
+                     K, optimize_mask);
+  std::vector<double> mu = ctx->mu, sg = ctx->sigma, lm = ctx->lambd, w = ctx->w, eta = ctx->eta;
+  int pos = 0;
+  if (o_mu) {
+    for (int i = 0; i < D * K; ++i) mu[i] = theta[i];
+    pos = D * K;
+  }
+  if (o_sg) {
+    for (int k = 0; k < K; ++k) sg[k] = std::exp(theta[pos + k]);
+    pos += K;
+  }
+  if (o_lm)
+    for (int d = 0; d < D; ++d) lm[d] = std::exp(theta[pos + d]);
+  if (o_w) {
+    const double* e = theta + (n_theta - K);
+    double mx = e[0];
+    for (int k = 1; k < K; ++k) mx = e[k] > mx ? e[k] : mx;
+    for (int k = 0; k < K; ++k) {
+      eta[k] = e[k] - mx;
+      w[k] = std::exp(eta[k]);
+    }
+  }
+  // lambda -> unit RMS, sigma absorbs it (variational_posterior.py:749-752)
+  double s2 = 0.0;
+  for (int d = 0; d < D; ++d) s2 += lm[d] * lm[d];
+  const double nl = std::sqrt(s2 / D);
+  for (int d = 0; d < D; ++d) lm[d] /= nl;
+  for (int k = 0; k < K; ++k) sg[k] *= nl;
+  if (o_w) {
+    double ws = 0.0;
+    for (int k = 0; k < K; ++k) ws += w[k];
+    for (int k = 0; k < K; ++k) w[k] /= ws;
+  }
+  for (int i = 0; i < n_theta; ++i)
+    if (!std::isfinite(theta[i]))
+      return vbmc_fail(ctx, VBMC_E_NONFINITE, "theta[%d] is not finite", i);
+  int rc = set_mixture_host(ctx, D, K, mu.data(), sg.data(), lm.data(), w.data(), eta.data());
+  if (rc) return rc;
+  if (mu_KxD) memcpy(mu_KxD, mu.data(), sizeof(double) * D * K);
+  if (sigma_K) memcpy(sigma_K, sg.data(), sizeof(double) * K);
+  if (lambd_D) memcpy(lambd_D, lm.data(), sizeof(double) * D);
+  if (w_K) memcpy(w_K, w.data(), sizeof(double) * K);
+  if (eta_K) memcpy(eta_K, eta.data(), sizeof(double) * K);
+  return VBMC_OK;
+}
+
+int vbmc_set_eps(vbmc_ctx* ctx, int K, int64_t n_half, int D, const double* eps_half,
+                 int64_t row_begin, int64_t row_count) {
+  if (!ctx || !eps_half || K < 1 || D < 1 || n_half < 0) return VBMC_E_ARG;
+  if (row_begin < 0 || row_count < 0 || row_begin + row_count > n_half)
+    return vbmc_fail(ctx, VBMC_E_ARG, "set_eps: rows [%lld,+%lld) outside [0,%lld)",
+                     (long long)row_begin, (long long)row_count, (long long)n_half);
+  NEED_DEVICE(ctx);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t n = (size_t)K * (size_t)row_count * (size_t)D;
+  int rc = ensure_dev(ctx, &ctx->d_eps, &ctx->d_eps_cap, n ? n : 1);
+  if (rc) return rc;
+  for (int j = 0; j < K && row_count > 0; ++j) {
+    const double* src = eps_half + ((size_t)j * (size_t)n_half + (size_t)row_begin) * D;
+    double* dst = ctx->d_eps + (size_t)j * (size_t)row_count * D;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)row_count * D,
+                                hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->eps_K = K;
+  ctx->eps_D = D;
+  ctx->eps_rows = row_count;
+  ctx->eps_row_begin = row_begin;
+  ctx->eps_n_half = n_half;
+  return VBMC_OK;
+}
+
+}  // extern "C"

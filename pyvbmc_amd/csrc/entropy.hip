@@ -1,0 +1,421 @@
+// Monte-Carlo entropy of the Gaussian mixture (reference: entropy/entmc_vbmc.py:6-134)
+// and the Jensen lower bound (entropy/entlb_vbmc.py:6-180), as HIP kernels for gfx950.
+//
+// Work decomposition of entmc: one workgroup = (component j, chunk of 256
+// antithetic-pair rows).  A thread owns one row eps (D normals) and evaluates BOTH
+// samples x+- = mu_j +- sigma_j lambda o eps, which share the dot product
+// Delta_k . eps of the squared distance to every component k:
+//     |x'+- - mu'_k|^2 = |Delta_k|^2 + sigma_j^2 |eps|^2 +- 2 sigma_j Delta_k . eps,
+//     Delta_k = (mu_j - mu_k) / lambda    (per-j centred, so the expansion is benign).
+// Per-workgroup partial sums go to HBM; two tiny kernels reduce them in a fixed
+// order (bit-reproducible) into the raw accumulator vector
+//     [H | mu (K blocks of D) | sigma (K) | lambda (D) | w (K)]
+// that the host finalises (Jacobians) and that the multi-GPU path all-reduces.
+#include "common.h"
+#include "philox.h"
+
+namespace {
+
+constexpr int WG = 256;
+constexpr int WAVES = WG / 64;
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+struct EntArgs {
+  const double* mix;
+  MixLayout ml;
+  const double* eps;   // resident draws [K][eps_rows][D] or nullptr
+  int64_t eps_rows;    // rows resident per component (== row_count of the ctx slice)
+  int64_t n_half;      // antithetic pairs per component in the whole job
+  int64_t row_begin;   // first row of this ctx's slice
+  int64_t row_count;   // rows of this ctx's slice
+  uint64_t seed;
+  int eps_mode;
+  int want_grad;
+  double* partial;     // [K][chunks][stride]
+  int chunks;
+  int stride;          // 2 + 2D + K
+};
+
+// Partial row layout: [Slog | mu(D) | sig | lam(D) | W(K)]
+template <int DP>
+__global__ __launch_bounds__(WG) void entmc_valu_kernel(EntArgs a) {
+  extern __shared__ double lds[];
+  const int D = a.ml.D, K = a.ml.K;
+  const int j = blockIdx.y;
+  const int chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+
+  double* sDelta = lds;                 // [K][DP]
+  double* sA = sDelta + K * DP;         // [K] |Delta_k|^2
+  double* sIs2 = sA + K;                // [K]
+  double* sWc = sIs2 + K;               // [K]
+  double* sRed = sWc + K;               // [WAVES][2*DP+1]
+  double* sW = sRed + WAVES * (2 * DP + 1);  // [WAVES][K]
+
+  const double* mup = a.mix + a.ml.o_mup;
+  for (int idx = tid; idx < K * DP; idx += WG) {
+    int k = idx / DP, d = idx - k * DP;
+    sDelta[idx] = (d < D) ? (mup[j * D + d] - mup[k * D + d]) : 0.0;
+  }
+  for (int k = tid; k < K; k += WG) {
+    sIs2[k] = a.mix[a.ml.o_is2 + k];
+    sWc[k] = a.mix[a.ml.o_wc + k];
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += WG) {
+    double s = 0.0;
+    for (int d = 0; d < DP; ++d) s = fma(sDelta[k * DP + d], sDelta[k * DP + d], s);
+    sA[k] = s;
+  }
+  __syncthreads();
+
+  const double sig_j = a.mix[a.ml.o_sig + j];
+  const int64_t i_loc = (int64_t)chunk * WG + tid;  // row within this ctx's slice
+  const bool valid = i_loc < a.row_count;
+
+  double e[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) e[d] = 0.0;
+  if (valid) {
+    if (a.eps_mode == VBMC_EPS_RESIDENT) {
+      const double* row = a.eps + ((int64_t)j * a.eps_rows + i_loc) * D;
+#pragma unroll
+      for (int d = 0; d < DP; ++d)
+        if (d < D) e[d] = row[d];
+    } else {
+      const uint64_t grow = (uint64_t)j * (uint64_t)a.n_half + (uint64_t)(a.row_begin + i_loc);
+#pragma unroll
+      for (int p = 0; p < DP / 2; ++p) {
+        if (2 * p < D) {
+          double z0, z1;
+          philox_normal_pair(grow, (uint32_t)p, a.seed, z0, z1);
+          e[2 * p] = z0;
+          if (2 * p + 1 < D) e[2 * p + 1] = z1;
+        }
+      }
+    }
+  }
+  double e2 = 0.0;
+#pragma unroll
+  for (int d = 0; d < DP; ++d) e2 = fma(e[d], e[d], e2);
+  const double b = sig_j * sig_j * e2;
+  const double two_sj = 2.0 * sig_j;
+
+  double qp = 0.0, qm = 0.0, gsp = 0.0, gsm = 0.0;
+  double Ap[DP], Am[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) Ap[d] = Am[d] = 0.0;
+
+  for (int k = 0; k < K; ++k) {
+    const double* dk = sDelta + k * DP;
+    double c = 0.0;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) c = fma(dk[d], e[d], c);
+    const double ab = sA[k] + b;
+    const double is2 = sIs2[k];
+    const double sp = fmax(fma(two_sj, c, ab), 0.0);
+    const double sm = fmax(fma(-two_sj, c, ab), 0.0);
+    const double wrp = sWc[k] * exp(-0.5 * sp * is2);
+    const double wrm = sWc[k] * exp(-0.5 * sm * is2);
+    qp += wrp;
+    qm += wrm;
+    if (a.want_grad) {
+      const double gp = wrp * is2, gm = wrm * is2;
+      gsp += gp;
+      gsm += gm;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        Ap[d] = fma(gp, dk[d], Ap[d]);
+        Am[d] = fma(gm, dk[d], Am[d]);
+      }
+    }
+  }
+
+  double slog = valid ? (log(qp) + log(qm)) : 0.0;
+  const double ip = valid ? 1.0 / qp : 0.0;
+  const double im = valid ? 1.0 / qm : 0.0;
+
+  // ---- block reduction of [Slog, mu(DP), lam(DP)] ----
+  {
+    double v = wave_sum(slog);
+    if (lane == 0) sRed[wave * (2 * DP + 1)] = v;
+  }
+  if (a.want_grad) {
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      const double se = sig_j * e[d];
+      const double lp = fma(se, gsp, Ap[d]) * ip;
+      const double lm = fma(-se, gsm, Am[d]) * im;
+      double vmu = wave_sum(lp + lm);
+      double vlam = wave_sum((lp - lm) * e[d]);
+      if (lane == 0) {
+        sRed[wave * (2 * DP + 1) + 1 + d] = vmu;
+        sRed[wave * (2 * DP + 1) + 1 + DP + d] = vlam;
+      }
+    }
+    // ---- second pass: sum_n exp_k(x_n) / q(x_n) for every k ----
+    for (int k = 0; k < K; ++k) {
+      const double* dk = sDelta + k * DP;
+      double c = 0.0;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) c = fma(dk[d], e[d], c);
+      const double ab = sA[k] + b;
+      const double is2 = sIs2[k];
+      const double sp = fmax(fma(two_sj, c, ab), 0.0);
+      const double sm = fmax(fma(-two_sj, c, ab), 0.0);
+      double v = exp(-0.5 * sp * is2) * ip + exp(-0.5 * sm * is2) * im;
+      v = wave_sum(v);
+      if (lane == 0) sW[wave * K + k] = v;
+    }
+  }
+  __syncthreads();
+
+  double* out = a.partial + ((int64_t)j * a.chunks + chunk) * a.stride;
+  for (int t = tid; t < a.stride; t += WG) {
+    double v = 0.0;
+    if (t == 0) {
+      for (int wv = 0; wv < WAVES; ++wv) v += sRed[wv * (2 * DP + 1)];
+    } else if (a.want_grad) {
+      if (t <= D) {
+        for (int wv = 0; wv < WAVES; ++wv) v += sRed[wv * (2 * DP + 1) + t];
+      } else if (t == D + 1) {
+        for (int d = 0; d < D; ++d)
+          for (int wv = 0; wv < WAVES; ++wv) v += sRed[wv * (2 * DP + 1) + 1 + DP + d];
+      } else if (t < 2 * D + 2) {
+        const int d = t - (D + 2);
+        for (int wv = 0; wv < WAVES; ++wv) v += sRed[wv * (2 * DP + 1) + 1 + DP + d];
+      } else {
+        const int k = t - (2 * D + 2);
+        for (int wv = 0; wv < WAVES; ++wv) v += sW[wv * K + k];
+      }
+    }
+    out[t] = v;
+  }
+}
+
+// Level-1 reduce: block j sums its chunk rows in chunk order.
+__global__ __launch_bounds__(256) void entmc_reduce_chunks(const double* __restrict__ partial,
+                                                           int chunks, int stride,
+                                                           double* __restrict__ perj) {
+  const int j = blockIdx.x;
+  for (int t = threadIdx.x; t < stride; t += blockDim.x) {
+    const double* p = partial + (int64_t)j * chunks * stride + t;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int c = 0;
+    for (; c + 3 < chunks; c += 4) {
+      s0 += p[(int64_t)(c + 0) * stride];
+      s1 += p[(int64_t)(c + 1) * stride];
+      s2 += p[(int64_t)(c + 2) * stride];
+      s3 += p[(int64_t)(c + 3) * stride];
+    }
+    for (; c < chunks; ++c) s0 += p[(int64_t)c * stride];
+    perj[(int64_t)j * stride + t] = (s0 + s1) + (s2 + s3);
+  }
+}
+
+// Level-2: combine the per-component rows into the raw accumulator vector
+// (entmc_vbmc.py:80,98,102-112 with the 1/Ns and w_j factors applied).
+__global__ __launch_bounds__(256) void entmc_combine(const double* __restrict__ perj,
+                                                     const double* __restrict__ mix, MixLayout ml,
+                                                     int stride, double inv_ns, int want_grad,
+                                                     double* __restrict__ raw) {
+  const int D = ml.D, K = ml.K;
+  const double* w = mix + ml.o_w;
+  const double* sig = mix + ml.o_sig;
+  const double* ilam = mix + ml.o_ilam;
+  const double* rc = mix + ml.o_rc;
+  const int n = 1 + D * K + 2 * K + D;
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    double v = 0.0;
+    if (t == 0) {
+      for (int j = 0; j < K; ++j) v -= w[j] * perj[(int64_t)j * stride];
+      v *= inv_ns;
+    } else if (want_grad) {
+      int u = t - 1;
+      if (u < D * K) {
+        int j = u / D, d = u - j * D;
+        v = w[j] * inv_ns * perj[(int64_t)j * stride + 1 + d] * ilam[d];
+      } else if ((u -= D * K) < K) {
+        v = w[u] * inv_ns * perj[(int64_t)u * stride + 1 + D];
+      } else if ((u -= K) < D) {
+        for (int j = 0; j < K; ++j) v += w[j] * sig[j] * perj[(int64_t)j * stride + 2 + D + u];
+        v *= inv_ns * ilam[u];
+      } else {
+        u -= D;
+        double s = 0.0;
+        for (int j = 0; j < K; ++j) s += w[j] * perj[(int64_t)j * stride + 2 + 2 * D + u];
+        v = -inv_ns * (perj[(int64_t)u * stride] + rc[u] * s);
+      }
+    }
+    raw[t] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// entlb: one workgroup; wave w handles rows j = w, w+WAVES, ...; lanes run over i.
+// Output layout: [H | mu (K x D) | sigma (K) | lambda (D) | w (K)] (pre-Jacobian,
+// sigma already carrying the reference's explicit sigma_j factor, entlb_vbmc.py:133).
+__global__ __launch_bounds__(256) void entlb_kernel(const double* __restrict__ mix, MixLayout ml,
+                                                    int want_grad, double* __restrict__ res) {
+  extern __shared__ double lds[];
+  const int D = ml.D, K = ml.K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double* mup = mix + ml.o_mup;  // mu / lambda
+  const double* sig = mix + ml.o_sig;
+  const double* w = mix + ml.o_w;
+  const double* lam = mix + ml.o_lam;
+  double* sGsum = lds;               // [K]
+  double* sLam = sGsum + K;          // [WAVES][D]
+  double* sH = sLam + WAVES * D;     // [WAVES]
+
+  double nconst = 1.0;
+  for (int d = 0; d < D; ++d) nconst /= lam[d];
+  nconst *= pow(2.0 * M_PI, -0.5 * D);
+
+  // phase 1: gsum_j = sum_i w_i gamma_ij
+  for (int j = wave; j < K; j += WAVES) {
+    double acc = 0.0;
+    for (int i = lane; i < K; i += 64) {
+      const double s2 = sig[i] * sig[i] + sig[j] * sig[j];
+      double d2 = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double t = mup[i * D + d] - mup[j * D + d];
+        d2 = fma(t, t, d2);
+      }
+      const double g = nconst * pow(s2, -0.5 * D) * exp(-0.5 * d2 / s2);
+      acc += w[i] * g;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) sGsum[j] = acc;
+  }
+  for (int t = tid; t < WAVES * D; t += 256) sLam[t] = 0.0;
+  __syncthreads();
+
+  double hacc = 0.0;
+  for (int j = wave; j < K; j += WAVES) {
+    const double gj = sGsum[j];
+    if (lane == 0) hacc -= w[j] * log(gj);
+    if (!want_grad) continue;
+    // per-lane partial sums over i for this j
+    double a_sig = 0.0, a_w = 0.0;
+    for (int d = 0; d < D; ++d) {
+      double a_mu = 0.0, a_lam = 0.0;
+      for (int i = lane; i < K; i += 64) {
+        const double s2 = sig[i] * sig[i] + sig[j] * sig[j];
+        double d2 = 0.0;
+        for (int dd = 0; dd < D; ++dd) {
+          const double t = mup[i * D + dd] - mup[j * D + dd];
+          d2 = fma(t, t, d2);
+        }
+        const double g = nconst * pow(s2, -0.5 * D) * exp(-0.5 * d2 / s2);
+        const double wg = w[i] * g;
+        const double coef = wg * (1.0 / sGsum[i] + 1.0 / gj);
+        const double t = mup[i * D + d] - mup[j * D + d];  // (mu_i - mu_j)_d / lambda_d
+        a_mu += coef * t / s2;                              // still to divide by lambda_d
+        a_lam += wg * (t * t / s2 - 1.0);
+        if (d == 0) {
+          a_sig += coef * (-(double)D / s2 + d2 / (s2 * s2));
+          a_w += wg / sGsum[i];
+        }
+      }
+      a_mu = wave_sum(a_mu);
+      a_lam = wave_sum(a_lam);
+      if (lane == 0) {
+        res[1 + j * D + d] = -w[j] * a_mu / lam[d];
+        sLam[wave * D + d] += (w[j] / gj) * a_lam;
+      }
+    }
+    a_sig = wave_sum(a_sig);
+    a_w = wave_sum(a_w);
+    if (lane == 0) {
+      res[1 + K * D + j] = -w[j] * sig[j] * a_sig;
+      res[1 + K * D + K + D + j] = -log(gj) - a_w;
+    }
+  }
+  if (lane == 0) sH[wave] = hacc;
+  __syncthreads();
+  if (tid == 0) {
+    double h = 0.0;
+    for (int wv = 0; wv < WAVES; ++wv) h += sH[wv];
+    res[0] = h;
+  }
+  if (want_grad)
+    for (int d = tid; d < D; d += 256) {
+      double s = 0.0;
+      for (int wv = 0; wv < WAVES; ++wv) s += sLam[wv * D + d];
+      res[1 + K * D + K + d] = -s / lam[d];
+    }
+}
+
+template <int DP>
+int launch_entmc_dp(vbmc_ctx* ctx, const EntArgs& a) {
+  const int K = a.ml.K;
+  size_t lds = sizeof(double) * ((size_t)K * DP + 3 * K + WAVES * (2 * DP + 1) + (size_t)WAVES * K);
+  dim3 grid(a.chunks, K);
+  hipLaunchKernelGGL(entmc_valu_kernel<DP>, grid, dim3(WG), lds, ctx->stream, a);
+  return 0;
+}
+
+}  // namespace
+
+int launch_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed,
+                 int64_t row_begin, int64_t row_count, int want_grad, double* d_raw) {
+  const int D = ctx->D, K = ctx->K;
+  if (D > 32) return vbmc_fail(ctx, VBMC_E_UNSUP, "entmc: D=%d > 32 not supported", D);
+  EntArgs a;
+  a.mix = ctx->d_mix;
+  a.ml = ctx->ml;
+  a.eps = ctx->d_eps;
+  a.eps_rows = ctx->eps_rows;
+  a.n_half = ns_per_comp / 2;
+  a.row_begin = row_begin;
+  a.row_count = row_count;
+  a.seed = seed;
+  a.eps_mode = eps_mode;
+  a.want_grad = want_grad;
+  a.chunks = (int)((row_count + WG - 1) / WG);
+  if (a.chunks < 1) a.chunks = 1;
+  a.stride = 2 + 2 * D + K;
+  size_t need = (size_t)K * a.chunks * a.stride + (size_t)K * a.stride;
+  int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, need);
+  if (rc) return rc;
+  a.partial = ctx->d_scratch;
+  double* perj = ctx->d_scratch + (size_t)K * a.chunks * a.stride;
+
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  if (D <= 2) launch_entmc_dp<2>(ctx, a);
+  else if (D <= 4) launch_entmc_dp<4>(ctx, a);
+  else if (D <= 6) launch_entmc_dp<6>(ctx, a);
+  else if (D <= 8) launch_entmc_dp<8>(ctx, a);
+  else if (D <= 10) launch_entmc_dp<10>(ctx, a);
+  else if (D <= 12) launch_entmc_dp<12>(ctx, a);
+  else if (D <= 16) launch_entmc_dp<16>(ctx, a);
+  else if (D <= 20) launch_entmc_dp<20>(ctx, a);
+  else if (D <= 24) launch_entmc_dp<24>(ctx, a);
+  else launch_entmc_dp<32>(ctx, a);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  ctx->ev_valid[0] = true;
+  HIP_TRY(ctx, hipGetLastError());
+
+  hipLaunchKernelGGL(entmc_reduce_chunks, dim3(K), dim3(256), 0, ctx->stream, a.partial, a.chunks,
+                     a.stride, perj);
+  hipLaunchKernelGGL(entmc_combine, dim3(1), dim3(256), 0, ctx->stream, perj, ctx->d_mix, ctx->ml,
+                     a.stride, 1.0 / (double)ns_per_comp, want_grad, d_raw);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_entlb(vbmc_ctx* ctx, double* d_res) {
+  const int D = ctx->D, K = ctx->K;
+  size_t lds = sizeof(double) * ((size_t)K + WAVES * D + WAVES);
+  hipLaunchKernelGGL(entlb_kernel, dim3(1), dim3(256), lds, ctx->stream, ctx->d_mix, ctx->ml, 1,
+                     d_res);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,382 @@
+// GP side of the ELBO path on gfx950:
+//   * expected log joint of the mixture under the GP surrogate (Bayesian quadrature),
+//     reference vbmc/variational_optimization.py:1374-1514 (_gp_log_joint);
+//   * its variance: the reference's K(K+1)/2 pairs of triangular solves (:1489-1501)
+//     restructured as ONE product V = Z L^-1 (K x N x N, triangular) + a K x K Gram
+//     matrix, with L^-1 formed once per GP update (the GP is fixed during the
+//     thousands of ELBO evaluations of one variational optimisation);
+//   * GP.predict of gpyreg (third party): K* block, mean,
+//     variance via the same L^-1.
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+
+namespace {
+
+constexpr int WAVES = 4;
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// res[(s*K+k)*(1+2D) + it]: it=0: sum_n z_n alpha_n; 1..D: sum_n delta_nd z_n alpha_n;
+// D+1..2D: sum_n delta_nd^2 z_n alpha_n   with delta_nd = (mu_dk - X_nd)/tau_dk.
+// Optionally stores z (without alpha) to Z[s][k][n] for the variance.
+__global__ __launch_bounds__(256) void gp_log_joint_kernel(
+    const double* __restrict__ mix, MixLayout ml, const double* __restrict__ X,
+    const double* __restrict__ alpha, const double* __restrict__ hyp, int N, int P, int want_grad,
+    double* __restrict__ res, double* __restrict__ Z) {
+  extern __shared__ double lds[];
+  const int D = ml.D, K = ml.K;
+  const int k = blockIdx.x, s = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* sItau = lds;        // [D] 1/tau
+  double* sMu = sItau + D;    // [D]
+  double* sZa = sMu + D;      // [N]
+  double* sMisc = sZa + N;    // [1] lnnf
+  const double* h = hyp + (size_t)s * P;
+  const double sigk = mix[ml.o_sig + k];
+  if (tid < D) {
+    const double ell = exp(h[tid]);
+    const double lam = mix[ml.o_lam + tid];
+    const double tau = sqrt(sigk * sigk * lam * lam + ell * ell);
+    sItau[tid] = 1.0 / tau;
+    sMu[tid] = mix[ml.o_mu + k * D + tid];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double lnnf = 2.0 * h[D];
+    for (int d = 0; d < D; ++d) lnnf += h[d] + log(sItau[d]);
+    sMisc[0] = lnnf;
+  }
+  __syncthreads();
+  const double lnnf = sMisc[0];
+  for (int n = tid; n < N; n += 256) {
+    double d2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const double dl = (sMu[d] - X[(size_t)n * D + d]) * sItau[d];
+      d2 = fma(dl, dl, d2);
+    }
+    const double z = exp(lnnf - 0.5 * d2);
+    sZa[n] = z * alpha[(size_t)s * N + n];
+    if (Z) Z[((size_t)s * K + k) * N + n] = z;
+  }
+  __syncthreads();
+  const int items = want_grad ? 1 + 2 * D : 1;
+  for (int it = wave; it < items; it += WAVES) {
+    double acc = 0.0;
+    if (it == 0) {
+      for (int n = lane; n < N; n += 64) acc += sZa[n];
+    } else {
+      const int d = (it - 1) % D;
+      const bool sq = it > D;
+      for (int n = lane; n < N; n += 64) {
+        const double dl = (sMu[d] - X[(size_t)n * D + d]) * sItau[d];
+        acc = fma(sq ? dl * dl : dl, sZa[n], acc);
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) res[((size_t)s * K + k) * (1 + 2 * D) + it] = acc;
+  }
+}
+
+// Inverse of an upper-triangular matrix, one thread per column (back substitution);
+// run once per vbmc_set_gp.
+__global__ void trinv_upper_kernel(const double* __restrict__ L, int N, double* __restrict__ Li) {
+  const int s = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double* A = L + (size_t)s * N * N;
+  double* B = Li + (size_t)s * N * N;
+  for (int r = N - 1; r > i; --r) B[(size_t)r * N + i] = 0.0;
+  B[(size_t)i * N + i] = 1.0 / A[(size_t)i * N + i];
+  for (int r = i - 1; r >= 0; --r) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int m = r + 1;
+    for (; m + 3 <= i; m += 4) {
+      a0 = fma(A[(size_t)r * N + m], B[(size_t)m * N + i], a0);
+      a1 = fma(A[(size_t)r * N + m + 1], B[(size_t)(m + 1) * N + i], a1);
+      a2 = fma(A[(size_t)r * N + m + 2], B[(size_t)(m + 2) * N + i], a2);
+      a3 = fma(A[(size_t)r * N + m + 3], B[(size_t)(m + 3) * N + i], a3);
+    }
+    for (; m <= i; ++m) a0 = fma(A[(size_t)r * N + m], B[(size_t)m * N + i], a0);
+    B[(size_t)r * N + i] = -((a0 + a1) + (a2 + a3)) / A[(size_t)r * N + r];
+  }
+}
+
+// C[r][c] = sum_{n in range} A[r][n] * B[n][c];  A is R x N (row-major), B is N x N.
+// upper!=0: B is upper triangular, only n <= c contributes.
+// block = 256 threads = 4 waves; lane <-> column c (coalesced B reads), each wave
+// keeps RB rows of A in flight (A values are wave-uniform -> scalar loads).
+constexpr int RB = 8;
+__global__ __launch_bounds__(256) void rows_times_square_kernel(const double* __restrict__ A,
+                                                                const double* __restrict__ B,
+                                                                int R, int N, int upper,
+                                                                double* __restrict__ C) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = (blockIdx.y * WAVES + wave) * RB;
+  const int s = blockIdx.z;
+  A += (size_t)s * R * N;
+  B += (size_t)s * N * N;
+  C += (size_t)s * R * N;
+  if (r0 >= R) return;
+  double acc[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) acc[i] = 0.0;
+  const int cmax = upper ? min(N - 1, blockIdx.x * 64 + 63) : N - 1;
+  const bool cok = c < N;
+  for (int n = 0; n <= cmax; ++n) {
+    const double b = (cok && (!upper || n <= c)) ? B[(size_t)n * N + c] : 0.0;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int r = r0 + i;
+      const double av = (r < R) ? A[(size_t)r * N + n] : 0.0;
+      acc[i] = fma(av, b, acc[i]);
+    }
+  }
+  if (cok)
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+      if (r0 + i < R) C[(size_t)(r0 + i) * N + c] = acc[i];
+}
+
+// Q[s][j][k] = sum_c U[s][j][c] * V[s][k][c]   (one wave per (j,k))
+__global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ U,
+                                                   const double* __restrict__ V, int K, int N,
+                                                   double* __restrict__ Q) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = blockIdx.y;
+  const int pair = blockIdx.x * WAVES + wave;
+  if (pair >= K * K) return;
+  const int j = pair / K, k = pair - j * K;
+  const double* u = U + ((size_t)s * K + j) * N;
+  const double* v = V + ((size_t)s * K + k) * N;
+  double acc = 0.0;
+  for (int c = lane; c < N; c += 64) acc = fma(u[c], v[c], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) Q[((size_t)s * K + j) * K + k] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// predict, stage 1: Ks[m][n] = sf^2 exp(-1/2 sum_d ((X_nd - x*_md)/ell_d)^2) (times
+// sW[n] if scale), and fmu[m] = m(x*_m) + sum_n Ks[m][n] alpha_n.   16 points / block.
+constexpr int TMP = 16;
+__global__ __launch_bounds__(256) void predict_kstar_kernel(
+    const double* __restrict__ X, const double* __restrict__ xs, const double* __restrict__ alpha,
+    const double* __restrict__ sW, const double* __restrict__ hyp, int N, int D, int mean_kind,
+    int64_t M, int scale_sw, double* __restrict__ Ks, double* __restrict__ fmu) {
+  extern __shared__ double lds[];
+  double* sXs = lds;              // [TMP][D]  x* / ell
+  double* sIell = sXs + TMP * D;  // [D]
+  double* sRed = sIell + D;       // [WAVES][TMP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * TMP;
+  if (tid < D) sIell[tid] = exp(-hyp[tid]);
+  __syncthreads();
+  for (int idx = tid; idx < TMP * D; idx += 256) {
+    const int mm = idx / D, d = idx - mm * D;
+    const int64_t m = m0 + mm;
+    sXs[idx] = (m < M) ? xs[m * D + d] * sIell[d] : 0.0;
+  }
+  __syncthreads();
+  const double sf2 = exp(2.0 * hyp[D]);
+  double part[TMP];
+#pragma unroll
+  for (int mm = 0; mm < TMP; ++mm) part[mm] = 0.0;
+  for (int n = tid; n < N; n += 256) {
+    const double an = alpha[n];
+    const double sc = scale_sw ? sW[n] : 1.0;
+#pragma unroll
+    for (int mm = 0; mm < TMP; ++mm) {
+      double d2 = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double t = X[(size_t)n * D + d] * sIell[d] - sXs[mm * D + d];
+        d2 = fma(t, t, d2);
+      }
+      const double kv = sf2 * exp(-0.5 * d2);
+      part[mm] = fma(kv, an, part[mm]);
+      if (m0 + mm < M) Ks[(size_t)(m0 + mm) * N + n] = kv * sc;
+    }
+  }
+#pragma unroll
+  for (int mm = 0; mm < TMP; ++mm) {
+    const double v = wave_sum(part[mm]);
+    if (lane == 0) sRed[wave * TMP + mm] = v;
+  }
+  __syncthreads();
+  if (tid < TMP && m0 + tid < M) {
+    double v = 0.0;
+    for (int wv = 0; wv < WAVES; ++wv) v += sRed[wv * TMP + tid];
+    // mean function at x* (variational_optimization.py:1383-1392 layout)
+    double mean = 0.0;
+    const double* hm = hyp + D + 2;
+    if (mean_kind == VBMC_MEAN_CONST) mean = hm[0];
+    if (mean_kind == VBMC_MEAN_NEGQUAD) {
+      mean = hm[0];
+      for (int d = 0; d < D; ++d) {
+        const double t = (xs[(m0 + tid) * D + d] - hm[1 + d]) * exp(-hm[1 + D + d]);
+        mean -= 0.5 * t * t;
+      }
+    }
+    fmu[m0 + tid] = mean + v;
+  }
+}
+
+// predict, stage 2: tiled GEMM T = A (M x N) * B (N x N) with a fused row epilogue
+//   mode 0 (L_chol): B = L^-1 upper triangular; part[ct][m] = sum_{c in tile} T[m][c]^2
+//   mode 1         : B = L (full, symmetric);   part[ct][m] = sum_{c in tile} A[m][c] T[m][c]
+// 64 x 64 output tile per block, 4 x 4 outputs per thread, 16-deep LDS panels.
+constexpr int TS = 64, TKD = 16;
+__global__ __launch_bounds__(256) void predict_var_gemm_kernel(const double* __restrict__ A,
+                                                               const double* __restrict__ B,
+                                                               int64_t M, int N, int mode,
+                                                               double* __restrict__ part) {
+  __shared__ double sA[TKD][TS + 1];
+  __shared__ double sB[TKD][TS + 1];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;  // tx -> columns, ty -> rows
+  const int64_t m0 = (int64_t)blockIdx.y * TS;
+  const int c0 = blockIdx.x * TS;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  const int nmax = (mode == 0) ? min(N, c0 + TS) : N;  // upper-triangular: n <= c
+  for (int n0 = 0; n0 < nmax; n0 += TKD) {
+    // A panel: 64 rows x 16 cols ; B panel: 16 rows x 64 cols
+    for (int idx = tid; idx < TS * TKD; idx += 256) {
+      const int r = idx / TKD, kk = idx - r * TKD;
+      const int64_t m = m0 + r;
+      const int n = n0 + kk;
+      sA[kk][r] = (m < M && n < N) ? A[(size_t)m * N + n] : 0.0;
+      const int kb = idx / TS, cc = idx - kb * TS;
+      const int nb = n0 + kb, c = c0 + cc;
+      sB[kb][cc] = (nb < N && c < N) ? B[(size_t)nb * N + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TKD; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = sA[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = sB[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  // epilogue: per-row reduction over this tile's 64 columns
+  __shared__ double sRow[TS][17];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + tx * 4 + j;
+      const int64_t m = m0 + ty * 4 + i;
+      if (c < N && m < M) {
+        const double t = acc[i][j];
+        v += (mode == 0) ? t * t : A[(size_t)m * N + c] * t;
+      }
+    }
+    sRow[ty * 4 + i][tx] = v;
+  }
+  __syncthreads();
+  if (tid < TS && m0 + tid < M) {
+    double v = 0.0;
+    for (int j = 0; j < 16; ++j) v += sRow[tid][j];
+    part[(size_t)blockIdx.x * M + m0 + tid] = v;
+  }
+}
+
+__global__ void predict_var_finish_kernel(const double* __restrict__ part, int ntiles, int64_t M,
+                                          double sf2, double sign, double add,
+                                          double* __restrict__ fs2) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double s = 0.0;
+  for (int t = 0; t < ntiles; ++t) s += part[(size_t)t * M + m];
+  fs2[m] = fmax(sf2 + sign * s, 0.0) + add;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+int launch_gp_log_joint(vbmc_ctx* ctx, int want_grad, double* d_res, double* d_Z) {
+  const GpState& g = ctx->gp;
+  const int D = ctx->D, K = ctx->K;
+  size_t lds = sizeof(double) * ((size_t)2 * D + g.N + 1);
+  if (lds > 150 * 1024) return vbmc_fail(ctx, VBMC_E_UNSUP, "gp_log_joint: N=%d too large", g.N);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+  hipLaunchKernelGGL(gp_log_joint_kernel, dim3(K, g.S), dim3(256), lds, ctx->stream, ctx->d_mix,
+                     ctx->ml, g.d_X, g.d_alpha, g.d_hyp, g.N, g.P, want_grad, d_res, d_Z);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+  ctx->ev_valid[1] = true;
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+// Q[s][j][k] = z_j^T (L^T L)^-1 z_k (L_chol)  or  z_j^T L z_k (otherwise), from Z.
+int launch_gp_var(vbmc_ctx* ctx, const double* d_Z, double* d_V, double* d_Q) {
+  const GpState& g = ctx->gp;
+  const int K = ctx->K, N = g.N;
+  bool all_chol = true, none_chol = true;
+  for (int s = 0; s < g.S; ++s) {
+    all_chol = all_chol && g.L_chol[s];
+    none_chol = none_chol && !g.L_chol[s];
+  }
+  dim3 grid((N + 63) / 64, (K + WAVES * RB - 1) / (WAVES * RB), 1);
+  for (int s = 0; s < g.S; ++s) {
+    const int chol = g.L_chol[s];
+    const double* Bm = (chol ? g.d_Linv : g.d_L) + (size_t)s * N * N;
+    hipLaunchKernelGGL(rows_times_square_kernel, grid, dim3(256), 0, ctx->stream,
+                       d_Z + (size_t)s * K * N, Bm, K, N, chol, d_V + (size_t)s * K * N);
+    const double* U = chol ? d_V + (size_t)s * K * N : d_Z + (size_t)s * K * N;
+    hipLaunchKernelGGL(gram_kernel, dim3((K * K + WAVES - 1) / WAVES, 1), dim3(256), 0, ctx->stream,
+                       U, d_V + (size_t)s * K * N, K, N, d_Q + (size_t)s * K * K);
+  }
+  (void)all_chol;
+  (void)none_chol;
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_trinv(vbmc_ctx* ctx) {
+  GpState& g = ctx->gp;
+  hipLaunchKernelGGL(trinv_upper_kernel, dim3((g.N + 63) / 64, g.S), dim3(64), 0, ctx->stream,
+                     g.d_L, g.N, g.d_Linv);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+// One GP sample s, one batch of M points already on the device.
+int launch_gp_predict_sample(vbmc_ctx* ctx, int s, int64_t M, const double* d_xs, double* d_Ks,
+                             double* d_part, int add_noise, double* d_fmu, double* d_fs2) {
+  const GpState& g = ctx->gp;
+  const int N = g.N, D = g.D;
+  const double* h = g.hyp.data() + (size_t)s * g.P;
+  const int chol = g.L_chol[s];
+  size_t lds = sizeof(double) * ((size_t)TMP * D + D + WAVES * TMP);
+  hipLaunchKernelGGL(predict_kstar_kernel, dim3((unsigned)((M + TMP - 1) / TMP)), dim3(256), lds,
+                     ctx->stream, g.d_X, d_xs, g.d_alpha + (size_t)s * N, g.d_sW + (size_t)s * N,
+                     g.d_hyp + (size_t)s * g.P, N, D, g.mean_kind, M, chol, d_Ks, d_fmu);
+  const int ntiles = (N + TS - 1) / TS;
+  const double* Bm = (chol ? g.d_Linv : g.d_L) + (size_t)s * N * N;
+  hipLaunchKernelGGL(predict_var_gemm_kernel, dim3(ntiles, (unsigned)((M + TS - 1) / TS)), dim3(256),
+                     0, ctx->stream, d_Ks, Bm, M, N, chol ? 0 : 1, d_part);
+  const double sf2 = std::exp(2.0 * h[D]);
+  const double add = add_noise ? std::exp(2.0 * h[D + 1]) * g.sn2_mult[s] : 0.0;
+  hipLaunchKernelGGL(predict_var_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
+                     ctx->stream, d_part, ntiles, M, sf2, chol ? -1.0 : 1.0, add, d_fs2);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}

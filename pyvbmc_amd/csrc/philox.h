@@ -1,0 +1,54 @@
+// Counter-based standard-normal generator used by the entropy kernels in
+// VBMC_EPS_PHILOX mode.  Philox4x32-10 (Salmon et al., SC'11) + Box-Muller in
+// float64.  oracle/philox_ref.py restates this bit-for-bit on the integer side so
+// the parity tests can evaluate the oracle on identical draws.
+//
+//   counter = (row_lo, row_hi, pair, 0)   key = (seed_lo, seed_hi)
+//   row   = global antithetic-pair row index  j * n_half + i
+//   pair  = d / 2  (one Philox call yields the normals of dimensions 2p, 2p+1)
+//   u1 = (((x0<<32 | x1) >> 11) + 1) * 2^-53   in (0,1]
+//   u2 =  ((x2<<32 | x3) >> 11)      * 2^-53   in [0,1)
+//   z0 = sqrt(-2 ln u1) cos(2 pi u2),  z1 = sqrt(-2 ln u1) sin(2 pi u2)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+struct Philox4 {
+  uint32_t x[4];
+};
+
+__host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
+                                                 uint32_t c3, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)M0 * c0;
+    uint64_t p1 = (uint64_t)M1 * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0;
+    k1 += W1;
+  }
+  Philox4 o;
+  o.x[0] = c0; o.x[1] = c1; o.x[2] = c2; o.x[3] = c3;
+  return o;
+}
+
+__device__ inline void philox_normal_pair(uint64_t row, uint32_t pair, uint64_t seed,
+                                          double& z0, double& z1) {
+  Philox4 r = philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), pair, 0u, (uint32_t)seed,
+                            (uint32_t)(seed >> 32));
+  uint64_t a = (((uint64_t)r.x[0] << 32) | r.x[1]) >> 11;
+  uint64_t b = (((uint64_t)r.x[2] << 32) | r.x[3]) >> 11;
+  double u1 = (double)(a + 1) * 0x1.0p-53;
+  double u2 = (double)b * 0x1.0p-53;
+  double rad = sqrt(-2.0 * log(u1));
+  double s, c;
+  sincospi(2.0 * u2, &s, &c);
+  z0 = rad * c;
+  z1 = rad * s;
+}

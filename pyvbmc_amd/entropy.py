@@ -1,0 +1,95 @@
+"""``entmc_vbmc`` / ``entlb_vbmc`` -- the reference's entropy estimators on the MI355X.
+
+Same call signatures and return values as
+/root/reference/pyvbmc/entropy/entmc_vbmc.py:6-134 and entlb_vbmc.py:6-180:
+``(H: float, dH: ndarray)`` with ``dH = [mu 'F' | sigma | lambda | w]`` holding only
+the enabled blocks.  All arithmetic runs in HIP kernels (vbmc_entmc / vbmc_entlb);
+there is no NumPy fallback.
+
+Random draws of ``entmc_vbmc``.  The reference consumes NumPy's global legacy
+stream: for every component j ascending, ``np.random.randn(Ns//2, D)``
+(entmc_vbmc.py:64-68).  ``rng="numpy"`` (default) does exactly that on the host and
+ships the draws to HBM, so a seeded call returns the reference's value to
+rounding.  ``rng="philox"`` generates the draws inside the kernel (Philox4x32-10 +
+Box-Muller) from a 64-bit seed taken from ``np.random`` (one ``randint`` call, so
+runs stay reproducible under ``np.random.seed``): statistically equivalent, not
+stream-identical, and removes the host RNG + PCIe cost.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+DEFAULT_RNG = os.environ.get("VBMC_HIP_RNG", "numpy")
+
+
+def _even_ns(Ns):
+    """The reference rounds Ns up to even (entmc_vbmc.py:61)."""
+    return int(np.ceil(Ns / 2)) * 2
+
+
+def draw_eps_half(K, D, Ns):
+    h = _even_ns(Ns) // 2
+    eps = np.empty((K, h, D))
+    for j in range(K):
+        eps[j] = np.random.randn(h, D)
+    return eps
+
+
+def _n_grad(vp, bits):
+    D, K = vp.D, vp.K
+    return D * K * bool(bits & 1) + K * bool(bits & 2) + D * bool(bits & 4) + K * bool(bits & 8)
+
+
+def entmc_vbmc(vp, Ns, grad_flags=tuple([True] * 4), jacobian_flag=True, *, rng=None, seed=None,
+               eps_half=None, ctx=None, return_raw=False):
+    """Monte-Carlo entropy of the variational posterior and its gradient."""
+    ctx = vp.ctx if ctx is None else ctx
+    vp._upload(ctx)
+    D, K = vp.D, vp.K
+    ns = _even_ns(Ns)
+    h = ns // 2
+    rng = DEFAULT_RNG if rng is None else rng
+    # this context's share of the antithetic-pair rows (all of them on one GPU)
+    r0 = h * ctx.rank // ctx.world
+    r1 = h * (ctx.rank + 1) // ctx.world
+    if eps_half is not None or rng == "numpy":
+        if eps_half is None:
+            eps_half = draw_eps_half(K, D, ns)
+        eps_half = np.ascontiguousarray(eps_half, dtype=np.float64)
+        if eps_half.shape != (K, h, D):
+            raise ValueError(f"eps_half must have shape {(K, h, D)}, got {eps_half.shape}")
+        ctx.set_eps(eps_half, r0, r1 - r0)
+        mode, seed = _lib.EPS_RESIDENT, 0
+    elif rng == "philox":
+        if seed is None:
+            seed = int(np.random.randint(0, 2**63 - 1, dtype=np.int64))
+        mode = _lib.EPS_PHILOX
+    else:
+        raise ValueError(f"unknown rng {rng!r}")
+    bits = _lib.flags_to_bits(grad_flags)
+    H = C.c_double()
+    dH = np.empty(_n_grad(vp, bits))
+    raw = np.empty(1 + D * K + 2 * K + D) if return_raw else None
+    ctx.check(
+        ctx._lib.vbmc_entmc(
+            ctx._h, ns, mode, C.c_uint64(seed), r0, r1 - r0, bits, int(bool(jacobian_flag)),
+            C.byref(H), _lib.ptr(dH), _lib.ptr(raw),
+        )
+    )
+    if return_raw:
+        return H.value, dH, raw
+    return H.value, dH
+
+
+def entlb_vbmc(vp, grad_flags=tuple([True] * 4), jacobian_flag=True, *, ctx=None):
+    """Entropy lower bound (Jensen) of the variational posterior and its gradient."""
+    ctx = vp.ctx if ctx is None else ctx
+    vp._upload(ctx)
+    bits = _lib.flags_to_bits(grad_flags)
+    H = C.c_double()
+    dH = np.empty(_n_grad(vp, bits))
+    ctx.check(ctx._lib.vbmc_entlb(ctx._h, bits, int(bool(jacobian_flag)), C.byref(H), _lib.ptr(dH)))
+    return H.value, dH

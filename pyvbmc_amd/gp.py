@@ -1,0 +1,222 @@
+"""GP container for the ELBO path: the subset of ``gpyreg.GP`` PyVBMC touches on it.
+
+gpyreg is a third-party dependency of the reference that is not part of its tree
+(`gpyreg >= 0.1.0`, /root/reference/pyproject.toml:13).  What PyVBMC needs from it
+on this path is (a) the posterior record per hyper-parameter
+sample -- ``posteriors[s].{hyp, alpha, sW, L, sn2_mult, L_chol}`` -- and (b)
+``predict``.  This module provides a duck-type with the same attribute/method
+names so the hot-path functions accept either it or a real ``gpyreg.GP``:
+
+* ``update(X_new, y_new, s2_new, hyp)`` builds the posterior records on the host.
+  That is the O(N^3) Cholesky done ONCE per GP fit -- an input of the path
+  (SURVEY 8a row a11), not part of it; hyper-parameter fitting itself (slice
+  sampling) is out of scope.
+* ``predict`` runs on the MI355X (vbmc_gp_predict).
+"""
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+import scipy.linalg as sla
+
+from . import _lib
+
+
+class SquaredExponential:
+    """SE-ARD: k(a,b) = sf^2 exp(-1/2 sum_d ((a_d-b_d)/ell_d)^2); hyp = [log ell (D), log sf]."""
+
+    def hyperparameter_count(self, D):
+        return D + 1
+
+    def compute(self, hyp, X, X_star=None):
+        X = np.atleast_2d(X)
+        Xs = X if X_star is None else np.atleast_2d(X_star)
+        D = X.shape[1]
+        ell = np.exp(hyp[:D])
+        d2 = np.zeros((X.shape[0], Xs.shape[0]))
+        for d in range(D):
+            d2 += ((X[:, d] / ell[d])[:, None] - (Xs[:, d] / ell[d])[None, :]) ** 2
+        return np.exp(2 * hyp[D]) * np.exp(-0.5 * d2)
+
+
+class ZeroMean:
+    kind = _lib.MEAN_ZERO
+
+    def hyperparameter_count(self, D):
+        return 0
+
+    def compute(self, hyp, X):
+        return np.zeros(X.shape[0])
+
+
+class ConstantMean:
+    kind = _lib.MEAN_CONST
+
+    def hyperparameter_count(self, D):
+        return 1
+
+    def compute(self, hyp, X):
+        return np.full(X.shape[0], hyp[0])
+
+
+class NegativeQuadratic:
+    """m(x) = m0 - 1/2 sum_d ((x_d - xm_d)/omega_d)^2; hyp = [m0, xm (D), log omega (D)]
+    (layout used at variational_optimization.py:1383-1392)."""
+
+    kind = _lib.MEAN_NEGQUAD
+
+    def hyperparameter_count(self, D):
+        return 1 + 2 * D
+
+    def compute(self, hyp, X):
+        D = X.shape[1]
+        return hyp[0] - 0.5 * np.sum(((X - hyp[1 : 1 + D]) / np.exp(hyp[1 + D : 1 + 2 * D])) ** 2, 1)
+
+
+class GaussianNoise:
+    def __init__(self, constant_add=False, user_provided_add=False, scale_user_provided=False,
+                 rectified_linear_output_dependent_add=False):
+        if scale_user_provided or rectified_linear_output_dependent_add:
+            raise NotImplementedError("only constant and user-provided additive noise are supported")
+        self.constant_add = constant_add
+        self.user_provided_add = user_provided_add
+
+    def hyperparameter_count(self):
+        return 1
+
+    def compute(self, hyp, X, y=None, s2=None):
+        sn2 = np.full((X.shape[0], 1), np.exp(2 * hyp[0]) if self.constant_add else np.spacing(1.0))
+        if self.user_provided_add and s2 is not None:
+            sn2 = sn2 + np.reshape(s2, (-1, 1))
+        return sn2
+
+
+_MEAN_KINDS = {"ZeroMean": _lib.MEAN_ZERO, "ConstantMean": _lib.MEAN_CONST,
+               "NegativeQuadratic": _lib.MEAN_NEGQUAD}
+
+
+def mean_kind_of(gp):
+    """Mean-function kind of a GP duck type (ours or a real gpyreg.GP), by class name."""
+    name = type(gp.mean).__name__
+    if name not in _MEAN_KINDS:
+        raise NotImplementedError(f"mean function {name} is not supported on the ELBO path")
+    return _MEAN_KINDS[name]
+
+
+def upload_gp(gp, ctx):
+    """Ship X and the posterior records of ``gp`` to the context (cached per GP state)."""
+    key = (id(gp.posteriors), id(gp.X), len(gp.posteriors))
+    if getattr(ctx, "_gp_key", None) == key and getattr(ctx, "_gp_ref", None) is gp.posteriors:
+        return
+    X = _lib.f64(gp.X)
+    N, D = X.shape
+    posts = list(gp.posteriors)
+    S = len(posts)
+    hyp = _lib.f64(np.stack([np.ravel(p.hyp) for p in posts]))
+    alpha = _lib.f64(np.stack([np.ravel(p.alpha) for p in posts]))
+    L = _lib.f64(np.stack([np.asarray(p.L) for p in posts]))
+    sW = _lib.f64(np.stack([np.ravel(p.sW) * np.ones(N) for p in posts]))
+    chol = np.ascontiguousarray([1 if p.L_chol else 0 for p in posts], dtype=np.int32)
+    mult = _lib.f64([float(getattr(p, "sn2_mult", 1.0)) for p in posts])
+    ctx.check(
+        ctx._lib.vbmc_set_gp(
+            ctx._h, N, D, S, hyp.shape[1], mean_kind_of(gp), _lib.ptr(X), _lib.ptr(hyp),
+            _lib.ptr(alpha), _lib.ptr(L), chol.ctypes.data_as(C.POINTER(C.c_int32)), _lib.ptr(sW),
+            _lib.ptr(mult),
+        )
+    )
+    ctx._gp_key, ctx._gp_ref = key, gp.posteriors
+
+
+class GP:
+    def __init__(self, D, covariance, mean, noise):
+        if not isinstance(covariance, SquaredExponential):
+            raise NotImplementedError("only the squared-exponential ARD kernel is on the ELBO path")
+        self.D = D
+        self.covariance = covariance
+        self.mean = mean
+        self.noise = noise
+        self.X = None
+        self.y = None
+        self.s2 = None
+        self.posteriors = None
+        self.temporary_data = {}
+        self._ctx = None
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = _lib.default_context()
+        return self._ctx
+
+    @ctx.setter
+    def ctx(self, v):
+        self._ctx = v
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_ctx"] = None
+        return st
+
+    def _posterior(self, hyp):
+        """alpha, L, sW for one hyper-parameter vector (SURVEY Appendix A 'Posterior')."""
+        X, y = self.X, self.y
+        N, D = X.shape
+        cov_n = self.covariance.hyperparameter_count(D)
+        noise_n = self.noise.hyperparameter_count()
+        Kxx = self.covariance.compute(hyp[:cov_n], X)
+        m = self.mean.compute(hyp[cov_n + noise_n :], X)
+        sn2 = self.noise.compute(hyp[cov_n : cov_n + noise_n], X, y, self.s2).ravel()
+        sn2_div = np.min(sn2)
+        sn2_mult = 1.0
+        resid = y.ravel() - m
+        if sn2_div * sn2_mult >= 1e-6:
+            sl = sn2_div * sn2_mult
+            L = sla.cholesky(Kxx / sl + np.diag(sn2 / sn2_div), lower=False)
+            alpha = sla.cho_solve((L, False), resid) / sl
+            L_chol = True
+        else:
+            L_chol = False
+            L = -np.linalg.inv(Kxx + sn2_mult * np.diag(sn2))
+            alpha = -L @ resid
+        return SimpleNamespace(
+            hyp=np.array(hyp, dtype=np.float64), alpha=alpha.reshape(-1, 1),
+            sW=np.ones(N) / np.sqrt(sn2_div * sn2_mult), L=L, sn2_mult=sn2_mult, L_chol=L_chol,
+        )
+
+    def update(self, X_new=None, y_new=None, s2_new=None, hyp=None, compute_posterior=True):
+        if X_new is not None:
+            self.X = np.atleast_2d(np.asarray(X_new, dtype=np.float64))
+            self.y = np.asarray(y_new, dtype=np.float64).reshape(-1, 1)
+            self.s2 = None if s2_new is None else np.asarray(s2_new, dtype=np.float64).reshape(-1, 1)
+        if hyp is None:
+            hyp = np.stack([p.hyp for p in self.posteriors])
+        hyp = np.atleast_2d(np.asarray(hyp, dtype=np.float64))
+        posts = np.empty(hyp.shape[0], dtype=object)
+        for i, h in enumerate(hyp):
+            posts[i] = self._posterior(h)
+        self.posteriors = posts
+
+    def get_hyperparameters(self, as_array=True):
+        return np.stack([p.hyp for p in self.posteriors])
+
+    def predict(self, x_star, y_star=None, s2_star=0, add_noise=False, separate_samples=False, *,
+                ctx=None):
+        """Posterior predictive mean/variance at ``x_star`` (M, D) on the MI355X.
+        Returns (M, S) arrays when ``separate_samples`` else (M, 1)."""
+        if self.noise.user_provided_add and add_noise and np.any(np.asarray(s2_star) != 0):
+            raise NotImplementedError("add_noise with user-provided s2_star is not supported")
+        ctx = self.ctx if ctx is None else ctx
+        upload_gp(self, ctx)
+        xs = _lib.f64(np.atleast_2d(x_star))
+        M = xs.shape[0]
+        S = len(self.posteriors)
+        shape = (M, S) if separate_samples else (M, 1)
+        fmu, fs2 = np.empty(shape), np.empty(shape)
+        ctx.check(
+            ctx._lib.vbmc_gp_predict(
+                ctx._h, M, _lib.ptr(xs), int(bool(add_noise)), int(bool(separate_samples)),
+                _lib.ptr(fmu), _lib.ptr(fs2),
+            )
+        )
+        return fmu, fs2

@@ -1,0 +1,282 @@
+"""The ELBO objective on the MI355X: ``_gp_log_joint``, ``_neg_elcbo`` and the
+soft-bound losses, with the reference's signatures and return conventions.
+
+Mirrors /root/reference/pyvbmc/vbmc/variational_optimization.py:
+``_soft_bound_loss`` (:609-657), ``_vp_bound_loss`` (:503-606),
+``_neg_elcbo`` (:991-1235), ``_gp_log_joint`` (:1238-1606).  The optimiser loop
+that calls them (``optimize_vp``, ``_sieve``, ``minimize_adam``) is the next row
+of SURVEY.md section 8f and is not part of this module.
+
+All ELBO arithmetic happens behind the C ABI; ``_neg_elcbo`` without
+``separate_K`` is ONE library call (vbmc_neg_elcbo: theta -> mixture, G/dG
+kernel, entropy kernels, optional all-reduce, bound losses) with a single
+device round trip.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .entropy import DEFAULT_RNG, _even_ns, draw_eps_half, entlb_vbmc, entmc_vbmc
+from .gp import upload_gp
+
+
+def _soft_bound_loss(x, slb, sub, tol_con=1e-3, compute_grad=False):
+    """Quadratic penalty outside the soft bounds (host; O(len(x)), not a kernel)."""
+    x = np.asarray(x, dtype=np.float64)
+    ell = (sub - slb) * tol_con
+    below = x < slb
+    above = x > sub
+    y = 0.0
+    dy = np.zeros(x.shape)
+    if np.any(below):
+        y += 0.5 * np.sum(((slb[below] - x[below]) / ell[below]) ** 2)
+        dy[below] = (x[below] - slb[below]) / ell[below] ** 2
+    if np.any(above):
+        y += 0.5 * np.sum(((x[above] - sub[above]) / ell[above]) ** 2)
+        dy[above] = (x[above] - sub[above]) / ell[above] ** 2
+    return (y, dy) if compute_grad else y
+
+
+def _vp_bound_loss(vp, theta, theta_bnd, tol_con=1e-3, compute_grad=True):
+    """Soft-bound loss on (mu, ln sigma*lambda, eta) and its gradient wrt theta (host)."""
+    D, K = vp.D, vp.K
+    pos = 0
+    if vp.optimize_mu:
+        mu = theta[: D * K]
+        pos = D * K
+    else:
+        mu = vp.mu.ravel(order="F")
+    if vp.optimize_sigma:
+        ln_sigma = theta[pos : pos + K]
+        pos += K
+    else:
+        ln_sigma = np.log(vp.sigma.ravel())
+    ln_lambd = theta[pos : pos + D] if vp.optimize_lambd else np.log(vp.lambd.ravel())
+    ln_scale = np.reshape(ln_lambd, (-1, 1)) + np.reshape(ln_sigma, (1, -1))
+    parts = []
+    if vp.optimize_mu:
+        parts.append(np.ravel(mu))
+    if vp.optimize_sigma or vp.optimize_lambd:
+        parts.append(ln_scale.ravel(order="F"))
+    if vp.optimize_weights:
+        parts.append(np.ravel(theta[-K:]))
+    ext = np.concatenate(parts)
+    lb, ub = theta_bnd["lb"].ravel(), theta_bnd["ub"].ravel()
+    if not compute_grad:
+        return _soft_bound_loss(ext, lb, ub, tol_con)
+    L, dL = _soft_bound_loss(ext, lb, ub, tol_con, compute_grad=True)
+    out = []
+    pos = 0
+    if vp.optimize_mu:
+        out.append(dL[: D * K])
+        pos = D * K
+    if vp.optimize_sigma or vp.optimize_lambd:
+        block = np.reshape(dL[pos : pos + D * K], (D, K))  # C-order, as the reference (:585-587)
+        if vp.optimize_sigma:
+            out.append(block.sum(axis=0))
+        if vp.optimize_lambd:
+            out.append(block.sum(axis=1))
+    if vp.optimize_weights:
+        out.append(dL[-K:])
+    return L, np.concatenate(out)
+
+
+def _gp_log_joint(vp, gp, grad_flags, avg_flag=True, jacobian_flag=True, compute_var=False,
+                  separate_K=False, *, ctx=None):
+    """Expected variational log joint under the GP surrogate.
+
+    Returns ``(G, dG, varG, dvarG, var_ss)`` or, with ``separate_K``,
+    ``(G, dG, varG, dvarG, var_ss, I_sk, J_sjk)`` exactly like the reference
+    (shapes: S==1 squeezes G/dG, varG stays an array, :1599-1602).
+    """
+    if np.isscalar(grad_flags):
+        grad_flags = (bool(grad_flags),) * 4
+    bits = _lib.flags_to_bits(grad_flags)
+    ctx = vp.ctx if ctx is None else ctx
+    vp._upload(ctx)
+    upload_gp(gp, ctx)
+    D, K, S = vp.D, vp.K, len(gp.posteriors)
+    jac = bool(jacobian_flag)
+    n_dG = (D * K * bool(bits & 1) + jac * (K * bool(bits & 2) + D * bool(bits & 4) + K * bool(bits & 8)))
+    averaged = S > 1 and avg_flag
+    G = np.empty(S)
+    dG = np.empty((n_dG, S)) if bits else None
+    varG = np.empty(S) if compute_var else None
+    var_ss = C.c_double(0.0)
+    I_sk = np.empty((S, K)) if separate_K else None
+    J_sjk = np.empty((S, K, K)) if (separate_K and compute_var) else None
+    ctx.check(
+        ctx._lib.vbmc_gp_log_joint(
+            ctx._h, bits, int(bool(avg_flag)), int(jac), int(compute_var), _lib.ptr(G),
+            _lib.ptr(dG), _lib.ptr(varG), C.byref(var_ss), _lib.ptr(I_sk), _lib.ptr(J_sjk),
+        )
+    )
+    if averaged:
+        G_out = G[0]
+        dG_out = dG.ravel()[:n_dG].copy() if bits else None
+        varG_out = varG[0] if compute_var else None
+    else:
+        G_out = G[0] if S == 1 else G
+        dG_out = (dG[:, 0].copy() if S == 1 else dG) if bits else None
+        varG_out = varG if compute_var else None
+    vss = var_ss.value if (averaged and compute_var) else 0
+    if separate_K:
+        return G_out, dG_out, varG_out, None, vss, I_sk, J_sjk
+    return G_out, dG_out, varG_out, None, vss
+
+
+def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=None, theta_bnd=None,
+               _entropy_alpha=0.0, separate_K=False, *, rng=None, seed=None, eps_half=None, ctx=None):
+    """Negative evidence lower (confidence) bound and its gradient.
+
+    Same positional signature, mutation of ``vp`` (and of the caller's ``theta``
+    eta tail, :1082-1085) and return arity as the reference: ``(F, dF, G, H, varF)``
+    or the 11-tuple when ``separate_K``.  Keyword-only extras select the source of
+    the Monte-Carlo draws (see pyvbmc_amd.entropy).
+    """
+    if not np.isfinite(beta):
+        beta = 0
+    if compute_var is None:
+        compute_var = beta != 0
+    if compute_grad and beta != 0 and compute_var != 2:
+        raise NotImplementedError(
+            "Computation of the gradient of ELBO with full variance not supported"
+        )
+    if separate_K and compute_grad:
+        raise ValueError(
+            "Computing the gradient of variational parameters and "
+            "requesting per-component results at the same time."
+        )
+    ctx = vp.ctx if ctx is None else ctx
+    K, D = vp.K, vp.D
+
+    if separate_K or compute_var or beta != 0:
+        return _neg_elcbo_composed(theta, gp, vp, beta, Ns, compute_grad, compute_var, theta_bnd,
+                                   separate_K, rng, seed, eps_half, ctx)
+
+    # ---- fused path: one library call ---------------------------------------------------
+    theta_in = theta
+    th = np.ascontiguousarray(theta, dtype=np.float64)
+    vp._upload(ctx)  # establishes (D, K) and the values of non-optimised blocks
+    upload_gp(gp, ctx)
+    opts = _lib.ElboOpts()
+    ns = _even_ns(Ns) if Ns > 0 else 0
+    opts.ns_per_comp = ns
+    opts.compute_grad = int(bool(compute_grad))
+    opts.optimize_mask = vp.optimize_mask()
+    opts.row_begin, opts.row_count = 0, -1
+    opts.seed = 0
+    keep = []
+    if ns > 0:
+        mode = DEFAULT_RNG if rng is None else rng
+        h = ns // 2
+        if eps_half is not None or mode == "numpy":
+            if eps_half is None:
+                eps_half = draw_eps_half(K, D, ns)
+            r0 = h * ctx.rank // ctx.world
+            r1 = h * (ctx.rank + 1) // ctx.world
+            ctx.set_eps(np.ascontiguousarray(eps_half, dtype=np.float64), r0, r1 - r0)
+            opts.eps_mode = _lib.EPS_RESIDENT
+        elif mode == "philox":
+            if seed is None:
+                seed = int(np.random.randint(0, 2**63 - 1, dtype=np.int64))
+            opts.eps_mode, opts.seed = _lib.EPS_PHILOX, seed
+        else:
+            raise ValueError(f"unknown rng {mode!r}")
+    if theta_bnd is not None:
+        lb, ub = _lib.f64(theta_bnd["lb"].ravel()), _lib.f64(theta_bnd["ub"].ravel())
+        keep += [lb, ub]
+        opts.bnd_lb, opts.bnd_ub, opts.n_bnd = _lib.ptr(lb), _lib.ptr(ub), lb.size
+        opts.tol_con = float(theta_bnd["tol_con"])
+        opts.weight_threshold = float(theta_bnd.get("weight_threshold", 0.0))
+        opts.weight_penalty = float(theta_bnd.get("weight_penalty", 0.0))
+    F, G, H = C.c_double(), C.c_double(), C.c_double()
+    dF = np.empty(th.size) if compute_grad else None
+    mu = np.empty((K, D))
+    sg, lm, w, eta = np.empty(K), np.empty(D), np.empty(K), np.empty(K)
+    ctx.check(
+        ctx._lib.vbmc_neg_elcbo(
+            ctx._h, _lib.ptr(th), th.size, C.byref(opts), C.byref(F), _lib.ptr(dF), C.byref(G),
+            C.byref(H), _lib.ptr(mu), _lib.ptr(sg), _lib.ptr(lm), _lib.ptr(w), _lib.ptr(eta),
+        )
+    )
+    # mirror the reference's side effects on vp and on the caller's theta
+    vp.mu = mu.T.copy()
+    vp.sigma = sg.reshape(1, -1)
+    vp.lambd = lm.reshape(-1, 1)
+    vp.w = w.reshape(1, -1)
+    if vp.optimize_weights:
+        vp.eta = eta.reshape(1, -1)
+        if isinstance(theta_in, np.ndarray) and theta_in.dtype == np.float64:
+            theta_in[-K:] = th[-K:]
+    vp._mode = None
+    return F.value, dF, G.value, H.value, 0
+
+
+def _neg_elcbo_composed(theta, gp, vp, beta, Ns, compute_grad, compute_var, theta_bnd, separate_K,
+                        rng, seed, eps_half, ctx):
+    """Variance / per-component variants (used by ``_eval_full_elcbo``, not by the
+    optimiser's inner loop): composed from the individual device calls, following
+    the reference's control flow (:1080-1235)."""
+    K = vp.K
+    vp.set_parameters(theta)
+    if vp.optimize_weights:
+        # in-place on the caller's array, like the reference's view arithmetic
+        tail = theta[-K:]
+        tail -= np.amax(tail)
+        vp.eta = np.reshape(tail, (1, -1))
+    if compute_grad:
+        grad_flags = (vp.optimize_mu, vp.optimize_sigma, vp.optimize_lambd, vp.optimize_weights)
+    else:
+        grad_flags = (False,) * 4
+    I_sk = J_sjk = None
+    dG = dvarG = None
+    if separate_K:
+        if compute_var:
+            G, _, varG, _, varG_ss, I_sk, J_sjk = _gp_log_joint(vp, gp, grad_flags, 1, 1, compute_var, True, ctx=ctx)
+        else:
+            G, dG, _, _, _, I_sk, _ = _gp_log_joint(vp, gp, grad_flags, 1, 1, 0, True, ctx=ctx)
+            varG = varG_ss = 0
+    elif compute_var:
+        G, dG, varG, dvarG, varG_ss = _gp_log_joint(vp, gp, grad_flags, 1, 1, compute_var, ctx=ctx)
+    else:
+        G, dG, _, _, _ = _gp_log_joint(vp, gp, grad_flags, 1, 1, 0, ctx=ctx)
+        varG = varG_ss = 0
+    if Ns > 0:
+        H, dH = entmc_vbmc(vp, Ns, grad_flags, 1, rng=rng, seed=seed, eps_half=eps_half, ctx=ctx)
+    else:
+        H, dH = entlb_vbmc(vp, grad_flags, 1, ctx=ctx)
+    F = -G - H
+    if compute_grad:
+        dF = -dG - dH
+    else:
+        dF = None
+        dH = None
+    varH = 0
+    varF = varG + varH if compute_var else 0
+    if beta != 0:
+        F = F + beta * np.sqrt(varF)
+        if compute_grad:
+            dF = dF + 0.5 * beta * dvarG / np.sqrt(varF)
+    if theta_bnd is not None:
+        if compute_grad:
+            L, dL = _vp_bound_loss(vp, theta, theta_bnd, tol_con=theta_bnd["tol_con"])
+            dF = dF + dL
+        else:
+            L = _vp_bound_loss(vp, theta, theta_bnd, tol_con=theta_bnd["tol_con"], compute_grad=False)
+        F = F + L
+        if vp.optimize_weights:
+            thresh = theta_bnd["weight_threshold"]
+            small = vp.w < thresh
+            F = F + np.sum(vp.w * small + thresh * (~small)) * theta_bnd["weight_penalty"]
+            if compute_grad:
+                ee = np.exp(vp.eta.ravel())
+                es = ee.sum()
+                wg = theta_bnd["weight_penalty"] * small.ravel()
+                dL = np.zeros(dF.shape)
+                dL[-K:] = -ee * (ee @ wg) / es**2 + ee * wg / es
+                dF = dF + dL
+    if separate_K:
+        return F, dF, G, H, varF, dH, varG_ss, varG, varH, I_sk, J_sjk
+    return F, dF, G, H, varF

@@ -1,0 +1,431 @@
+"""GPU parity: the HIP path (through the C ABI) vs the reference's outputs (golden
+fixtures) and vs the oracle on the same seeded inputs.  Run with ``-m gpu``.
+
+Tolerances (BASELINE.json north_star): 1e-6 relative on ELBO / entropy, 1e-10 on
+GP predictive mean / variance.  The assertions below are tighter where the
+arithmetic allows (documented per test).
+"""
+import itertools
+
+import numpy as np
+import pytest
+from conftest import CASES
+from helpers import oracle_gp, oracle_mix, rel_err
+
+from oracle import elbo_ref, entropy_ref, gp_ref, mixture_ref, philox_ref
+from pyvbmc_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+TOL_ELBO = 1e-6  # the contract
+TIGHT = 1e-10  # what float64 kernels should actually achieve on these sizes
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pyvbmc_amd import _lib
+
+    c = _lib.Context(0)
+    _lib.set_default_context(c)
+    yield c
+    _lib.set_default_context(None)
+    c.close()
+
+
+def make_vp(g, ctx):
+    from pyvbmc_amd import VariationalPosterior
+
+    vp = VariationalPosterior(int(g["D"]), int(g["K"]))
+    vp.mu = g["mu"].copy()
+    vp.sigma = g["sigma"].reshape(1, -1).copy()
+    vp.lambd = g["lambd"].reshape(-1, 1).copy()
+    vp.w = g["w"].reshape(1, -1).copy()
+    vp.eta = g["eta"].reshape(1, -1).copy()
+    vp.ctx = ctx
+    return vp
+
+
+def make_gp(g, ctx, hyp=None):
+    from pyvbmc_amd import gp as gpm
+
+    s2 = g["s2"] if g["s2"].size else None
+    gp = gpm.GP(
+        int(g["D"]), gpm.SquaredExponential(), gpm.NegativeQuadratic(),
+        gpm.GaussianNoise(constant_add=True, user_provided_add=s2 is not None),
+    )
+    gp.ctx = ctx
+    gp.update(X_new=g["X"], y_new=g["y"], s2_new=s2, hyp=g["hyp"] if hyp is None else hyp)
+    return gp
+
+
+def fl(f):
+    return "".join("1" if b else "0" for b in f)
+
+
+def test_device_is_gfx950(ctx):
+    info = ctx.device_info()
+    assert "gfx950" in info["name"], info
+    assert info["cu_count"] >= 200
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_entmc_vs_reference(ctx, golden, name):
+    """Seeded NumPy draws (the reference's stream) -> reference values."""
+    from pyvbmc_amd import entmc_vbmc
+
+    g = golden(name)
+    NsK, seed = int(g["NsK"]), int(g["seed"])
+    combos = list(itertools.product([False, True], repeat=4)) if name == "c1" else [(False,) * 4, (True,) * 4]
+    for gf in combos:
+        for jac in (True, False):
+            np.random.seed(seed)
+            H, dH = entmc_vbmc(make_vp(g, ctx), NsK, gf, jac)
+            Href = g[f"entmc_H_{fl(gf)}_{int(jac)}"]
+            dref = g[f"entmc_dH_{fl(gf)}_{int(jac)}"]
+            assert abs(H - Href) <= TIGHT * abs(Href), (name, gf, jac, H, Href)
+            assert dH.shape == dref.shape
+            if dref.size:
+                assert rel_err(dH, dref) < 1e-9, (name, gf, jac, rel_err(dH, dref))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_entmc_philox_vs_oracle(ctx, golden, name):
+    """Device RNG mode: the oracle evaluated on the restated Philox draws."""
+    from pyvbmc_amd import entmc_vbmc
+
+    g = golden(name)
+    K, D, NsK = int(g["K"]), int(g["D"]), int(g["NsK"])
+    seed = 0x1234ABCD5678 + int(g["cfg"])
+    H, dH = entmc_vbmc(make_vp(g, ctx), NsK, (True,) * 4, True, rng="philox", seed=seed)
+    eps = philox_ref.eps_half(K, NsK // 2, D, seed)
+    Ho, dHo = entropy_ref.entmc(oracle_mix(g), NsK, (True,) * 4, True, eps_half=eps)
+    assert abs(H - Ho) <= 1e-9 * abs(Ho)
+    assert rel_err(dH, dHo) < 1e-8
+    # a different seed gives a different (but statistically close) estimate
+    H2, _ = entmc_vbmc(make_vp(g, ctx), NsK, (False,) * 4, True, rng="philox", seed=seed + 1)
+    assert H2 != H and abs(H2 - H) < 0.5 * max(1.0, abs(H))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_entmc_sharded_rows_add_up(ctx, golden, name):
+    """Row shards are additive in the raw accumulator (what the all-reduce sums)."""
+    from pyvbmc_amd import _lib
+
+    g = golden(name)
+    K, D, NsK, seed = int(g["K"]), int(g["D"]), int(g["NsK"]), int(g["seed"])
+    eps = synthetic.draw_eps_half(K, D, NsK, seed)
+    vp = make_vp(g, ctx)
+    vp._upload(ctx)
+    h = NsK // 2
+    n = 1 + D * K + 2 * K + D
+    import ctypes as C
+
+    def raw_of(r0, r1):
+        ctx.set_eps(eps, r0, r1 - r0)
+        H = C.c_double()
+        raw = np.empty(n)
+        ctx.check(ctx._lib.vbmc_entmc(ctx._h, NsK, _lib.EPS_RESIDENT, 0, r0, r1 - r0, 15, 1,
+                                      C.byref(H), None, _lib.ptr(raw)))
+        return raw
+
+    full = raw_of(0, h)
+    cut = h // 3
+    parts = raw_of(0, cut) + raw_of(cut, h)
+    assert rel_err(parts, full) < 1e-12
+    # and the raw vector is the oracle's partial
+    p = entropy_ref.pack_partial(entropy_ref.entmc_partial(oracle_mix(g), eps, NsK, (True,) * 4))
+    assert rel_err(full, p) < 1e-9
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_entlb_vs_reference(ctx, golden, name):
+    from pyvbmc_amd import entlb_vbmc
+
+    g = golden(name)
+    combos = list(itertools.product([False, True], repeat=4)) if name == "c1" else [(False,) * 4, (True,) * 4]
+    for gf in combos:
+        for jac in (True, False):
+            H, dH = entlb_vbmc(make_vp(g, ctx), gf, jac)
+            Href = g[f"entlb_H_{fl(gf)}_{int(jac)}"]
+            dref = g[f"entlb_dH_{fl(gf)}_{int(jac)}"]
+            assert abs(H - Href) <= TIGHT * abs(Href)
+            assert dH.shape == dref.shape
+            if dref.size:
+                assert rel_err(dH, dref) < 1e-9
+
+
+def test_entlb_single_component(ctx):
+    from pyvbmc_amd import VariationalPosterior, entlb_vbmc
+
+    vp = VariationalPosterior(3, 1)
+    vp.ctx = ctx
+    vp.sigma = np.array([[0.7]])
+    vp.lambd = np.array([[1.0], [2.0], [0.5]])
+    H, dH = entlb_vbmc(vp, (True,) * 4, False)
+    Ho, dHo = entropy_ref.entlb(mixture_ref.Mixture.make(vp.mu, vp.sigma, vp.lambd, vp.w, vp.eta), (True,) * 4, False)
+    assert np.isclose(H, Ho, rtol=1e-14) and np.allclose(dH, dHo, rtol=1e-13)
+    assert dH.shape == (3 + 1 + 3 + 1,)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gp_log_joint_vs_reference(ctx, golden, name):
+    from pyvbmc_amd.variational_optimization import _gp_log_joint
+
+    g = golden(name)
+    for tag, hyp in (("S1", g["hyp"][:1]), ("SM", g["hyp"])):
+        gp = make_gp(g, ctx, hyp)
+        vp = make_vp(g, ctx)
+        G, dG, varG, dvarG, vss = _gp_log_joint(vp, gp, True, True, True, False, False)
+        assert abs(G - g[f"glj_{tag}_G"]) <= TIGHT * abs(G)
+        assert rel_err(dG, g[f"glj_{tag}_dG"]) < 1e-9
+        assert varG is None and dvarG is None and vss == 0
+        G, dG, varG, _, var_ss, I_sk, J_sjk = _gp_log_joint(vp, gp, False, True, True, True, True)
+        assert dG is None
+        assert abs(G - g[f"glj_{tag}_var_G"]) <= TIGHT * abs(G)
+        assert rel_err(I_sk, g[f"glj_{tag}_I_sk"]) < 1e-10
+        # variance: difference of O(sf^2) terms -> relative to the J scale
+        assert rel_err(J_sjk, g[f"glj_{tag}_J_sjk"]) < 1e-7
+        assert rel_err(np.ravel(varG), np.ravel(g[f"glj_{tag}_varG"])) < 1e-5
+        assert abs(var_ss - g[f"glj_{tag}_var_ss"]) <= 1e-5 * max(abs(var_ss), 1e-300)
+
+
+def test_gp_log_joint_unsupported_combinations(ctx, golden):
+    from pyvbmc_amd.variational_optimization import _gp_log_joint
+
+    g = golden("c1")
+    gp, vp = make_gp(g, ctx), make_vp(g, ctx)
+    with pytest.raises(NotImplementedError):
+        _gp_log_joint(vp, gp, True, True, True, True, False)  # variance gradient
+    with pytest.raises(NotImplementedError):
+        _gp_log_joint(vp, gp, False, True, True, 2, False)  # diagonal approximation
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_neg_elcbo_vs_reference(ctx, golden, name):
+    from pyvbmc_amd.variational_optimization import _neg_elcbo
+
+    g = golden(name)
+    K, D, NsK, seed = int(g["K"]), int(g["D"]), int(g["NsK"]), int(g["seed"])
+    wl = synthetic.make_workload(int(g["cfg"]), S=1, D=D, K=K, N=int(g["N"]), Ns_total=int(g["Ns_total"]))
+    bnd = synthetic.default_theta_bnd(wl)
+    gp = make_gp(g, ctx, g["hyp"][:1])
+    for tag, th, tb in (("nobnd", g["theta"], None), ("bnd", g["theta"], bnd), ("bndout", g["theta_out"], bnd)):
+        for ns_tag, Ns in (("mc", NsK), ("lb", 0)):
+            th_in = th.copy()
+            vp = make_vp(g, ctx)
+            np.random.seed(seed)
+            F, dF, G, H, varF = _neg_elcbo(th_in, gp, vp, 0.0, Ns, True, False, tb, 0.0, False)
+            key = f"elbo_{tag}_{ns_tag}"
+            assert abs(F - g[key + "_F"]) <= 1e-9 * abs(g[key + "_F"]), (key, F, g[key + "_F"])
+            assert rel_err(dF, g[key + "_dF"]) < 1e-8, key
+            assert abs(G - g[key + "_G"]) <= 1e-9 * abs(G) and abs(H - g[key + "_H"]) <= 1e-9 * abs(H)
+            assert varF == 0
+            assert np.allclose(th_in, g[key + "_theta_after"], rtol=0, atol=1e-15), key
+            # side effect on vp: parameters now those of theta (set_parameters)
+            mix = oracle_mix(g)
+            mixture_ref.set_parameters(mix, th)
+            assert rel_err(vp.mu, mix.mu) < 1e-15 and rel_err(vp.sigma.ravel(), mix.sigma) < 1e-14
+            assert rel_err(vp.w.ravel(), mix.w) < 1e-14 and rel_err(vp.lambd.ravel(), mix.lambd) < 1e-14
+    # value-only, variance, per-component (the _eval_full_elcbo call)
+    vp = make_vp(g, ctx)
+    np.random.seed(seed)
+    r = _neg_elcbo(g["theta"].copy(), gp, vp, 0.0, NsK, False, True, None, 0.0, True)
+    assert len(r) == 11 and r[1] is None and r[5] is None
+    assert abs(r[0] - g["elbo_full_F"]) <= 1e-9 * abs(r[0])
+    assert rel_err(np.ravel(r[4]), np.ravel(g["elbo_full_varF"])) < 1e-5
+    assert rel_err(r[9], g["elbo_full_I_sk"]) < 1e-10
+    assert rel_err(r[10], g["elbo_full_J_sjk"]) < 1e-7
+
+
+def test_neg_elcbo_argument_errors(ctx, golden):
+    from pyvbmc_amd.variational_optimization import _neg_elcbo
+
+    g = golden("c1")
+    gp, vp = make_gp(g, ctx, g["hyp"][:1]), make_vp(g, ctx)
+    with pytest.raises(NotImplementedError):
+        _neg_elcbo(g["theta"].copy(), gp, vp, 1.0, 0, True, None, None)
+    with pytest.raises(ValueError):
+        _neg_elcbo(g["theta"].copy(), gp, vp, 0.0, 0, True, False, None, 0.0, True)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_pdf_vs_reference(ctx, golden, name):
+    g = golden(name)
+    vp = make_vp(g, ctx)
+    x = g["pdf_x"]
+    y = vp.pdf(x, orig_flag=False)
+    assert y.shape == (x.shape[0], 1)
+    assert rel_err(y, g["pdf_y"]) < 1e-11
+    ly = vp.pdf(x, orig_flag=False, log_flag=True)
+    fin = np.isfinite(g["pdf_logy"])
+    assert np.array_equal(np.isneginf(ly), np.isneginf(g["pdf_logy"]))
+    assert rel_err(ly[fin], g["pdf_logy"][fin]) < 1e-11
+    _, dy = vp.pdf(x, orig_flag=False, grad_flag=True)
+    assert rel_err(dy, g["pdf_dy"]) < 1e-10
+    _, dly = vp.log_pdf(x, orig_flag=False, grad_flag=True)
+    ok = np.isfinite(g["pdf_dlogy"])
+    assert rel_err(dly[ok], g["pdf_dlogy"][ok]) < 1e-9
+    for df in (10.0, -2.0, 3.5, -7.0):
+        assert rel_err(vp.pdf(x, orig_flag=False, df=df), g[f"pdf_y_df{df}"]) < 1e-10
+        assert rel_err(vp.pdf(x, orig_flag=False, log_flag=True, df=df), g[f"pdf_logy_df{df}"]) < 1e-10
+    # 1-D input -> raveled output (handle_0D_1D_input)
+    y1 = vp.pdf(x[0], orig_flag=False)
+    assert y1.shape == g["pdf_1d"].shape and rel_err(y1, g["pdf_1d"]) < 1e-11
+    with pytest.raises(NotImplementedError):
+        vp.pdf(x, orig_flag=False, grad_flag=True, df=5.0)
+    # default orig_flag=True with the identity transformer is the same density
+    assert rel_err(vp.pdf(x), g["pdf_y"]) < 1e-11
+
+
+def test_pdf_empty_and_ragged(ctx, golden):
+    g = golden("c2s")
+    vp = make_vp(g, ctx)
+    assert vp.pdf(np.zeros((0, int(g["D"]))), orig_flag=False).shape == (0, 1)
+    for n in (1, 63, 64, 65, 257, 1000):
+        x = np.random.default_rng(n).standard_normal((n, int(g["D"])))
+        y = vp.pdf(x, orig_flag=False, log_flag=True)
+        yo = mixture_ref.pdf(oracle_mix(g), x, log_flag=True)
+        assert rel_err(y, yo) < 1e-11
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gp_predict_vs_oracle(ctx, golden, name):
+    """1e-10 on predictive mean / variance (relative to the kernel scale sf^2)."""
+    g = golden(name)
+    D = int(g["D"])
+    gp = make_gp(g, ctx)
+    ogp = oracle_gp(g)
+    rng = np.random.default_rng(11)
+    xs = np.vstack([rng.standard_normal((300, D)), g["X"][:40] + 1e-3 * rng.standard_normal((40, D)),
+                    g["X"][:5], 8.0 * rng.standard_normal((20, D))])
+    sf2 = float(np.exp(2 * g["hyp"][0, D]))
+    for sep in (True, False):
+        fmu, fs2 = gp.predict(xs, separate_samples=sep)
+        omu, os2 = gp_ref.predict(ogp, xs, separate_samples=sep)
+        assert fmu.shape == omu.shape and fs2.shape == os2.shape
+        scale = max(1.0, float(np.max(np.abs(omu))))
+        assert np.max(np.abs(fmu - omu)) <= 1e-10 * scale, np.max(np.abs(fmu - omu))
+        assert np.max(np.abs(fs2 - os2)) <= 1e-10 * max(1.0, sf2), np.max(np.abs(fs2 - os2))
+    fmu, ys2 = gp.predict(xs[:50], add_noise=True, separate_samples=True)
+    omu, oys2 = gp_ref.predict(ogp, xs[:50], add_noise=True, separate_samples=True)
+    assert np.max(np.abs(ys2 - oys2)) <= 1e-10 * max(1.0, sf2)
+
+
+def test_gp_predict_matlab_known(ctx, golden):
+    """The reference's MATLAB fixture for gp.predict (test_active_importance_sampling.py:178-250)."""
+    from pyvbmc_amd import gp as gpm
+
+    m = golden("matlab_known")
+    D = 3
+    X = np.arange(-7, 8).reshape((5, 3), order="F").astype(float)
+    y = (-0.5 * np.sum(X**2, axis=1) - 0.5 * D * np.log(2 * np.pi)).reshape(-1, 1)
+    hyp = np.array([-2.0, -3.0, -4.0, 1.0, 0.0, -(D / 2) * np.log(2 * np.pi), 0.0, 0.25, 0.5, -0.5, 0.0, 0.5])
+    gp = gpm.GP(D, gpm.SquaredExponential(), gpm.NegativeQuadratic(), gpm.GaussianNoise(constant_add=True))
+    gp.ctx = ctx
+    gp.update(X_new=X, y_new=y, hyp=np.vstack([hyp, 2 * hyp]))
+    Xa = 2 * np.arange(-4, 5).reshape((3, 3), order="F") / np.pi
+    fmu, fs2 = gp.predict(Xa, separate_samples=True)
+    assert np.allclose(fs2, m["activesample_proposalpdf_f_s2_viqr"])
+
+
+def test_matlab_known_answers_on_gpu(ctx, golden):
+    """The reference's own known-answer tests, through the GPU path."""
+    from pyvbmc_amd import VariationalPosterior, entlb_vbmc, entmc_vbmc
+    from pyvbmc_amd import gp as gpm
+    from pyvbmc_amd.variational_optimization import _gp_log_joint, _neg_elcbo
+
+    m = golden("matlab_known")
+    D, K = int(m["ent_D"]), int(m["ent_K"])
+    vp = VariationalPosterior(D, K)
+    vp.ctx = ctx
+    vp.mu, vp.sigma, vp.lambd = m["ent_mu"], m["ent_sigma"].reshape(1, -1), m["ent_lambd"].reshape(-1, 1)
+    vp.w, vp.eta = m["ent_w"].reshape(1, -1), m["ent_eta"].reshape(1, -1)
+    Hl, dHl = entlb_vbmc(vp, jacobian_flag=bool(m["ent_jacobian_flag"]))
+    assert np.isclose(Hl, m["ent_Hl"]) and np.allclose(dHl, m["ent_dHl"])
+    np.random.seed(42)
+    H, dH = entmc_vbmc(vp, int(m["ent_Ns"]), jacobian_flag=bool(m["ent_jacobian_flag"]))
+    assert np.isclose(H, m["ent_H"], rtol=1e-2) and np.allclose(dH, m["ent_dH"], rtol=1e-2, atol=1e-2)
+
+    D = K = 2
+    vp = VariationalPosterior(D, K)
+    vp.ctx = ctx
+    vp.mu = m["vbmc_mu"]
+    gp = gpm.GP(D, gpm.SquaredExponential(), gpm.NegativeQuadratic(), gpm.GaussianNoise(constant_add=True))
+    gp.ctx = ctx
+    gp.update(X_new=m["vbmc_X"], y_new=m["vbmc_y"].reshape(-1, 1), hyp=m["vbmc_hyp"])
+    G, dG, varG, dvarG, var_ss, I_sk, J_sjk = _gp_log_joint(vp, gp, False, True, True, True, True)
+    assert np.isclose(G, m["vbmc_G"]) and dG is None
+    assert np.isclose(varG, m["vbmc_varG"]) and np.isclose(var_ss, m["vbmc_var_ss"])
+    G, dG, _, _, _ = _gp_log_joint(vp, gp, True, True, True, False, False)
+    assert np.allclose(dG, m["vbmc_dG_gp_log_joint"])
+    theta = vp.get_parameters()
+    r = _neg_elcbo(theta, gp, vp, 0.0, 0, False, True, None, 0.0, True)
+    assert np.isclose(r[0], m["vbmc_F"]) and np.isclose(r[3], m["vbmc_H"])
+    F, dF, _, _, _ = _neg_elcbo(theta, gp, vp, 0.0, 0, True, False, None, 0.0, False)
+    assert np.allclose(dF, m["vbmc_dF"])
+
+
+def test_entmc_analytic_single_gaussian(ctx):
+    """Reference test_entmc_vbmc.py:52-71: K=1 entropy is known in closed form."""
+    from pyvbmc_amd import VariationalPosterior, entmc_vbmc
+
+    D, K, Ns = 3, 1, 100000
+    vp = VariationalPosterior(D, K)
+    vp.ctx = ctx
+    vp.mu = np.ones((D, K))
+    vp.sigma = np.ones((1, K))
+    H_exact = 0.5 * D * (1 + np.log(2 * np.pi))
+    np.random.seed(0)
+    H, dH = entmc_vbmc(vp, Ns, jacobian_flag=False)
+    assert np.isclose(H, H_exact, rtol=0.01, atol=0.01)
+    assert np.allclose(dH, np.concatenate([np.zeros(D), [D], np.ones(D), [H_exact - 1]]), rtol=0.01, atol=0.01)
+    _, dH0 = entmc_vbmc(vp, 10, grad_flags=(False,) * 4)
+    assert dH0.shape == (0,)
+    _, dH1 = entmc_vbmc(vp, 11, grad_flags=(False, False, False, True))  # odd Ns rounds up
+    assert dH1.shape == (K,)
+
+
+def test_full_size_config3_against_oracle(ctx):
+    """BASELINE config 3 at full size (D=10, K=50, N=400, Ns=1e6): entropy value
+    vs the oracle (value-only keeps the oracle at a few seconds), gradient via
+    size-independent properties."""
+    from pyvbmc_amd import VariationalPosterior, entmc_vbmc
+
+    wl = synthetic.make_workload(3)
+    K, D, NsK = wl.K, wl.D, wl.NsK
+    assert NsK == 20000
+    vp = VariationalPosterior(D, K)
+    vp.ctx = ctx
+    vp.mu, vp.sigma, vp.lambd = wl.mu.copy(), wl.sigma.reshape(1, -1), wl.lambd.reshape(-1, 1)
+    vp.w, vp.eta = wl.w.reshape(1, -1), wl.eta.reshape(1, -1)
+    eps = synthetic.draw_eps_half(K, D, NsK, 3)
+    H, dH = entmc_vbmc(vp, NsK, (True,) * 4, True, eps_half=eps)
+    mix = mixture_ref.Mixture.make(wl.mu, wl.sigma, wl.lambd, wl.w, wl.eta)
+    Ho, _ = entropy_ref.entmc(mix, NsK, (False,) * 4, True, eps_half=eps)
+    assert abs(H - Ho) <= TOL_ELBO * abs(Ho)
+    assert abs(H - Ho) <= 1e-10 * abs(Ho)
+    # determinism: same inputs -> bit-identical outputs
+    H2, dH2 = entmc_vbmc(vp, NsK, (True,) * 4, True, eps_half=eps)
+    assert H2 == H and np.array_equal(dH, dH2)
+    # antithetic symmetry: negating every draw leaves the estimate unchanged (sample set identical)
+    H3, dH3 = entmc_vbmc(vp, NsK, (True,) * 4, True, eps_half=-eps)
+    assert abs(H3 - H) <= 1e-13 * abs(H) and rel_err(dH3, dH) < 1e-11
+    # softmax-Jacobian'd weight gradient sums to ~0 (rows of J_w sum to zero)
+    assert abs(np.sum(dH[-K:])) < 1e-10 * np.max(np.abs(dH[-K:]))
+    # gradient wrt mu by central finite differences on the same draws (a few coordinates)
+    theta0 = wl.theta
+    idx = [0, 7, D * K - 1]
+    for i in idx:
+        hstep = 1e-5
+        vals = []
+        for sgn in (+1, -1):
+            vq = VariationalPosterior(D, K)
+            vq.ctx = ctx
+            th = theta0.copy()
+            th[i] += sgn * hstep
+            vq.mu = th[: D * K].reshape((D, K), order="F")
+            vq.sigma, vq.lambd = wl.sigma.reshape(1, -1), wl.lambd.reshape(-1, 1)
+            vq.w, vq.eta = wl.w.reshape(1, -1), wl.eta.reshape(1, -1)
+            vals.append(entmc_vbmc(vq, NsK, (False,) * 4, True, eps_half=eps)[0])
+        fd = (vals[0] - vals[1]) / (2 * hstep)
+        assert abs(fd - dH[i]) <= 1e-5 * max(1.0, abs(dH[i])), (i, fd, dH[i])
