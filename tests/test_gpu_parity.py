@@ -78,8 +78,9 @@ def test_entmc_vs_reference(ctx, golden, name):
     combos = list(itertools.product([False, True], repeat=4)) if name == "c1" else [(False,) * 4, (True,) * 4]
     for gf in combos:
         for jac in (True, False):
+            vp = make_vp(g, ctx)  # the constructor consumes np.random: build first, seed after
             np.random.seed(seed)
-            H, dH = entmc_vbmc(make_vp(g, ctx), NsK, gf, jac)
+            H, dH = entmc_vbmc(vp, NsK, gf, jac)
             Href = g[f"entmc_H_{fl(gf)}_{int(jac)}"]
             dref = g[f"entmc_dH_{fl(gf)}_{int(jac)}"]
             assert abs(H - Href) <= TIGHT * abs(Href), (name, gf, jac, H, Href)
@@ -412,7 +413,9 @@ def test_full_size_config3_against_oracle(ctx):
     assert abs(H3 - H) <= 1e-13 * abs(H) and rel_err(dH3, dH) < 1e-11
     # softmax-Jacobian'd weight gradient sums to ~0 (rows of J_w sum to zero)
     assert abs(np.sum(dH[-K:])) < 1e-10 * np.max(np.abs(dH[-K:]))
-    # gradient wrt mu by central finite differences on the same draws (a few coordinates)
+    # gradient wrt mu vs central finite differences on the same draws.  The reference's
+    # estimator drops a zero-mean term of the pathwise derivative (entmc_vbmc.py:98), so
+    # the two agree only to Monte-Carlo accuracy (the reference's own check uses rtol 1e-2)
     theta0 = wl.theta
     idx = [0, 7, D * K - 1]
     for i in idx:
@@ -428,4 +431,4 @@ def test_full_size_config3_against_oracle(ctx):
             vq.w, vq.eta = wl.w.reshape(1, -1), wl.eta.reshape(1, -1)
             vals.append(entmc_vbmc(vq, NsK, (False,) * 4, True, eps_half=eps)[0])
         fd = (vals[0] - vals[1]) / (2 * hstep)
-        assert abs(fd - dH[i]) <= 1e-5 * max(1.0, abs(dH[i])), (i, fd, dH[i])
+        assert abs(fd - dH[i]) <= 2e-2 * np.max(np.abs(dH[: D * K])), (i, fd, dH[i])

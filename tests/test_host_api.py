@@ -1,0 +1,180 @@
+"""CPU tests: the C-ABI library loads and exports every declared symbol, it fails
+loudly without a GPU, and the host-side logic (parameter vector <-> mixture,
+entropy finalisation, VariationalPosterior bookkeeping) matches the oracle and
+the reference's golden values.  No compute kernels are launched here."""
+import ctypes as C
+import pickle
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+from conftest import CASES
+from helpers import oracle_mix, rel_err
+
+from oracle import entropy_ref, mixture_ref
+from pyvbmc_amd import VariationalPosterior, _lib, synthetic
+from pyvbmc_amd.variational_optimization import _soft_bound_loss, _vp_bound_loss
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "vbmc_hip.h").read_text()
+    declared = set(re.findall(r"\b(vbmc_[a-z_0-9]+)\s*\(", header))
+    declared -= {"vbmc_ctx"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = C.CDLL(str(_lib.LIB_PATH))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().vbmc_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.NoDeviceError):
+        _lib.Context(0)
+    h = _lib.Context(-1)  # host-only context
+    h.set_mixture(np.zeros((3, 2)), np.ones(2), np.ones(3), np.ones(2) / 2, np.zeros(2))
+    with pytest.raises(_lib.NoDeviceError):
+        h.set_eps(np.zeros((2, 4, 3)))
+    vp = VariationalPosterior(3, 2)
+    vp.ctx = h
+    with pytest.raises(_lib.NoDeviceError):
+        vp.pdf(np.zeros((5, 3)), orig_flag=False)
+    from pyvbmc_amd import entlb_vbmc, entmc_vbmc
+
+    with pytest.raises(_lib.NoDeviceError):
+        entmc_vbmc(vp, 10)
+    with pytest.raises(_lib.NoDeviceError):
+        entlb_vbmc(vp)
+
+
+def _vp_from(g):
+    vp = VariationalPosterior(int(g["D"]), int(g["K"]))
+    vp.mu = g["mu"].copy()
+    vp.sigma = g["sigma"].reshape(1, -1).copy()
+    vp.lambd = g["lambd"].reshape(-1, 1).copy()
+    vp.w = g["w"].reshape(1, -1).copy()
+    vp.eta = g["eta"].reshape(1, -1).copy()
+    return vp
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_vp_parameters_and_moments_match_reference(golden, name):
+    g = golden(name)
+    vp = _vp_from(g)
+    m, c = vp.moments(orig_flag=False, cov_flag=True)
+    assert m.shape == (1, int(g["D"])) and rel_err(m, g["mom_mean"]) < 1e-13
+    assert rel_err(c, g["mom_cov"]) < 1e-13
+    vp.set_parameters(g["rt_theta_in"])
+    assert vp.mu.shape == (vp.D, vp.K) and vp.sigma.shape == (1, vp.K)
+    assert vp.lambd.shape == (vp.D, 1) and vp.w.shape == (1, vp.K)
+    for k, v in (("mu", vp.mu), ("sigma", vp.sigma), ("lambd", vp.lambd), ("w", vp.w)):
+        assert rel_err(np.ravel(v), np.ravel(g["rt_" + k])) < 1e-14
+    assert rel_err(vp.get_parameters(), g["rt_theta_out"]) < 1e-14
+    assert rel_err(vp.get_parameters(raw_flag=False), g["rt_theta_out_noraw"]) < 1e-14
+    with pytest.raises(ValueError):
+        vp.set_parameters(-np.ones_like(g["rt_theta_in"]), raw_flag=False)
+
+
+def test_vp_constructor_and_sampling_contract():
+    np.random.seed(3)
+    vp = VariationalPosterior(3, 2, np.array([[5.0]]) * np.ones((1, 3)))
+    assert vp.mu.shape == (3, 2) and np.allclose(vp.mu, 5.0, atol=1e-4)
+    assert np.all(vp.sigma == 1e-3) and np.all(vp.lambd == 1) and np.allclose(vp.w, 0.5)
+    x, i = vp.sample(0)
+    assert x.shape == (0, 3) and i.shape == (0, 1)
+    vp.mu = np.array([[-10.0, 10.0]] * 3)
+    vp.w = np.array([[0.25, 0.75]])
+    x, i = vp.sample(4000, orig_flag=False, balance_flag=True)
+    assert x.shape == (4000, 3) and np.sum(i == 1) == 3000
+    m = vp.moments(N=20000)  # Monte-Carlo branch (orig space, identity transform)
+    assert np.allclose(m, 5.0, atol=0.05)
+    x, i = vp.sample(1000, df=4.0)
+    assert np.all(np.isfinite(x))
+    st = pickle.loads(pickle.dumps(vp))  # the ctx handle is never pickled
+    assert st._ctx is None and np.array_equal(st.mu, vp.mu)
+
+
+def test_get_bounds_matches_reference_layout(golden):
+    m = golden("matlab_known")
+    vp = VariationalPosterior(2, 2)
+    vp.mu = m["vbmc_mu"]
+    options = {"tol_con_loss": 0.01, "tol_weight": 1e-2, "weight_penalty": 0.1, "tol_length": 1e-6}
+    bnd = vp.get_bounds(m["vbmc_X"], options, 2)
+    assert bnd["lb"].shape == (2 * 2 + 2 * 2 + 2,)
+    assert bnd["weight_threshold"] == 1 / 8 and bnd["tol_con"] == 0.01
+    theta = vp.get_parameters()
+    L, dL = _vp_bound_loss(vp, theta, bnd)
+    assert L == 0.0 and np.all(dL == 0.0)
+    theta[-1] = 1.0
+    L, dL = _vp_bound_loss(vp, theta, bnd, tol_con=0.01)
+    # known answer asserted by the reference (test_variational_optimization.py:238-241)
+    assert np.isclose(L, 178.1123635679098) and np.isclose(dL[-1], 356.2247271358195)
+    assert np.all(dL[:-1] == 0.0)
+    x = np.array([15.0, -20.0, 0.0])
+    L4, dL4 = _soft_bound_loss(x, np.full(3, -10.0), np.full(3, 10.0), compute_grad=True)
+    assert np.isclose(L4, 156250.0) and np.allclose(dL4, [12500.0, -25000.0, 0.0])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_theta_to_mixture_matches_set_parameters(golden, name):
+    """The C restatement of set_parameters used by the fused objective."""
+    g = golden(name)
+    D, K = int(g["D"]), int(g["K"])
+    h = _lib.Context(-1)
+    h.set_mixture(g["mu"], g["sigma"], g["lambd"], g["w"], g["eta"])
+    th = _lib.f64(g["rt_theta_in"])
+    mu, sg, lm, w, eta = np.empty((K, D)), np.empty(K), np.empty(D), np.empty(K), np.empty(K)
+    h.check(h._lib.vbmc_theta_to_mixture(h._h, _lib.ptr(th), th.size, 15, _lib.ptr(mu), _lib.ptr(sg),
+                                         _lib.ptr(lm), _lib.ptr(w), _lib.ptr(eta)))
+    assert rel_err(mu.T, g["rt_mu"]) < 1e-15 and rel_err(sg, g["rt_sigma"]) < 1e-14
+    assert rel_err(lm, g["rt_lambd"]) < 1e-14 and rel_err(w, g["rt_w"]) < 1e-14
+    assert np.allclose(eta, th[-K:] - th[-K:].max(), atol=0, rtol=0)
+    with pytest.raises(ValueError):
+        h.check(h._lib.vbmc_theta_to_mixture(h._h, _lib.ptr(th), th.size - 1, 15, None, None, None, None, None))
+    # partial masks: only mu and weights optimised
+    th2 = _lib.f64(np.concatenate([g["rt_theta_in"][: D * K], g["rt_theta_in"][-K:]]))
+    h.set_mixture(g["mu"], g["sigma"], g["lambd"], g["w"], g["eta"])
+    h.check(h._lib.vbmc_theta_to_mixture(h._h, _lib.ptr(th2), th2.size, 1 | 8, _lib.ptr(mu), _lib.ptr(sg),
+                                         _lib.ptr(lm), _lib.ptr(w), _lib.ptr(eta)))
+    mix = oracle_mix(g)
+    mix.optimize_sigma = mix.optimize_lambd = False
+    mixture_ref.set_parameters(mix, th2)
+    assert rel_err(sg, mix.sigma) < 1e-14 and rel_err(w, mix.w) < 1e-14 and rel_err(mu.T, mix.mu) < 1e-15
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_entmc_finalize_matches_oracle(golden, name):
+    """Host finalisation (Jacobians + packing) of a raw accumulator vector."""
+    g = golden(name)
+    K, D, NsK, seed = int(g["K"]), int(g["D"]), int(g["NsK"]), int(g["seed"])
+    eps = synthetic.draw_eps_half(K, D, min(NsK, 40), seed)
+    mix = oracle_mix(g)
+    raw = _lib.f64(entropy_ref.pack_partial(entropy_ref.entmc_partial(mix, eps, eps.shape[1] * 2, (True,) * 4)))
+    h = _lib.Context(-1)
+    h.set_mixture(g["mu"], g["sigma"], g["lambd"], g["w"], g["eta"])
+    for bits, gf in ((15, (True,) * 4), (0, (False,) * 4), (9, (True, False, False, True)), (6, (False, True, True, False))):
+        for jac in (1, 0):
+            p = entropy_ref.unpack_partial(raw, D, K)
+            Ho, dHo = entropy_ref.entmc_finalize(mix, p, gf, bool(jac))
+            H = C.c_double()
+            dH = np.empty(dHo.size)
+            h.check(h._lib.vbmc_entmc_finalize(h._h, _lib.ptr(raw), bits, jac, C.byref(H), _lib.ptr(dH)))
+            assert H.value == Ho
+            if dHo.size:
+                assert rel_err(dH, dHo) < 1e-13
+
+
+def test_workload_generator_is_stable(golden):
+    """bench/tests/golden share one input generator; the fixtures pin it."""
+    for name in CASES:
+        g = golden(name)
+        wl = synthetic.make_workload(int(g["cfg"]), S=g["hyp"].shape[0], D=int(g["D"]), K=int(g["K"]),
+                                     N=int(g["N"]), Ns_total=int(g["Ns_total"]))
+        assert np.array_equal(wl.mu, g["mu"]) and np.array_equal(wl.X, g["X"])
+        assert np.array_equal(wl.hyp, g["hyp"]) and wl.NsK == int(g["NsK"])
+    assert synthetic.ns_per_component(1_000_000, 50) == 20000
+    assert synthetic.ns_per_component(1000, 3) == 334
