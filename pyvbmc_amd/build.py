@@ -17,7 +17,6 @@ LIB = HERE / "libvbmc_hip.so"
 SOURCES = [
     "ctx.hip",
     "entropy.hip",
-    "entropy_mfma.hip",
     "api_entropy.hip",
     "mixture.hip",
     "gp.hip",
@@ -37,15 +36,27 @@ FLAGS = [
 ]
 
 
+WS_DPS = [2, 4, 6, 8, 10, 12, 16, 20, 24, 32]  # must match VBMC_WS_DPS in entropy_args.h
+
+
 def _sources():
     return [CSRC / s for s in SOURCES if (CSRC / s).exists()]
+
+
+def _jobs(bdir):
+    """(source, object, extra flags) for every translation unit; the wave-split entropy
+    kernel is compiled once per padded D so the instantiations build in parallel."""
+    jobs = [(src, bdir / (src.stem + ".o"), []) for src in _sources()]
+    for dp in WS_DPS:
+        jobs.append((CSRC / "entropy_ws.hip", bdir / f"entropy_ws_dp{dp}.o", [f"-DVBMC_DP={dp}"]))
+    return jobs
 
 
 def needs_build():
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    deps = _sources() + list(CSRC.glob("*.h")) + [HERE.parent / "include" / "vbmc_hip.h"]
+    deps = _sources() + [CSRC / "entropy_ws.hip"] + list(CSRC.glob("*.h")) + [HERE.parent / "include" / "vbmc_hip.h"]
     return any(p.stat().st_mtime > t for p in deps)
 
 
@@ -56,16 +67,25 @@ def build(force=False, verbose=True):
     procs = []
     bdir = CSRC / "_obj"
     bdir.mkdir(exist_ok=True)
-    for src in _sources():
-        obj = bdir / (src.stem + ".o")
-        cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]
+    import concurrent.futures as cf
+
+    def run(job):
+        src, obj, extra = job
+        cmd = [HIPCC, *FLAGS, *extra, "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        return obj, p
+
+    jobs = _jobs(bdir)
+    with cf.ThreadPoolExecutor(max_workers=max(2, (os.cpu_count() or 4))) as ex:
+        results = list(ex.map(run, jobs))
+    for (src, obj, _), (_, p) in zip(jobs, results):
         objs.append(obj)
+        procs.append((obj, p))
     failed = False
     for src, p in procs:
-        out, _ = p.communicate()
+        out = p.stdout
         if p.returncode != 0:
             failed = True
             sys.stderr.write(f"--- {src.name} failed ---\n{out.decode()}\n")

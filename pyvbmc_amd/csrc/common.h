@@ -21,6 +21,7 @@ struct MixLayout {
   int o_is2 = 0;    // [K]     1 / sigma_k^2
   int o_wc = 0;     // [K]     w_k * nconst / sigma_k^D   (nconst = (2pi)^(-D/2) / prod lambda)
   int o_rc = 0;     // [K]     nconst / sigma_k^D
+  int o_lrc = 0;    // [K]     log2(nconst / sigma_k^D)
   int o_sig = 0;    // [K]     sigma_k
   int o_w = 0;      // [K]     w_k
   int o_lam = 0;    // [D]     lambda_d
@@ -35,6 +36,7 @@ struct MixLayout {
     o_is2 = o; o += K;
     o_wc = o; o += K;
     o_rc = o; o += K;
+    o_lrc = o; o += K;
     o_sig = o; o += K;
     o_w = o; o += K;
     o_lam = o; o += D;

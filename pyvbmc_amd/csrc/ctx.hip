@@ -185,6 +185,7 @@ static int upload_mixture(vbmc_ctx* ctx) {
     const double sD = std::pow(s, (double)D);
     p[ml.o_is2 + k] = 1.0 / (s * s);
     p[ml.o_rc + k] = nconst / sD;
+    p[ml.o_lrc + k] = std::log2(nconst) - D * std::log2(s);
     p[ml.o_wc + k] = ctx->w[k] * nconst / sD;
     p[ml.o_sig + k] = s;
     p[ml.o_w + k] = ctx->w[k];

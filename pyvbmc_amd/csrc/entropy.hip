@@ -11,7 +11,10 @@
 // order (bit-reproducible) into the raw accumulator vector
 //     [H | mu (K blocks of D) | sigma (K) | lambda (D) | w (K)]
 // that the host finalises (Jacobians) and that the multi-GPU path all-reduces.
+#include <cstdlib>
+
 #include "common.h"
+#include "entropy_args.h"
 #include "philox.h"
 
 namespace {
@@ -25,21 +28,6 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
-struct EntArgs {
-  const double* mix;
-  MixLayout ml;
-  const double* eps;   // resident draws [K][eps_rows][D] or nullptr
-  int64_t eps_rows;    // rows resident per component (== row_count of the ctx slice)
-  int64_t n_half;      // antithetic pairs per component in the whole job
-  int64_t row_begin;   // first row of this ctx's slice
-  int64_t row_count;   // rows of this ctx's slice
-  uint64_t seed;
-  int eps_mode;
-  int want_grad;
-  double* partial;     // [K][chunks][stride]
-  int chunks;
-  int stride;          // 2 + 2D + K
-};
 
 // Partial row layout: [Slog | mu(D) | sig | lam(D) | W(K)]
 template <int DP>
@@ -55,7 +43,8 @@ __global__ __launch_bounds__(WG) void entmc_valu_kernel(EntArgs a) {
   double* sA = sDelta + K * DP;         // [K] |Delta_k|^2
   double* sIs2 = sA + K;                // [K]
   double* sWc = sIs2 + K;               // [K]
-  double* sRed = sWc + K;               // [WAVES][2*DP+1]
+  double* sRc = sWc + K;                // [K]
+  double* sRed = sRc + K;               // [WAVES][2*DP+1]
   double* sW = sRed + WAVES * (2 * DP + 1);  // [WAVES][K]
 
   const double* mup = a.mix + a.ml.o_mup;
@@ -66,6 +55,7 @@ __global__ __launch_bounds__(WG) void entmc_valu_kernel(EntArgs a) {
   for (int k = tid; k < K; k += WG) {
     sIs2[k] = a.mix[a.ml.o_is2 + k];
     sWc[k] = a.mix[a.ml.o_wc + k];
+    sRc[k] = a.mix[a.ml.o_rc + k];
   }
   __syncthreads();
   for (int k = tid; k < K; k += WG) {
@@ -171,7 +161,7 @@ __global__ __launch_bounds__(WG) void entmc_valu_kernel(EntArgs a) {
       const double sm = fmax(fma(-two_sj, c, ab), 0.0);
       double v = exp(-0.5 * sp * is2) * ip + exp(-0.5 * sm * is2) * im;
       v = wave_sum(v);
-      if (lane == 0) sW[wave * K + k] = v;
+      if (lane == 0) sW[wave * K + k] = v * sRc[k];  // norm_j1 / q of the reference
     }
   }
   __syncthreads();
@@ -221,6 +211,7 @@ __global__ __launch_bounds__(256) void entmc_reduce_chunks(const double* __restr
 
 // Level-2: combine the per-component rows into the raw accumulator vector
 // (entmc_vbmc.py:80,98,102-112 with the 1/Ns and w_j factors applied).
+// One wave per output element; lanes run over the components j it sums.
 __global__ __launch_bounds__(256) void entmc_combine(const double* __restrict__ perj,
                                                      const double* __restrict__ mix, MixLayout ml,
                                                      int stride, double inv_ns, int want_grad,
@@ -229,32 +220,33 @@ __global__ __launch_bounds__(256) void entmc_combine(const double* __restrict__ 
   const double* w = mix + ml.o_w;
   const double* sig = mix + ml.o_sig;
   const double* ilam = mix + ml.o_ilam;
-  const double* rc = mix + ml.o_rc;
   const int n = 1 + D * K + 2 * K + D;
-  for (int t = threadIdx.x; t < n; t += blockDim.x) {
-    double v = 0.0;
-    if (t == 0) {
-      for (int j = 0; j < K; ++j) v -= w[j] * perj[(int64_t)j * stride];
-      v *= inv_ns;
-    } else if (want_grad) {
-      int u = t - 1;
-      if (u < D * K) {
-        int j = u / D, d = u - j * D;
-        v = w[j] * inv_ns * perj[(int64_t)j * stride + 1 + d] * ilam[d];
-      } else if ((u -= D * K) < K) {
-        v = w[u] * inv_ns * perj[(int64_t)u * stride + 1 + D];
-      } else if ((u -= K) < D) {
-        for (int j = 0; j < K; ++j) v += w[j] * sig[j] * perj[(int64_t)j * stride + 2 + D + u];
-        v *= inv_ns * ilam[u];
-      } else {
-        u -= D;
-        double s = 0.0;
-        for (int j = 0; j < K; ++j) s += w[j] * perj[(int64_t)j * stride + 2 + 2 * D + u];
-        v = -inv_ns * (perj[(int64_t)u * stride] + rc[u] * s);
-      }
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (t >= n) return;
+  double v = 0.0;
+  if (t == 0) {
+    for (int j = lane; j < K; j += 64) v -= w[j] * perj[(int64_t)j * stride];
+    v = wave_sum(v) * inv_ns;
+  } else if (want_grad) {
+    int u = t - 1;
+    if (u < D * K) {
+      const int j = u / D, d = u - j * D;
+      v = w[j] * inv_ns * perj[(int64_t)j * stride + 1 + d] * ilam[d];
+    } else if ((u -= D * K) < K) {
+      v = w[u] * inv_ns * perj[(int64_t)u * stride + 1 + D];
+    } else if ((u -= K) < D) {
+      for (int j = lane; j < K; j += 64) v += w[j] * sig[j] * perj[(int64_t)j * stride + 2 + D + u];
+      v = wave_sum(v) * inv_ns * ilam[u];
+    } else {
+      u -= D;
+      double s = 0.0;
+      for (int j = lane; j < K; j += 64) s += w[j] * perj[(int64_t)j * stride + 2 + 2 * D + u];
+      s = wave_sum(s);
+      v = -inv_ns * (perj[(int64_t)u * stride] + s);
     }
-    raw[t] = v;
   }
+  if (lane == 0) raw[t] = v;
 }
 
 // ---------------------------------------------------------------------------
@@ -356,7 +348,7 @@ __global__ __launch_bounds__(256) void entlb_kernel(const double* __restrict__ m
 template <int DP>
 int launch_entmc_dp(vbmc_ctx* ctx, const EntArgs& a) {
   const int K = a.ml.K;
-  size_t lds = sizeof(double) * ((size_t)K * DP + 3 * K + WAVES * (2 * DP + 1) + (size_t)WAVES * K);
+  size_t lds = sizeof(double) * ((size_t)K * DP + 4 * K + WAVES * (2 * DP + 1) + (size_t)WAVES * K);
   dim3 grid(a.chunks, K);
   hipLaunchKernelGGL(entmc_valu_kernel<DP>, grid, dim3(WG), lds, ctx->stream, a);
   return 0;
@@ -364,10 +356,27 @@ int launch_entmc_dp(vbmc_ctx* ctx, const EntArgs& a) {
 
 }  // namespace
 
+static bool use_ws_kernel(int D, int K) {
+  static const int forced = [] {
+    const char* e = getenv("VBMC_ENTMC_KERNEL");
+    return (e && e[0] == 'v') ? 1 : 0;  // VBMC_ENTMC_KERNEL=valu forces the generic kernel
+  }();
+  if (forced == 1) return false;
+  return D <= 32 && K <= 128;
+}
+
+static int padded_d(int D) {
+  const int dps[] = {2, 4, 6, 8, 10, 12, 16, 20, 24, 32};
+  for (int dp : dps)
+    if (D <= dp) return dp;
+  return -1;
+}
+
 int launch_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed,
                  int64_t row_begin, int64_t row_count, int want_grad, double* d_raw) {
   const int D = ctx->D, K = ctx->K;
-  if (D > 32) return vbmc_fail(ctx, VBMC_E_UNSUP, "entmc: D=%d > 32 not supported", D);
+  const int DP = padded_d(D);
+  if (DP < 0) return vbmc_fail(ctx, VBMC_E_UNSUP, "entmc: D=%d > 32 not supported", D);
   EntArgs a;
   a.mix = ctx->d_mix;
   a.ml = ctx->ml;
@@ -379,34 +388,65 @@ int launch_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed
   a.seed = seed;
   a.eps_mode = eps_mode;
   a.want_grad = want_grad;
-  a.chunks = (int)((row_count + WG - 1) / WG);
+  const bool ws = use_ws_kernel(D, K);
+  int rows_per_wg = WG;
+  a.rg = 1;
+  size_t n_table = 0;
+  if (ws) {
+    // 64*rg rows per workgroup.  Two workgroups are resident per CU (2 waves/SIMD): size
+    // the grid to about one full round of 2*CUs workgroups, which also amortises the
+    // end-of-workgroup reductions over many batches.
+    const int64_t total_rows = row_count * K;
+    const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    int64_t rg = (total_rows + 64 * 2 * cus - 1) / (64 * 2 * cus);
+    if (rg < 1) rg = 1;
+    if (rg > 16) rg = 16;
+    a.rg = (int)rg;
+    rows_per_wg = 64 * a.rg;
+    n_table = (size_t)K * (size_t)(((K + 3) / 4) * 4) * (size_t)(DP + 6);
+  }
+  a.chunks = (int)((row_count + rows_per_wg - 1) / rows_per_wg);
   if (a.chunks < 1) a.chunks = 1;
   a.stride = 2 + 2 * D + K;
-  size_t need = (size_t)K * a.chunks * a.stride + (size_t)K * a.stride;
-  int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, need);
+  const size_t n_part = (size_t)K * a.chunks * a.stride, n_perj = (size_t)K * a.stride;
+  int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, n_part + n_perj + n_table);
   if (rc) return rc;
   a.partial = ctx->d_scratch;
-  double* perj = ctx->d_scratch + (size_t)K * a.chunks * a.stride;
+  double* perj = ctx->d_scratch + n_part;
+  double* table = perj + n_perj;
 
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  if (D <= 2) launch_entmc_dp<2>(ctx, a);
-  else if (D <= 4) launch_entmc_dp<4>(ctx, a);
-  else if (D <= 6) launch_entmc_dp<6>(ctx, a);
-  else if (D <= 8) launch_entmc_dp<8>(ctx, a);
-  else if (D <= 10) launch_entmc_dp<10>(ctx, a);
-  else if (D <= 12) launch_entmc_dp<12>(ctx, a);
-  else if (D <= 16) launch_entmc_dp<16>(ctx, a);
-  else if (D <= 20) launch_entmc_dp<20>(ctx, a);
-  else if (D <= 24) launch_entmc_dp<24>(ctx, a);
-  else launch_entmc_dp<32>(ctx, a);
+  if (ws) {
+    // (the table kernel is launched by the per-DP launcher, in front of the timed main kernel)
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    switch (DP) {
+#define VBMC_CASE_WS(dp) case dp: launch_entmc_ws_dp##dp(ctx->stream, a, table); break;
+      VBMC_WS_DPS(VBMC_CASE_WS)
+#undef VBMC_CASE_WS
+    }
+  } else {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    switch (DP) {
+      case 2: launch_entmc_dp<2>(ctx, a); break;
+      case 4: launch_entmc_dp<4>(ctx, a); break;
+      case 6: launch_entmc_dp<6>(ctx, a); break;
+      case 8: launch_entmc_dp<8>(ctx, a); break;
+      case 10: launch_entmc_dp<10>(ctx, a); break;
+      case 12: launch_entmc_dp<12>(ctx, a); break;
+      case 16: launch_entmc_dp<16>(ctx, a); break;
+      case 20: launch_entmc_dp<20>(ctx, a); break;
+      case 24: launch_entmc_dp<24>(ctx, a); break;
+      default: launch_entmc_dp<32>(ctx, a); break;
+    }
+  }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   ctx->ev_valid[0] = true;
   HIP_TRY(ctx, hipGetLastError());
 
   hipLaunchKernelGGL(entmc_reduce_chunks, dim3(K), dim3(256), 0, ctx->stream, a.partial, a.chunks,
                      a.stride, perj);
-  hipLaunchKernelGGL(entmc_combine, dim3(1), dim3(256), 0, ctx->stream, perj, ctx->d_mix, ctx->ml,
-                     a.stride, 1.0 / (double)ns_per_comp, want_grad, d_raw);
+  const int n_out = raw_len(D, K);
+  hipLaunchKernelGGL(entmc_combine, dim3((n_out + 3) / 4), dim3(256), 0, ctx->stream, perj,
+                     ctx->d_mix, ctx->ml, a.stride, 1.0 / (double)ns_per_comp, want_grad, d_raw);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }

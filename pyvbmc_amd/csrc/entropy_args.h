@@ -1,0 +1,27 @@
+// Kernel argument block shared by the entropy kernels (entropy.hip, entropy_quad.hip).
+#pragma once
+#include "common.h"
+
+struct EntArgs {
+  const double* mix;
+  MixLayout ml;
+  const double* eps;   // resident draws [K][eps_rows][D] or nullptr
+  int64_t eps_rows;    // rows resident per component (== row_count of the ctx slice)
+  int64_t n_half;      // antithetic pairs per component in the whole job
+  int64_t row_begin;   // first row of this ctx's slice
+  int64_t row_count;   // rows of this ctx's slice
+  uint64_t seed;
+  int eps_mode;
+  int want_grad;
+  double* partial;     // [K][chunks][stride]
+  int chunks;          // workgroups per component
+  int stride;          // 2 + 2D + K : [Slog | mu(D) | sig | lam(D) | W(K)]
+  int rg;              // wave-split kernel: 64-row batches per workgroup
+};
+
+// padded-D instantiations of the wave-split kernel (entropy_ws.hip), one translation
+// unit each; d_table: K * 4*ceil(K/4) * (dp+6) doubles of scratch for the (j,k) table
+#define VBMC_WS_DPS(X) X(2) X(4) X(6) X(8) X(10) X(12) X(16) X(20) X(24) X(32)
+#define VBMC_DECL_WS(dp) void launch_entmc_ws_dp##dp(hipStream_t st, const EntArgs& a, double* d_table);
+VBMC_WS_DPS(VBMC_DECL_WS)
+#undef VBMC_DECL_WS

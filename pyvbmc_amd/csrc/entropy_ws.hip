@@ -1,0 +1,315 @@
+// Monte-Carlo entropy, main kernel -- reference entropy/entmc_vbmc.py:64-112.
+//
+// Per evaluated (sample, component) pair the work is ~3D FMAs + one exp, all float64.
+// On gfx950 the FP64 vector FMA and the FP64 MFMA share one pipe and one peak
+// (78.6 TFLOP/s; measured 70 / 78.8 with NO overlap between the two,
+// tools/ubench_fp64.hip), so recasting the K x D distance block as a matrix product
+// buys nothing: this is a VALU kernel whose job is to spend as few issue slots per
+// pair as possible and to keep the VALU fed.
+//
+//   * antithetic samples x+- = mu_j +- sigma_j lambda o eps share the dot product
+//     Delta_k . eps of their squared distances (D FMAs for two samples);
+//   * each exp() is evaluated ONCE.  The K densities of a sample are needed twice
+//     (for q = sum_k w_k r_k and, once q is known, for sum_n r_k/q), so they stay in
+//     registers; to make that fit, the K components are split over the 4 waves of a
+//     workgroup ("ws" = wave-split):
+//                 lane = antithetic-pair row (64 rows per batch),
+//                 wave w owns components k = w, w+4, w+8, ...  (KT = ceil(K/4)).
+//     Everything indexed by k is therefore wave-uniform: the per-(j,k) constants
+//     (Delta_jk row, |Delta|^2, exponent scale, log2 normaliser, weights) come from a
+//     small precomputed table through SCALAR loads and feed the FMAs as SGPR operands
+//     -- the inner loop issues no vector-memory or LDS instruction at all;
+//   * only q+ and q- cross waves (one LDS exchange + barrier per 64-row batch); every
+//     gradient accumulator is linear in the per-wave partial sums and is reduced once
+//     per workgroup;
+//   * exp is exp2 with log2(e), -1/(2 sigma_k^2) and log2 of the normalisation folded
+//     into one FMA; log is an atanh series (fastmath.h).
+// Output: the same per-workgroup partial rows as entropy.hip, reduced by its kernels.
+#include "common.h"
+#include "entropy_args.h"
+#include "fastmath.h"
+#include "philox.h"
+
+#ifndef VBMC_DP
+#error "compile with -DVBMC_DP=<padded D>"
+#endif
+#ifndef VBMC_WS_PREFETCH
+#define VBMC_WS_PREFETCH 0
+#endif
+
+namespace {
+
+constexpr int WG = 256;
+constexpr int WAVES = WG / 64;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Table row for (j,k): [Delta_jk (DP) | a | c | lrc | w | wis2 | pad]  (TS = DP+6 doubles)
+//   a = |Delta_jk|^2, c = -log2(e)/(2 sigma_k^2), lrc = log2(nconst/sigma_k^D),
+//   wis2 = w_k/sigma_k^2;  rows k >= K are padding with density exactly 0.
+template <int DP>
+__global__ __launch_bounds__(256) void entmc_table_kernel(const double* __restrict__ mix,
+                                                          MixLayout ml, int K4,
+                                                          double* __restrict__ T) {
+  constexpr int TS = DP + 6;
+  const int D = ml.D, K = ml.K;
+  const int j = blockIdx.x;
+  const double* mup = mix + ml.o_mup;
+  for (int k = threadIdx.x; k < K4; k += blockDim.x) {
+    double* row = T + ((size_t)j * K4 + k) * TS;
+    double s = 0.0;
+    for (int d = 0; d < DP; ++d) {
+      const double v = (d < D && k < K) ? (mup[j * D + d] - mup[k * D + d]) : 0.0;
+      row[d] = v;
+      s = fma(v, v, s);
+    }
+    if (k < K) {
+      const double is2 = mix[ml.o_is2 + k];
+      const double w = mix[ml.o_w + k];
+      row[DP + 0] = s;
+      row[DP + 1] = -0.5 * 0x1.71547652b82fep+0 * is2;
+      row[DP + 2] = mix[ml.o_lrc + k];
+      row[DP + 3] = w;
+      row[DP + 4] = w * is2;
+    } else {
+      row[DP + 0] = 0.0; row[DP + 1] = 0.0; row[DP + 2] = -2000.0; row[DP + 3] = 0.0; row[DP + 4] = 0.0;
+    }
+    row[DP + 5] = 0.0;
+  }
+}
+
+template <int DP, int KTMAX, bool GRAD>
+__global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double* __restrict__ T) {
+  constexpr int TS = DP + 6;
+  __shared__ double sQ[2][WAVES][2][64];          // q partials, double-buffered by batch parity
+  __shared__ double sE[DP][64];                   // Philox mode: the batch's normals
+  __shared__ double sRed[WAVES][2 * DP + 1];
+  extern __shared__ double sW[];                  // [K4]
+
+  const int D = a.ml.D, K = a.ml.K;
+  const int KT = (K + 3) >> 2, K4 = KT * 4;
+  const int j = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const double sig_j = a.mix[a.ml.o_sig + j];
+  const double two_sj = 2.0 * sig_j;
+  const double sj2 = sig_j * sig_j;
+  const double* Tj = T + (size_t)j * K4 * TS;
+
+  double slog_acc = 0.0;
+  double mu_acc[DP], lam_acc[DP], Wacc[KTMAX];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) mu_acc[d] = lam_acc[d] = 0.0;
+#pragma unroll
+  for (int kk = 0; kk < KTMAX; ++kk) Wacc[kk] = 0.0;
+
+  const int rows_per_wg = a.rg * 64;
+  for (int it = 0; it < a.rg; ++it) {
+    const int64_t i_loc = (int64_t)chunk * rows_per_wg + it * 64 + lane;
+    const bool valid = i_loc < a.row_count;
+
+    // ---- this row's D standard normals ----
+    double e[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) e[d] = 0.0;
+    if (a.eps_mode == VBMC_EPS_RESIDENT) {
+      if (valid) {
+        const double* rp = a.eps + ((int64_t)j * a.eps_rows + i_loc) * D;
+#pragma unroll
+        for (int d = 0; d < DP; ++d)
+          if (d < D) e[d] = rp[d];
+      }
+    } else {
+      // wave w generates the Box-Muller pairs p = w, w+4, ... of the 64 rows; LDS hands
+      // them to the other waves (each pair is generated exactly once per workgroup)
+      const uint64_t grow = (uint64_t)j * (uint64_t)a.n_half + (uint64_t)(a.row_begin + i_loc);
+      constexpr int NP = DP / 2;
+      __syncthreads();  // previous batch's readers are done with sE
+#pragma unroll
+      for (int i = 0; i < (NP + 3) / 4; ++i) {
+        const int p = wave + 4 * i;
+        if (p < NP && 2 * p < D) {
+          double z0, z1;
+          philox_normal_pair(grow, (uint32_t)p, a.seed, z0, z1);
+          sE[2 * p][lane] = z0;
+          sE[2 * p + 1][lane] = z1;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int d = 0; d < DP; ++d)
+        if (valid && d < D) e[d] = sE[d][lane];
+    }
+    double e2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) e2 = fma(e[d], e[d], e2);
+    const double b = sj2 * e2;
+
+    // ---- this wave's components: densities, partial q, partial gradient sums ----
+    double qp = 0.0, qm = 0.0, gsp = 0.0, gsm = 0.0;
+    double Ap[DP], Am[DP], rp_[KTMAX], rm_[KTMAX];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) Ap[d] = Am[d] = 0.0;
+    // table rows are fetched one component ahead (scalar loads into SGPRs) so their
+    // latency hides behind the ~75 VALU instructions of the current component
+    double cur[TS], nxt[TS];
+    {
+      const double* tr = Tj + (size_t)wave * TS;
+#pragma unroll
+      for (int i = 0; i < TS - 1; ++i) cur[i] = tr[i];
+    }
+#pragma unroll
+    for (int kk = 0; kk < KTMAX; ++kk) {
+      rp_[kk] = rm_[kk] = 0.0;
+      if (kk < KT) {
+#if VBMC_WS_PREFETCH
+        if (kk + 1 < KT) {
+          const double* tn = Tj + (size_t)(4 * (kk + 1) + wave) * TS;  // wave-uniform
+#pragma unroll
+          for (int i = 0; i < TS - 1; ++i) nxt[i] = tn[i];
+        }
+#else
+        {
+          const double* tn = Tj + (size_t)(4 * kk + wave) * TS;  // wave-uniform
+#pragma unroll
+          for (int i = 0; i < TS - 1; ++i) cur[i] = tn[i];
+        }
+#endif
+        double c = 0.0;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) c = fma(cur[d], e[d], c);
+        const double ab = cur[DP + 0] + b;
+        const double sp = fma(two_sj, c, ab);
+        const double sm = fma(-two_sj, c, ab);
+        const double rp = fm::exp2_fast(fma(cur[DP + 1], sp, cur[DP + 2]));  // norm_j1 of the reference
+        const double rm = fm::exp2_fast(fma(cur[DP + 1], sm, cur[DP + 2]));
+        rp_[kk] = rp;
+        rm_[kk] = rm;
+        qp = fma(cur[DP + 3], rp, qp);
+        qm = fma(cur[DP + 3], rm, qm);
+        if (GRAD) {
+          const double gp = rp * cur[DP + 4], gm = rm * cur[DP + 4];
+          gsp += gp;
+          gsm += gm;
+#pragma unroll
+          for (int d = 0; d < DP; ++d) {
+            Ap[d] = fma(gp, cur[d], Ap[d]);
+            Am[d] = fma(gm, cur[d], Am[d]);
+          }
+        }
+#if VBMC_WS_PREFETCH
+#pragma unroll
+        for (int i = 0; i < TS - 1; ++i) cur[i] = nxt[i];
+#endif
+      }
+    }
+    // ---- q = sum over the 4 waves ----
+    const int buf = it & 1;
+    sQ[buf][wave][0][lane] = qp;
+    sQ[buf][wave][1][lane] = qm;
+    __syncthreads();
+    qp = (sQ[buf][0][0][lane] + sQ[buf][1][0][lane]) + (sQ[buf][2][0][lane] + sQ[buf][3][0][lane]);
+    qm = (sQ[buf][0][1][lane] + sQ[buf][1][1][lane]) + (sQ[buf][2][1][lane] + sQ[buf][3][1][lane]);
+
+    // log q: wave 0 takes the + samples, wave 1 the - samples
+    if (wave < 2) {
+      const double lq = fm::log_fast(wave == 0 ? qp : qm);
+      slog_acc += valid ? lq : 0.0;
+    }
+    if (GRAD) {
+      const double ip = valid ? fm::rcp_fast(qp) : 0.0;
+      const double im = valid ? fm::rcp_fast(qm) : 0.0;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        const double se = sig_j * e[d];
+        const double lp = fma(se, gsp, Ap[d]) * ip;
+        const double lm = fma(-se, gsm, Am[d]) * im;
+        mu_acc[d] += lp + lm;
+        lam_acc[d] = fma(lp - lm, e[d], lam_acc[d]);
+      }
+#pragma unroll
+      for (int kk = 0; kk < KTMAX; ++kk)
+        if (kk < KT) Wacc[kk] = fma(rp_[kk], ip, fma(rm_[kk], im, Wacc[kk]));
+    }
+  }
+
+  // ---- workgroup reduction ----
+  {
+    const double v = wave_sum(slog_acc);
+    if (lane == 0) sRed[wave][0] = v;
+  }
+  if (GRAD) {
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      const double vmu = wave_sum(mu_acc[d]);
+      const double vlam = wave_sum(lam_acc[d]);
+      if (lane == 0) {
+        sRed[wave][1 + d] = vmu;
+        sRed[wave][1 + DP + d] = vlam;
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KTMAX; ++kk)
+      if (kk < KT) {
+        const double v = wave_sum(Wacc[kk]);
+        if (lane == 0) sW[4 * kk + wave] = v;
+      }
+  }
+  __syncthreads();
+
+  double* out = a.partial + ((int64_t)j * a.chunks + chunk) * a.stride;
+  for (int t = tid; t < a.stride; t += WG) {
+    double v = 0.0;
+    if (t == 0) {
+      for (int wv = 0; wv < WAVES; ++wv) v += sRed[wv][0];
+    } else if (GRAD) {
+      if (t <= D) {
+        for (int wv = 0; wv < WAVES; ++wv) v += sRed[wv][t];
+      } else if (t == D + 1) {
+        for (int d = 0; d < D; ++d)
+          for (int wv = 0; wv < WAVES; ++wv) v += sRed[wv][1 + DP + d];
+      } else if (t < 2 * D + 2) {
+        const int d = t - (D + 2);
+        for (int wv = 0; wv < WAVES; ++wv) v += sRed[wv][1 + DP + d];
+      } else {
+        v = sW[t - (2 * D + 2)];
+      }
+    }
+    out[t] = v;
+  }
+}
+
+template <int DP, int KTMAX>
+void launch_one(hipStream_t st, const EntArgs& a, double* d_table) {
+  const int K = a.ml.K;
+  const int K4 = ((K + 3) / 4) * 4;
+  hipLaunchKernelGGL((entmc_table_kernel<DP>), dim3(K), dim3(256), 0, st, a.mix, a.ml, K4, d_table);
+  const size_t lds = sizeof(double) * (size_t)K4;
+  if (a.want_grad)
+    hipLaunchKernelGGL((entmc_ws_kernel<DP, KTMAX, true>), dim3(a.chunks, K), dim3(WG), lds, st, a,
+                       (const double*)d_table);
+  else
+    hipLaunchKernelGGL((entmc_ws_kernel<DP, KTMAX, false>), dim3(a.chunks, K), dim3(WG), lds, st, a,
+                       (const double*)d_table);
+}
+
+}  // namespace
+
+#define VBMC_CAT2(a, b) a##b
+#define VBMC_CAT(a, b) VBMC_CAT2(a, b)
+
+// one exported launcher per padded D; picks the smallest register-array size that holds KT.
+// d_table must hold K * 4*ceil(K/4) * (DP+6) doubles.
+void VBMC_CAT(launch_entmc_ws_dp, VBMC_DP)(hipStream_t st, const EntArgs& a, double* d_table) {
+  const int KT = (a.ml.K + 3) / 4;
+  if (KT <= 8) launch_one<VBMC_DP, 8>(st, a, d_table);
+  else if (KT <= 13) launch_one<VBMC_DP, 13>(st, a, d_table);
+  else if (KT <= 16) launch_one<VBMC_DP, 16>(st, a, d_table);
+  else if (KT <= 25) launch_one<VBMC_DP, 25>(st, a, d_table);
+  else launch_one<VBMC_DP, 32>(st, a, d_table);
+}

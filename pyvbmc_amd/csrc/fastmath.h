@@ -1,0 +1,98 @@
+// float64 elementary functions tailored to the entropy kernels (gfx950).
+//
+// The Monte-Carlo entropy spends most of its issue slots in exp(): ocml's exp() costs
+// ~110 cycles per wave (tools/ubench_fp64.hip), log() ~370.  These versions drop the
+// generality the kernels do not need (no NaN/Inf plumbing, known argument ranges) and
+// keep full double accuracy (<= 1-2 ulp; coefficients from tools/fit_polys.py, a
+// high-precision Chebyshev-node fit).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fm {
+
+// 2^x for x <= ~1000 (finite); large negative x underflows smoothly to 0.
+// rint + exact remainder + degree-11 polynomial on [-1/2,1/2] + v_ldexp_f64.
+__device__ __forceinline__ double exp2_fast(double x) {
+  x = fmax(x, -1100.0);
+  const double t = __builtin_rint(x);
+  const double f = x - t;  // exact, |f| <= 1/2
+  const int n = (int)t;
+  double p = 0x1.e9ec1fcb69a7fp-32;
+  p = fma(p, f, 0x1.e6228acd1c6e5p-28);
+  p = fma(p, f, 0x1.b524ebd13a55fp-24);
+  p = fma(p, f, 0x1.62bfc2c86d700p-20);
+  p = fma(p, f, 0x1.ffcbfc6da6ed1p-17);
+  p = fma(p, f, 0x1.430913112c61bp-13);
+  p = fma(p, f, 0x1.5d87fe78a3f9cp-10);
+  p = fma(p, f, 0x1.3b2ab6fb9f1a5p-7);
+  p = fma(p, f, 0x1.c6b08d704a0c6p-5);
+  p = fma(p, f, 0x1.ebfbdff82c5aep-3);
+  p = fma(p, f, 0x1.62e42fefa39efp-1);
+  p = fma(p, f, 1.0);
+  return __builtin_amdgcn_ldexp(p, n);
+}
+
+// 1/x to ~1 ulp: v_rcp_f64 + two Newton steps.
+__device__ __forceinline__ double rcp_fast(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// ln(x) for finite x > 0 (normal or subnormal); x == 0 -> -inf.
+// x = 2^e m, m in [sqrt(1/2), sqrt(2)); ln m = 2 atanh(s), s = (m-1)/(m+1).
+__device__ __forceinline__ double log_fast(double x) {
+  if (x == 0.0) return -INFINITY;
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool lo = m < 0x1.6a09e667f3bcdp-1;  // sqrt(1/2)
+  m = lo ? 2.0 * m : m;
+  e = lo ? e - 1 : e;
+  const double den = m + 1.0, num = m - 1.0;
+  const double r = rcp_fast(den);
+  double s = num * r;
+  s = fma(fma(-s, den, num), r, s);  // one correction step of the quotient
+  const double u = s * s;
+  double p = 0x1.0f9b9e3c7c9f8p-4;
+  p = fma(p, u, 0x1.0f55accc791adp-4);
+  p = fma(p, u, 0x1.3b2109cc7b988p-4);
+  p = fma(p, u, 0x1.745cdb9f0b4c8p-4);
+  p = fma(p, u, 0x1.c71c726358ec5p-4);
+  p = fma(p, u, 0x1.249249241f857p-3);
+  p = fma(p, u, 0x1.9999999999ee0p-3);
+  p = fma(p, u, 0x1.5555555555555p-2);
+  // ln m = 2 s (1 + u p)
+  const double lm = fma(2.0 * s * u, p, 2.0 * s);
+  const double ed = (double)e;
+  return fma(ed, 0x1.62e42fefa39efp-1, fma(ed, 0x1.abc9e3b39803fp-56, lm));  // e ln2 (hi+lo)
+}
+
+// sin(pi y), cos(pi y) for y in [0, 2).
+__device__ __forceinline__ void sincospi_fast(double y, double& s, double& c) {
+  const double k = __builtin_rint(2.0 * y);  // 0..4
+  const double r = fma(-0.5, k, y);          // [-1/4, 1/4], exact
+  const double u = r * r;
+  double ps = 0x1.e3f38399551bfp-12;
+  ps = fma(ps, u, -0x1.e30071afc3e59p-8);
+  ps = fma(ps, u, 0x1.50782fda12d96p-4);
+  ps = fma(ps, u, -0x1.32d2cce2e5b19p-1);
+  ps = fma(ps, u, 0x1.466bc677587f8p+1);
+  ps = fma(ps, u, -0x1.4abbce625be41p+2);
+  ps = fma(ps, u, 0x1.921fb54442d18p+1);
+  ps *= r;
+  double pc = 0x1.f3dbcea61b1a4p-10;
+  pc = fma(pc, u, -0x1.a6c9c1be9eb49p-6);
+  pc = fma(pc, u, 0x1.e1f4fb60281f6p-3);
+  pc = fma(pc, u, -0x1.55d3c7dbfd139p+0);
+  pc = fma(pc, u, 0x1.03c1f081b0780p+2);
+  pc = fma(pc, u, -0x1.3bd3cc9be458bp+2);
+  pc = fma(pc, u, 1.0);
+  const int q = (int)k & 3;
+  const double ss = (q & 1) ? pc : ps;
+  const double cc = (q & 1) ? ps : pc;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
+}
+
+}  // namespace fm

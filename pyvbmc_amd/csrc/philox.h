@@ -14,6 +14,8 @@
 
 #include <cstdint>
 
+#include "fastmath.h"
+
 struct Philox4 {
   uint32_t x[4];
 };
@@ -46,9 +48,9 @@ __device__ inline void philox_normal_pair(uint64_t row, uint32_t pair, uint64_t 
   uint64_t b = (((uint64_t)r.x[2] << 32) | r.x[3]) >> 11;
   double u1 = (double)(a + 1) * 0x1.0p-53;
   double u2 = (double)b * 0x1.0p-53;
-  double rad = sqrt(-2.0 * log(u1));
+  double rad = sqrt(-2.0 * fm::log_fast(u1));
   double s, c;
-  sincospi(2.0 * u2, &s, &c);
+  fm::sincospi_fast(2.0 * u2, s, c);
   z0 = rad * c;
   z1 = rad * s;
 }
