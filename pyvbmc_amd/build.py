@@ -17,6 +17,7 @@ LIB = HERE / "libvbmc_hip.so"
 SOURCES = [
     "ctx.hip",
     "entropy.hip",
+    "prep.hip",
     "api_entropy.hip",
     "mixture.hip",
     "gp.hip",

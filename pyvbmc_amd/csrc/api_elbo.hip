@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "entropy_args.h"
 
 // _soft_bound_loss (:645-657)
 static double soft_bound_loss(const std::vector<double>& x, const double* lb, const double* ub,
@@ -74,35 +75,52 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
       return vbmc_fail(ctx, VBMC_E_ARG, "neg_elcbo: resident eps does not match the request");
   }
 
-  // d_out: [gp res | raw entropy]; the entmc launcher uses d_scratch for its partials
-  rc = ensure_dev(ctx, &ctx->d_out, &ctx->d_out_cap, n_res + (size_t)n_raw);
-  if (rc) return rc;
+  // Results land in pinned host memory: the GP sums are written there directly by the
+  // prep kernel and, on one GPU, so is the raw entropy vector by the finish kernel (no
+  // D2H copy).  With a communicator the raw vector goes through device memory for the
+  // all-reduce and is copied back afterwards.
   rc = ensure_pinned(ctx, n_res + (size_t)n_raw);
   if (rc) return rc;
-  double* d_res = ctx->d_out;
-  double* d_raw = ctx->d_out + n_res;
+  double* hp_dev = nullptr;  // device-side address of the pinned block
+  HIP_TRY(ctx, hipHostGetDevicePointer((void**)&hp_dev, ctx->h_pinned, 0));
+  double* res_out = hp_dev;
+  double* raw_host = hp_dev + n_res;
+  const bool multi = ctx->comm != nullptr && ctx->world > 1;
+  double* raw_out = raw_host;
+  if (multi && mc) {
+    rc = ensure_dev(ctx, &ctx->d_out, &ctx->d_out_cap, (size_t)n_raw);
+    if (rc) return rc;
+    raw_out = ctx->d_out;
+  }
 
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[8], ctx->stream));
-  rc = launch_gp_log_joint(ctx, grad_flags != 0, d_res, nullptr);
+  PrepArgs pa;
+  glj_fill_prep(ctx, grad_flags != 0, res_out, nullptr, pa);
+  EntPlan plan;
+  if (mc) {
+    rc = entmc_plan(ctx, opts->ns_per_comp, opts->eps_mode, opts->seed, row_begin, row_count,
+                    grad_flags != 0, plan);
+    if (rc) return rc;
+    entmc_fill_prep(ctx, plan, pa);
+  }
+  rc = launch_prep(ctx, pa);  // GP sums + (j,k) table rows, one launch
   if (rc) return rc;
   if (mc) {
-    rc = launch_entmc(ctx, opts->ns_per_comp, opts->eps_mode, opts->seed, row_begin, row_count,
-                      grad_flags != 0, d_raw);
+    rc = entmc_launch_main(ctx, plan);
     if (rc) return rc;
-    if (ctx->comm) {
-      rc = comm_allreduce_sum(ctx, d_raw, n_raw);
+    rc = entmc_launch_finish(ctx, plan, raw_out);
+    if (rc) return rc;
+    if (multi) {
+      rc = comm_allreduce_sum(ctx, raw_out, n_raw);
       if (rc) return rc;
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned + n_res, raw_out, sizeof(double) * n_raw,
+                                  hipMemcpyDeviceToHost, ctx->stream));
     }
   } else if (lb_dev) {
-    rc = launch_entlb(ctx, d_raw);
+    rc = launch_entlb(ctx, raw_host);
     if (rc) return rc;
   }
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[9], ctx->stream));
-  ctx->ev_valid[4] = true;
-  const size_t n_copy = n_res + ((mc || lb_dev) ? (size_t)n_raw : 0);
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_out, sizeof(double) * n_copy,
-                              hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->pack_in_flight = false;
 
   // ---- host finalisation ---------------------------------------------------
   GljHost o;

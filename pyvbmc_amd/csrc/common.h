@@ -75,7 +75,6 @@ struct vbmc_ctx {
   MixLayout ml;
   double* d_mix = nullptr;
   size_t d_mix_cap = 0;
-  std::vector<double> h_mixpack;
 
   // resident antithetic half draws: [K][eps_rows][D]
   double* d_eps = nullptr;
@@ -88,8 +87,13 @@ struct vbmc_ctx {
   size_t d_scratch_cap = 0;
   double* d_out = nullptr;  // small result vectors
   size_t d_out_cap = 0;
-  double* h_pinned = nullptr;  // pinned host staging for results
+  double* h_pinned = nullptr;  // pinned host staging for results (also written directly by kernels)
   size_t h_pinned_cap = 0;
+  double* h_pack = nullptr;    // pinned source of the mixture pack upload
+  size_t h_pack_cap = 0;
+  hipEvent_t pack_ev = nullptr;  // completion of the last mixture-pack upload
+  bool pack_in_flight = false;
+  bool timing = true;          // record the HIP event pair around the dominant kernel
 
   GpState gp;
 
@@ -127,6 +131,33 @@ int ensure_pinned(vbmc_ctx* ctx, size_t n_doubles);
 
 // raw-vector length of the entropy accumulator
 static inline int raw_len(int D, int K) { return 1 + D * K + 2 * K + D; }
+
+// arguments of the prep launch (prep.hip): table rows for the wave-split entropy kernel
+// and/or the GP expected-log-joint sums
+struct PrepArgs {
+  const double* mix = nullptr;
+  MixLayout ml;
+  // table part (n_table = K blocks, or 0)
+  int n_table = 0, DP = 0, K4 = 0;
+  double* table = nullptr;
+  // GP part (n_glj = S*K blocks, or 0)
+  int n_glj = 0, N = 0, P = 0, want_grad = 0;
+  const double* X = nullptr;
+  const double* alpha = nullptr;
+  const double* hyp = nullptr;
+  double* res = nullptr;  // [S][K][1+2D]  (device or device-visible pinned host memory)
+  double* Z = nullptr;    // optional [S][K][N]
+};
+int launch_prep(vbmc_ctx* ctx, const PrepArgs& a);
+
+// staged launch of the Monte-Carlo entropy (entropy.hip)
+struct EntPlan;
+int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, int64_t row_begin,
+               int64_t row_count, int want_grad, EntPlan& p);
+void entmc_fill_prep(const vbmc_ctx* ctx, const EntPlan& p, PrepArgs& a);
+int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p);
+int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out);
+void glj_fill_prep(const vbmc_ctx* ctx, int want_grad, double* res, double* Z, PrepArgs& a);
 
 // kernels' host launchers (one per .hip file) -------------------------------
 // entropy

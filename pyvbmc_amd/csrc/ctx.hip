@@ -91,6 +91,7 @@ int vbmc_ctx_create(int device_id, vbmc_ctx** out) {
   if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_id);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   for (int i = 0; i < 10 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pack_ev, hipEventDisableTiming);
   if (e != hipSuccess) {
     int rc = vbmc_fail(nullptr, VBMC_E_HIP, "context setup failed: %s", hipGetErrorString(e));
     delete ctx;
@@ -120,8 +121,10 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   for (double* b : bufs)
     if (b) (void)hipFree(b);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
   for (int i = 0; i < 10; ++i)
     if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  if (ctx->pack_ev) (void)hipEventDestroy(ctx->pack_ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -170,8 +173,22 @@ static int upload_mixture(vbmc_ctx* ctx) {
   ctx->ml.plan(D, K);
   const MixLayout& ml = ctx->ml;
   if (ctx->device < 0) return 0;  // host-only context keeps just the host copies
-  ctx->h_mixpack.assign((size_t)ml.total, 0.0);
-  double* p = ctx->h_mixpack.data();
+  if (ctx->h_pack_cap < (size_t)ml.total) {
+    if (ctx->h_pack) {
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      HIP_TRY(ctx, hipHostFree(ctx->h_pack));
+      ctx->h_pack = nullptr;
+    }
+    const size_t want = (size_t)ml.total * 2 + 64;
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_pack, want * sizeof(double), hipHostMallocDefault));
+    ctx->h_pack_cap = want;
+  }
+  if (ctx->pack_in_flight) {
+    // the pinned pack may still be the source of the previous asynchronous upload
+    HIP_TRY(ctx, hipEventSynchronize(ctx->pack_ev));
+    ctx->pack_in_flight = false;
+  }
+  double* p = ctx->h_pack;
   double prod_lam = 1.0;
   for (int d = 0; d < D; ++d) prod_lam *= ctx->lambd[d];
   // nconst = 1 / (2 pi)^(D/2) / prod(lambda)   (entmc_vbmc.py:54-56)
@@ -196,10 +213,11 @@ static int upload_mixture(vbmc_ctx* ctx) {
   }
   int rc = ensure_dev(ctx, &ctx->d_mix, &ctx->d_mix_cap, (size_t)ml.total);
   if (rc) return rc;
-  // pageable source: hipMemcpyAsync from pageable memory stages synchronously,
-  // so h_mixpack may be rewritten right after this returns.
+  // pinned source: a true asynchronous copy (pack_ev guards the buffer's reuse)
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mix, p, sizeof(double) * ml.total, hipMemcpyHostToDevice,
                               ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->pack_ev, ctx->stream));
+  ctx->pack_in_flight = true;
   return 0;
 }
 

@@ -189,33 +189,17 @@ __global__ __launch_bounds__(WG) void entmc_valu_kernel(EntArgs a) {
   }
 }
 
-// Level-1 reduce: block j sums its chunk rows in chunk order.
-__global__ __launch_bounds__(256) void entmc_reduce_chunks(const double* __restrict__ partial,
-                                                           int chunks, int stride,
-                                                           double* __restrict__ perj) {
-  const int j = blockIdx.x;
-  for (int t = threadIdx.x; t < stride; t += blockDim.x) {
-    const double* p = partial + (int64_t)j * chunks * stride + t;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int c = 0;
-    for (; c + 3 < chunks; c += 4) {
-      s0 += p[(int64_t)(c + 0) * stride];
-      s1 += p[(int64_t)(c + 1) * stride];
-      s2 += p[(int64_t)(c + 2) * stride];
-      s3 += p[(int64_t)(c + 3) * stride];
-    }
-    for (; c < chunks; ++c) s0 += p[(int64_t)c * stride];
-    perj[(int64_t)j * stride + t] = (s0 + s1) + (s2 + s3);
-  }
-}
-
-// Level-2: combine the per-component rows into the raw accumulator vector
+// Finish: reduce the per-workgroup partial rows in a fixed order (bit-reproducible) and
+// combine them into the raw accumulator vector
+//     [H | mu (K blocks of D) | sigma (K) | lambda (D) | w (K)]
 // (entmc_vbmc.py:80,98,102-112 with the 1/Ns and w_j factors applied).
-// One wave per output element; lanes run over the components j it sums.
-__global__ __launch_bounds__(256) void entmc_combine(const double* __restrict__ perj,
-                                                     const double* __restrict__ mix, MixLayout ml,
-                                                     int stride, double inv_ns, int want_grad,
-                                                     double* __restrict__ raw) {
+// One wave per output element; lanes run over the (component j, chunk c) rows it sums.
+// `raw` may be device memory or device-visible pinned host memory.
+__global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restrict__ partial,
+                                                           int chunks, int stride,
+                                                           const double* __restrict__ mix,
+                                                           MixLayout ml, double inv_ns,
+                                                           int want_grad, double* __restrict__ raw) {
   const int D = ml.D, K = ml.K;
   const double* w = mix + ml.o_w;
   const double* sig = mix + ml.o_sig;
@@ -226,24 +210,31 @@ __global__ __launch_bounds__(256) void entmc_combine(const double* __restrict__ 
   if (t >= n) return;
   double v = 0.0;
   if (t == 0) {
-    for (int j = lane; j < K; j += 64) v -= w[j] * perj[(int64_t)j * stride];
+    for (int i = lane; i < K * chunks; i += 64) v -= w[i / chunks] * partial[(int64_t)i * stride];
     v = wave_sum(v) * inv_ns;
   } else if (want_grad) {
     int u = t - 1;
     if (u < D * K) {
       const int j = u / D, d = u - j * D;
-      v = w[j] * inv_ns * perj[(int64_t)j * stride + 1 + d] * ilam[d];
+      for (int c = lane; c < chunks; c += 64) v += partial[((int64_t)j * chunks + c) * stride + 1 + d];
+      v = wave_sum(v) * w[j] * inv_ns * ilam[d];
     } else if ((u -= D * K) < K) {
-      v = w[u] * inv_ns * perj[(int64_t)u * stride + 1 + D];
+      for (int c = lane; c < chunks; c += 64) v += partial[((int64_t)u * chunks + c) * stride + 1 + D];
+      v = wave_sum(v) * w[u] * inv_ns;
     } else if ((u -= K) < D) {
-      for (int j = lane; j < K; j += 64) v += w[j] * sig[j] * perj[(int64_t)j * stride + 2 + D + u];
+      for (int i = lane; i < K * chunks; i += 64) {
+        const int j = i / chunks;
+        v += w[j] * sig[j] * partial[(int64_t)i * stride + 2 + D + u];
+      }
       v = wave_sum(v) * inv_ns * ilam[u];
     } else {
       u -= D;
-      double s = 0.0;
-      for (int j = lane; j < K; j += 64) s += w[j] * perj[(int64_t)j * stride + 2 + 2 * D + u];
+      double s = 0.0, sl = 0.0;
+      for (int i = lane; i < K * chunks; i += 64) s += w[i / chunks] * partial[(int64_t)i * stride + 2 + 2 * D + u];
+      for (int c = lane; c < chunks; c += 64) sl += partial[((int64_t)u * chunks + c) * stride];
       s = wave_sum(s);
-      v = -inv_ns * (perj[(int64_t)u * stride] + s);
+      sl = wave_sum(sl);
+      v = -inv_ns * (sl + s);
     }
   }
   if (lane == 0) raw[t] = v;
@@ -372,12 +363,13 @@ static int padded_d(int D) {
   return -1;
 }
 
-int launch_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed,
-                 int64_t row_begin, int64_t row_count, int want_grad, double* d_raw) {
+// Decide the launch geometry and carve the scratch buffer.
+int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, int64_t row_begin,
+               int64_t row_count, int want_grad, EntPlan& p) {
   const int D = ctx->D, K = ctx->K;
-  const int DP = padded_d(D);
-  if (DP < 0) return vbmc_fail(ctx, VBMC_E_UNSUP, "entmc: D=%d > 32 not supported", D);
-  EntArgs a;
+  p.DP = padded_d(D);
+  if (p.DP < 0) return vbmc_fail(ctx, VBMC_E_UNSUP, "entmc: D=%d > 32 not supported", D);
+  EntArgs& a = p.a;
   a.mix = ctx->d_mix;
   a.ml = ctx->ml;
   a.eps = ctx->d_eps;
@@ -388,11 +380,12 @@ int launch_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed
   a.seed = seed;
   a.eps_mode = eps_mode;
   a.want_grad = want_grad;
-  const bool ws = use_ws_kernel(D, K);
+  p.ws = use_ws_kernel(D, K);
+  p.inv_ns = 1.0 / (double)ns_per_comp;
   int rows_per_wg = WG;
   a.rg = 1;
   size_t n_table = 0;
-  if (ws) {
+  if (p.ws) {
     // 64*rg rows per workgroup.  Two workgroups are resident per CU (2 waves/SIMD): size
     // the grid to about one full round of 2*CUs workgroups, which also amortises the
     // end-of-workgroup reductions over many batches.
@@ -403,29 +396,41 @@ int launch_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed
     if (rg > 16) rg = 16;
     a.rg = (int)rg;
     rows_per_wg = 64 * a.rg;
-    n_table = (size_t)K * (size_t)(((K + 3) / 4) * 4) * (size_t)(DP + 6);
+    n_table = (size_t)K * (size_t)(((K + 3) / 4) * 4) * (size_t)(p.DP + 6);
   }
   a.chunks = (int)((row_count + rows_per_wg - 1) / rows_per_wg);
   if (a.chunks < 1) a.chunks = 1;
   a.stride = 2 + 2 * D + K;
-  const size_t n_part = (size_t)K * a.chunks * a.stride, n_perj = (size_t)K * a.stride;
-  int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, n_part + n_perj + n_table);
+  const size_t n_part = (size_t)K * a.chunks * a.stride;
+  int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, n_part + n_table);
   if (rc) return rc;
   a.partial = ctx->d_scratch;
-  double* perj = ctx->d_scratch + n_part;
-  double* table = perj + n_perj;
+  p.table = p.ws ? ctx->d_scratch + n_part : nullptr;
+  return 0;
+}
 
-  if (ws) {
-    // (the table kernel is launched by the per-DP launcher, in front of the timed main kernel)
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    switch (DP) {
-#define VBMC_CASE_WS(dp) case dp: launch_entmc_ws_dp##dp(ctx->stream, a, table); break;
+void entmc_fill_prep(const vbmc_ctx* ctx, const EntPlan& p, PrepArgs& a) {
+  a.mix = ctx->d_mix;
+  a.ml = ctx->ml;
+  if (p.ws) {
+    a.n_table = ctx->K;
+    a.DP = p.DP;
+    a.K4 = ((ctx->K + 3) / 4) * 4;
+    a.table = p.table;
+  }
+}
+
+int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p) {
+  const EntArgs& a = p.a;
+  if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  if (p.ws) {
+    switch (p.DP) {
+#define VBMC_CASE_WS(dp) case dp: launch_entmc_ws_dp##dp(ctx->stream, a, p.table); break;
       VBMC_WS_DPS(VBMC_CASE_WS)
 #undef VBMC_CASE_WS
     }
   } else {
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    switch (DP) {
+    switch (p.DP) {
       case 2: launch_entmc_dp<2>(ctx, a); break;
       case 4: launch_entmc_dp<4>(ctx, a); break;
       case 6: launch_entmc_dp<6>(ctx, a); break;
@@ -438,17 +443,36 @@ int launch_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed
       default: launch_entmc_dp<32>(ctx, a); break;
     }
   }
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-  ctx->ev_valid[0] = true;
-  HIP_TRY(ctx, hipGetLastError());
-
-  hipLaunchKernelGGL(entmc_reduce_chunks, dim3(K), dim3(256), 0, ctx->stream, a.partial, a.chunks,
-                     a.stride, perj);
-  const int n_out = raw_len(D, K);
-  hipLaunchKernelGGL(entmc_combine, dim3((n_out + 3) / 4), dim3(256), 0, ctx->stream, perj,
-                     ctx->d_mix, ctx->ml, a.stride, 1.0 / (double)ns_per_comp, want_grad, d_raw);
+  if (ctx->timing) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    ctx->ev_valid[0] = true;
+  }
   HIP_TRY(ctx, hipGetLastError());
   return 0;
+}
+
+int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out) {
+  const int n_out = raw_len(ctx->D, ctx->K);
+  hipLaunchKernelGGL(entmc_finish_kernel, dim3((n_out + 3) / 4), dim3(256), 0, ctx->stream,
+                     p.a.partial, p.a.chunks, p.a.stride, ctx->d_mix, ctx->ml, p.inv_ns,
+                     p.a.want_grad, raw_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+// Stand-alone entropy: prep (table only) -> main -> finish.
+int launch_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed,
+                 int64_t row_begin, int64_t row_count, int want_grad, double* d_raw) {
+  EntPlan p;
+  int rc = entmc_plan(ctx, ns_per_comp, eps_mode, seed, row_begin, row_count, want_grad, p);
+  if (rc) return rc;
+  PrepArgs pa;
+  entmc_fill_prep(ctx, p, pa);
+  rc = launch_prep(ctx, pa);
+  if (rc) return rc;
+  rc = entmc_launch_main(ctx, p);
+  if (rc) return rc;
+  return entmc_launch_finish(ctx, p, d_raw);
 }
 
 int launch_entlb(vbmc_ctx* ctx, double* d_res) {

@@ -19,9 +19,17 @@ struct EntArgs {
   int rg;              // wave-split kernel: 64-row batches per workgroup
 };
 
+struct EntPlan {
+  EntArgs a;
+  bool ws = false;
+  int DP = 0;
+  double inv_ns = 0.0;
+  double* table = nullptr;  // ws only
+};
+
 // padded-D instantiations of the wave-split kernel (entropy_ws.hip), one translation
 // unit each; d_table: K * 4*ceil(K/4) * (dp+6) doubles of scratch for the (j,k) table
 #define VBMC_WS_DPS(X) X(2) X(4) X(6) X(8) X(10) X(12) X(16) X(20) X(24) X(32)
-#define VBMC_DECL_WS(dp) void launch_entmc_ws_dp##dp(hipStream_t st, const EntArgs& a, double* d_table);
+#define VBMC_DECL_WS(dp) void launch_entmc_ws_dp##dp(hipStream_t st, const EntArgs& a, const double* d_table);
 VBMC_WS_DPS(VBMC_DECL_WS)
 #undef VBMC_DECL_WS

@@ -48,40 +48,7 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// Table row for (j,k): [Delta_jk (DP) | a | c | lrc | w | wis2 | pad]  (TS = DP+6 doubles)
-//   a = |Delta_jk|^2, c = -log2(e)/(2 sigma_k^2), lrc = log2(nconst/sigma_k^D),
-//   wis2 = w_k/sigma_k^2;  rows k >= K are padding with density exactly 0.
-template <int DP>
-__global__ __launch_bounds__(256) void entmc_table_kernel(const double* __restrict__ mix,
-                                                          MixLayout ml, int K4,
-                                                          double* __restrict__ T) {
-  constexpr int TS = DP + 6;
-  const int D = ml.D, K = ml.K;
-  const int j = blockIdx.x;
-  const double* mup = mix + ml.o_mup;
-  for (int k = threadIdx.x; k < K4; k += blockDim.x) {
-    double* row = T + ((size_t)j * K4 + k) * TS;
-    double s = 0.0;
-    for (int d = 0; d < DP; ++d) {
-      const double v = (d < D && k < K) ? (mup[j * D + d] - mup[k * D + d]) : 0.0;
-      row[d] = v;
-      s = fma(v, v, s);
-    }
-    if (k < K) {
-      const double is2 = mix[ml.o_is2 + k];
-      const double w = mix[ml.o_w + k];
-      row[DP + 0] = s;
-      row[DP + 1] = -0.5 * 0x1.71547652b82fep+0 * is2;
-      row[DP + 2] = mix[ml.o_lrc + k];
-      row[DP + 3] = w;
-      row[DP + 4] = w * is2;
-    } else {
-      row[DP + 0] = 0.0; row[DP + 1] = 0.0; row[DP + 2] = -2000.0; row[DP + 3] = 0.0; row[DP + 4] = 0.0;
-    }
-    row[DP + 5] = 0.0;
-  }
-}
-
+// The (j,k) table rows [Delta_jk (DP) | a | c | lrc | w | wis2 | pad] are written by prep.hip.
 template <int DP, int KTMAX, bool GRAD>
 __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double* __restrict__ T) {
   constexpr int TS = DP + 6;
@@ -157,7 +124,10 @@ __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double
     for (int d = 0; d < DP; ++d) Ap[d] = Am[d] = 0.0;
     // table rows are fetched one component ahead (scalar loads into SGPRs) so their
     // latency hides behind the ~75 VALU instructions of the current component
-    double cur[TS], nxt[TS];
+    double cur[TS];
+#if VBMC_WS_PREFETCH
+    double nxt[TS];
+#endif
     {
       const double* tr = Tj + (size_t)wave * TS;
 #pragma unroll
@@ -285,17 +255,16 @@ __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double
 }
 
 template <int DP, int KTMAX>
-void launch_one(hipStream_t st, const EntArgs& a, double* d_table) {
+void launch_one(hipStream_t st, const EntArgs& a, const double* d_table) {
   const int K = a.ml.K;
   const int K4 = ((K + 3) / 4) * 4;
-  hipLaunchKernelGGL((entmc_table_kernel<DP>), dim3(K), dim3(256), 0, st, a.mix, a.ml, K4, d_table);
   const size_t lds = sizeof(double) * (size_t)K4;
   if (a.want_grad)
     hipLaunchKernelGGL((entmc_ws_kernel<DP, KTMAX, true>), dim3(a.chunks, K), dim3(WG), lds, st, a,
-                       (const double*)d_table);
+                       d_table);
   else
     hipLaunchKernelGGL((entmc_ws_kernel<DP, KTMAX, false>), dim3(a.chunks, K), dim3(WG), lds, st, a,
-                       (const double*)d_table);
+                       d_table);
 }
 
 }  // namespace
@@ -305,7 +274,7 @@ void launch_one(hipStream_t st, const EntArgs& a, double* d_table) {
 
 // one exported launcher per padded D; picks the smallest register-array size that holds KT.
 // d_table must hold K * 4*ceil(K/4) * (DP+6) doubles.
-void VBMC_CAT(launch_entmc_ws_dp, VBMC_DP)(hipStream_t st, const EntArgs& a, double* d_table) {
+void VBMC_CAT(launch_entmc_ws_dp, VBMC_DP)(hipStream_t st, const EntArgs& a, const double* d_table) {
   const int KT = (a.ml.K + 3) / 4;
   if (KT <= 8) launch_one<VBMC_DP, 8>(st, a, d_table);
   else if (KT <= 13) launch_one<VBMC_DP, 13>(st, a, d_table);

@@ -22,68 +22,6 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
-// ---------------------------------------------------------------------------
-// res[(s*K+k)*(1+2D) + it]: it=0: sum_n z_n alpha_n; 1..D: sum_n delta_nd z_n alpha_n;
-// D+1..2D: sum_n delta_nd^2 z_n alpha_n   with delta_nd = (mu_dk - X_nd)/tau_dk.
-// Optionally stores z (without alpha) to Z[s][k][n] for the variance.
-__global__ __launch_bounds__(256) void gp_log_joint_kernel(
-    const double* __restrict__ mix, MixLayout ml, const double* __restrict__ X,
-    const double* __restrict__ alpha, const double* __restrict__ hyp, int N, int P, int want_grad,
-    double* __restrict__ res, double* __restrict__ Z) {
-  extern __shared__ double lds[];
-  const int D = ml.D, K = ml.K;
-  const int k = blockIdx.x, s = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double* sItau = lds;        // [D] 1/tau
-  double* sMu = sItau + D;    // [D]
-  double* sZa = sMu + D;      // [N]
-  double* sMisc = sZa + N;    // [1] lnnf
-  const double* h = hyp + (size_t)s * P;
-  const double sigk = mix[ml.o_sig + k];
-  if (tid < D) {
-    const double ell = exp(h[tid]);
-    const double lam = mix[ml.o_lam + tid];
-    const double tau = sqrt(sigk * sigk * lam * lam + ell * ell);
-    sItau[tid] = 1.0 / tau;
-    sMu[tid] = mix[ml.o_mu + k * D + tid];
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double lnnf = 2.0 * h[D];
-    for (int d = 0; d < D; ++d) lnnf += h[d] + log(sItau[d]);
-    sMisc[0] = lnnf;
-  }
-  __syncthreads();
-  const double lnnf = sMisc[0];
-  for (int n = tid; n < N; n += 256) {
-    double d2 = 0.0;
-    for (int d = 0; d < D; ++d) {
-      const double dl = (sMu[d] - X[(size_t)n * D + d]) * sItau[d];
-      d2 = fma(dl, dl, d2);
-    }
-    const double z = exp(lnnf - 0.5 * d2);
-    sZa[n] = z * alpha[(size_t)s * N + n];
-    if (Z) Z[((size_t)s * K + k) * N + n] = z;
-  }
-  __syncthreads();
-  const int items = want_grad ? 1 + 2 * D : 1;
-  for (int it = wave; it < items; it += WAVES) {
-    double acc = 0.0;
-    if (it == 0) {
-      for (int n = lane; n < N; n += 64) acc += sZa[n];
-    } else {
-      const int d = (it - 1) % D;
-      const bool sq = it > D;
-      for (int n = lane; n < N; n += 64) {
-        const double dl = (sMu[d] - X[(size_t)n * D + d]) * sItau[d];
-        acc = fma(sq ? dl * dl : dl, sZa[n], acc);
-      }
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) res[((size_t)s * K + k) * (1 + 2 * D) + it] = acc;
-  }
-}
-
 // Inverse of an upper-triangular matrix, one thread per column (back substitution);
 // run once per vbmc_set_gp.
 __global__ void trinv_upper_kernel(const double* __restrict__ L, int N, double* __restrict__ Li) {
@@ -311,17 +249,31 @@ __global__ void predict_var_finish_kernel(const double* __restrict__ part, int n
 }  // namespace
 
 // ---------------------------------------------------------------------------
-int launch_gp_log_joint(vbmc_ctx* ctx, int want_grad, double* d_res, double* d_Z) {
+void glj_fill_prep(const vbmc_ctx* ctx, int want_grad, double* res, double* Z, PrepArgs& a) {
   const GpState& g = ctx->gp;
-  const int D = ctx->D, K = ctx->K;
-  size_t lds = sizeof(double) * ((size_t)2 * D + g.N + 1);
-  if (lds > 150 * 1024) return vbmc_fail(ctx, VBMC_E_UNSUP, "gp_log_joint: N=%d too large", g.N);
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-  hipLaunchKernelGGL(gp_log_joint_kernel, dim3(K, g.S), dim3(256), lds, ctx->stream, ctx->d_mix,
-                     ctx->ml, g.d_X, g.d_alpha, g.d_hyp, g.N, g.P, want_grad, d_res, d_Z);
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-  ctx->ev_valid[1] = true;
-  HIP_TRY(ctx, hipGetLastError());
+  a.mix = ctx->d_mix;
+  a.ml = ctx->ml;
+  a.n_glj = g.S * ctx->K;
+  a.N = g.N;
+  a.P = g.P;
+  a.want_grad = want_grad;
+  a.X = g.d_X;
+  a.alpha = g.d_alpha;
+  a.hyp = g.d_hyp;
+  a.res = res;
+  a.Z = Z;
+}
+
+int launch_gp_log_joint(vbmc_ctx* ctx, int want_grad, double* d_res, double* d_Z) {
+  PrepArgs a;
+  glj_fill_prep(ctx, want_grad, d_res, d_Z, a);
+  if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+  int rc = launch_prep(ctx, a);
+  if (rc) return rc;
+  if (ctx->timing) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->ev_valid[1] = true;
+  }
   return 0;
 }
 

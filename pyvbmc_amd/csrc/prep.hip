@@ -1,0 +1,141 @@
+// "prep" launch of one ELBO evaluation: two independent small jobs share ONE grid so
+// they run side by side in front of the long entropy kernel:
+//   blocks [0, n_table)          : row j of the (j,k) constant table the wave-split
+//                                  entropy kernel reads through scalar loads (entropy_ws.hip)
+//   blocks [n_table, n_table+S*K): the GP expected-log-joint sums of component k under GP
+//                                  sample s -- reference vbmc/variational_optimization.py:1400-1465:
+//        res[(s*K+k)*(1+2D) + it],  it = 0     : sum_n z_n alpha_n
+//                                   it = 1..D  : sum_n delta_nd   z_n alpha_n
+//                                   it = D+1..2D: sum_n delta_nd^2 z_n alpha_n
+//        z_n = exp(lnnf - 1/2 sum_d delta_nd^2),  delta_nd = (mu_dk - X_nd)/tau_dk,
+//        tau_dk = sqrt(sigma_k^2 lambda_d^2 + ell_d^2);  optionally Z[s][k][n] = z_n.
+//      The host turns these into G, dG (api_gp.hip: glj_finalize).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
+  extern __shared__ double lds[];
+  const int D = a.ml.D, K = a.ml.K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  if ((int)blockIdx.x < a.n_table) {
+    // ---- table row block: T[j][k] = [Delta_jk (DP) | a | c | lrc | w | wis2 | pad] ----
+    const int j = blockIdx.x;
+    const int DP = a.DP, TS = a.DP + 6, K4 = a.K4;
+    const double* mup = a.mix + a.ml.o_mup;
+    for (int k = tid; k < K4; k += 256) {
+      double* row = a.table + ((size_t)j * K4 + k) * TS;
+      double s = 0.0;
+      for (int d = 0; d < DP; ++d) {
+        const double v = (d < D && k < K) ? (mup[j * D + d] - mup[k * D + d]) : 0.0;
+        row[d] = v;
+        s = fma(v, v, s);
+      }
+      if (k < K) {
+        const double is2 = a.mix[a.ml.o_is2 + k];
+        const double w = a.mix[a.ml.o_w + k];
+        row[DP + 0] = s;
+        row[DP + 1] = -0.5 * 0x1.71547652b82fep+0 * is2;  // -log2(e) / (2 sigma_k^2)
+        row[DP + 2] = a.mix[a.ml.o_lrc + k];
+        row[DP + 3] = w;
+        row[DP + 4] = w * is2;
+      } else {  // padding component: density exactly 0
+        row[DP + 0] = 0.0; row[DP + 1] = 0.0; row[DP + 2] = -2000.0; row[DP + 3] = 0.0; row[DP + 4] = 0.0;
+      }
+      row[DP + 5] = 0.0;
+    }
+    return;
+  }
+
+  // ---- GP expected-log-joint block (s,k) ----
+  const int b = blockIdx.x - a.n_table;
+  const int s = b / K, k = b - s * K;
+  const int N = a.N;
+  double* sItau = lds;             // [D]
+  double* sMu = sItau + D;         // [D]
+  double* sZa = sMu + D;           // [N]
+  double* sPart = sZa + N;         // [4][2D+1]
+  double* sMisc = sPart + 4 * (2 * D + 1);  // [1]
+  const double* h = a.hyp + (size_t)s * a.P;
+  const double sigk = a.mix[a.ml.o_sig + k];
+  if (tid < 64) {
+    // wave 0: 1/tau_d, mu_dk and lnnf = 2 hyp[D] + sum_d (hyp[d] - log tau_d)
+    double term = 0.0;
+    for (int d = tid; d < D; d += 64) {
+      const double ell = exp(h[d]);
+      const double lam = a.mix[a.ml.o_lam + d];
+      const double tau2 = sigk * sigk * lam * lam + ell * ell;
+      sItau[d] = rsqrt(tau2);
+      sMu[d] = a.mix[a.ml.o_mu + k * D + d];
+      term += h[d] - 0.5 * log(tau2);
+    }
+    term = wave_sum(term);
+    if (tid == 0) sMisc[0] = 2.0 * h[D] + term;
+  }
+  __syncthreads();
+  const double lnnf = sMisc[0];
+  for (int n = tid; n < N; n += 256) {
+    double d2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const double dl = (sMu[d] - a.X[(size_t)n * D + d]) * sItau[d];
+      d2 = fma(dl, dl, d2);
+    }
+    const double z = exp(lnnf - 0.5 * d2);
+    sZa[n] = z * a.alpha[(size_t)s * N + n];
+    if (a.Z) a.Z[((size_t)s * K + k) * N + n] = z;
+  }
+  __syncthreads();
+  const int items = a.want_grad ? 1 + 2 * D : 1;
+  {
+    double acc = 0.0;
+    for (int n = tid; n < N; n += 256) acc += sZa[n];
+    acc = wave_sum(acc);
+    if (lane == 0) sPart[wave * (2 * D + 1)] = acc;
+  }
+  if (a.want_grad) {
+    for (int d = 0; d < D; ++d) {
+      double au = 0.0, at = 0.0;
+      for (int n = tid; n < N; n += 256) {
+        const double dl = (sMu[d] - a.X[(size_t)n * D + d]) * sItau[d];
+        const double t = dl * sZa[n];
+        au += t;
+        at = fma(dl, t, at);
+      }
+      au = wave_sum(au);
+      at = wave_sum(at);
+      if (lane == 0) {
+        sPart[wave * (2 * D + 1) + 1 + d] = au;
+        sPart[wave * (2 * D + 1) + 1 + D + d] = at;
+      }
+    }
+  }
+  __syncthreads();
+  for (int it = tid; it < items; it += 256) {
+    const double v = (sPart[it] + sPart[(2 * D + 1) + it]) + (sPart[2 * (2 * D + 1) + it] + sPart[3 * (2 * D + 1) + it]);
+    a.res[((size_t)s * K + k) * (1 + 2 * D) + it] = v;
+  }
+}
+
+}  // namespace
+
+int launch_prep(vbmc_ctx* ctx, const PrepArgs& a) {
+  const int D = a.ml.D;
+  const int gblocks = a.n_glj;
+  const int grid = a.n_table + gblocks;
+  if (grid <= 0) return 0;
+  size_t lds = 0;
+  if (gblocks > 0) {
+    lds = sizeof(double) * ((size_t)2 * D + a.N + 4 * (2 * D + 1) + 1);
+    if (lds > 150 * 1024) return vbmc_fail(ctx, VBMC_E_UNSUP, "gp_log_joint: N=%d too large", a.N);
+  }
+  hipLaunchKernelGGL(elbo_prep_kernel, dim3(grid), dim3(256), lds, ctx->stream, a);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}

@@ -158,7 +158,10 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
     # ---- fused path: one library call ---------------------------------------------------
     theta_in = theta
     th = np.ascontiguousarray(theta, dtype=np.float64)
-    vp._upload(ctx)  # establishes (D, K) and the values of non-optimised blocks
+    # theta overwrites every optimised block; the current attributes only need to be on
+    # the device when some block is NOT optimised or the context holds another (D, K)
+    if vp.optimize_mask() != 15 or getattr(ctx, "D", None) != D or getattr(ctx, "K", None) != K:
+        vp._upload(ctx)
     upload_gp(gp, ctx)
     opts = _lib.ElboOpts()
     ns = _even_ns(Ns) if Ns > 0 else 0
