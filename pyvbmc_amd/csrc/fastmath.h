@@ -10,10 +10,11 @@
 
 namespace fm {
 
-// 2^x for x <= ~1000 (finite); large negative x underflows smoothly to 0.
+// 2^x for finite x <= ~1000; large negative x underflows smoothly to 0: v_cvt_i32_f64
+// saturates, so n = INT_MIN for x < -2^31 and v_ldexp_f64 then returns 0 (p is in
+// [0.7, 1.42]); no clamp needed.
 // rint + exact remainder + degree-11 polynomial on [-1/2,1/2] + v_ldexp_f64.
 __device__ __forceinline__ double exp2_fast(double x) {
-  x = fmax(x, -1100.0);
   const double t = __builtin_rint(x);
   const double f = x - t;  // exact, |f| <= 1/2
   const int n = (int)t;
