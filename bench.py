@@ -154,10 +154,12 @@ def main():
     ctx.comm_barrier()
     ctx.synchronize()
     kern_ms = []
+    host_us = np.zeros(5)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
         kern_ms.append(ctx.last_kernel_ms(0))  # HIP events on the ctx stream around the main kernel
+        host_us += ctx.last_host_us()
     ctx.synchronize()
     ctx.comm_barrier()
     dt = time.perf_counter() - t0
@@ -210,6 +212,8 @@ def main():
             "hbm_peak_GBs": HBM_PEAK_GBS,
         },
         "F": F,
+        "host_us_per_step": dict(zip(["pack_upload", "launch", "wait_device", "finalize", "c_total"],
+                                     (host_us / a.steps).round(2).tolist())),
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(wl, a.cpu_sample_nsk)

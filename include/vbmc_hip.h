@@ -92,6 +92,12 @@ int vbmc_synchronize(vbmc_ctx* ctx);
  *        3 = gp_predict, 4 = whole last vbmc_neg_elcbo device section. */
 int vbmc_last_kernel_ms(vbmc_ctx* ctx, int which, double* ms_out);
 
+/* Host-side wall-clock breakdown (microseconds) of the most recent vbmc_neg_elcbo:
+ * out[0] theta -> mixture + pack upload issue, out[1] kernel launches,
+ * out[2] wait for the device, out[3] host finalisation, out[4] total.
+ * Profiling aid for bench.py / DESIGN.md; no reference counterpart. */
+int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
+
 /* ---- mixture state: VariationalPosterior attributes --------------------- */
 
 /* Upload the mixture (variational_posterior.py:106-138: mu (D,K), sigma (1,K),

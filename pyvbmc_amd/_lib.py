@@ -64,6 +64,7 @@ SIGNATURES = {
     ),
     "vbmc_synchronize": (C.c_int, [_vp]),
     "vbmc_last_kernel_ms": (C.c_int, [_vp, C.c_int, _dp]),
+    "vbmc_last_host_us": (C.c_int, [_vp, _dp]),
     "vbmc_set_mixture": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "vbmc_theta_to_mixture": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "vbmc_mixture_pdf": (C.c_int, [_vp, C.c_int64, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp]),
@@ -199,6 +200,11 @@ class Context:
         v = C.c_double()
         self.check(self._lib.vbmc_last_kernel_ms(self._h, which, C.byref(v)))
         return v.value
+
+    def last_host_us(self):
+        out = np.zeros(5)
+        self.check(self._lib.vbmc_last_host_us(self._h, ptr(out)))
+        return out
 
     def set_mixture(self, mu_DK, sigma, lambd, w, eta):
         mu_DK = np.asarray(mu_DK, dtype=np.float64)

@@ -1,6 +1,7 @@
 // The fused objective: one call = one evaluation of the negative ELBO
 // (reference vbmc/variational_optimization.py:991-1235 _neg_elcbo) with a single
 // host<->device round trip.
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -37,6 +38,11 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   if (!ctx->mix_set) return vbmc_fail(ctx, VBMC_E_ARG, "neg_elcbo: mixture (D,K) not set");
   if (!ctx->gp.set) return vbmc_fail(ctx, VBMC_E_ARG, "neg_elcbo: GP not set");
   if (ctx->gp.D != ctx->D) return vbmc_fail(ctx, VBMC_E_ARG, "neg_elcbo: GP/mixture D mismatch");
+  using clk = std::chrono::steady_clock;
+  const auto t_begin = clk::now();
+  auto us_since = [](clk::time_point a) {
+    return std::chrono::duration<double, std::micro>(clk::now() - a).count();
+  };
   const int D = ctx->D, K = ctx->K;
   const int mask = opts->optimize_mask;
   const bool o_mu = mask & 1, o_sg = mask & 2, o_lm = mask & 4, o_w = mask & 8;
@@ -93,6 +99,8 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     raw_out = ctx->d_out;
   }
 
+  ctx->host_us[0] = us_since(t_begin);
+  const auto t_launch = clk::now();
   PrepArgs pa;
   glj_fill_prep(ctx, grad_flags != 0, res_out, nullptr, pa);
   EntPlan plan;
@@ -119,8 +127,12 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     rc = launch_entlb(ctx, raw_host);
     if (rc) return rc;
   }
+  ctx->host_us[1] = us_since(t_launch);
+  const auto t_wait = clk::now();
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->pack_in_flight = false;
+  ctx->host_us[2] = us_since(t_wait);
+  const auto t_fin = clk::now();
 
   // ---- host finalisation ---------------------------------------------------
   GljHost o;
@@ -232,9 +244,17 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
       }
     }
   }
+  ctx->host_us[3] = us_since(t_fin);
+  ctx->host_us[4] = us_since(t_begin);
   if (F) *F = Fv;
   if (G) *G = Gv;
   if (H) *H = Hv;
   if (dF && grad_flags) memcpy(dF, dFv.data(), sizeof(double) * n_theta);
+  return VBMC_OK;
+}
+
+extern "C" int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]) {
+  if (!ctx || !out) return VBMC_E_ARG;
+  for (int i = 0; i < 5; ++i) out[i] = ctx->host_us[i];
   return VBMC_OK;
 }

@@ -94,6 +94,7 @@ struct vbmc_ctx {
   hipEvent_t pack_ev = nullptr;  // completion of the last mixture-pack upload
   bool pack_in_flight = false;
   bool timing = true;          // record the HIP event pair around the dominant kernel
+  double host_us[5] = {0, 0, 0, 0, 0};  // see vbmc_last_host_us
 
   GpState gp;
 

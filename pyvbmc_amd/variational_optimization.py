@@ -156,65 +156,88 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
                                    separate_K, rng, seed, eps_half, ctx)
 
     # ---- fused path: one library call ---------------------------------------------------
-    theta_in = theta
-    th = np.ascontiguousarray(theta, dtype=np.float64)
     # theta overwrites every optimised block; the current attributes only need to be on
     # the device when some block is NOT optimised or the context holds another (D, K)
-    if vp.optimize_mask() != 15 or getattr(ctx, "D", None) != D or getattr(ctx, "K", None) != K:
+    mask = vp.optimize_mask()
+    if mask != 15 or getattr(ctx, "D", None) != D or getattr(ctx, "K", None) != K:
         vp._upload(ctx)
     upload_gp(gp, ctx)
-    opts = _lib.ElboOpts()
+    n_theta = np.size(theta)
+    fc = _fused_call(ctx, D, K, n_theta, theta_bnd)
+    fc.th[:] = theta
+    opts = fc.opts
     ns = _even_ns(Ns) if Ns > 0 else 0
     opts.ns_per_comp = ns
-    opts.compute_grad = int(bool(compute_grad))
-    opts.optimize_mask = vp.optimize_mask()
-    opts.row_begin, opts.row_count = 0, -1
-    opts.seed = 0
-    keep = []
+    opts.compute_grad = 1 if compute_grad else 0
+    opts.optimize_mask = mask
     if ns > 0:
         mode = DEFAULT_RNG if rng is None else rng
-        h = ns // 2
         if eps_half is not None or mode == "numpy":
             if eps_half is None:
                 eps_half = draw_eps_half(K, D, ns)
+            h = ns // 2
             r0 = h * ctx.rank // ctx.world
             r1 = h * (ctx.rank + 1) // ctx.world
             ctx.set_eps(np.ascontiguousarray(eps_half, dtype=np.float64), r0, r1 - r0)
-            opts.eps_mode = _lib.EPS_RESIDENT
+            opts.eps_mode, opts.seed = _lib.EPS_RESIDENT, 0
         elif mode == "philox":
             if seed is None:
                 seed = int(np.random.randint(0, 2**63 - 1, dtype=np.int64))
             opts.eps_mode, opts.seed = _lib.EPS_PHILOX, seed
         else:
             raise ValueError(f"unknown rng {mode!r}")
-    if theta_bnd is not None:
-        lb, ub = _lib.f64(theta_bnd["lb"].ravel()), _lib.f64(theta_bnd["ub"].ravel())
-        keep += [lb, ub]
-        opts.bnd_lb, opts.bnd_ub, opts.n_bnd = _lib.ptr(lb), _lib.ptr(ub), lb.size
-        opts.tol_con = float(theta_bnd["tol_con"])
-        opts.weight_threshold = float(theta_bnd.get("weight_threshold", 0.0))
-        opts.weight_penalty = float(theta_bnd.get("weight_penalty", 0.0))
-    F, G, H = C.c_double(), C.c_double(), C.c_double()
-    dF = np.empty(th.size) if compute_grad else None
-    mu = np.empty((K, D))
-    sg, lm, w, eta = np.empty(K), np.empty(D), np.empty(K), np.empty(K)
-    ctx.check(
-        ctx._lib.vbmc_neg_elcbo(
-            ctx._h, _lib.ptr(th), th.size, C.byref(opts), C.byref(F), _lib.ptr(dF), C.byref(G),
-            C.byref(H), _lib.ptr(mu), _lib.ptr(sg), _lib.ptr(lm), _lib.ptr(w), _lib.ptr(eta),
-        )
-    )
+    rc = fc.fn(*fc.args)
+    if rc != 0:
+        ctx.check(rc)
     # mirror the reference's side effects on vp and on the caller's theta
-    vp.mu = mu.T.copy()
-    vp.sigma = sg.reshape(1, -1)
-    vp.lambd = lm.reshape(-1, 1)
-    vp.w = w.reshape(1, -1)
+    vp.mu = fc.mu.T.copy()
+    vp.sigma = fc.sg.reshape(1, -1).copy()
+    vp.lambd = fc.lm.reshape(-1, 1).copy()
+    vp.w = fc.w.reshape(1, -1).copy()
     if vp.optimize_weights:
-        vp.eta = eta.reshape(1, -1)
-        if isinstance(theta_in, np.ndarray) and theta_in.dtype == np.float64:
-            theta_in[-K:] = th[-K:]
+        vp.eta = fc.eta.reshape(1, -1).copy()
+        if isinstance(theta, np.ndarray) and theta.dtype == np.float64:
+            theta[-K:] = fc.th[-K:]
     vp._mode = None
-    return F.value, dF, G.value, H.value, 0
+    return fc.F.value, (fc.dF.copy() if compute_grad else None), fc.G.value, fc.H.value, 0
+
+
+class _FusedCall:
+    """Pre-built argument block of vbmc_neg_elcbo for one (ctx, D, K, theta_bnd): the
+    ctypes pointers of the persistent buffers are created once, not per evaluation."""
+
+    def __init__(self, ctx, D, K, n_theta, theta_bnd):
+        self.th = np.empty(n_theta)
+        self.dF = np.empty(n_theta)
+        self.mu = np.empty((K, D))
+        self.sg, self.lm, self.w, self.eta = np.empty(K), np.empty(D), np.empty(K), np.empty(K)
+        self.F, self.G, self.H = C.c_double(), C.c_double(), C.c_double()
+        o = self.opts = _lib.ElboOpts()
+        o.row_begin, o.row_count, o.seed = 0, -1, 0
+        self.bnd = theta_bnd
+        if theta_bnd is not None:
+            self.lb, self.ub = _lib.f64(theta_bnd["lb"].ravel()), _lib.f64(theta_bnd["ub"].ravel())
+            o.bnd_lb, o.bnd_ub, o.n_bnd = _lib.ptr(self.lb), _lib.ptr(self.ub), self.lb.size
+            o.tol_con = float(theta_bnd["tol_con"])
+            o.weight_threshold = float(theta_bnd.get("weight_threshold", 0.0))
+            o.weight_penalty = float(theta_bnd.get("weight_penalty", 0.0))
+        self.fn = ctx._lib.vbmc_neg_elcbo
+        self.args = (
+            ctx._h, _lib.ptr(self.th), n_theta, C.byref(o), C.byref(self.F), _lib.ptr(self.dF),
+            C.byref(self.G), C.byref(self.H), _lib.ptr(self.mu), _lib.ptr(self.sg), _lib.ptr(self.lm),
+            _lib.ptr(self.w), _lib.ptr(self.eta),
+        )
+
+
+def _fused_call(ctx, D, K, n_theta, theta_bnd):
+    cache = ctx.__dict__.setdefault("_fused_cache", {})
+    key = (D, K, n_theta, id(theta_bnd))
+    fc = cache.get(key)
+    if fc is None or fc.bnd is not theta_bnd:
+        if len(cache) > 16:
+            cache.clear()
+        fc = cache[key] = _FusedCall(ctx, D, K, n_theta, theta_bnd)
+    return fc
 
 
 def _neg_elcbo_composed(theta, gp, vp, beta, Ns, compute_grad, compute_var, theta_bnd, separate_K,
