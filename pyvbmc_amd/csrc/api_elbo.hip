@@ -2,6 +2,7 @@
 // (reference vbmc/variational_optimization.py:991-1235 _neg_elcbo) with a single
 // host<->device round trip.
 #include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 
@@ -91,7 +92,11 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   HIP_TRY(ctx, hipHostGetDevicePointer((void**)&hp_dev, ctx->h_pinned, 0));
   double* res_out = hp_dev;
   double* raw_host = hp_dev + n_res;
-  const bool multi = ctx->comm != nullptr && ctx->world > 1;
+  static const bool force_coll = [] {
+    const char* e = getenv("VBMC_FORCE_COLLECTIVE");
+    return e && e[0] == '1';
+  }();
+  const bool multi = ctx->comm != nullptr && (ctx->world > 1 || force_coll);
   double* raw_out = raw_host;
   if (multi && mc) {
     rc = ensure_dev(ctx, &ctx->d_out, &ctx->d_out_cap, (size_t)n_raw);

@@ -6,6 +6,7 @@
 // ctx stream right behind the reduce kernels and in front of the D2H copy.
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -18,7 +19,13 @@
   } while (0)
 
 int comm_allreduce_sum(vbmc_ctx* ctx, double* d_buf, int n) {
-  if (!ctx->comm || ctx->world <= 1) return 0;
+  // world == 1 normally skips the collective; VBMC_FORCE_COLLECTIVE=1 keeps it (a 1-rank
+  // all-reduce) so the RCCL call path can be exercised on a single-GPU box
+  static const bool force = [] {
+    const char* e = getenv("VBMC_FORCE_COLLECTIVE");
+    return e && e[0] == '1';
+  }();
+  if (!ctx->comm || (ctx->world <= 1 && !force)) return 0;
   NCCL_TRY(ctx, ncclAllReduce(d_buf, d_buf, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm,
                               ctx->stream));
   return 0;

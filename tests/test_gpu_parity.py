@@ -432,3 +432,46 @@ def test_full_size_config3_against_oracle(ctx):
             vals.append(entmc_vbmc(vq, NsK, (False,) * 4, True, eps_half=eps)[0])
         fd = (vals[0] - vals[1]) / (2 * hstep)
         assert abs(fd - dH[i]) <= 2e-2 * np.max(np.abs(dH[: D * K])), (i, fd, dH[i])
+
+
+def test_rccl_call_path_single_rank(golden):
+    """A 1-rank RCCL communicator with the collective forced on: exercises
+    ncclCommInitRank / ncclAllReduce(sum, f64) on the library stream and the
+    device-raw -> all-reduce -> copy-back branch of the fused objective."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from pyvbmc_amd import _lib, synthetic, VariationalPosterior
+from pyvbmc_amd import gp as gpm
+from pyvbmc_amd.variational_optimization import _neg_elcbo
+from pyvbmc_amd import entmc_vbmc
+ctx = _lib.Context(0); _lib.set_default_context(ctx)
+ctx.comm_init(_lib.comm_unique_id(), 0, 1)
+ctx.comm_barrier()
+assert ctx.comm_max(3.5) == 3.5
+wl = synthetic.make_workload(2, Ns_total=20 * 400)
+def mk():
+    vp = VariationalPosterior(wl.D, wl.K)
+    vp.mu, vp.sigma, vp.lambd = wl.mu.copy(), wl.sigma.reshape(1, -1), wl.lambd.reshape(-1, 1)
+    vp.w, vp.eta = wl.w.reshape(1, -1), wl.eta.reshape(1, -1)
+    return vp
+gp = gpm.GP(wl.D, gpm.SquaredExponential(), gpm.NegativeQuadratic(), gpm.GaussianNoise(constant_add=True))
+gp.update(X_new=wl.X, y_new=wl.y, hyp=wl.hyp)
+eps = synthetic.draw_eps_half(wl.K, wl.D, wl.NsK, 7)
+r = _neg_elcbo(wl.theta.copy(), gp, mk(), 0.0, wl.NsK, True, False, None, eps_half=eps)
+H, dH = entmc_vbmc(mk(), wl.NsK, eps_half=eps)
+print("RESULT", repr(r[0]), repr(r[3]), repr(H), repr(float(np.abs(dH).sum())))
+""" % (str(root), str(root / "tests"))
+    outs = []
+    for force in ("0", "1"):
+        env = dict(os.environ, VBMC_FORCE_COLLECTIVE=force)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0])
+    assert outs[0] == outs[1]  # a 1-rank sum is the identity: bit-identical results
