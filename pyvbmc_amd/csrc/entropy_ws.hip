@@ -28,6 +28,20 @@
 #include "common.h"
 #include "entropy_args.h"
 #include "fastmath.h"
+
+// exp2 with its 11 polynomial coefficients held in VGPRs (frees 22 SGPRs for table rows)
+__device__ __forceinline__ double exp2_vc(double x, const double (&c)[11]) {
+  const double t = __builtin_rint(x);
+  const double f = x - t;
+  const int n = (int)t;
+  double p = c[10];
+#pragma unroll
+  for (int i = 9; i >= 0; --i) p = fma(p, f, c[i]);
+  p = fma(p, f, 1.0);
+  return __builtin_amdgcn_ldexp(p, n);
+}
+__device__ const double kExp2C[11] = {0x1.62e42fefa39efp-1, 0x1.ebfbdff82c5aep-3, 0x1.c6b08d704a0c6p-5, 0x1.3b2ab6fb9f1a5p-7, 0x1.5d87fe78a3f9cp-10, 0x1.430913112c61bp-13, 0x1.ffcbfc6da6ed1p-17, 0x1.62bfc2c86d700p-20, 0x1.b524ebd13a55fp-24, 0x1.e6228acd1c6e5p-28, 0x1.e9ec1fcb69a7fp-32};
+
 #include "philox.h"
 
 #ifndef VBMC_DP
@@ -49,7 +63,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // The (j,k) table rows [Delta_jk (DP) | a | c | lrc | w | wis2 | pad] are written by prep.hip.
-template <int DP, int KTMAX, bool GRAD>
+// EXACT: ceil(K/4) == KTMAX (padding components have zero density): the per-component guards fold away.
+template <int DP, int KTMAX, bool GRAD, bool EXACT, bool PHILOX>
 __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double* __restrict__ T) {
   constexpr int TS = DP + 6;
   __shared__ double sQ[2][WAVES][2][64];          // q partials, double-buffered by batch parity
@@ -58,7 +73,7 @@ __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double
   extern __shared__ double sW[];                  // [K4]
 
   const int D = a.ml.D, K = a.ml.K;
-  const int KT = (K + 3) >> 2, K4 = KT * 4;
+  const int KT = EXACT ? KTMAX : ((K + 3) >> 2), K4 = KT * 4;
   const int j = blockIdx.y, chunk = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,6 +83,13 @@ __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double
   const double sj2 = sig_j * sig_j;
   const double* Tj = T + (size_t)j * K4 * TS;
 
+  double ec[11];
+  {
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));  // opaque per-lane zero: keeps the loads vector loads
+#pragma unroll
+    for (int i = 0; i < 11; ++i) ec[i] = kExp2C[i + vz];
+  }
   double slog_acc = 0.0;
   double mu_acc[DP], lam_acc[DP], Wacc[KTMAX];
 #pragma unroll
@@ -84,7 +106,7 @@ __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double
     double e[DP];
 #pragma unroll
     for (int d = 0; d < DP; ++d) e[d] = 0.0;
-    if (a.eps_mode == VBMC_EPS_RESIDENT) {
+    if (!PHILOX) {
       if (valid) {
         const double* rp = a.eps + ((int64_t)j * a.eps_rows + i_loc) * D;
 #pragma unroll
@@ -117,65 +139,52 @@ __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double
     for (int d = 0; d < DP; ++d) e2 = fma(e[d], e[d], e2);
     const double b = sj2 * e2;
 
-    // ---- this wave's components: densities, partial q, partial gradient sums ----
-    double qp = 0.0, qm = 0.0, gsp = 0.0, gsm = 0.0;
-    double Ap[DP], Am[DP], rp_[KTMAX], rm_[KTMAX];
-#pragma unroll
-    for (int d = 0; d < DP; ++d) Ap[d] = Am[d] = 0.0;
-    // table rows are fetched one component ahead (scalar loads into SGPRs) so their
-    // latency hides behind the ~75 VALU instructions of the current component
-    double cur[TS];
-#if VBMC_WS_PREFETCH
-    double nxt[TS];
-#endif
+    // The wave's table rows do not depend on the batch; left alone the compiler hoists all
+    // of them out of the batch loop into spilled SGPRs (hundreds of v_readlane).  An opaque
+    // zero offset ties the loads to this iteration so they stay streaming scalar loads.
+    int zoff;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zoff));
+    const double* Tw = Tj + (size_t)wave * TS + zoff;
+
+    // ---- pass 1 over this wave's components: densities (cached) and partial q ----
+    // The table row of component kk+1 is requested (scalar loads -> SGPRs) as soon as row kk
+    // has landed, so its latency hides behind the ~45 VALU instructions of component kk.
+    // Scalar loads return out of order, hence the explicit "wait, then issue" sequence.
+    double qp = 0.0, qm = 0.0;
+    double rp_[KTMAX], rm_[KTMAX];
+    constexpr int NR1 = DP + 4;  // Delta, a, c, lrc, w
+    double cur[NR1], nxt[NR1];
     {
-      const double* tr = Tj + (size_t)wave * TS;
+      const double* tr = Tw;
 #pragma unroll
-      for (int i = 0; i < TS - 1; ++i) cur[i] = tr[i];
+      for (int i = 0; i < NR1; ++i) cur[i] = tr[i];
     }
 #pragma unroll
     for (int kk = 0; kk < KTMAX; ++kk) {
-      rp_[kk] = rm_[kk] = 0.0;
-      if (kk < KT) {
-#if VBMC_WS_PREFETCH
-        if (kk + 1 < KT) {
-          const double* tn = Tj + (size_t)(4 * (kk + 1) + wave) * TS;  // wave-uniform
+      if (!EXACT) rp_[kk] = rm_[kk] = 0.0;
+      if (EXACT || kk < KT) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): row kk is in SGPRs
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 1 < KTMAX && (EXACT || kk + 1 < KT)) {
+          const double* tn = Tw + (size_t)(4 * (kk + 1)) * TS;  // wave-uniform
 #pragma unroll
-          for (int i = 0; i < TS - 1; ++i) nxt[i] = tn[i];
+          for (int i = 0; i < NR1; ++i) nxt[i] = tn[i];
         }
-#else
-        {
-          const double* tn = Tj + (size_t)(4 * kk + wave) * TS;  // wave-uniform
-#pragma unroll
-          for (int i = 0; i < TS - 1; ++i) cur[i] = tn[i];
-        }
-#endif
+        __builtin_amdgcn_sched_barrier(0);
         double c = 0.0;
 #pragma unroll
         for (int d = 0; d < DP; ++d) c = fma(cur[d], e[d], c);
         const double ab = cur[DP + 0] + b;
         const double sp = fma(two_sj, c, ab);
         const double sm = fma(-two_sj, c, ab);
-        const double rp = fm::exp2_fast(fma(cur[DP + 1], sp, cur[DP + 2]));  // norm_j1 of the reference
-        const double rm = fm::exp2_fast(fma(cur[DP + 1], sm, cur[DP + 2]));
+        const double rp = exp2_vc(fma(cur[DP + 1], sp, cur[DP + 2]), ec);  // norm_j1 of the reference
+        const double rm = exp2_vc(fma(cur[DP + 1], sm, cur[DP + 2]), ec);
         rp_[kk] = rp;
         rm_[kk] = rm;
         qp = fma(cur[DP + 3], rp, qp);
         qm = fma(cur[DP + 3], rm, qm);
-        if (GRAD) {
-          const double gp = rp * cur[DP + 4], gm = rm * cur[DP + 4];
-          gsp += gp;
-          gsm += gm;
 #pragma unroll
-          for (int d = 0; d < DP; ++d) {
-            Ap[d] = fma(gp, cur[d], Ap[d]);
-            Am[d] = fma(gm, cur[d], Am[d]);
-          }
-        }
-#if VBMC_WS_PREFETCH
-#pragma unroll
-        for (int i = 0; i < TS - 1; ++i) cur[i] = nxt[i];
-#endif
+        for (int i = 0; i < NR1; ++i) cur[i] = nxt[i];
       }
     }
     // ---- q = sum over the 4 waves ----
@@ -192,19 +201,60 @@ __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double
       slog_acc += valid ? lq : 0.0;
     }
     if (GRAD) {
+      // ---- pass 2: with 1/q known, every gradient sum is accumulated already normalised.
+      // lsum_d/q of the two samples (entmc_vbmc.py:93-106), u_dk = Delta_dk +- s e_d:
+      //   lp_d = sum_k gp_k (Delta_dk + s e_d),  lm_d = sum_k gm_k (Delta_dk - s e_d),
+      //   gp_k = w_k r+_k / (sigma_k^2 q+), gm_k likewise;
+      //   mu  += lp + lm       = sum_k (gp+gm) Delta_dk + s e_d sum_k (gp-gm)
+      //   lam += (lp - lm) e_d = e_d [ sum_k (gp-gm) Delta_dk + s e_d sum_k (gp+gm) ]
       const double ip = valid ? fm::rcp_fast(qp) : 0.0;
       const double im = valid ? fm::rcp_fast(qm) : 0.0;
+      double sgs = 0.0, sgd = 0.0;
+      double Td[DP];
 #pragma unroll
-      for (int d = 0; d < DP; ++d) {
-        const double se = sig_j * e[d];
-        const double lp = fma(se, gsp, Ap[d]) * ip;
-        const double lm = fma(-se, gsm, Am[d]) * im;
-        mu_acc[d] += lp + lm;
-        lam_acc[d] = fma(lp - lm, e[d], lam_acc[d]);
+      for (int d = 0; d < DP; ++d) Td[d] = 0.0;
+      constexpr int NR2 = DP + 5;  // Delta, (a, c, lrc, w skipped), wis2
+      double c2[NR2], n2[NR2];
+      {
+        const double* tr = Tw;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) c2[d] = tr[d];
+        c2[DP + 4] = tr[DP + 4];
       }
 #pragma unroll
-      for (int kk = 0; kk < KTMAX; ++kk)
-        if (kk < KT) Wacc[kk] = fma(rp_[kk], ip, fma(rm_[kk], im, Wacc[kk]));
+      for (int kk = 0; kk < KTMAX; ++kk) {
+        if (EXACT || kk < KT) {
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kk + 1 < KTMAX && (EXACT || kk + 1 < KT)) {
+            const double* tn = Tw + (size_t)(4 * (kk + 1)) * TS;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) n2[d] = tn[d];
+            n2[DP + 4] = tn[DP + 4];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const double t1 = rp_[kk] * ip, t2 = rm_[kk] * im;  // norm_j1 / q
+          Wacc[kk] += t1 + t2;
+          const double gp = t1 * c2[DP + 4], gm = t2 * c2[DP + 4];
+          const double gs = gp + gm, gd = gp - gm;
+          sgs += gs;
+          sgd += gd;
+#pragma unroll
+          for (int d = 0; d < DP; ++d) {
+            mu_acc[d] = fma(gs, c2[d], mu_acc[d]);
+            Td[d] = fma(gd, c2[d], Td[d]);
+          }
+#pragma unroll
+          for (int d = 0; d < DP; ++d) c2[d] = n2[d];
+          c2[DP + 4] = n2[DP + 4];
+        }
+      }
+      const double cs = sig_j * sgs, cd = sig_j * sgd;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        mu_acc[d] = fma(e[d], cd, mu_acc[d]);
+        lam_acc[d] = fma(e[d], fma(e[d], cs, Td[d]), lam_acc[d]);
+      }
     }
   }
 
@@ -225,7 +275,7 @@ __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double
     }
 #pragma unroll
     for (int kk = 0; kk < KTMAX; ++kk)
-      if (kk < KT) {
+      if (EXACT || kk < KT) {
         const double v = wave_sum(Wacc[kk]);
         if (lane == 0) sW[4 * kk + wave] = v;
       }
@@ -259,12 +309,21 @@ void launch_one(hipStream_t st, const EntArgs& a, const double* d_table) {
   const int K = a.ml.K;
   const int K4 = ((K + 3) / 4) * 4;
   const size_t lds = sizeof(double) * (size_t)K4;
-  if (a.want_grad)
-    hipLaunchKernelGGL((entmc_ws_kernel<DP, KTMAX, true>), dim3(a.chunks, K), dim3(WG), lds, st, a,
-                       d_table);
-  else
-    hipLaunchKernelGGL((entmc_ws_kernel<DP, KTMAX, false>), dim3(a.chunks, K), dim3(WG), lds, st, a,
-                       d_table);
+  // the table carries zero-density padding rows up to 4*ceil(K/4), so the guard-free
+  // variant applies whenever ceil(K/4) == KTMAX
+  const bool exact = ((K + 3) / 4 == KTMAX);
+  const bool philox = a.eps_mode == VBMC_EPS_PHILOX;
+  const dim3 grid(a.chunks, K), block(WG);
+#define VBMC_LAUNCH_WS(G, E, P) \
+  hipLaunchKernelGGL((entmc_ws_kernel<DP, KTMAX, G, E, P>), grid, block, lds, st, a, d_table)
+  if (a.want_grad) {
+    if (exact) { if (philox) VBMC_LAUNCH_WS(true, true, true); else VBMC_LAUNCH_WS(true, true, false); }
+    else       { if (philox) VBMC_LAUNCH_WS(true, false, true); else VBMC_LAUNCH_WS(true, false, false); }
+  } else {
+    if (exact) { if (philox) VBMC_LAUNCH_WS(false, true, true); else VBMC_LAUNCH_WS(false, true, false); }
+    else       { if (philox) VBMC_LAUNCH_WS(false, false, true); else VBMC_LAUNCH_WS(false, false, false); }
+  }
+#undef VBMC_LAUNCH_WS
 }
 
 }  // namespace
