@@ -40,6 +40,24 @@ __device__ __forceinline__ double exp2_vc(double x, const double (&c)[11]) {
   p = fma(p, f, 1.0);
   return __builtin_amdgcn_ldexp(p, n);
 }
+// two independent exp2 evaluations with their Horner chains interleaved step by step
+// (a dependent v_fma_f64 chain alone leaves the FP64 pipe half idle)
+__device__ __forceinline__ void exp2_vc2(double x1, double x2, const double (&c)[11], double& r1,
+                                         double& r2) {
+  const double t1 = __builtin_rint(x1), t2 = __builtin_rint(x2);
+  const double f1 = x1 - t1, f2 = x2 - t2;
+  const int n1 = (int)t1, n2 = (int)t2;
+  double p1 = c[10], p2 = c[10];
+#pragma unroll
+  for (int i = 9; i >= 0; --i) {
+    p1 = fma(p1, f1, c[i]);
+    p2 = fma(p2, f2, c[i]);
+  }
+  p1 = fma(p1, f1, 1.0);
+  p2 = fma(p2, f2, 1.0);
+  r1 = __builtin_amdgcn_ldexp(p1, n1);
+  r2 = __builtin_amdgcn_ldexp(p2, n2);
+}
 __device__ const double kExp2C[11] = {0x1.62e42fefa39efp-1, 0x1.ebfbdff82c5aep-3, 0x1.c6b08d704a0c6p-5, 0x1.3b2ab6fb9f1a5p-7, 0x1.5d87fe78a3f9cp-10, 0x1.430913112c61bp-13, 0x1.ffcbfc6da6ed1p-17, 0x1.62bfc2c86d700p-20, 0x1.b524ebd13a55fp-24, 0x1.e6228acd1c6e5p-28, 0x1.e9ec1fcb69a7fp-32};
 
 #include "philox.h"
@@ -177,8 +195,8 @@ __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double
         const double ab = cur[DP + 0] + b;
         const double sp = fma(two_sj, c, ab);
         const double sm = fma(-two_sj, c, ab);
-        const double rp = exp2_vc(fma(cur[DP + 1], sp, cur[DP + 2]), ec);  // norm_j1 of the reference
-        const double rm = exp2_vc(fma(cur[DP + 1], sm, cur[DP + 2]), ec);
+        double rp, rm;  // norm_j1 of the reference for the + and - sample
+        exp2_vc2(fma(cur[DP + 1], sp, cur[DP + 2]), fma(cur[DP + 1], sm, cur[DP + 2]), ec, rp, rm);
         rp_[kk] = rp;
         rm_[kk] = rm;
         qp = fma(cur[DP + 3], rp, qp);
