@@ -1,0 +1,155 @@
+#!/usr/bin/env python
+"""Secondary measurements: every SURVEY section-8 row other than the headline objective,
+HIP path vs the oracle (CPU, NumPy port) on the same inputs, at BASELINE config 3 shapes.
+
+    python tools/bench_rows.py [--config 3] > profiles/rNN_rows.json
+
+One JSON object per row: device time (median of repeats, wall clock around the call incl.
+host<->device copies of the boundary), CPU time of the oracle on a bounded sample (scaled
+linearly, stated), max parity error observed on the sample.
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from oracle import elbo_ref, entropy_ref, gp_ref, mixture_ref  # noqa: E402
+from pyvbmc_amd import VariationalPosterior, _lib, entlb_vbmc, entmc_vbmc, synthetic  # noqa: E402
+from pyvbmc_amd import gp as gpm  # noqa: E402
+from pyvbmc_amd.variational_optimization import _gp_log_joint, _neg_elcbo  # noqa: E402
+
+
+def med(fn, reps=7, warm=2):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), out
+
+
+def once(fn):
+    t0 = time.perf_counter()
+    out = fn()
+    return time.perf_counter() - t0, out
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=3)
+    a = ap.parse_args()
+    ctx = _lib.Context(0)
+    _lib.set_default_context(ctx)
+    wl1 = synthetic.make_workload(a.config, S=1)
+    wl8 = synthetic.make_workload(a.config, S=8)
+    D, K, N = wl1.D, wl1.K, wl1.N
+
+    def mkvp(wl):
+        vp = VariationalPosterior(D, K)
+        vp.mu, vp.sigma, vp.lambd = wl.mu.copy(), wl.sigma.reshape(1, -1), wl.lambd.reshape(-1, 1)
+        vp.w, vp.eta = wl.w.reshape(1, -1), wl.eta.reshape(1, -1)
+        return vp
+
+    def mkgp(wl):
+        g = gpm.GP(D, gpm.SquaredExponential(), gpm.NegativeQuadratic(),
+                   gpm.GaussianNoise(constant_add=True, user_provided_add=wl.s2 is not None))
+        g.update(X_new=wl.X, y_new=wl.y, s2_new=wl.s2, hyp=wl.hyp)
+        return g
+
+    mix = mixture_ref.Mixture.make(wl1.mu, wl1.sigma, wl1.lambd, wl1.w, wl1.eta)
+    rows = []
+    info = ctx.device_info()
+
+    def emit(name, ref, shape, t_dev, t_cpu, cpu_note, err, extra=None):
+        r = {"row": name, "reference": ref, "shape": shape, "device_ms": 1e3 * t_dev,
+             "cpu_oracle_ms": 1e3 * t_cpu, "cpu_note": cpu_note, "speedup": t_cpu / t_dev,
+             "parity_max_rel_err": err, "device": info["name"].strip()}
+        if extra:
+            r.update(extra)
+        rows.append(r)
+        print(json.dumps(r), flush=True)
+
+    rng = np.random.default_rng(0)
+    # ---- a3: mixture log-pdf --------------------------------------------------
+    vp = mkvp(wl1)
+    for n in (8192, 1_000_000):
+        comp = rng.integers(0, K, size=n)
+        x = wl1.mu.T[comp] + wl1.lambd * wl1.sigma[comp, None] * rng.standard_normal((n, D))
+        t, y = med(lambda: vp.pdf(x, orig_flag=False, log_flag=True), reps=5)
+        ns = min(n, 20000)
+        tc, yo = once(lambda: mixture_ref.pdf(mix, x[:ns], log_flag=True))
+        ctx.last_kernel_ms(2)
+        emit("a3 vp.pdf(log)", "variational_posterior.py:365-564", f"n={n} D={D} K={K}", t, tc * n / ns,
+             f"oracle on {ns} points, scaled", rel(y[:ns], yo),
+             {"kernel_ms": ctx.last_kernel_ms(2), "algorithmic_bytes": 8.0 * n * (D + 1)})
+    t, (y, dy) = med(lambda: vp.pdf(x[:8192], orig_flag=False, log_flag=True, grad_flag=True), reps=5)
+    tc, (yo, dyo) = once(lambda: mixture_ref.pdf(mix, x[:8192], log_flag=True, grad_flag=True))
+    emit("a3 vp.pdf(log,grad)", "variational_posterior.py:464-469,532", f"n=8192 D={D} K={K}", t, tc, "full", rel(dy, dyo))
+    # ---- a7: entlb -------------------------------------------------------------
+    t, (H, dH) = med(lambda: entlb_vbmc(mkvp(wl1)))
+    tc, (Ho, dHo) = once(lambda: entropy_ref.entlb(mix))
+    emit("a7 entlb_vbmc", "entropy/entlb_vbmc.py:6-180", f"D={D} K={K}", t, tc, "full", max(rel(H, Ho), rel(dH, dHo)))
+    # ---- a6: entmc value-only / value+grad (Philox draws) ------------------------
+    for gf, tag in (((False,) * 4, "value"), ((True,) * 4, "value+grad")):
+        vpp = mkvp(wl1)
+        t, _ = med(lambda: entmc_vbmc(vpp, wl1.NsK, gf, True, rng="philox", seed=5), reps=9)
+        nsk = 2000
+        eps = synthetic.draw_eps_half(K, D, nsk, 1)
+        tc, (Ho, dHo) = once(lambda: entropy_ref.entmc(mix, nsk, gf, True, eps_half=eps))
+        Hd, dHd = entmc_vbmc(mkvp(wl1), nsk, gf, True, eps_half=eps)
+        err = rel(Hd, Ho) if not dHo.size else max(rel(Hd, Ho), rel(dHd, dHo))
+        emit(f"a6 entmc_vbmc {tag}", "entropy/entmc_vbmc.py:6-134", f"D={D} K={K} NsK={wl1.NsK}", t,
+             tc * wl1.NsK / nsk, f"oracle at NsK={nsk}, scaled", err, {"kernel_ms": ctx.last_kernel_ms(0)})
+    # ---- a8: _gp_log_joint -------------------------------------------------------
+    for wl, tag in ((wl1, "S=1"), (wl8, "S=8")):
+        g, ogp = mkgp(wl), gp_ref.make_gp(wl.X, wl.y, wl.hyp, s2=wl.s2, noise_user=wl.s2 is not None)
+        v = mkvp(wl)
+        t, r = med(lambda: _gp_log_joint(v, g, True, True, True, False, False))
+        tc, ro = once(lambda: gp_ref.gp_log_joint(mix, ogp, True, True, True, False, False))
+        emit(f"a8 _gp_log_joint grad {tag}", "vbmc/variational_optimization.py:1238-1606", f"N={N} K={K} {tag}",
+             t, tc, "full", max(rel(r[0], ro[0]), rel(r[1], ro[1])))
+        t, r = med(lambda: _gp_log_joint(v, g, False, True, True, True, True), reps=5)
+        tc, ro = once(lambda: gp_ref.gp_log_joint(mix, ogp, False, True, True, True, True))
+        emit(f"a8 _gp_log_joint var+separate_K {tag}", "vbmc/variational_optimization.py:1473-1514",
+             f"N={N} K={K} {tag}", t, tc, "full", max(rel(np.ravel(r[2]), np.ravel(ro[2])), rel(r[6], ro[6])))
+    # ---- a12: gp.predict -----------------------------------------------------------
+    for wl, tag in ((wl1, "S=1"), (wl8, "S=8")):
+        g, ogp = mkgp(wl), gp_ref.make_gp(wl.X, wl.y, wl.hyp, s2=wl.s2, noise_user=wl.s2 is not None)
+        M = 8192
+        xs = rng.standard_normal((M, D))
+        t, (fmu, fs2) = med(lambda: g.predict(xs, separate_samples=True), reps=5)
+        ms = 1024
+        tc, (omu, os2) = once(lambda: gp_ref.predict(ogp, xs[:ms], separate_samples=True))
+        sf2 = float(np.exp(2 * wl.hyp[0, D]))
+        err = max(np.max(np.abs(fmu[:ms] - omu)) / max(1.0, np.max(np.abs(omu))), np.max(np.abs(fs2[:ms] - os2)) / max(1.0, sf2))
+        emit(f"a12 gp.predict {tag}", "gpyreg GP.predict (third party; SURVEY App. A)", f"M={M} N={N} D={D} {tag}",
+             t, tc * M / ms, f"oracle on {ms} points, scaled", float(err),
+             {"kernel_ms_first_sample": ctx.last_kernel_ms(3), "gemm_flops": 1.0 * M * N * N})
+    # ---- a9 secondary: _eval_full_elcbo call (value, variance, separate_K) -------------
+    g, ogp = mkgp(wl1), gp_ref.make_gp(wl1.X, wl1.y, wl1.hyp)
+    nsk = 4096
+    v = mkvp(wl1)
+    t, r = med(lambda: _neg_elcbo(wl1.theta.copy(), g, v, 0.0, nsk, False, True, None, 0.0, True, rng="philox", seed=3), reps=5)
+    eps = synthetic.draw_eps_half(K, D, 200, 2)
+    tc, ro = once(lambda: elbo_ref.neg_elcbo(wl1.theta.copy(), ogp, mix.copy(), 0.0, 200, False, True, None, True, eps_half=eps))
+    rd = _neg_elcbo(wl1.theta.copy(), g, mkvp(wl1), 0.0, 200, False, True, None, 0.0, True, eps_half=eps)
+    emit("a9 _neg_elcbo(value,var,separate_K)", "vbmc/variational_optimization.py:474-485", f"NsK={nsk} N={N} K={K}",
+         t, tc, "oracle at NsK=200 (variance part dominates CPU time; unscaled)", max(rel(rd[0], ro[0]), rel(rd[10], ro[10])))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
