@@ -241,99 +241,120 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
 }
 
 // ---------------------------------------------------------------------------
-// entlb: one workgroup; wave w handles rows j = w, w+WAVES, ...; lanes run over i.
-// Output layout: [H | mu (K x D) | sigma (K) | lambda (D) | w (K)] (pre-Jacobian,
-// sigma already carrying the reference's explicit sigma_j factor, entlb_vbmc.py:133).
+// entlb (entropy/entlb_vbmc.py:80-159): workgroup j owns row j of the K x K table
+//   gamma_ij = nconst / (s_i^2+s_j^2)^(D/2) exp(-1/2 |mu'_i-mu'_j|^2 / (s_i^2+s_j^2)).
+// Every workgroup first forms all gsum_i = sum_i' w_i' gamma_ii' (K^2 cheap terms, one
+// wave per row, fixed order), then the terms of its own j.  Raw output layout:
+// [H | mu (K x D) | sigma (K) | lambda (D) | w (K)] (pre-Jacobian, sigma already carrying
+// the reference's explicit sigma_j factor, entlb_vbmc.py:133); H and lambda are summed
+// over j by entlb_finish_kernel from the per-j partials in `part` ([K] | [K][D]).
+__device__ inline double entlb_gamma(const double* __restrict__ mup, const double* __restrict__ sig,
+                                     int D, int i, int j, double lnc, double& s2_out,
+                                     double& d2_out) {
+  const double s2 = sig[i] * sig[i] + sig[j] * sig[j];
+  double d2 = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const double t = mup[i * D + d] - mup[j * D + d];
+    d2 = fma(t, t, d2);
+  }
+  s2_out = s2;
+  d2_out = d2;
+  return exp(lnc - 0.5 * D * log(s2) - 0.5 * d2 / s2);
+}
+
 __global__ __launch_bounds__(256) void entlb_kernel(const double* __restrict__ mix, MixLayout ml,
-                                                    int want_grad, double* __restrict__ res) {
+                                                    int want_grad, double* __restrict__ res,
+                                                    double* __restrict__ part) {
   extern __shared__ double lds[];
   const int D = ml.D, K = ml.K;
+  const int j = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const double* mup = mix + ml.o_mup;  // mu / lambda
   const double* sig = mix + ml.o_sig;
   const double* w = mix + ml.o_w;
   const double* lam = mix + ml.o_lam;
-  double* sGsum = lds;               // [K]
-  double* sLam = sGsum + K;          // [WAVES][D]
-  double* sH = sLam + WAVES * D;     // [WAVES]
+  double* sG = lds;             // [K] gsum
+  double* sRed = sG + K;        // [WAVES][2D+2]
 
-  double nconst = 1.0;
-  for (int d = 0; d < D; ++d) nconst /= lam[d];
-  nconst *= pow(2.0 * M_PI, -0.5 * D);
+  double lnc = -0.5 * D * log(2.0 * M_PI);
+  for (int d = 0; d < D; ++d) lnc -= log(lam[d]);
 
-  // phase 1: gsum_j = sum_i w_i gamma_ij
-  for (int j = wave; j < K; j += WAVES) {
-    double acc = 0.0;
-    for (int i = lane; i < K; i += 64) {
-      const double s2 = sig[i] * sig[i] + sig[j] * sig[j];
-      double d2 = 0.0;
-      for (int d = 0; d < D; ++d) {
-        const double t = mup[i * D + d] - mup[j * D + d];
-        d2 = fma(t, t, d2);
-      }
-      const double g = nconst * pow(s2, -0.5 * D) * exp(-0.5 * d2 / s2);
-      acc += w[i] * g;
-    }
+  for (int i = wave; i < K; i += WAVES) {
+    double acc = 0.0, s2, d2;
+    for (int i2 = lane; i2 < K; i2 += 64) acc += w[i2] * entlb_gamma(mup, sig, D, i, i2, lnc, s2, d2);
     acc = wave_sum(acc);
-    if (lane == 0) sGsum[j] = acc;
+    if (lane == 0) sG[i] = acc;
   }
-  for (int t = tid; t < WAVES * D; t += 256) sLam[t] = 0.0;
   __syncthreads();
+  const double gj = sG[j];
+  if (tid == 0) part[j] = -w[j] * log(gj);
+  if (!want_grad) return;
 
-  double hacc = 0.0;
-  for (int j = wave; j < K; j += WAVES) {
-    const double gj = sGsum[j];
-    if (lane == 0) hacc -= w[j] * log(gj);
-    if (!want_grad) continue;
-    // per-lane partial sums over i for this j
-    double a_sig = 0.0, a_w = 0.0;
-    for (int d = 0; d < D; ++d) {
-      double a_mu = 0.0, a_lam = 0.0;
-      for (int i = lane; i < K; i += 64) {
-        const double s2 = sig[i] * sig[i] + sig[j] * sig[j];
-        double d2 = 0.0;
-        for (int dd = 0; dd < D; ++dd) {
-          const double t = mup[i * D + dd] - mup[j * D + dd];
-          d2 = fma(t, t, d2);
-        }
-        const double g = nconst * pow(s2, -0.5 * D) * exp(-0.5 * d2 / s2);
-        const double wg = w[i] * g;
-        const double coef = wg * (1.0 / sGsum[i] + 1.0 / gj);
-        const double t = mup[i * D + d] - mup[j * D + d];  // (mu_i - mu_j)_d / lambda_d
-        a_mu += coef * t / s2;                              // still to divide by lambda_d
-        a_lam += wg * (t * t / s2 - 1.0);
-        if (d == 0) {
-          a_sig += coef * (-(double)D / s2 + d2 / (s2 * s2));
-          a_w += wg / sGsum[i];
-        }
-      }
-      a_mu = wave_sum(a_mu);
-      a_lam = wave_sum(a_lam);
-      if (lane == 0) {
-        res[1 + j * D + d] = -w[j] * a_mu / lam[d];
-        sLam[wave * D + d] += (w[j] / gj) * a_lam;
-      }
-    }
-    a_sig = wave_sum(a_sig);
-    a_w = wave_sum(a_w);
-    if (lane == 0) {
-      res[1 + K * D + j] = -w[j] * sig[j] * a_sig;
-      res[1 + K * D + K + D + j] = -log(gj) - a_w;
-    }
-  }
-  if (lane == 0) sH[wave] = hacc;
+  // this thread's rows i (K <= 256: one) against column j
+  const int NS = 2 * D + 2;
+  for (int it = tid; it < WAVES * NS; it += 256) sRed[it] = 0.0;
   __syncthreads();
-  if (tid == 0) {
-    double h = 0.0;
-    for (int wv = 0; wv < WAVES; ++wv) h += sH[wv];
-    res[0] = h;
+  double a_sig = 0.0, a_w = 0.0;
+  for (int d = 0; d < D; ++d) {
+    double a_mu = 0.0, a_lam = 0.0;
+    for (int i = tid; i < K; i += 256) {
+      double s2, d2;
+      const double g = entlb_gamma(mup, sig, D, i, j, lnc, s2, d2);
+      const double wg = w[i] * g;
+      const double coef = wg * (1.0 / sG[i] + 1.0 / gj);
+      const double t = mup[i * D + d] - mup[j * D + d];  // (mu_i - mu_j)_d / lambda_d
+      a_mu += coef * t / s2;
+      a_lam += wg * (t * t / s2 - 1.0);
+      if (d == 0) {
+        a_sig += coef * (-(double)D / s2 + d2 / (s2 * s2));
+        a_w += wg / sG[i];
+      }
+    }
+    a_mu = wave_sum(a_mu);
+    a_lam = wave_sum(a_lam);
+    if (lane == 0) {
+      sRed[wave * NS + d] = a_mu;
+      sRed[wave * NS + D + d] = a_lam;
+    }
   }
-  if (want_grad)
-    for (int d = tid; d < D; d += 256) {
-      double s = 0.0;
-      for (int wv = 0; wv < WAVES; ++wv) s += sLam[wv * D + d];
+  a_sig = wave_sum(a_sig);
+  a_w = wave_sum(a_w);
+  if (lane == 0) {
+    sRed[wave * NS + 2 * D] = a_sig;
+    sRed[wave * NS + 2 * D + 1] = a_w;
+  }
+  __syncthreads();
+  for (int it = tid; it < NS; it += 256) {
+    const double v = (sRed[it] + sRed[NS + it]) + (sRed[2 * NS + it] + sRed[3 * NS + it]);
+    if (it < D) {
+      res[1 + j * D + it] = -w[j] * v / lam[it];
+    } else if (it < 2 * D) {
+      part[K + j * D + (it - D)] = (w[j] / gj) * v;
+    } else if (it == 2 * D) {
+      res[1 + K * D + j] = -w[j] * sig[j] * v;
+    } else {
+      res[1 + K * D + K + D + j] = -log(gj) - v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void entlb_finish_kernel(const double* __restrict__ mix,
+                                                          MixLayout ml, int want_grad,
+                                                          const double* __restrict__ part,
+                                                          double* __restrict__ res) {
+  const int D = ml.D, K = ml.K;
+  const double* lam = mix + ml.o_lam;
+  for (int t = threadIdx.x; t < 1 + D; t += 64) {
+    double s = 0.0;
+    if (t == 0) {
+      for (int j = 0; j < K; ++j) s += part[j];
+      res[0] = s;
+    } else if (want_grad) {
+      const int d = t - 1;
+      for (int j = 0; j < K; ++j) s += part[K + j * D + d];
       res[1 + K * D + K + d] = -s / lam[d];
     }
+  }
 }
 
 template <int DP>
@@ -477,9 +498,14 @@ int launch_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed
 
 int launch_entlb(vbmc_ctx* ctx, double* d_res) {
   const int D = ctx->D, K = ctx->K;
-  size_t lds = sizeof(double) * ((size_t)K + WAVES * D + WAVES);
-  hipLaunchKernelGGL(entlb_kernel, dim3(1), dim3(256), lds, ctx->stream, ctx->d_mix, ctx->ml, 1,
-                     d_res);
+  const size_t n_part = (size_t)K + (size_t)K * D;
+  int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, n_part);
+  if (rc) return rc;
+  size_t lds = sizeof(double) * ((size_t)K + WAVES * (2 * D + 2));
+  hipLaunchKernelGGL(entlb_kernel, dim3(K), dim3(256), lds, ctx->stream, ctx->d_mix, ctx->ml, 1,
+                     d_res, ctx->d_scratch);
+  hipLaunchKernelGGL(entlb_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_mix, ctx->ml, 1,
+                     ctx->d_scratch, d_res);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }

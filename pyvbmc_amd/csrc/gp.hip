@@ -165,75 +165,85 @@ __global__ __launch_bounds__(256) void predict_kstar_kernel(
   }
 }
 
-// predict, stage 2: tiled GEMM T = A (M x N) * B (N x N) with a fused row epilogue
+// predict, stage 2: T = A (M x N) * B (N x N) on the FP64 matrix cores, fused row epilogue
 //   mode 0 (L_chol): B = L^-1 upper triangular; part[ct][m] = sum_{c in tile} T[m][c]^2
 //   mode 1         : B = L (full, symmetric);   part[ct][m] = sum_{c in tile} A[m][c] T[m][c]
-// 64 x 64 output tile per block, 4 x 4 outputs per thread, 16-deep LDS panels.
-constexpr int TS = 64, TKD = 16;
-__global__ __launch_bounds__(256) void predict_var_gemm_kernel(const double* __restrict__ A,
+// v_mfma_f64_16x16x4_f64: lane l holds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15] and 4 results
+// C[row=(l>>4)+4r][col=l&15]  (cdna_hip_programming.md section 3, f64 layout).
+// Workgroup = 64 x 64 output tile, 4 waves x (2 x 2) MFMA tiles, 16-deep LDS panels:
+//   sA[64][17]  (row-major, +1 pad: the 16 rows of an A fragment hit distinct banks)
+//   sB[16][80]  (row stride = 32 banks mod 64: the 4 k-rows of a B fragment do not collide)
+// On gfx950 the FP64 MFMA peak equals the FP64 vector peak (78.6 TFLOP/s); what the
+// matrix instruction buys here is issue efficiency: 1024 FMAs per instruction and no
+// per-FMA operand traffic.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int TS = 64, TKD = 16, LDA = TKD + 1, LDB = TS + 16;
+__global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __restrict__ A,
                                                                const double* __restrict__ B,
                                                                int64_t M, int N, int mode,
                                                                double* __restrict__ part) {
-  __shared__ double sA[TKD][TS + 1];
-  __shared__ double sB[TKD][TS + 1];
-  const int tid = threadIdx.x;
-  const int tx = tid & 15, ty = tid >> 4;  // tx -> columns, ty -> rows
+  __shared__ double sA[TS * LDA];
+  __shared__ double sB[TKD * LDB];
+  __shared__ double sRow[TS][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wc = wave & 1;
+  const int li = lane & 15, lk = lane >> 4;
   const int64_t m0 = (int64_t)blockIdx.y * TS;
   const int c0 = blockIdx.x * TS;
-  double acc[4][4];
+  double4_t acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-  const int nmax = (mode == 0) ? min(N, c0 + TS) : N;  // upper-triangular: n <= c
+    for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const int nmax = (mode == 0) ? min(N, c0 + TS) : N;  // upper-triangular B: n <= c
   for (int n0 = 0; n0 < nmax; n0 += TKD) {
-    // A panel: 64 rows x 16 cols ; B panel: 16 rows x 64 cols
     for (int idx = tid; idx < TS * TKD; idx += 256) {
       const int r = idx / TKD, kk = idx - r * TKD;
       const int64_t m = m0 + r;
       const int n = n0 + kk;
-      sA[kk][r] = (m < M && n < N) ? A[(size_t)m * N + n] : 0.0;
+      sA[r * LDA + kk] = (m < M && n < N) ? A[(size_t)m * N + n] : 0.0;
       const int kb = idx / TS, cc = idx - kb * TS;
       const int nb = n0 + kb, c = c0 + cc;
-      sB[kb][cc] = (nb < N && c < N) ? B[(size_t)nb * N + c] : 0.0;
+      sB[kb * LDB + cc] = (nb < N && c < N) ? B[(size_t)nb * N + c] : 0.0;
     }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < TKD; ++kk) {
-      double a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = sA[kk][ty * 4 + i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = sB[kk][tx * 4 + j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+    for (int kq = 0; kq < TKD / 4; ++kq) {
+      const double a0 = sA[(wm * 32 + li) * LDA + kq * 4 + lk];
+      const double a1 = sA[(wm * 32 + 16 + li) * LDA + kq * 4 + lk];
+      const double b0 = sB[(kq * 4 + lk) * LDB + wc * 32 + li];
+      const double b1 = sB[(kq * 4 + lk) * LDB + wc * 32 + 16 + li];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
     __syncthreads();
   }
-  // epilogue: per-row reduction over this tile's 64 columns
-  __shared__ double sRow[TS][17];
+  // epilogue: per-row reduction over this wave's 32 columns, then over the two column waves
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    double v = 0.0;
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = c0 + tx * 4 + j;
-      const int64_t m = m0 + ty * 4 + i;
-      if (c < N && m < M) {
-        const double t = acc[i][j];
-        v += (mode == 0) ? t * t : A[(size_t)m * N + c] * t;
+    for (int r = 0; r < 4; ++r) {
+      const int row = wm * 32 + mt * 16 + lk + 4 * r;
+      const int64_t m = m0 + row;
+      double v = 0.0;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int c = c0 + wc * 32 + ct * 16 + li;
+        if (c < N && m < M) {
+          const double t = acc[mt][ct][r];
+          v += (mode == 0) ? t * t : A[(size_t)m * N + c] * t;
+        }
       }
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      if (li == 0) sRow[row][wc] = v;
     }
-    sRow[ty * 4 + i][tx] = v;
-  }
   __syncthreads();
-  if (tid < TS && m0 + tid < M) {
-    double v = 0.0;
-    for (int j = 0; j < 16; ++j) v += sRow[tid][j];
-    part[(size_t)blockIdx.x * M + m0 + tid] = v;
-  }
+  if (tid < TS && m0 + tid < M) part[(size_t)blockIdx.x * M + m0 + tid] = sRow[tid][0] + sRow[tid][1];
 }
 
 __global__ void predict_var_finish_kernel(const double* __restrict__ part, int ntiles, int64_t M,
@@ -323,7 +333,7 @@ int launch_gp_predict_sample(vbmc_ctx* ctx, int s, int64_t M, const double* d_xs
                      g.d_hyp + (size_t)s * g.P, N, D, g.mean_kind, M, chol, d_Ks, d_fmu);
   const int ntiles = (N + TS - 1) / TS;
   const double* Bm = (chol ? g.d_Linv : g.d_L) + (size_t)s * N * N;
-  hipLaunchKernelGGL(predict_var_gemm_kernel, dim3(ntiles, (unsigned)((M + TS - 1) / TS)), dim3(256),
+  hipLaunchKernelGGL(predict_var_mfma_kernel, dim3(ntiles, (unsigned)((M + TS - 1) / TS)), dim3(256),
                      0, ctx->stream, d_Ks, Bm, M, N, chol ? 0 : 1, d_part);
   const double sf2 = std::exp(2.0 * h[D]);
   const double add = add_noise ? std::exp(2.0 * h[D + 1]) * g.sn2_mult[s] : 0.0;
