@@ -86,7 +86,8 @@ template <int DP, int KTMAX, bool GRAD, bool EXACT, bool PHILOX>
 __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double* __restrict__ T) {
   constexpr int TS = DP + 6;
   __shared__ double sQ[2][WAVES][2][64];          // q partials, double-buffered by batch parity
-  __shared__ double sE[DP][64];                   // Philox mode: the batch's normals
+  constexpr int GB = 4;                           // Philox mode: batches generated per round
+  __shared__ double sE[PHILOX ? GB : 1][DP][64];  // their normals
   __shared__ double sRed[WAVES][2 * DP + 1];
   extern __shared__ double sW[];                  // [K4]
 
@@ -132,25 +133,30 @@ __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double
           if (d < D) e[d] = rp[d];
       }
     } else {
-      // wave w generates the Box-Muller pairs p = w, w+4, ... of the 64 rows; LDS hands
-      // them to the other waves (each pair is generated exactly once per workgroup)
-      const uint64_t grow = (uint64_t)j * (uint64_t)a.n_half + (uint64_t)(a.row_begin + i_loc);
+      // Every GB-th batch the four waves generate the Box-Muller pairs of the next GB
+      // batches together: (batch, pair) slots are dealt round-robin over the waves, so each
+      // pair is generated exactly once per workgroup and the waves stay balanced (D/2 pairs
+      // per batch do not divide by 4, GB*D/2 does).  LDS hands the normals to all waves.
       constexpr int NP = DP / 2;
-      __syncthreads();  // previous batch's readers are done with sE
-#pragma unroll
-      for (int i = 0; i < (NP + 3) / 4; ++i) {
-        const int p = wave + 4 * i;
-        if (p < NP && 2 * p < D) {
+      const int np = (D + 1) / 2;  // pairs actually needed
+      if ((it % GB) == 0) {
+        const int nb = min(GB, a.rg - it);
+        __syncthreads();  // readers of the previous round are done with sE
+        for (int q = wave; q < nb * np; q += WAVES) {
+          const int bq = q / np, p = q - bq * np;
+          const int64_t il = (int64_t)chunk * rows_per_wg + (it + bq) * 64 + lane;
+          const uint64_t grow = (uint64_t)j * (uint64_t)a.n_half + (uint64_t)(a.row_begin + il);
           double z0, z1;
           philox_normal_pair(grow, (uint32_t)p, a.seed, z0, z1);
-          sE[2 * p][lane] = z0;
-          sE[2 * p + 1][lane] = z1;
+          sE[bq][2 * p][lane] = z0;
+          if (2 * p + 1 < DP) sE[bq][2 * p + 1][lane] = z1;
         }
+        __syncthreads();
       }
-      __syncthreads();
+      (void)NP;
 #pragma unroll
       for (int d = 0; d < DP; ++d)
-        if (valid && d < D) e[d] = sE[d][lane];
+        if (valid && d < D) e[d] = sE[it % GB][d][lane];
     }
     double e2 = 0.0;
 #pragma unroll
