@@ -175,6 +175,13 @@ def main():
     flops = algorithmic_flops(D, K, ns_job / world, grad=True)  # per launch (this rank's rows)
     achieved = flops / (k_ms * 1e-3) / 1e12
     eps_bytes = (ns_job / world / 2) * D * 8 if a.rng == "resident" else 0.0
+    traffic = None
+    try:  # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc passes, see profiles/README.md)
+        tj = json.load(open(ROOT / "profiles" / "traffic.json"))
+        if a.config == 3 and a.rng in tj:
+            traffic = tj[a.rng]["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     res = {
         "metric": "ELBO+entropy evals/sec at D=10, K=50, N=400, Ns=1e6 (1e6-sample-equivalent evals/s)",
         "value": value,
@@ -204,7 +211,7 @@ def main():
             "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP64_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": traffic,
             "kernel_ms": k_ms,
             "algorithmic_flops_per_launch": flops,
             "hbm_bytes_per_launch_algorithmic": eps_bytes,
