@@ -198,41 +198,19 @@ extern "C" int vbmc_gp_log_joint(vbmc_ctx* ctx, int grad_flags, int avg_flag, in
 
   std::vector<double> vG(S, 0.0);
   if (compute_var) {
-    const double* Q = ctx->h_pinned + n_res;
-    std::vector<double> tjk(D);
+    const double* Jd = ctx->h_pinned + n_res;  // J_sjk as computed on the device (gram_kernel)
     for (int s = 0; s < S; ++s) {
-      const double* h = g.hyp.data() + (size_t)s * g.P;
-      double sum_lnell = 0.0;
-      for (int d = 0; d < D; ++d) sum_lnell += h[d];
-      const double ln_sf2 = 2.0 * h[D];
       for (int k = 0; k < K; ++k)
         for (int j = 0; j <= k; ++j) {
-          double lnnf = ln_sf2 + sum_lnell, d2 = 0.0;
-          const double ss = ctx->sigma[j] * ctx->sigma[j] + ctx->sigma[k] * ctx->sigma[k];
-          for (int d = 0; d < D; ++d) {
-            const double lam = ctx->lambd[d];
-            const double t = std::sqrt(ss * lam * lam + std::exp(2.0 * h[d]));
-            lnnf -= std::log(t);
-            const double dl = (ctx->mu[(size_t)j * D + d] - ctx->mu[(size_t)k * D + d]) / t;
-            d2 += dl * dl;
-          }
-          double J = std::exp(lnnf - 0.5 * d2);
-          const double q = Q[((size_t)s * K + j) * K + k];
-          if (g.L_chol[s])
-            J -= q / g.sn2_eff[s];
-          else
-            J += q;
+          const double J = Jd[((size_t)s * K + j) * K + k];
           if (j == k)
             vG[s] += ctx->w[k] * ctx->w[k] * (J > kTiny ? J : kTiny);
           else
             vG[s] += 2.0 * ctx->w[j] * ctx->w[k] * J;
-          if (J_SxKxK) {
-            J_SxKxK[((size_t)s * K + j) * K + k] = J;
-            J_SxKxK[((size_t)s * K + k) * K + j] = J;
-          }
         }
       if (vG[s] < kTiny) vG[s] = kTiny;
     }
+    if (J_SxKxK) memcpy(J_SxKxK, Jd, sizeof(double) * (size_t)S * K * K);
   }
 
   // gradients per sample

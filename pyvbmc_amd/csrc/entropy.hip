@@ -262,8 +262,38 @@ __device__ inline double entlb_gamma(const double* __restrict__ mup, const doubl
   return exp(lnc - 0.5 * D * log(s2) - 0.5 * d2 / s2);
 }
 
+// stage A: workgroup i -> row i of gamma (stored) and gsum_i = sum_i' w_i' gamma_ii'
+__global__ __launch_bounds__(256) void entlb_rows_kernel(const double* __restrict__ mix,
+                                                         MixLayout ml, double* __restrict__ Gm,
+                                                         double* __restrict__ gsum) {
+  __shared__ double sRed[WAVES];
+  const int D = ml.D, K = ml.K;
+  const int i = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double* mup = mix + ml.o_mup;
+  const double* sig = mix + ml.o_sig;
+  const double* w = mix + ml.o_w;
+  const double* lam = mix + ml.o_lam;
+  double lnc = -0.5 * D * log(2.0 * M_PI);
+  for (int d = 0; d < D; ++d) lnc -= log(lam[d]);
+  double acc = 0.0;
+  for (int i2 = tid; i2 < K; i2 += 256) {
+    double s2, d2;
+    const double g = entlb_gamma(mup, sig, D, i, i2, lnc, s2, d2);
+    Gm[(size_t)i * K + i2] = g;
+    acc += w[i2] * g;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) sRed[wave] = acc;
+  __syncthreads();
+  if (tid == 0) gsum[i] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+}
+
+// stage B: workgroup j -> gradient terms of component j (entlb_vbmc.py:99-159)
 __global__ __launch_bounds__(256) void entlb_kernel(const double* __restrict__ mix, MixLayout ml,
-                                                    int want_grad, double* __restrict__ res,
+                                                    int want_grad, const double* __restrict__ Gm,
+                                                    const double* __restrict__ gsum,
+                                                    double* __restrict__ res,
                                                     double* __restrict__ part) {
   extern __shared__ double lds[];
   const int D = ml.D, K = ml.K;
@@ -273,41 +303,31 @@ __global__ __launch_bounds__(256) void entlb_kernel(const double* __restrict__ m
   const double* sig = mix + ml.o_sig;
   const double* w = mix + ml.o_w;
   const double* lam = mix + ml.o_lam;
-  double* sG = lds;             // [K] gsum
-  double* sRed = sG + K;        // [WAVES][2D+2]
+  double* sRed = lds;  // [WAVES][2D+2]
 
-  double lnc = -0.5 * D * log(2.0 * M_PI);
-  for (int d = 0; d < D; ++d) lnc -= log(lam[d]);
-
-  for (int i = wave; i < K; i += WAVES) {
-    double acc = 0.0, s2, d2;
-    for (int i2 = lane; i2 < K; i2 += 64) acc += w[i2] * entlb_gamma(mup, sig, D, i, i2, lnc, s2, d2);
-    acc = wave_sum(acc);
-    if (lane == 0) sG[i] = acc;
-  }
-  __syncthreads();
-  const double gj = sG[j];
+  const double gj = gsum[j];
   if (tid == 0) part[j] = -w[j] * log(gj);
   if (!want_grad) return;
-
-  // this thread's rows i (K <= 256: one) against column j
   const int NS = 2 * D + 2;
-  for (int it = tid; it < WAVES * NS; it += 256) sRed[it] = 0.0;
-  __syncthreads();
   double a_sig = 0.0, a_w = 0.0;
   for (int d = 0; d < D; ++d) {
     double a_mu = 0.0, a_lam = 0.0;
     for (int i = tid; i < K; i += 256) {
-      double s2, d2;
-      const double g = entlb_gamma(mup, sig, D, i, j, lnc, s2, d2);
-      const double wg = w[i] * g;
-      const double coef = wg * (1.0 / sG[i] + 1.0 / gj);
+      const double s2 = sig[i] * sig[i] + sig[j] * sig[j];
+      const double wg = w[i] * Gm[(size_t)j * K + i];  // gamma is symmetric
+      const double gi = gsum[i];
+      const double coef = wg * (1.0 / gi + 1.0 / gj);
       const double t = mup[i * D + d] - mup[j * D + d];  // (mu_i - mu_j)_d / lambda_d
       a_mu += coef * t / s2;
       a_lam += wg * (t * t / s2 - 1.0);
       if (d == 0) {
+        double d2 = 0.0;
+        for (int dd = 0; dd < D; ++dd) {
+          const double u = mup[i * D + dd] - mup[j * D + dd];
+          d2 = fma(u, u, d2);
+        }
         a_sig += coef * (-(double)D / s2 + d2 / (s2 * s2));
-        a_w += wg / sG[i];
+        a_w += wg / gi;
       }
     }
     a_mu = wave_sum(a_mu);
@@ -338,22 +358,26 @@ __global__ __launch_bounds__(256) void entlb_kernel(const double* __restrict__ m
   }
 }
 
-__global__ __launch_bounds__(64) void entlb_finish_kernel(const double* __restrict__ mix,
-                                                          MixLayout ml, int want_grad,
-                                                          const double* __restrict__ part,
-                                                          double* __restrict__ res) {
+// stage C: H and the lambda gradient are sums over j of the per-j partials (one wave each)
+__global__ __launch_bounds__(256) void entlb_finish_kernel(const double* __restrict__ mix,
+                                                           MixLayout ml, int want_grad,
+                                                           const double* __restrict__ part,
+                                                           double* __restrict__ res) {
   const int D = ml.D, K = ml.K;
   const double* lam = mix + ml.o_lam;
-  for (int t = threadIdx.x; t < 1 + D; t += 64) {
-    double s = 0.0;
-    if (t == 0) {
-      for (int j = 0; j < K; ++j) s += part[j];
-      res[0] = s;
-    } else if (want_grad) {
-      const int d = t - 1;
-      for (int j = 0; j < K; ++j) s += part[K + j * D + d];
-      res[1 + K * D + K + d] = -s / lam[d];
-    }
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (t > D || (t > 0 && !want_grad)) return;
+  double s = 0.0;
+  if (t == 0) {
+    for (int j = lane; j < K; j += 64) s += part[j];
+    s = wave_sum(s);
+    if (lane == 0) res[0] = s;
+  } else {
+    const int d = t - 1;
+    for (int j = lane; j < K; j += 64) s += part[K + j * D + d];
+    s = wave_sum(s);
+    if (lane == 0) res[1 + K * D + K + d] = -s / lam[d];
   }
 }
 
@@ -498,14 +522,19 @@ int launch_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed
 
 int launch_entlb(vbmc_ctx* ctx, double* d_res) {
   const int D = ctx->D, K = ctx->K;
-  const size_t n_part = (size_t)K + (size_t)K * D;
-  int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, n_part);
+  const size_t n_part = (size_t)K + (size_t)K * D, n_G = (size_t)K * K;
+  int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, n_part + n_G + K);
   if (rc) return rc;
-  size_t lds = sizeof(double) * ((size_t)K + WAVES * (2 * D + 2));
+  double* part = ctx->d_scratch;
+  double* Gm = part + n_part;
+  double* gsum = Gm + n_G;
+  hipLaunchKernelGGL(entlb_rows_kernel, dim3(K), dim3(256), 0, ctx->stream, ctx->d_mix, ctx->ml, Gm,
+                     gsum);
+  size_t lds = sizeof(double) * (size_t)(WAVES * (2 * D + 2));
   hipLaunchKernelGGL(entlb_kernel, dim3(K), dim3(256), lds, ctx->stream, ctx->d_mix, ctx->ml, 1,
-                     d_res, ctx->d_scratch);
-  hipLaunchKernelGGL(entlb_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_mix, ctx->ml, 1,
-                     ctx->d_scratch, d_res);
+                     (const double*)Gm, (const double*)gsum, d_res, part);
+  hipLaunchKernelGGL(entlb_finish_kernel, dim3((1 + D + 3) / 4), dim3(256), 0, ctx->stream,
+                     ctx->d_mix, ctx->ml, 1, (const double*)part, d_res);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }

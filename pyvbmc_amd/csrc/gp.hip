@@ -46,58 +46,43 @@ __global__ void trinv_upper_kernel(const double* __restrict__ L, int N, double* 
   }
 }
 
-// C[r][c] = sum_{n in range} A[r][n] * B[n][c];  A is R x N (row-major), B is N x N.
-// upper!=0: B is upper triangular, only n <= c contributes.
-// block = 256 threads = 4 waves; lane <-> column c (coalesced B reads), each wave
-// keeps RB rows of A in flight (A values are wave-uniform -> scalar loads).
-constexpr int RB = 8;
-__global__ __launch_bounds__(256) void rows_times_square_kernel(const double* __restrict__ A,
-                                                                const double* __restrict__ B,
-                                                                int R, int N, int upper,
-                                                                double* __restrict__ C) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  const int r0 = (blockIdx.y * WAVES + wave) * RB;
-  const int s = blockIdx.z;
-  A += (size_t)s * R * N;
-  B += (size_t)s * N * N;
-  C += (size_t)s * R * N;
-  if (r0 >= R) return;
-  double acc[RB];
-#pragma unroll
-  for (int i = 0; i < RB; ++i) acc[i] = 0.0;
-  const int cmax = upper ? min(N - 1, blockIdx.x * 64 + 63) : N - 1;
-  const bool cok = c < N;
-  for (int n = 0; n <= cmax; ++n) {
-    const double b = (cok && (!upper || n <= c)) ? B[(size_t)n * N + c] : 0.0;
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const int r = r0 + i;
-      const double av = (r < R) ? A[(size_t)r * N + n] : 0.0;
-      acc[i] = fma(av, b, acc[i]);
-    }
-  }
-  if (cok)
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-      if (r0 + i < R) C[(size_t)(r0 + i) * N + c] = acc[i];
-}
-
-// Q[s][j][k] = sum_c U[s][j][c] * V[s][k][c]   (one wave per (j,k))
+// J[j][k] of one GP sample (variational_optimization.py:1473-1503), one wave per pair j<=k:
+//   J_jk = exp(lnnf_jk - 1/2 sum_d delta_jk_d^2)  -/+  sum_c U[j][c] V[k][c] (/ sn2_eff),
+//   tau_jk_d = sqrt((sigma_j^2+sigma_k^2) lambda_d^2 + ell_d^2), delta = (mu_j - mu_k)/tau,
+//   lnnf_jk = 2 hyp[D] + sum_d hyp[d] - sum_d log tau_jk_d.   Writes both triangles.
 __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ U,
-                                                   const double* __restrict__ V, int K, int N,
-                                                   double* __restrict__ Q) {
+                                                   const double* __restrict__ V,
+                                                   const double* __restrict__ mix, MixLayout ml,
+                                                   const double* __restrict__ hyp, int N, int chol,
+                                                   double inv_sn2, double* __restrict__ J) {
+  const int D = ml.D, K = ml.K;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int s = blockIdx.y;
   const int pair = blockIdx.x * WAVES + wave;
   if (pair >= K * K) return;
   const int j = pair / K, k = pair - j * K;
-  const double* u = U + ((size_t)s * K + j) * N;
-  const double* v = V + ((size_t)s * K + k) * N;
+  if (j > k) return;
+  const double* u = U + (size_t)j * N;
+  const double* v = V + (size_t)k * N;
   double acc = 0.0;
   for (int c = lane; c < N; c += 64) acc = fma(u[c], v[c], acc);
+  // closed-form part: lanes run over d
+  double term = 0.0;
+  const double sj = mix[ml.o_sig + j], sk = mix[ml.o_sig + k];
+  const double ss = sj * sj + sk * sk;
+  for (int d = lane; d < D; d += 64) {
+    const double lam = mix[ml.o_lam + d];
+    const double t2 = ss * lam * lam + exp(2.0 * hyp[d]);
+    const double dm = mix[ml.o_mu + j * D + d] - mix[ml.o_mu + k * D + d];
+    term += hyp[d] - 0.5 * log(t2) - 0.5 * dm * dm / t2;
+  }
   acc = wave_sum(acc);
-  if (lane == 0) Q[((size_t)s * K + j) * K + k] = acc;
+  term = wave_sum(term);
+  if (lane == 0) {
+    double Jv = exp(2.0 * hyp[D] + term);
+    Jv = chol ? Jv - acc * inv_sn2 : Jv + acc;
+    J[(size_t)j * K + k] = Jv;
+    J[(size_t)k * K + j] = Jv;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -168,6 +153,7 @@ __global__ __launch_bounds__(256) void predict_kstar_kernel(
 // predict, stage 2: T = A (M x N) * B (N x N) on the FP64 matrix cores, fused row epilogue
 //   mode 0 (L_chol): B = L^-1 upper triangular; part[ct][m] = sum_{c in tile} T[m][c]^2
 //   mode 1         : B = L (full, symmetric);   part[ct][m] = sum_{c in tile} A[m][c] T[m][c]
+//   Cout != null   : also/only store T (used by the log-joint variance: V = Z L^-1 or Z L)
 // v_mfma_f64_16x16x4_f64: lane l holds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15] and 4 results
 // C[row=(l>>4)+4r][col=l&15]  (cdna_hip_programming.md section 3, f64 layout).
 // Workgroup = 64 x 64 output tile, 4 waves x (2 x 2) MFMA tiles, 16-deep LDS panels:
@@ -181,7 +167,8 @@ constexpr int TS = 64, TKD = 16, LDA = TKD + 1, LDB = TS + 16;
 __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __restrict__ A,
                                                                const double* __restrict__ B,
                                                                int64_t M, int N, int mode,
-                                                               double* __restrict__ part) {
+                                                               double* __restrict__ part,
+                                                               double* __restrict__ Cout) {
   __shared__ double sA[TS * LDA];
   __shared__ double sB[TKD * LDB];
   __shared__ double sRow[TS][2];
@@ -220,6 +207,19 @@ __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __r
     }
     __syncthreads();
   }
+  if (Cout) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t m = m0 + wm * 32 + mt * 16 + lk + 4 * r;
+          const int c = c0 + wc * 32 + ct * 16 + li;
+          if (m < M && c < N) Cout[(size_t)m * N + c] = acc[mt][ct][r];
+        }
+  }
+  if (!part) return;
   // epilogue: per-row reduction over this wave's 32 columns, then over the two column waves
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -296,15 +296,18 @@ int launch_gp_var(vbmc_ctx* ctx, const double* d_Z, double* d_V, double* d_Q) {
     all_chol = all_chol && g.L_chol[s];
     none_chol = none_chol && !g.L_chol[s];
   }
-  dim3 grid((N + 63) / 64, (K + WAVES * RB - 1) / (WAVES * RB), 1);
   for (int s = 0; s < g.S; ++s) {
     const int chol = g.L_chol[s];
     const double* Bm = (chol ? g.d_Linv : g.d_L) + (size_t)s * N * N;
-    hipLaunchKernelGGL(rows_times_square_kernel, grid, dim3(256), 0, ctx->stream,
-                       d_Z + (size_t)s * K * N, Bm, K, N, chol, d_V + (size_t)s * K * N);
+    // V = Z L^-1 (upper-triangular skip) or Z L, on the FP64 matrix cores
+    hipLaunchKernelGGL(predict_var_mfma_kernel, dim3((N + TS - 1) / TS, (K + TS - 1) / TS), dim3(256),
+                       0, ctx->stream, d_Z + (size_t)s * K * N, Bm, (int64_t)K, N, chol ? 0 : 1,
+                       (double*)nullptr, d_V + (size_t)s * K * N);
     const double* U = chol ? d_V + (size_t)s * K * N : d_Z + (size_t)s * K * N;
     hipLaunchKernelGGL(gram_kernel, dim3((K * K + WAVES - 1) / WAVES, 1), dim3(256), 0, ctx->stream,
-                       U, d_V + (size_t)s * K * N, K, N, d_Q + (size_t)s * K * K);
+                       U, (const double*)(d_V + (size_t)s * K * N), (const double*)ctx->d_mix,
+                       ctx->ml, (const double*)(g.d_hyp + (size_t)s * g.P), N, chol,
+                       1.0 / g.sn2_eff[s], d_Q + (size_t)s * K * K);
   }
   (void)all_chol;
   (void)none_chol;
@@ -334,7 +337,7 @@ int launch_gp_predict_sample(vbmc_ctx* ctx, int s, int64_t M, const double* d_xs
   const int ntiles = (N + TS - 1) / TS;
   const double* Bm = (chol ? g.d_Linv : g.d_L) + (size_t)s * N * N;
   hipLaunchKernelGGL(predict_var_mfma_kernel, dim3(ntiles, (unsigned)((M + TS - 1) / TS)), dim3(256),
-                     0, ctx->stream, d_Ks, Bm, M, N, chol ? 0 : 1, d_part);
+                     0, ctx->stream, d_Ks, Bm, M, N, chol ? 0 : 1, d_part, (double*)nullptr);
   const double sf2 = std::exp(2.0 * h[D]);
   const double add = add_noise ? std::exp(2.0 * h[D + 1]) * g.sn2_mult[s] : 0.0;
   hipLaunchKernelGGL(predict_var_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
