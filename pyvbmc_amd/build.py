@@ -95,7 +95,7 @@ def build(force=False, verbose=True):
     if failed:
         raise RuntimeError("hipcc failed")
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB),
-           "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+           "-ldl", "-Wl,-rpath,/opt/rocm/lib"]  # librccl is dlopen'ed lazily (csrc/comm.hip)
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -7,8 +7,6 @@ product's host code).  On the GPU the per-rank accumulator comes from the HIP
 kernels and the all-reduce is RCCL inside libvbmc_hip.so; here, without GPUs,
 the per-rank accumulator comes from the oracle and the all-reduce from gloo --
 which checks the partition, the additivity and the finalisation, not the kernels."""
-import ctypes as C
-import os
 import socket
 import sys
 from pathlib import Path
@@ -27,41 +25,16 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
-    sys.path.insert(0, str(ROOT))
-    sys.path.insert(0, str(ROOT / "tests"))
-    import torch.distributed as dist
-
-    from helpers import oracle_mix
-    from oracle import entropy_ref
-    from pyvbmc_amd import _lib, comm, synthetic
-
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    grp = comm.GlooGroup()
-    g = dict(np.load(ROOT / "tests" / "golden" / "c2s.npz"))
-    K, D, NsK, seed = int(g["K"]), int(g["D"]), int(g["NsK"]), int(g["seed"])
-    eps = synthetic.draw_eps_half(K, D, NsK, seed)
-    r0, r1 = comm.shard_rows(NsK // 2, grp.rank, grp.world)
-    mix = oracle_mix(g)
-    part = entropy_ref.pack_partial(entropy_ref.entmc_partial(mix, eps[:, r0:r1, :], NsK, (True,) * 4))
-    total = grp.allreduce_sum(part)
-    h = _lib.Context(-1)
-    h.set_mixture(g["mu"], g["sigma"], g["lambd"], g["w"], g["eta"])
-    H = C.c_double()
-    dH = np.empty(D * K + 2 * K + D)
-    raw = _lib.f64(total)
-    h.check(h._lib.vbmc_entmc_finalize(h._h, _lib.ptr(raw), 15, 1, C.byref(H), _lib.ptr(dH)))
-    np.savez(Path(out_dir) / f"rank{rank}.npz", H=H.value, dH=dH, rows=np.array([r0, r1]))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_entropy_matches_reference(tmp_path, world):
-    import torch.multiprocessing as mp
+    import subprocess
 
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    worker = str(ROOT / "tests" / "gloo_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(tmp_path)])
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
     g = dict(np.load(ROOT / "tests" / "golden" / "c2s.npz"))
     rows = []
     for r in range(world):
