@@ -229,6 +229,16 @@ int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta, const vbmc_elbo_op
                    double* F, double* dF, double* G, double* H, double* mu_KxD,
                    double* sigma_K, double* lambd_D, double* w_K, double* eta_K);
 
+/* ---- the sieve's batch of candidate evaluations ---------- */
+
+/* B candidate parameter vectors (rows of thetas_BxN) through the call _sieve makes per
+ * candidate (vbmc/variational_optimization.py:775-787): Ns = 0 (lower-bound entropy), no
+ * gradient, soft bounds as in `opts`; F_B[b] = -G_b - H_b + bound losses.  opts->ns_per_comp
+ * must be 0 and opts->compute_grad 0 (VBMC_E_UNSUP otherwise).  Unlike vbmc_neg_elcbo this
+ * neither changes the ctx mixture nor touches the theta rows.  G_B / H_B nullable. */
+int vbmc_neg_elcbo_batch(vbmc_ctx* ctx, const double* thetas_BxN, int B, int n_theta,
+                         const vbmc_elbo_opts* opts, double* F_B, double* G_B, double* H_B);
+
 /* ---- multi-GPU: one process per GPU, one collective ---------- */
 
 /* 128-byte RCCL unique id, created on rank 0 and shipped to the other ranks by

@@ -89,6 +89,10 @@ SIGNATURES = {
         C.c_int,
         [_vp, _dp, C.c_int, C.POINTER(ElboOpts), _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     ),
+    "vbmc_neg_elcbo_batch": (
+        C.c_int,
+        [_vp, _dp, C.c_int, C.c_int, C.POINTER(ElboOpts), _dp, _dp, _dp],
+    ),
     "vbmc_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "vbmc_comm_init": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
     "vbmc_comm_destroy": (C.c_int, [_vp]),

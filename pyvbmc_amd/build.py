@@ -23,6 +23,7 @@ SOURCES = [
     "gp.hip",
     "api_gp.hip",
     "api_elbo.hip",
+    "api_batch.hip",
     "comm.hip",
 ]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

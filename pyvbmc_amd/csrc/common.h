@@ -123,6 +123,10 @@ extern thread_local std::string g_create_err;
                        "(libvbmc_hip has no CPU fallback)");                                 \
   } while (0)
 
+void write_mixture_pack(const MixLayout& ml, const double* mu_KxD, const double* sigma,
+                        const double* lambd, const double* w, double* p);
+int theta_to_arrays(int D, int K, const double* theta, int n_theta, int optimize_mask, double* mu,
+                    double* sg, double* lm, double* w, double* eta);
 int set_mixture_host(vbmc_ctx* ctx, int D, int K, const double* mu_KxD, const double* sigma_K,
                      const double* lambd_D, const double* w_K, const double* eta_K);
 
@@ -143,6 +147,8 @@ struct PrepArgs {
   double* table = nullptr;
   // GP part (n_glj = S*K blocks, or 0)
   int n_glj = 0, N = 0, P = 0, want_grad = 0;
+  int batch = 1;              // candidates (grid.y); candidate b uses mix + b*mix_stride, res + b*res_stride
+  size_t mix_stride = 0, res_stride = 0;
   const double* X = nullptr;
   const double* alpha = nullptr;
   const double* hyp = nullptr;

@@ -167,6 +167,79 @@ int vbmc_last_kernel_ms(vbmc_ctx* ctx, int which, double* ms_out) {
 
 }  // extern "C"
 
+// The kernel-friendly mixture pack (MixLayout) of one mixture.
+void write_mixture_pack(const MixLayout& ml, const double* mu_KxD, const double* sigma,
+                        const double* lambd, const double* w, double* p) {
+  const int D = ml.D, K = ml.K;
+  double prod_lam = 1.0;
+  for (int d = 0; d < D; ++d) prod_lam *= lambd[d];
+  // nconst = 1 / (2 pi)^(D/2) / prod(lambda)   (entmc_vbmc.py:54-56)
+  const double nconst = 1.0 / std::pow(2.0 * M_PI, 0.5 * D) / prod_lam;
+  for (int k = 0; k < K; ++k) {
+    for (int d = 0; d < D; ++d) {
+      p[ml.o_mu + k * D + d] = mu_KxD[(size_t)k * D + d];
+      p[ml.o_mup + k * D + d] = mu_KxD[(size_t)k * D + d] / lambd[d];
+    }
+    const double s = sigma[k];
+    const double sD = std::pow(s, (double)D);
+    p[ml.o_is2 + k] = 1.0 / (s * s);
+    p[ml.o_rc + k] = nconst / sD;
+    p[ml.o_lrc + k] = std::log2(nconst) - D * std::log2(s);
+    p[ml.o_wc + k] = w[k] * nconst / sD;
+    p[ml.o_sig + k] = s;
+    p[ml.o_w + k] = w[k];
+  }
+  for (int d = 0; d < D; ++d) {
+    p[ml.o_lam + d] = lambd[d];
+    p[ml.o_ilam + d] = 1.0 / lambd[d];
+  }
+}
+
+// VariationalPosterior.set_parameters (raw) on plain arrays (variational_posterior.py:680-759)
+// plus eta = theta[-K:] - max (variational_optimization.py:1082-1085).  In/out arrays start
+// from the current attribute values; blocks whose optimize bit is clear are left alone.
+int theta_to_arrays(int D, int K, const double* theta, int n_theta, int optimize_mask, double* mu,
+                    double* sg, double* lm, double* w, double* eta) {
+  const bool o_mu = optimize_mask & 1, o_sg = optimize_mask & 2, o_lm = optimize_mask & 4,
+             o_w = optimize_mask & 8;
+  const int need = (o_mu ? D * K : 0) + (o_sg ? K : 0) + (o_lm ? D : 0) + (o_w ? K : 0);
+  if (n_theta != need) return -1;
+  for (int i = 0; i < n_theta; ++i)
+    if (!std::isfinite(theta[i])) return -2;
+  int pos = 0;
+  if (o_mu) {
+    for (int i = 0; i < D * K; ++i) mu[i] = theta[i];
+    pos = D * K;
+  }
+  if (o_sg) {
+    for (int k = 0; k < K; ++k) sg[k] = std::exp(theta[pos + k]);
+    pos += K;
+  }
+  if (o_lm)
+    for (int d = 0; d < D; ++d) lm[d] = std::exp(theta[pos + d]);
+  if (o_w) {
+    const double* e = theta + (n_theta - K);
+    double mx = e[0];
+    for (int k = 1; k < K; ++k) mx = e[k] > mx ? e[k] : mx;
+    for (int k = 0; k < K; ++k) {
+      eta[k] = e[k] - mx;
+      w[k] = std::exp(eta[k]);
+    }
+  }
+  // lambda -> unit RMS, sigma absorbs it (variational_posterior.py:749-752)
+  double s2 = 0.0;
+  for (int d = 0; d < D; ++d) s2 += lm[d] * lm[d];
+  const double nl = std::sqrt(s2 / D);
+  for (int d = 0; d < D; ++d) lm[d] /= nl;
+  for (int k = 0; k < K; ++k) sg[k] *= nl;
+  if (o_w) {
+    double ws = 0.0;
+    for (int k = 0; k < K; ++k) ws += w[k];
+    for (int k = 0; k < K; ++k) w[k] /= ws;
+  }
+  return 0;
+}
+
 // Host-side derivation of the kernel-friendly mixture pack + upload.
 static int upload_mixture(vbmc_ctx* ctx) {
   const int D = ctx->D, K = ctx->K;
@@ -189,28 +262,7 @@ static int upload_mixture(vbmc_ctx* ctx) {
     ctx->pack_in_flight = false;
   }
   double* p = ctx->h_pack;
-  double prod_lam = 1.0;
-  for (int d = 0; d < D; ++d) prod_lam *= ctx->lambd[d];
-  // nconst = 1 / (2 pi)^(D/2) / prod(lambda)   (entmc_vbmc.py:54-56)
-  const double nconst = 1.0 / std::pow(2.0 * M_PI, 0.5 * D) / prod_lam;
-  for (int k = 0; k < K; ++k) {
-    for (int d = 0; d < D; ++d) {
-      p[ml.o_mu + k * D + d] = ctx->mu[(size_t)k * D + d];
-      p[ml.o_mup + k * D + d] = ctx->mu[(size_t)k * D + d] / ctx->lambd[d];
-    }
-    const double s = ctx->sigma[k];
-    const double sD = std::pow(s, (double)D);
-    p[ml.o_is2 + k] = 1.0 / (s * s);
-    p[ml.o_rc + k] = nconst / sD;
-    p[ml.o_lrc + k] = std::log2(nconst) - D * std::log2(s);
-    p[ml.o_wc + k] = ctx->w[k] * nconst / sD;
-    p[ml.o_sig + k] = s;
-    p[ml.o_w + k] = ctx->w[k];
-  }
-  for (int d = 0; d < D; ++d) {
-    p[ml.o_lam + d] = ctx->lambd[d];
-    p[ml.o_ilam + d] = 1.0 / ctx->lambd[d];
-  }
+  write_mixture_pack(ml, ctx->mu.data(), ctx->sigma.data(), ctx->lambd.data(), ctx->w.data(), p);
   int rc = ensure_dev(ctx, &ctx->d_mix, &ctx->d_mix_cap, (size_t)ml.total);
   if (rc) return rc;
   // pinned source: a true asynchronous copy (pack_ev guards the buffer's reuse)
@@ -262,47 +314,13 @@ int vbmc_theta_to_mixture(vbmc_ctx* ctx, const double* theta, int n_theta, int o
   if (!ctx->mix_set) return vbmc_fail(ctx, VBMC_E_ARG, "theta_to_mixture: mixture (D,K) not set");
   if (ctx->device >= 0) HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int D = ctx->D, K = ctx->K;
-  const bool o_mu = optimize_mask & 1, o_sg = optimize_mask & 2, o_lm = optimize_mask & 4,
-             o_w = optimize_mask & 8;
-  const int need = (o_mu ? D * K : 0) + (o_sg ? K : 0) + (o_lm ? D : 0) + (o_w ? K : 0);
-  if (n_theta != need)
-    return vbmc_fail(ctx, VBMC_E_ARG, "theta length %d != %d for D=%d K=%d mask=%d", n_theta, need, D,
-                     K, optimize_mask);
   std::vector<double> mu = ctx->mu, sg = ctx->sigma, lm = ctx->lambd, w = ctx->w, eta = ctx->eta;
-  int pos = 0;
-  if (o_mu) {
-    for (int i = 0; i < D * K; ++i) mu[i] = theta[i];
-    pos = D * K;
-  }
-  if (o_sg) {
-    for (int k = 0; k < K; ++k) sg[k] = std::exp(theta[pos + k]);
-    pos += K;
-  }
-  if (o_lm)
-    for (int d = 0; d < D; ++d) lm[d] = std::exp(theta[pos + d]);
-  if (o_w) {
-    const double* e = theta + (n_theta - K);
-    double mx = e[0];
-    for (int k = 1; k < K; ++k) mx = e[k] > mx ? e[k] : mx;
-    for (int k = 0; k < K; ++k) {
-      eta[k] = e[k] - mx;
-      w[k] = std::exp(eta[k]);
-    }
-  }
-  // lambda -> unit RMS, sigma absorbs it (variational_posterior.py:749-752)
-  double s2 = 0.0;
-  for (int d = 0; d < D; ++d) s2 += lm[d] * lm[d];
-  const double nl = std::sqrt(s2 / D);
-  for (int d = 0; d < D; ++d) lm[d] /= nl;
-  for (int k = 0; k < K; ++k) sg[k] *= nl;
-  if (o_w) {
-    double ws = 0.0;
-    for (int k = 0; k < K; ++k) ws += w[k];
-    for (int k = 0; k < K; ++k) w[k] /= ws;
-  }
-  for (int i = 0; i < n_theta; ++i)
-    if (!std::isfinite(theta[i]))
-      return vbmc_fail(ctx, VBMC_E_NONFINITE, "theta[%d] is not finite", i);
+  const int st = theta_to_arrays(D, K, theta, n_theta, optimize_mask, mu.data(), sg.data(), lm.data(),
+                                 w.data(), eta.data());
+  if (st == -1)
+    return vbmc_fail(ctx, VBMC_E_ARG, "theta length %d does not match D=%d K=%d mask=%d", n_theta, D, K,
+                     optimize_mask);
+  if (st == -2) return vbmc_fail(ctx, VBMC_E_NONFINITE, "theta has a non-finite entry");
   int rc = set_mixture_host(ctx, D, K, mu.data(), sg.data(), lm.data(), w.data(), eta.data());
   if (rc) return rc;
   if (mu_KxD) memcpy(mu_KxD, mu.data(), sizeof(double) * D * K);

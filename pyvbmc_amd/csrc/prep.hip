@@ -24,6 +24,8 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
   extern __shared__ double lds[];
   const int D = a.ml.D, K = a.ml.K;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  a.mix += (size_t)blockIdx.y * a.mix_stride;  // batched sieve: one candidate mixture per grid.y
+  a.res += (size_t)blockIdx.y * a.res_stride;
 
   if ((int)blockIdx.x < a.n_table) {
     // ---- table row block: T[j][k] = [Delta_jk (DP) | a | c | lrc | w | wis2 | pad] ----
@@ -135,7 +137,7 @@ int launch_prep(vbmc_ctx* ctx, const PrepArgs& a) {
     lds = sizeof(double) * ((size_t)2 * D + a.N + 4 * (2 * D + 1) + 1);
     if (lds > 150 * 1024) return vbmc_fail(ctx, VBMC_E_UNSUP, "gp_log_joint: N=%d too large", a.N);
   }
-  hipLaunchKernelGGL(elbo_prep_kernel, dim3(grid), dim3(256), lds, ctx->stream, a);
+  hipLaunchKernelGGL(elbo_prep_kernel, dim3(grid, a.batch), dim3(256), lds, ctx->stream, a);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }

@@ -202,6 +202,36 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
     return fc.F.value, (fc.dF.copy() if compute_grad else None), fc.G.value, fc.H.value, 0
 
 
+def _neg_elcbo_batch(thetas, gp, vp, theta_bnd=None, *, ctx=None, return_parts=False):
+    """The sieve's inner loop in one call (reference ``_sieve``,
+    vbmc/variational_optimization.py:775-787): ``F[b] = _neg_elcbo(thetas[b], gp, vp, 0, 0,
+    compute_grad=False, theta_bnd=theta_bnd)[0]`` for every row of ``thetas`` -- lower-bound
+    entropy, no gradient.  ``vp`` supplies D, K, the optimise flags and the values of
+    non-optimised blocks; unlike the per-candidate call it is NOT mutated, nor are the rows."""
+    ctx = vp.ctx if ctx is None else ctx
+    thetas = np.ascontiguousarray(np.atleast_2d(thetas), dtype=np.float64)
+    B, n_theta = thetas.shape
+    vp._upload(ctx)
+    upload_gp(gp, ctx)
+    opts = _lib.ElboOpts()
+    opts.ns_per_comp, opts.compute_grad, opts.optimize_mask = 0, 0, vp.optimize_mask()
+    keep = []
+    if theta_bnd is not None:
+        lb, ub = _lib.f64(theta_bnd["lb"].ravel()), _lib.f64(theta_bnd["ub"].ravel())
+        keep += [lb, ub]
+        opts.bnd_lb, opts.bnd_ub, opts.n_bnd = _lib.ptr(lb), _lib.ptr(ub), lb.size
+        opts.tol_con = float(theta_bnd["tol_con"])
+        opts.weight_threshold = float(theta_bnd.get("weight_threshold", 0.0))
+        opts.weight_penalty = float(theta_bnd.get("weight_penalty", 0.0))
+    F, G, H = np.empty(B), np.empty(B), np.empty(B)
+    ctx.check(
+        ctx._lib.vbmc_neg_elcbo_batch(
+            ctx._h, _lib.ptr(thetas), B, n_theta, C.byref(opts), _lib.ptr(F), _lib.ptr(G), _lib.ptr(H)
+        )
+    )
+    return (F, G, H) if return_parts else F
+
+
 class _FusedCall:
     """Pre-built argument block of vbmc_neg_elcbo for one (ctx, D, K, theta_bnd): the
     ctypes pointers of the persistent buffers are created once, not per evaluation."""

@@ -475,3 +475,41 @@ print("RESULT", repr(r[0]), repr(r[3]), repr(H), repr(float(np.abs(dH).sum())))
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0])
     assert outs[0] == outs[1]  # a 1-rank sum is the identity: bit-identical results
+
+
+@pytest.mark.parametrize("name", ["c1", "c2s", "c3s"])
+def test_batched_sieve_matches_per_candidate_calls(ctx, golden, name):
+    """B candidates in one call == B reference-style calls."""
+    from pyvbmc_amd.variational_optimization import _neg_elcbo, _neg_elcbo_batch
+
+    g = golden(name)
+    K, D = int(g["K"]), int(g["D"])
+    wl = synthetic.make_workload(int(g["cfg"]), S=g["hyp"].shape[0], D=D, K=K, N=int(g["N"]), Ns_total=int(g["Ns_total"]))
+    bnd = synthetic.default_theta_bnd(wl)
+    gp = make_gp(g, ctx)  # all hyper-samples (S > 1 averages)
+    ogp = oracle_gp(g)
+    rng = np.random.default_rng(42)
+    B = 17
+    thetas = g["theta"][None, :] + 0.3 * rng.standard_normal((B, g["theta"].size))
+    thetas[3, 0] = bnd["ub"][0] + 0.5  # one candidate violates a bound
+    thetas[5, -1] += 3.0               # one has a positive eta before the max shift
+    keep = thetas.copy()
+    for tb in (None, bnd):
+        vp = make_vp(g, ctx)
+        F, G, H = _neg_elcbo_batch(thetas, gp, vp, tb, return_parts=True)
+        assert np.array_equal(thetas, keep)  # rows untouched
+        assert rel_err(vp.mu, g["mu"]) == 0  # vp untouched
+        for b in range(B):
+            Fo, _, Go, Ho, _ = elbo_ref.neg_elcbo(thetas[b].copy(), ogp, oracle_mix(g), 0.0, 0, False, False, tb, False)
+            assert abs(F[b] - Fo) <= 1e-10 * abs(Fo), (name, b, F[b], Fo)
+            assert abs(G[b] - Go) <= 1e-10 * abs(Go) and abs(H[b] - Ho) <= 1e-10 * abs(Ho)
+        # and equal to the per-candidate device call
+        F1 = _neg_elcbo(thetas[0].copy(), gp, make_vp(g, ctx), 0.0, 0, False, False, tb)[0]
+        assert abs(F1 - F[0]) <= 1e-12 * abs(F1)
+    with pytest.raises(NotImplementedError):
+        from pyvbmc_amd import _lib
+        import ctypes as C
+        o = _lib.ElboOpts()
+        o.ns_per_comp, o.compute_grad, o.optimize_mask = 10, 0, 15
+        Fb = np.empty(B)
+        ctx.check(ctx._lib.vbmc_neg_elcbo_batch(ctx._h, _lib.ptr(keep), B, keep.shape[1], C.byref(o), _lib.ptr(Fb), None, None))

@@ -22,7 +22,7 @@ sys.path.insert(0, str(ROOT))
 from oracle import elbo_ref, entropy_ref, gp_ref, mixture_ref  # noqa: E402
 from pyvbmc_amd import VariationalPosterior, _lib, entlb_vbmc, entmc_vbmc, synthetic  # noqa: E402
 from pyvbmc_amd import gp as gpm  # noqa: E402
-from pyvbmc_amd.variational_optimization import _gp_log_joint, _neg_elcbo  # noqa: E402
+from pyvbmc_amd.variational_optimization import _gp_log_joint, _neg_elcbo, _neg_elcbo_batch  # noqa: E402
 
 
 def med(fn, reps=7, warm=2):
@@ -148,6 +148,22 @@ def main():
     rd = _neg_elcbo(wl1.theta.copy(), g, mkvp(wl1), 0.0, 200, False, True, None, 0.0, True, eps_half=eps)
     emit("a9 _neg_elcbo(value,var,separate_K)", "vbmc/variational_optimization.py:474-485", f"NsK={nsk} N={N} K={K}",
          t, tc, "oracle at NsK=200 (variance part dominates CPU time; unscaled)", max(rel(rd[0], ro[0]), rel(rd[10], ro[10])))
+    # ---- 8f row 1: the sieve's batch of candidates (Ns=0, no gradient) ------------------------
+    B = 50 * K  # ns_elbo candidates of a full sieve (advanced_vbmc_options.ini:63)
+    bnd = synthetic.default_theta_bnd(wl1)
+    thetas = wl1.theta[None, :] + 0.3 * rng.standard_normal((B, wl1.theta.size))
+    v = mkvp(wl1)
+    t, Fb = med(lambda: _neg_elcbo_batch(thetas, g, v, bnd), reps=5)
+    nseq = 200
+    def seq():
+        vv = mkvp(wl1)
+        return [_neg_elcbo(thetas[b].copy(), g, vv, 0.0, 0, False, False, bnd)[0] for b in range(nseq)]
+    tseq, Fs = med(seq, reps=3, warm=1)
+    nb = 20
+    tc, Fo = once(lambda: [elbo_ref.neg_elcbo(thetas[b].copy(), ogp, mix.copy(), 0.0, 0, False, False, bnd, False)[0] for b in range(nb)])
+    emit("8f-1 sieve batch: _neg_elcbo x B (Ns=0, no grad)", "vbmc/variational_optimization.py:775-787", f"B={B} K={K} N={N}",
+         t, tc * B / nb, f"oracle on {nb} candidates, scaled", rel(Fb[:nb], Fo),
+         {"per_candidate_device_calls_ms": 1e3 * tseq * B / nseq, "batch_vs_sequential_device": tseq * B / nseq / t})
     ctx.close()
 
 
