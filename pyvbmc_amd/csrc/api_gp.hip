@@ -269,11 +269,12 @@ extern "C" int vbmc_gp_predict(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, i
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const GpState& g = ctx->gp;
   const int N = g.N, D = g.D, S = g.S;
+  if (D > 32) return vbmc_fail(ctx, VBMC_E_UNSUP, "gp_predict: D=%d > 32 not supported", D);
   const int ntiles = (N + 63) / 64;
   const int64_t BATCH = 1 << 16;
   const int64_t mb = M < BATCH ? M : BATCH;
-  // scratch: xs (mb*D) | Ks (mb*N) | part (ntiles*mb) | fmu (mb) | fs2 (mb)
-  const size_t need = (size_t)mb * D + (size_t)mb * N + (size_t)ntiles * mb + 2 * (size_t)mb;
+  // scratch: xs (mb*D) | Ks (mb*N) | part, fpart (2*ntiles*mb) | fmu (mb) | fs2 (mb)
+  const size_t need = (size_t)mb * D + (size_t)mb * N + 2 * (size_t)ntiles * mb + 2 * (size_t)mb;
   int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, need);
   if (rc) return rc;
   rc = ensure_pinned(ctx, 2 * (size_t)mb);
@@ -281,7 +282,7 @@ extern "C" int vbmc_gp_predict(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, i
   double* d_xs = ctx->d_scratch;
   double* d_Ks = d_xs + (size_t)mb * D;
   double* d_part = d_Ks + (size_t)mb * N;
-  double* d_fmu = d_part + (size_t)ntiles * mb;
+  double* d_fmu = d_part + 2 * (size_t)ntiles * mb;
   double* d_fs2 = d_fmu + mb;
   std::vector<double> mu_s, s2_s;
   if (!separate_samples) {

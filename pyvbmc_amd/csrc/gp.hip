@@ -11,10 +11,12 @@
 #include <cstring>
 
 #include "common.h"
+#include "fastmath.h"
 
 namespace {
 
 constexpr int WAVES = 4;
+typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __device__ inline double wave_sum(double v) {
 #pragma unroll
@@ -86,70 +88,6 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ U,
 }
 
 // ---------------------------------------------------------------------------
-// predict, stage 1: Ks[m][n] = sf^2 exp(-1/2 sum_d ((X_nd - x*_md)/ell_d)^2) (times
-// sW[n] if scale), and fmu[m] = m(x*_m) + sum_n Ks[m][n] alpha_n.   16 points / block.
-constexpr int TMP = 16;
-__global__ __launch_bounds__(256) void predict_kstar_kernel(
-    const double* __restrict__ X, const double* __restrict__ xs, const double* __restrict__ alpha,
-    const double* __restrict__ sW, const double* __restrict__ hyp, int N, int D, int mean_kind,
-    int64_t M, int scale_sw, double* __restrict__ Ks, double* __restrict__ fmu) {
-  extern __shared__ double lds[];
-  double* sXs = lds;              // [TMP][D]  x* / ell
-  double* sIell = sXs + TMP * D;  // [D]
-  double* sRed = sIell + D;       // [WAVES][TMP]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t m0 = (int64_t)blockIdx.x * TMP;
-  if (tid < D) sIell[tid] = exp(-hyp[tid]);
-  __syncthreads();
-  for (int idx = tid; idx < TMP * D; idx += 256) {
-    const int mm = idx / D, d = idx - mm * D;
-    const int64_t m = m0 + mm;
-    sXs[idx] = (m < M) ? xs[m * D + d] * sIell[d] : 0.0;
-  }
-  __syncthreads();
-  const double sf2 = exp(2.0 * hyp[D]);
-  double part[TMP];
-#pragma unroll
-  for (int mm = 0; mm < TMP; ++mm) part[mm] = 0.0;
-  for (int n = tid; n < N; n += 256) {
-    const double an = alpha[n];
-    const double sc = scale_sw ? sW[n] : 1.0;
-#pragma unroll
-    for (int mm = 0; mm < TMP; ++mm) {
-      double d2 = 0.0;
-      for (int d = 0; d < D; ++d) {
-        const double t = X[(size_t)n * D + d] * sIell[d] - sXs[mm * D + d];
-        d2 = fma(t, t, d2);
-      }
-      const double kv = sf2 * exp(-0.5 * d2);
-      part[mm] = fma(kv, an, part[mm]);
-      if (m0 + mm < M) Ks[(size_t)(m0 + mm) * N + n] = kv * sc;
-    }
-  }
-#pragma unroll
-  for (int mm = 0; mm < TMP; ++mm) {
-    const double v = wave_sum(part[mm]);
-    if (lane == 0) sRed[wave * TMP + mm] = v;
-  }
-  __syncthreads();
-  if (tid < TMP && m0 + tid < M) {
-    double v = 0.0;
-    for (int wv = 0; wv < WAVES; ++wv) v += sRed[wv * TMP + tid];
-    // mean function at x* (variational_optimization.py:1383-1392 layout)
-    double mean = 0.0;
-    const double* hm = hyp + D + 2;
-    if (mean_kind == VBMC_MEAN_CONST) mean = hm[0];
-    if (mean_kind == VBMC_MEAN_NEGQUAD) {
-      mean = hm[0];
-      for (int d = 0; d < D; ++d) {
-        const double t = (xs[(m0 + tid) * D + d] - hm[1 + d]) * exp(-hm[1 + D + d]);
-        mean -= 0.5 * t * t;
-      }
-    }
-    fmu[m0 + tid] = mean + v;
-  }
-}
-
 // predict, stage 2: T = A (M x N) * B (N x N) on the FP64 matrix cores, fused row epilogue
 //   mode 0 (L_chol): B = L^-1 upper triangular; part[ct][m] = sum_{c in tile} T[m][c]^2
 //   mode 1         : B = L (full, symmetric);   part[ct][m] = sum_{c in tile} A[m][c] T[m][c]
@@ -162,7 +100,6 @@ __global__ __launch_bounds__(256) void predict_kstar_kernel(
 // On gfx950 the FP64 MFMA peak equals the FP64 vector peak (78.6 TFLOP/s); what the
 // matrix instruction buys here is issue efficiency: 1024 FMAs per instruction and no
 // per-FMA operand traffic.
-typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int TS = 64, TKD = 16, LDA = TKD + 1, LDB = TS + 16;
 __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __restrict__ A,
                                                                const double* __restrict__ B,
@@ -183,17 +120,39 @@ __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __r
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
   const int nmax = (mode == 0) ? min(N, c0 + TS) : N;  // upper-triangular B: n <= c
-  for (int n0 = 0; n0 < nmax; n0 += TKD) {
-    for (int idx = tid; idx < TS * TKD; idx += 256) {
+  // software pipeline: the next panel's global loads are issued into registers before the
+  // MFMAs of the current panel and written to LDS afterwards, so HBM/L2 latency hides
+  // behind the matrix work
+  constexpr int PER = TS * TKD / 256;  // 4 elements of A and of B per thread per panel
+  double ra[PER], rb[PER];
+  auto fetch = [&](int n0) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = tid + 256 * i;
       const int r = idx / TKD, kk = idx - r * TKD;
       const int64_t m = m0 + r;
       const int n = n0 + kk;
-      sA[r * LDA + kk] = (m < M && n < N) ? A[(size_t)m * N + n] : 0.0;
+      ra[i] = (m < M && n < N) ? A[(size_t)m * N + n] : 0.0;
       const int kb = idx / TS, cc = idx - kb * TS;
       const int nb = n0 + kb, c = c0 + cc;
-      sB[kb * LDB + cc] = (nb < N && c < N) ? B[(size_t)nb * N + c] : 0.0;
+      rb[i] = (nb < N && c < N) ? B[(size_t)nb * N + c] : 0.0;
     }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = tid + 256 * i;
+      const int r = idx / TKD, kk = idx - r * TKD;
+      sA[r * LDA + kk] = ra[i];
+      const int kb = idx / TS, cc = idx - kb * TS;
+      sB[kb * LDB + cc] = rb[i];
+    }
+  };
+  fetch(0);
+  for (int n0 = 0; n0 < nmax; n0 += TKD) {
+    stash();
     __syncthreads();
+    if (n0 + TKD < nmax) fetch(n0 + TKD);
 #pragma unroll
     for (int kq = 0; kq < TKD / 4; ++kq) {
       const double a0 = sA[(wm * 32 + li) * LDA + kq * 4 + lk];
@@ -246,14 +205,122 @@ __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __r
   if (tid < TS && m0 + tid < M) part[(size_t)blockIdx.x * M + m0 + tid] = sRow[tid][0] + sRow[tid][1];
 }
 
-__global__ void predict_var_finish_kernel(const double* __restrict__ part, int ntiles, int64_t M,
-                                          double sf2, double sign, double add,
-                                          double* __restrict__ fs2) {
+// predict, stage 1 on the FP64 matrix cores: the dense pairwise-squared-distance block.
+//   d2[m][n] = |a_m|^2 + |b_n|^2 - 2 a_m . b_n,   a = x*/ell, b = X/ell
+// (the reference's own centred form, acquisition_functions/abstract_acq_fcn.py:195-222);
+// the cross term a . b is a 64 x 64 x D product on v_mfma_f64_16x16x4_f64 (D padded to a
+// multiple of 4), then Ks = sf^2 exp(-d2/2) (exp2 with folded constants), Ks * sW is stored
+// for stage 2 and the partial means sum_{n in tile} Ks alpha_n go to fpart[ntile][m].
+// Cancellation: |d2 error| <= ~1e-16 (|a|^2+|b|^2), i.e. a relative error of the same size
+// in Ks -- far inside the 1e-10 budget of the predictive variance.
+constexpr int KDP = 32 + 1;  // LDS row stride (max padded D = 32, +1 against bank conflicts)
+__global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
+    const double* __restrict__ X, const double* __restrict__ xs, const double* __restrict__ alpha,
+    const double* __restrict__ sW, const double* __restrict__ hyp, int N, int D, int64_t M,
+    int scale_sw, double* __restrict__ Ks, double* __restrict__ fpart) {
+  __shared__ double sAm[TS * KDP];  // [64 m][d]
+  __shared__ double sBn[TS * KDP];  // [64 n][d]
+  __shared__ double sA2[TS], sB2[TS], sAl[TS], sSc[TS];
+  __shared__ double sF[TS][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lk = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.y * TS;
+  const int n0 = blockIdx.x * TS;
+  const int DQ = (D + 3) / 4;  // k-steps of 4
+  for (int idx = tid; idx < TS * DQ * 4; idx += 256) {
+    const int r = idx / (DQ * 4), d = idx - r * (DQ * 4);
+    const double iell = (d < D) ? exp(-hyp[d]) : 0.0;
+    const int64_t m = m0 + r;
+    const int n = n0 + r;
+    sAm[r * KDP + d] = (d < D && m < M) ? xs[m * D + d] * iell : 0.0;
+    sBn[r * KDP + d] = (d < D && n < N) ? X[(size_t)n * D + d] * iell : 0.0;
+  }
+  __syncthreads();
+  if (tid < TS) {
+    double a2 = 0.0, b2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+      a2 = fma(sAm[tid * KDP + d], sAm[tid * KDP + d], a2);
+      b2 = fma(sBn[tid * KDP + d], sBn[tid * KDP + d], b2);
+    }
+    sA2[tid] = a2;
+    sB2[tid] = b2;
+    const int n = n0 + tid;
+    sAl[tid] = (n < N) ? alpha[n] : 0.0;
+    sSc[tid] = (n < N) ? (scale_sw ? sW[n] : 1.0) : 0.0;
+  }
+  __syncthreads();
+  double4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int kq = 0; kq < DQ; ++kq) {
+    const double a0 = sAm[(wm * 32 + li) * KDP + kq * 4 + lk];
+    const double a1 = sAm[(wm * 32 + 16 + li) * KDP + kq * 4 + lk];
+    const double b0 = sBn[(wn * 32 + li) * KDP + kq * 4 + lk];
+    const double b1 = sBn[(wn * 32 + 16 + li) * KDP + kq * 4 + lk];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  }
+  // epilogue: kernel values, store, partial means
+  const double l2sf2 = 2.0 * hyp[D] * 0x1.71547652b82fep+0;  // log2(sf^2)
+  const double c = -0.5 * 0x1.71547652b82fep+0;              // -log2(e)/2
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wm * 32 + mt * 16 + lk + 4 * r;
+      const int64_t m = m0 + row;
+      double f = 0.0;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int col = wn * 32 + nt * 16 + li;
+        const int n = n0 + col;
+        const double d2 = fmax(fma(-2.0, acc[mt][nt][r], sA2[row] + sB2[col]), 0.0);
+        const double kv = fm::exp2_fast(fma(c, d2, l2sf2));
+        if (m < M && n < N) Ks[(size_t)m * N + n] = kv * sSc[col];
+        f = fma(kv, sAl[col], f);  // alpha is 0 beyond N
+      }
+      f += __shfl_xor(f, 1, 64);
+      f += __shfl_xor(f, 2, 64);
+      f += __shfl_xor(f, 4, 64);
+      f += __shfl_xor(f, 8, 64);
+      if (li == 0) sF[row][wn] = f;
+    }
+  __syncthreads();
+  if (tid < TS && m0 + tid < M) fpart[(size_t)blockIdx.x * M + m0 + tid] = sF[tid][0] + sF[tid][1];
+}
+
+// predict, stage 3: fmu[m] = mean(x*_m) + sum of the stage-1 partial means,
+// fs2[m] = max(0, sf^2 -/+ sum of the stage-2 partial row sums) (+ noise).
+__global__ void predict_finish_kernel(const double* __restrict__ part, const double* __restrict__ fpart,
+                                      int ntiles, int64_t M, int D, int mean_kind,
+                                      const double* __restrict__ hyp, const double* __restrict__ xs,
+                                      double sf2, double sign, double add, double* __restrict__ fmu,
+                                      double* __restrict__ fs2) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
-  double s = 0.0;
-  for (int t = 0; t < ntiles; ++t) s += part[(size_t)t * M + m];
+  double s = 0.0, f = 0.0;
+  for (int t = 0; t < ntiles; ++t) {
+    s += part[(size_t)t * M + m];
+    f += fpart[(size_t)t * M + m];
+  }
   fs2[m] = fmax(sf2 + sign * s, 0.0) + add;
+  // mean function at x* (variational_optimization.py:1383-1392 layout)
+  double mean = 0.0;
+  const double* hm = hyp + D + 2;
+  if (mean_kind == VBMC_MEAN_CONST) mean = hm[0];
+  if (mean_kind == VBMC_MEAN_NEGQUAD) {
+    mean = hm[0];
+    for (int d = 0; d < D; ++d) {
+      const double t = (xs[m * D + d] - hm[1 + d]) * exp(-hm[1 + D + d]);
+      mean -= 0.5 * t * t;
+    }
+  }
+  fmu[m] = mean + f;
 }
 
 }  // namespace
@@ -291,11 +358,6 @@ int launch_gp_log_joint(vbmc_ctx* ctx, int want_grad, double* d_res, double* d_Z
 int launch_gp_var(vbmc_ctx* ctx, const double* d_Z, double* d_V, double* d_Q) {
   const GpState& g = ctx->gp;
   const int K = ctx->K, N = g.N;
-  bool all_chol = true, none_chol = true;
-  for (int s = 0; s < g.S; ++s) {
-    all_chol = all_chol && g.L_chol[s];
-    none_chol = none_chol && !g.L_chol[s];
-  }
   for (int s = 0; s < g.S; ++s) {
     const int chol = g.L_chol[s];
     const double* Bm = (chol ? g.d_Linv : g.d_L) + (size_t)s * N * N;
@@ -309,8 +371,6 @@ int launch_gp_var(vbmc_ctx* ctx, const double* d_Z, double* d_V, double* d_Q) {
                        ctx->ml, (const double*)(g.d_hyp + (size_t)s * g.P), N, chol,
                        1.0 / g.sn2_eff[s], d_Q + (size_t)s * K * K);
   }
-  (void)all_chol;
-  (void)none_chol;
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
@@ -330,18 +390,20 @@ int launch_gp_predict_sample(vbmc_ctx* ctx, int s, int64_t M, const double* d_xs
   const int N = g.N, D = g.D;
   const double* h = g.hyp.data() + (size_t)s * g.P;
   const int chol = g.L_chol[s];
-  size_t lds = sizeof(double) * ((size_t)TMP * D + D + WAVES * TMP);
-  hipLaunchKernelGGL(predict_kstar_kernel, dim3((unsigned)((M + TMP - 1) / TMP)), dim3(256), lds,
-                     ctx->stream, g.d_X, d_xs, g.d_alpha + (size_t)s * N, g.d_sW + (size_t)s * N,
-                     g.d_hyp + (size_t)s * g.P, N, D, g.mean_kind, M, chol, d_Ks, d_fmu);
   const int ntiles = (N + TS - 1) / TS;
+  double* d_fpart = d_part + (size_t)ntiles * M;  // caller provides 2 * ntiles * M doubles
+  const dim3 grid(ntiles, (unsigned)((M + TS - 1) / TS));
+  hipLaunchKernelGGL(predict_kstar_mfma_kernel, grid, dim3(256), 0, ctx->stream, g.d_X, d_xs,
+                     g.d_alpha + (size_t)s * N, g.d_sW + (size_t)s * N, g.d_hyp + (size_t)s * g.P, N, D,
+                     M, chol, d_Ks, d_fpart);
   const double* Bm = (chol ? g.d_Linv : g.d_L) + (size_t)s * N * N;
-  hipLaunchKernelGGL(predict_var_mfma_kernel, dim3(ntiles, (unsigned)((M + TS - 1) / TS)), dim3(256),
-                     0, ctx->stream, d_Ks, Bm, M, N, chol ? 0 : 1, d_part, (double*)nullptr);
+  hipLaunchKernelGGL(predict_var_mfma_kernel, grid, dim3(256), 0, ctx->stream, d_Ks, Bm, M, N,
+                     chol ? 0 : 1, d_part, (double*)nullptr);
   const double sf2 = std::exp(2.0 * h[D]);
   const double add = add_noise ? std::exp(2.0 * h[D + 1]) * g.sn2_mult[s] : 0.0;
-  hipLaunchKernelGGL(predict_var_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
-                     ctx->stream, d_part, ntiles, M, sf2, chol ? -1.0 : 1.0, add, d_fs2);
+  hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
+                     ctx->stream, d_part, (const double*)d_fpart, ntiles, M, D, g.mean_kind,
+                     g.d_hyp + (size_t)s * g.P, d_xs, sf2, chol ? -1.0 : 1.0, add, d_fmu, d_fs2);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
