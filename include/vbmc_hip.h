@@ -239,6 +239,36 @@ int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta, const vbmc_elbo_op
 int vbmc_neg_elcbo_batch(vbmc_ctx* ctx, const double* thetas_BxN, int B, int n_theta,
                          const vbmc_elbo_opts* opts, double* F_B, double* G_B, double* H_B);
 
+/* ---- the stochastic optimiser's loop, device resident ---- */
+
+/* minimize_adam (vbmc/minimize_adam.py:8-146) specialised to the objective PyVBMC gives it,
+ * vb_train_mc_fun = _neg_elcbo(theta, gp, vp0, beta, ns_ent_K, compute_grad=True,
+ * theta_bnd=...) (vbmc/variational_optimization.py:238-249).  theta, the Adam moments and
+ * the mixture stay on the device; one iteration is four kernel launches and no
+ * synchronisation.  The early-stopping decision (minimize_adam.py:107-140) stays with the
+ * caller, who sees y_tab / x_tab after every vbmc_adam_run -- the reference only tests it
+ * every 20 iterations.
+ *
+ * vbmc_adam_begin: theta0[n_theta] start point (not modified); `opts` as for vbmc_neg_elcbo
+ *   (ns_per_comp even and > 0, compute_grad set; with VBMC_EPS_PHILOX iteration i draws
+ *   from seed + i; with VBMC_EPS_RESIDENT every iteration reuses the resident draws);
+ *   lb/ub[n_theta] the optional box of minimize_adam (both NULL = unbounded); max_iter and
+ *   master_* as in the reference.  Non-optimised blocks keep the ctx mixture's values.
+ * vbmc_adam_run: the next n_iters iterations.  y_tab_out[n_iters] = objective values
+ *   (minimize_adam's y_tab slice), x_tab_out[n_iters][n_theta] = iterates after each update
+ *   (rows; the reference stores them as columns), G_out/H_out[n_iters] the two terms of the
+ *   objective.  All nullable.  VBMC_E_NONFINITE if an iterate became non-finite.
+ * vbmc_adam_end: ends the run; the ctx mixture becomes that of the last iterate (outputs as
+ *   in vbmc_theta_to_mixture, nullable; theta_out = last x with its eta tail max-shifted).
+ * Between begin and end no other entry point of the same ctx may be called. */
+int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta, const vbmc_elbo_opts* opts,
+                    const double* lb, const double* ub, int max_iter, double master_min,
+                    double master_max, double master_decay);
+int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, double* x_tab_out,
+                  double* G_out, double* H_out);
+int vbmc_adam_end(vbmc_ctx* ctx, double* theta_out, double* mu_KxD, double* sigma_K,
+                  double* lambd_D, double* w_K, double* eta_K, int* iterations);
+
 /* ---- multi-GPU: one process per GPU, one collective ---------- */
 
 /* 128-byte RCCL unique id, created on rank 0 and shipped to the other ranks by

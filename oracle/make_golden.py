@@ -27,6 +27,7 @@ import gpyreg as gpr  # noqa: E402  (the stand-in)
 import scipy.io  # noqa: E402
 from pyvbmc.entropy import entlb_vbmc, entmc_vbmc  # noqa: E402
 from pyvbmc.variational_posterior import VariationalPosterior  # noqa: E402
+from pyvbmc.vbmc.minimize_adam import minimize_adam  # noqa: E402
 from pyvbmc.vbmc.variational_optimization import (  # noqa: E402
     _gp_log_joint,
     _neg_elcbo,
@@ -216,11 +217,65 @@ def misc():
     np.savez_compressed(OUT / "misc.npz", **out)
 
 
+def adam():
+    """The reference's minimize_adam (vbmc/minimize_adam.py) on (1) a deterministic,
+    box-constrained quadratic with a wiggle and (2) the objective PyVBMC gives it,
+    _neg_elcbo with fresh np.random draws per iteration (variational_optimization.py:238-249),
+    on config 1 and a shrunken config 2."""
+    out = {}
+    rng = np.random.default_rng(123)
+    n = 7
+    a, c = np.exp(rng.standard_normal(n)), rng.standard_normal(n)
+    x0 = c + 2.0 * rng.standard_normal(n)
+    lb, ub = c - 0.5, c + 3.0
+    lb[0], ub[1] = c[0] + 0.2, c[1] - 0.3  # active constraints
+
+    def fq(x):
+        wob = 0.01 * np.sin(37.0 * np.sum(x))
+        return 0.5 * np.sum(a * (x - c) ** 2) + wob, a * (x - c) + 0.37 * np.cos(37.0 * np.sum(x))
+
+    out.update(quad_a=a, quad_c=c, quad_x0=x0.copy(), quad_lb=lb, quad_ub=ub)
+    for tag, kw in (("box", dict(lb=lb, ub=ub, max_iter=400)),
+                    ("free", dict(max_iter=90, master_max=0.05, use_early_stopping=False)),
+                    ("short", dict(max_iter=25, tol_fun=0.5))):
+        x, y, xt, yt, it = minimize_adam(fq, x0.copy(), **kw)
+        out[f"quad_{tag}_x"], out[f"quad_{tag}_y"] = x, y
+        out[f"quad_{tag}_x_tab"], out[f"quad_{tag}_y_tab"], out[f"quad_{tag}_iters"] = xt, yt, it
+    for name, cfg, shrink, max_iter in (("c1", 1, {}, 80), ("c2s", 2, dict(Ns_total=20 * 100), 45)):
+        wl = synthetic.make_workload(cfg, S=1, **shrink)
+        gp = ref_gp(wl, wl.hyp[:1])
+        bnd = synthetic.default_theta_bnd(wl)
+        vp = ref_vp(wl)
+        theta0 = wl.theta.copy()
+        theta0[0] = bnd["ub"][0] + 0.1  # start outside a soft bound
+        out[f"elbo_{name}_theta0"] = theta0.copy()
+        out[f"elbo_{name}_NsK"] = wl.NsK
+
+        def f(t):
+            r = _neg_elcbo(t, gp, vp, 0.0, wl.NsK, True, False, bnd)
+            return r[0], r[1]
+
+        np.random.seed(40 + cfg)
+        out[f"elbo_{name}_seed"] = 40 + cfg
+        x, y, xt, yt, it = minimize_adam(f, theta0, tol_fun=0.05, max_iter=max_iter,
+                                         master_min=0.001, master_max=0.1, master_decay=200)
+        out[f"elbo_{name}_x"], out[f"elbo_{name}_y"] = x, y
+        out[f"elbo_{name}_x_tab"], out[f"elbo_{name}_y_tab"], out[f"elbo_{name}_iters"] = xt, yt, it
+        print(f"adam elbo {name}: {it} iterations, y {yt[0]:.4f} -> {yt[-1]:.4f}")
+    np.savez_compressed(OUT / "adam.npz", **out)
+    print("wrote adam:", len(out), "keys")
+
+
 if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
-    case("c1", 1, S_multi=2, seed=1, all_flag_combos=True)
-    case("c2s", 2, S_multi=3, seed=2, Ns_total=20 * 200)
-    case("c3s", 3, S_multi=8, seed=3, Ns_total=50 * 200)
-    case("c5s", 5, S_multi=2, seed=5, Ns_total=100 * 100)
-    matlab_known()
-    misc()
+    jobs = {
+        "c1": lambda: case("c1", 1, S_multi=2, seed=1, all_flag_combos=True),
+        "c2s": lambda: case("c2s", 2, S_multi=3, seed=2, Ns_total=20 * 200),
+        "c3s": lambda: case("c3s", 3, S_multi=8, seed=3, Ns_total=50 * 200),
+        "c5s": lambda: case("c5s", 5, S_multi=2, seed=5, Ns_total=100 * 100),
+        "matlab_known": matlab_known,
+        "misc": misc,
+        "adam": adam,
+    }
+    for name in sys.argv[1:] or list(jobs):  # no argument: rewrite everything
+        jobs[name]()

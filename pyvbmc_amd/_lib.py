@@ -93,6 +93,12 @@ SIGNATURES = {
         C.c_int,
         [_vp, _dp, C.c_int, C.c_int, C.POINTER(ElboOpts), _dp, _dp, _dp],
     ),
+    "vbmc_adam_begin": (
+        C.c_int,
+        [_vp, _dp, C.c_int, C.POINTER(ElboOpts), _dp, _dp, C.c_int, C.c_double, C.c_double, C.c_double],
+    ),
+    "vbmc_adam_run": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
+    "vbmc_adam_end": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
     "vbmc_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "vbmc_comm_init": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
     "vbmc_comm_destroy": (C.c_int, [_vp]),

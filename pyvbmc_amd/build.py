@@ -24,6 +24,7 @@ SOURCES = [
     "api_gp.hip",
     "api_elbo.hip",
     "api_batch.hip",
+    "adam.hip",
     "comm.hip",
 ]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

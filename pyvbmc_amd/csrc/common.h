@@ -100,7 +100,10 @@ struct vbmc_ctx {
 
   ncclComm* comm = nullptr;
   int rank = 0, world = 1;
+
+  void* adam = nullptr;  // device-resident optimiser state (adam.hip)
 };
+void adam_free(vbmc_ctx* ctx);
 
 // error helpers -----------------------------------------------------------
 int vbmc_fail(vbmc_ctx* ctx, int code, const char* fmt, ...);

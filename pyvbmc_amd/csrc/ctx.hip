@@ -116,6 +116,7 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   vbmc_comm_destroy(ctx);
+  adam_free(ctx);
   double* bufs[] = {ctx->d_mix, ctx->d_eps, ctx->d_scratch, ctx->d_out, ctx->gp.d_X,
                     ctx->gp.d_alpha, ctx->gp.d_L, ctx->gp.d_Linv, ctx->gp.d_sW, ctx->gp.d_hyp};
   for (double* b : bufs)

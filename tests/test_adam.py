@@ -1,0 +1,256 @@
+"""the stochastic optimiser's loop (reference vbmc/minimize_adam.py).
+
+CPU part: the oracle's restatement and the host mirror against trajectories produced by
+the reference's own minimize_adam (tests/golden/adam.npz, oracle/make_golden.py adam).
+GPU part: the host loop around the device objective against the reference's trajectory
+(NumPy draw stream), and the device-resident loop against the oracle driven by the same
+Philox draws.
+"""
+import numpy as np
+import pytest
+from helpers import oracle_gp, oracle_mix, rel_err
+
+from oracle import adam_ref, elbo_ref, philox_ref
+from pyvbmc_amd import synthetic
+from pyvbmc_amd.minimize_adam import minimize_adam
+
+ELBO_CASES = {"c1": (1, {}), "c2s": (2, dict(Ns_total=20 * 100))}
+QUAD = {
+    "box": lambda g: dict(lb=g["quad_lb"], ub=g["quad_ub"], max_iter=400),
+    "free": lambda g: dict(max_iter=90, master_max=0.05, use_early_stopping=False),
+    "short": lambda g: dict(max_iter=25, tol_fun=0.5),
+}
+
+
+def quad_objective(g):
+    a, c = g["quad_a"], g["quad_c"]
+
+    def f(x):
+        wob = 0.01 * np.sin(37.0 * np.sum(x))
+        return 0.5 * np.sum(a * (x - c) ** 2) + wob, a * (x - c) + 0.37 * np.cos(37.0 * np.sum(x))
+
+    return f
+
+
+def workload_dict(name):
+    cfg, shrink = ELBO_CASES[name]
+    wl = synthetic.make_workload(cfg, S=1, **shrink)
+    g = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X,
+             y=wl.y, hyp=wl.hyp[:1], s2=np.zeros(0) if wl.s2 is None else wl.s2)
+    return wl, g
+
+
+def check_traj(got, g, pre, tol):
+    x, y, xt, yt, it = got
+    assert it == int(g[f"{pre}_iters"])
+    assert xt.shape == g[f"{pre}_x_tab"].shape and yt.shape == g[f"{pre}_y_tab"].shape
+    assert rel_err(xt, g[f"{pre}_x_tab"]) < tol, rel_err(xt, g[f"{pre}_x_tab"])
+    assert rel_err(yt, g[f"{pre}_y_tab"]) < tol, rel_err(yt, g[f"{pre}_y_tab"])
+    assert rel_err(x, g[f"{pre}_x"]) < tol and abs(y - g[f"{pre}_y"]) <= tol * max(1.0, abs(g[f"{pre}_y"]))
+
+
+# ---------------------------------------------------------------- CPU
+@pytest.mark.parametrize("impl", [adam_ref.minimize_adam, minimize_adam], ids=["oracle", "host-mirror"])
+@pytest.mark.parametrize("tag", list(QUAD))
+def test_adam_quadratic_vs_reference(golden, impl, tag):
+    g = golden("adam")
+    x0 = g["quad_x0"].copy()
+    got = impl(quad_objective(g), x0, **QUAD[tag](g))
+    check_traj(got, g, f"quad_{tag}", 1e-13)
+    # the reference applies its first update to the caller's array in place
+    assert np.array_equal(x0, g[f"quad_{tag}_x_tab"][:, 0]) or tag == "box"
+
+
+@pytest.mark.parametrize("name", list(ELBO_CASES))
+def test_oracle_adam_elbo_vs_reference(golden, name):
+    """oracle Adam around the oracle objective, NumPy draw stream == the reference's run."""
+    g = golden("adam")
+    wl, wd = workload_dict(name)
+    mix, gp = oracle_mix(wd), oracle_gp(wd)
+    bnd = synthetic.default_theta_bnd(wl)
+    NsK = int(g[f"elbo_{name}_NsK"])
+    assert NsK == wl.NsK
+
+    def f(t):
+        r = elbo_ref.neg_elcbo(t, gp, mix, 0.0, NsK, True, False, bnd)
+        return r[0], r[1]
+
+    np.random.seed(int(g[f"elbo_{name}_seed"]))
+    n_it = int(g[f"elbo_{name}_iters"])
+    got = adam_ref.minimize_adam(f, g[f"elbo_{name}_theta0"].copy(), tol_fun=0.05, max_iter=n_it,
+                                 master_min=0.001, master_max=0.1, master_decay=200)
+    check_traj(got, g, f"elbo_{name}", 1e-8)
+
+
+def test_window_stop_matches_polyfit_rule():
+    from pyvbmc_amd.minimize_adam import _window_stop
+
+    rng = np.random.default_rng(0)
+    y = 3.0 + 1e-4 * rng.standard_normal(20)
+    xa, xb = rng.standard_normal(5), rng.standard_normal(5)
+    assert _window_stop(y, xa, xa + 1e-5, 0.001)  # flat values, iterates at rest
+    assert not _window_stop(y - 0.5 * np.arange(20), xa, xa + 1e-5, 0.001)  # still descending fast
+    assert not _window_stop(y, xa, xb, 0.001)  # iterates still moving
+
+
+# ---------------------------------------------------------------- GPU
+@pytest.fixture(scope="module")
+def ctx():
+    from pyvbmc_amd import _lib
+
+    c = _lib.Context(0)
+    _lib.set_default_context(c)
+    yield c
+    _lib.set_default_context(None)
+    c.close()
+
+
+def device_objects(wd, ctx):
+    from test_gpu_parity import make_gp, make_vp
+
+    return make_vp(wd, ctx), make_gp(wd, ctx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(ELBO_CASES))
+def test_host_loop_device_objective_vs_reference(ctx, golden, name):
+    """minimize_adam (host mirror) around the fused device objective fed by the NumPy stream
+    reproduces the reference's own optimisation run."""
+    from pyvbmc_amd.variational_optimization import _neg_elcbo
+
+    g = golden("adam")
+    wl, wd = workload_dict(name)
+    vp, gp = device_objects(wd, ctx)
+    bnd = synthetic.default_theta_bnd(wl)
+    NsK = int(g[f"elbo_{name}_NsK"])
+
+    def f(t):
+        r = _neg_elcbo(t, gp, vp, 0.0, NsK, True, False, bnd, rng="numpy")
+        return r[0], r[1]
+
+    np.random.seed(int(g[f"elbo_{name}_seed"]))
+    got = minimize_adam(f, g[f"elbo_{name}_theta0"].copy(), tol_fun=0.05,
+                        max_iter=int(g[f"elbo_{name}_iters"]), master_min=0.001, master_max=0.1,
+                        master_decay=200)
+    check_traj(got, g, f"elbo_{name}", 1e-7)
+
+
+def oracle_philox_run(wl, wd, theta0, bnd, seed, max_iter, mask_flags=None, **kw):
+    mix, gp = oracle_mix(wd), oracle_gp(wd)
+    if mask_flags is not None:
+        mix.optimize_mu, mix.optimize_sigma, mix.optimize_lambd, mix.optimize_weights = mask_flags
+    it = [0]
+
+    def f(t):
+        eps = philox_ref.eps_half(wl.K, wl.NsK // 2, wl.D, seed + it[0])
+        it[0] += 1
+        r = elbo_ref.neg_elcbo(t, gp, mix, 0.0, wl.NsK, True, False, bnd, eps_half=eps)
+        return r[0], r[1]
+
+    return adam_ref.minimize_adam(f, theta0.copy(), max_iter=max_iter, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(ELBO_CASES))
+def test_device_loop_vs_oracle(ctx, golden, name):
+    """The device-resident loop (csrc/adam.hip) against oracle Adam around the oracle
+    objective, both drawing Philox(seed + i) at iteration i."""
+    from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+
+    g = golden("adam")
+    wl, wd = workload_dict(name)
+    vp, gp = device_objects(wd, ctx)
+    bnd = synthetic.default_theta_bnd(wl)
+    theta0 = g[f"elbo_{name}_theta0"].copy()
+    kw = dict(tol_fun=0.05, master_min=0.001, master_max=0.1, master_decay=200)
+    n_it = 60 if name == "c1" else 45
+    ref = oracle_philox_run(wl, wd, theta0, bnd, 1234, n_it, **kw)
+    keep = theta0.copy()
+    got = minimize_adam_elbo(theta0, gp, vp, wl.NsK, bnd, max_iter=n_it, seed=1234, rng="philox", **kw)
+    assert np.array_equal(theta0, keep)  # documented: the start point is not modified
+    assert got[4] == ref[4]
+    assert rel_err(got[3], ref[3]) < 1e-7, rel_err(got[3], ref[3])
+    assert rel_err(got[2], ref[2]) < 1e-7, rel_err(got[2], ref[2])
+    assert rel_err(got[0], ref[0]) < 1e-7 and abs(got[1] - ref[1]) < 1e-7 * max(1.0, abs(ref[1]))
+    # vp holds the last iterate's parameters
+    from oracle import mixture_ref
+
+    mix = oracle_mix(wd)
+    mixture_ref.set_parameters(mix, got[2][:, -1].copy())
+    assert rel_err(vp.mu, mix.mu) < 1e-12 and rel_err(vp.sigma.ravel(), mix.sigma.ravel()) < 1e-12
+    assert rel_err(vp.w.ravel(), mix.w.ravel()) < 1e-12 and rel_err(vp.lambd.ravel(), mix.lambd.ravel()) < 1e-12
+
+
+def masked_bounds(wl, flags):
+    """default_theta_bnd cut down to the blocks get_bounds emits for these optimise flags
+    (variational_posterior.py:205-239: mu | ln scale if sigma or lambda | eta)."""
+    full = synthetic.default_theta_bnd(wl)
+    DK, K = wl.D * wl.K, wl.K
+    keep = np.concatenate([np.full(DK, flags[0]), np.full(DK, flags[1] or flags[2]), np.full(K, flags[3])])
+    out = dict(full)
+    out["lb"], out["ub"] = full["lb"][keep], full["ub"][keep]
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [(True, True, True, False), (True, True, False, True), (False, True, True, True)],
+                         ids=["warmup-no-weights", "no-lambda", "no-mu"])
+def test_device_loop_partial_masks(ctx, flags):
+    """Blocks that are not optimised (warm-up runs without the weights) keep their values."""
+    from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+
+    wl, wd = workload_dict("c2s")
+    vp, gp = device_objects(wd, ctx)
+    vp.optimize_mu, vp.optimize_sigma, vp.optimize_lambd, vp.optimize_weights = flags
+    mix = oracle_mix(wd)
+    mix.optimize_mu, mix.optimize_sigma, mix.optimize_lambd, mix.optimize_weights = flags
+    from oracle import mixture_ref
+
+    theta0 = mixture_ref.get_parameters(mix)
+    theta0[0] += 5.0  # leave a soft bound so the penalty and its odd sigma/lambda reshape act
+    bnd = masked_bounds(wl, flags)
+    kw = dict(tol_fun=0.05, master_min=0.001, master_max=0.1, master_decay=200)
+    ref = oracle_philox_run(wl, wd, theta0, bnd, 99, 40, mask_flags=flags, **kw)
+    got = minimize_adam_elbo(theta0, gp, vp, wl.NsK, bnd, max_iter=40, seed=99, rng="philox", **kw)
+    assert got[4] == ref[4]
+    assert rel_err(got[2], ref[2]) < 1e-7, rel_err(got[2], ref[2])
+    assert rel_err(got[3], ref[3]) < 1e-7
+
+
+@pytest.mark.gpu
+def test_device_loop_box_and_no_early_stop(ctx):
+    """Box constraints clamp every iterate; without early stopping the loop is one enqueue."""
+    from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+
+    wl, wd = workload_dict("c1")
+    vp, gp = device_objects(wd, ctx)
+    bnd = synthetic.default_theta_bnd(wl)
+    theta0 = wl.theta.copy()
+    lb, ub = theta0 - 0.05, theta0 + 0.02
+    kw = dict(master_min=0.001, master_max=0.1, master_decay=200, use_early_stopping=False)
+    ref = oracle_philox_run(wl, wd, theta0, bnd, 7, 30, lb=lb, ub=ub, **kw)
+    got = minimize_adam_elbo(theta0, gp, vp, wl.NsK, bnd, lb=lb, ub=ub, max_iter=30, seed=7, rng="philox", **kw)
+    assert got[4] == 30
+    assert np.all(got[2] >= lb[:, None]) and np.all(got[2] <= ub[:, None])
+    assert rel_err(got[2], ref[2]) < 1e-7 and rel_err(got[3], ref[3]) < 1e-7
+
+
+@pytest.mark.gpu
+def test_device_loop_errors(ctx):
+    from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+
+    wl, wd = workload_dict("c1")
+    vp, gp = device_objects(wd, ctx)
+    with pytest.raises(ValueError):
+        minimize_adam_elbo(wl.theta.copy(), gp, vp, 0)  # Adam is only used with the MC entropy
+    with pytest.raises(ValueError):
+        minimize_adam_elbo(wl.theta[:-1].copy(), gp, vp, wl.NsK, max_iter=20)  # wrong length
+    with pytest.raises(NotImplementedError):
+        minimize_adam_elbo(wl.theta.copy(), gp, vp, wl.NsK, beta=1.0)
+    bad = wl.theta.copy()
+    bad[0] = np.nan
+    with pytest.raises(Exception):
+        minimize_adam_elbo(bad, gp, vp, wl.NsK, max_iter=20)
+    # the context is usable afterwards
+    out = minimize_adam_elbo(wl.theta.copy(), gp, vp, wl.NsK, max_iter=20, seed=3)
+    assert out[4] == 20 and np.all(np.isfinite(out[3]))

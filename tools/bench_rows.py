@@ -113,6 +113,7 @@ def main():
         err = rel(Hd, Ho) if not dHo.size else max(rel(Hd, Ho), rel(dHd, dHo))
         emit(f"a6 entmc_vbmc {tag}", "entropy/entmc_vbmc.py:6-134", f"D={D} K={K} NsK={wl1.NsK}", t,
              tc * wl1.NsK / nsk, f"oracle at NsK={nsk}, scaled", err, {"kernel_ms": ctx.last_kernel_ms(0)})
+        tc_entmc_grad = tc * wl1.NsK / nsk  # the gradient pass (last) stands in for one Adam objective
     # ---- a8: _gp_log_joint -------------------------------------------------------
     for wl, tag in ((wl1, "S=1"), (wl8, "S=8")):
         g, ogp = mkgp(wl), gp_ref.make_gp(wl.X, wl.y, wl.hyp, s2=wl.s2, noise_user=wl.s2 is not None)
@@ -164,6 +165,23 @@ def main():
     emit("8f-1 sieve batch: _neg_elcbo x B (Ns=0, no grad)", "vbmc/variational_optimization.py:775-787", f"B={B} K={K} N={N}",
          t, tc * B / nb, f"oracle on {nb} candidates, scaled", rel(Fb[:nb], Fo),
          {"per_candidate_device_calls_ms": 1e3 * tseq * B / nseq, "batch_vs_sequential_device": tseq * B / nseq / t})
+    # ---- 8f row 2: the stochastic optimiser's loop, device resident --------------------------
+    from pyvbmc_amd.minimize_adam import minimize_adam, minimize_adam_elbo
+    n_it = 200
+    kw = dict(max_iter=n_it, master_min=0.001, master_max=0.1, master_decay=200, use_early_stopping=False)
+    v = mkvp(wl1)
+    t, out = med(lambda: minimize_adam_elbo(wl1.theta.copy(), g, v, wl1.NsK, bnd, seed=11, rng="philox", **kw), reps=3, warm=1)
+    def host_loop():
+        vv, it = mkvp(wl1), [0]
+        def f(th):
+            r = _neg_elcbo(th, g, vv, 0.0, wl1.NsK, True, False, bnd, rng="philox", seed=11 + it[0])
+            it[0] += 1
+            return r[0], r[1]
+        return minimize_adam(f, wl1.theta.copy(), **kw)
+    th, oh = med(host_loop, reps=3, warm=1)
+    emit("8f-2 minimize_adam, device-resident loop (per iteration)", "vbmc/minimize_adam.py:84-105 + variational_optimization.py:238-249",
+         f"NsK={wl1.NsK} K={K} N={N} iters={n_it}", t / n_it, tc_entmc_grad, "oracle entropy value+grad of one evaluation, scaled (the GP part and the update are negligible)",
+         rel(out[3], oh[3]), {"host_loop_device_objective_ms_per_iter": 1e3 * th / n_it, "device_vs_host_loop": th / t})
     ctx.close()
 
 
