@@ -269,6 +269,37 @@ int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, double* x_tab_o
 int vbmc_adam_end(vbmc_ctx* ctx, double* theta_out, double* mu_KxD, double* sigma_K,
                   double* lambd_D, double* w_K, double* eta_K, int* iterations);
 
+/* ---- acquisition evaluation, pairwise distances -- */
+
+/* Closed-form acquisition functions of the reference. */
+enum {
+  VBMC_ACQ_STD = 0,     /* AcqFcn        acquisition_functions/acq_fcn.py:38-45          */
+  VBMC_ACQ_LOG = 1,     /* AcqFcnLog     acquisition_functions/acq_fcn_log.py:43-52      */
+  VBMC_ACQ_VANILLA = 2, /* AcqFcnVanilla acquisition_functions/acq_fcn_vanilla.py:38-42  */
+  VBMC_ACQ_NOISY = 3    /* AcqFcnNoisy   acquisition_functions/acq_fcn_noisy.py:33-41    */
+};
+
+/* The device part of AbstractAcqFcn.__call__ (acquisition_functions/abstract_acq_fcn.py:
+ * 80-131) for M points in transformed space: gp.predict(separate_samples=True) with the GP
+ * of vbmc_set_gp, f_bar / var_tot over the hyper-parameter samples (:82-97), the density of
+ * the ctx mixture (vp.pdf(Xs, orig_flag=False[, log_flag=True])), the formula selected by
+ * `kind` with y_max = function_logger.y_max, the variance regularisation (:112-128; off when
+ * tol_gp_var <= 0) and the clamp at -realmax (:130-131).  sn2_M: per-point observation noise,
+ * VBMC_ACQ_NOISY only.  Integer-variable rounding (:77-79) and the hard-bound mask
+ * (:133-139) involve the caller's parameter transformer and stay on the host.
+ * f_bar_M / var_tot_M nullable. */
+int vbmc_acq_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int kind, double y_max,
+                  double tol_gp_var, const double* sn2_M, double* acq_M, double* f_bar_M,
+                  double* var_tot_M);
+
+/* AbstractAcqFcn._sq_dist (acquisition_functions/abstract_acq_fcn.py:195-222):
+ * c[i][j] = max(|a_i - mu|^2 + |b_j - mu|^2 - 2 (a_i - mu).(b_j - mu), 0), mu the common
+ * mean the reference subtracts first.  argmin_n (nullable) = np.argmin(c, axis=1), the
+ * nearest-neighbour lookup of _estimate_observation_noise (:244-252); c_nxm nullable when
+ * only the argmin is wanted.  D <= 32. */
+int vbmc_sq_dist(vbmc_ctx* ctx, int64_t n, int64_t m, int D, const double* a_nxD,
+                 const double* b_mxD, double* c_nxm, int64_t* argmin_n);
+
 /* ---- multi-GPU: one process per GPU, one collective ---------- */
 
 /* 128-byte RCCL unique id, created on rank 0 and shipped to the other ranks by

@@ -266,6 +266,52 @@ def adam():
     print("wrote adam:", len(out), "keys")
 
 
+def acq():
+    """The reference's closed-form acquisition classes (acquisition_functions/acq_fcn*.py via
+    AbstractAcqFcn.__call__) on seeded points: gp.predict through the gpyreg stand-in, vp.pdf
+    and the formulas are the reference's own code."""
+    from types import SimpleNamespace
+
+    from pyvbmc.acquisition_functions import AcqFcn, AcqFcnLog, AcqFcnNoisy, AcqFcnVanilla
+    from pyvbmc.acquisition_functions.abstract_acq_fcn import AbstractAcqFcn
+
+    out = {}
+    rng = np.random.default_rng(2024)
+    # _sq_dist on its own (the reference's test_sq_dist checks it against a direct loop)
+    a, b = 3.0 + rng.standard_normal((37, 5)), 3.0 + 2.0 * rng.standard_normal((71, 5))
+    out["sq_a"], out["sq_b"], out["sq_c"] = a, b, AbstractAcqFcn._sq_dist(a, b)
+    for name, cfg, S, shrink in (("c1", 1, 2, {}), ("c2s", 2, 3, dict(Ns_total=20 * 100))):
+        wl = synthetic.make_workload(cfg, S=S, **shrink)
+        gp = ref_gp(wl, wl.hyp)
+        vp = ref_vp(wl)
+        M = 96
+        comp = rng.integers(0, wl.K, size=M)
+        Xs = wl.mu.T[comp] + 1.5 * wl.lambd * wl.sigma[comp, None] * rng.standard_normal((M, wl.D))
+        Xs[:8] = wl.X[:8] + 1e-3 * rng.standard_normal((8, wl.D))  # near training inputs: tiny variance
+        lo, hi = wl.X.min(axis=0) - 1.0, wl.X.max(axis=0) + 1.0
+        Xs[-3:] = hi + 0.5  # beyond the hard bounds
+        length = np.exp(wl.hyp[0, : wl.D])
+        gp.temporary_data["X_rescaled"] = wl.X / length
+        gp.temporary_data["sn2_new"] = 0.01 + rng.random(wl.N)
+        flog = SimpleNamespace(y_max=float(np.max(wl.y)))
+        base = dict(integer_vars=None, lb_eps_orig=lo, ub_eps_orig=hi, gp_length_scale=length)
+        out[f"{name}_Xs"], out[f"{name}_lo"], out[f"{name}_hi"] = Xs, lo, hi
+        out[f"{name}_sn2_new"], out[f"{name}_y_max"], out[f"{name}_S"] = gp.temporary_data["sn2_new"], flog.y_max, S
+        f_mu, f_s2 = gp.predict(Xs, separate_samples=True)
+        var_tot = f_s2.mean(axis=1) + f_mu.var(axis=1, ddof=1)
+        tol = float(np.sort(var_tot)[12])  # a dozen points fall below the variance tolerance
+        out[f"{name}_tol_gp_var"] = tol
+        for cls in (AcqFcn, AcqFcnLog, AcqFcnVanilla, AcqFcnNoisy):
+            for reg in (False, True):
+                st = dict(base, variance_regularized_acq_fcn=reg, tol_gp_var=tol)
+                with np.errstate(all="ignore"):
+                    v = cls()(Xs.copy(), gp, vp, flog, st)
+                out[f"{name}_{cls.__name__}_{int(reg)}"] = v
+        out[f"{name}_one"] = AcqFcnLog()(Xs[20].copy(), gp, vp, flog, dict(base))  # 1-D input
+    np.savez_compressed(OUT / "acq.npz", **out)
+    print("wrote acq:", len(out), "keys")
+
+
 if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
     jobs = {
@@ -276,6 +322,7 @@ if __name__ == "__main__":
         "matlab_known": matlab_known,
         "misc": misc,
         "adam": adam,
+        "acq": acq,
     }
     for name in sys.argv[1:] or list(jobs):  # no argument: rewrite everything
         jobs[name]()

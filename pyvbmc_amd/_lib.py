@@ -99,6 +99,11 @@ SIGNATURES = {
     ),
     "vbmc_adam_run": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
     "vbmc_adam_end": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
+    "vbmc_acq_eval": (
+        C.c_int,
+        [_vp, C.c_int64, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp, _dp],
+    ),
+    "vbmc_sq_dist": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, _dp, _dp, _dp, C.POINTER(C.c_int64)]),
     "vbmc_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "vbmc_comm_init": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
     "vbmc_comm_destroy": (C.c_int, [_vp]),

@@ -25,6 +25,7 @@ SOURCES = [
     "api_elbo.hip",
     "api_batch.hip",
     "adam.hip",
+    "api_acq.hip",
     "comm.hip",
 ]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1,0 +1,206 @@
+// acquisition-function evaluation, and row a13 (_sq_dist).
+//
+// AbstractAcqFcn.__call__ (acquisition_functions/abstract_acq_fcn.py:68-147) evaluates, for a
+// batch of points, gp.predict(separate_samples=True), the mean / total variance over the GP
+// hyper-parameter samples, vp.pdf (or log pdf) and one of the closed-form acquisition
+// formulas.  Here the points are uploaded once, the per-sample predictive moments stay on the
+// device, and one fused kernel turns them into the acquisition value: the only D2H traffic
+// is the M results.
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+
+namespace {
+
+constexpr double kRealMin = 2.2250738585072014e-308;   // sys.float_info.min
+constexpr double kRealMax = 1.7976931348623157e+308;   // sys.float_info.max
+constexpr double kLogRealMin = -708.3964185322641;     // np.log(sys.float_info.min)
+
+// fmu, fs2: [S][M] per-sample predictive moments; dens: pdf (or log pdf for VBMC_ACQ_LOG).
+__global__ __launch_bounds__(256) void acq_combine_kernel(
+    const double* __restrict__ fmu, const double* __restrict__ fs2, const double* __restrict__ dens,
+    const double* __restrict__ sn2, int S, int64_t M, int64_t ld, int kind, double y_max,
+    double tol_var, double* __restrict__ acq, double* __restrict__ f_bar_out,
+    double* __restrict__ var_tot_out) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  // abstract_acq_fcn.py:82-97
+  double fsum = 0.0, vsum = 0.0;
+  for (int s = 0; s < S; ++s) {
+    fsum += fmu[(size_t)s * ld + m];
+    vsum += fs2[(size_t)s * ld + m];
+  }
+  const double f_bar = fsum / S, var_bar = vsum / S;
+  double var_f = 0.0;
+  if (S > 1) {
+    double q = 0.0;
+    for (int s = 0; s < S; ++s) {
+      const double t = fmu[(size_t)s * ld + m] - f_bar;
+      q += t * t;
+    }
+    var_f = q / (S - 1);
+  }
+  const double var_tot = var_f + var_bar;
+  double a;
+  bool log_flag = false;
+  switch (kind) {
+    case VBMC_ACQ_LOG: {  // acq_fcn_log.py:43-52
+      const double log_p = fmax(dens[m], kLogRealMin);
+      a = -(log(var_tot) + f_bar - y_max + log_p);
+      log_flag = true;
+      break;
+    }
+    case VBMC_ACQ_VANILLA: {  // acq_fcn_vanilla.py:38-42
+      const double p = fmax(dens[m], kRealMin);
+      a = -var_tot * (p * p);
+      break;
+    }
+    case VBMC_ACQ_NOISY: {  // acq_fcn_noisy.py:33-41
+      const double p = fmax(dens[m], kRealMin);
+      const double sn = sn2[m];
+      a = -var_tot * (1.0 - sn / (var_tot + sn)) * exp(f_bar - y_max) * p;
+      break;
+    }
+    default: {  // VBMC_ACQ_STD, acq_fcn.py:38-45
+      const double p = fmax(dens[m], kRealMin);
+      a = -var_tot * exp(f_bar - y_max) * p;
+      break;
+    }
+  }
+  // variance regularisation (abstract_acq_fcn.py:112-128)
+  if (tol_var > 0.0 && var_tot < tol_var) {
+    const double pen = tol_var / var_tot - 1.0;
+    if (log_flag)
+      a += pen;
+    else
+      a *= exp(-pen);
+  }
+  acq[m] = fmax(a, -kRealMax);  // :130-131
+  if (f_bar_out) f_bar_out[m] = f_bar;
+  if (var_tot_out) var_tot_out[m] = var_tot;
+}
+
+}  // namespace
+
+extern "C" int vbmc_acq_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int kind, double y_max,
+                             double tol_gp_var, const double* sn2_M, double* acq_M, double* f_bar_M,
+                             double* var_tot_M) {
+  if (!ctx || (M > 0 && (!xs_MxD || !acq_M))) return VBMC_E_ARG;
+  NEED_DEVICE(ctx);
+  if (!ctx->gp.set) return vbmc_fail(ctx, VBMC_E_ARG, "acq_eval: GP not set");
+  if (!ctx->mix_set) return vbmc_fail(ctx, VBMC_E_ARG, "acq_eval: mixture not set");
+  if (ctx->gp.D != ctx->D) return vbmc_fail(ctx, VBMC_E_ARG, "acq_eval: GP/mixture D mismatch");
+  if (kind < VBMC_ACQ_STD || kind > VBMC_ACQ_NOISY)
+    return vbmc_fail(ctx, VBMC_E_UNSUP, "acq_eval: unknown acquisition kind %d", kind);
+  if (kind == VBMC_ACQ_NOISY && !sn2_M)
+    return vbmc_fail(ctx, VBMC_E_ARG, "acq_eval: the noisy acquisition needs sn2 per point");
+  if (M == 0) return VBMC_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const GpState& g = ctx->gp;
+  const int N = g.N, D = g.D, S = g.S;
+  if (D > 32) return vbmc_fail(ctx, VBMC_E_UNSUP, "acq_eval: D=%d > 32 not supported", D);
+  const int ntiles = (N + 63) / 64;
+  const int64_t BATCH = 1 << 16;
+  const int64_t mb = M < BATCH ? M : BATCH;
+  // scratch: xs | Ks | part,fpart | fmu[S] | fs2[S] | dens | sn2 | acq | f_bar | var_tot
+  const size_t need = (size_t)mb * D + (size_t)mb * N + 2 * (size_t)ntiles * mb + 2 * (size_t)S * mb +
+                      5 * (size_t)mb;
+  int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, need);
+  if (rc) return rc;
+  rc = ensure_pinned(ctx, 3 * (size_t)mb);
+  if (rc) return rc;
+  double* d_xs = ctx->d_scratch;
+  double* d_Ks = d_xs + (size_t)mb * D;
+  double* d_part = d_Ks + (size_t)mb * N;
+  double* d_fmu = d_part + 2 * (size_t)ntiles * mb;
+  double* d_fs2 = d_fmu + (size_t)S * mb;
+  double* d_dens = d_fs2 + (size_t)S * mb;
+  double* d_sn2 = d_dens + mb;
+  double* d_acq = d_sn2 + mb;  // acq | f_bar | var_tot, contiguous
+  for (int64_t o = 0; o < M; o += mb) {
+    const int64_t m = (M - o) < mb ? (M - o) : mb;
+    HIP_TRY(ctx, hipMemcpyAsync(d_xs, xs_MxD + o * D, sizeof(double) * m * D, hipMemcpyHostToDevice,
+                                ctx->stream));
+    if (kind == VBMC_ACQ_NOISY)
+      HIP_TRY(ctx, hipMemcpyAsync(d_sn2, sn2_M + o, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
+    for (int s = 0; s < S; ++s) {
+      rc = launch_gp_predict_sample(ctx, s, m, d_xs, d_Ks, d_part, 0, d_fmu + (size_t)s * mb,
+                                    d_fs2 + (size_t)s * mb);
+      if (rc) return rc;
+    }
+    rc = launch_mixture_pdf(ctx, m, d_xs, kind == VBMC_ACQ_LOG, 0, INFINITY, d_dens, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(acq_combine_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const double*)d_fmu, (const double*)d_fs2, (const double*)d_dens,
+                       (const double*)d_sn2, S, m, mb, kind, y_max, tol_gp_var, d_acq, d_acq + mb,
+                       d_acq + 2 * mb);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, d_acq, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+    if (f_bar_M)
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned + mb, d_acq + mb, sizeof(double) * m, hipMemcpyDeviceToHost,
+                                  ctx->stream));
+    if (var_tot_M)
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned + 2 * mb, d_acq + 2 * mb, sizeof(double) * m,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(acq_M + o, ctx->h_pinned, sizeof(double) * m);
+    if (f_bar_M) memcpy(f_bar_M + o, ctx->h_pinned + mb, sizeof(double) * m);
+    if (var_tot_M) memcpy(var_tot_M + o, ctx->h_pinned + 2 * mb, sizeof(double) * m);
+  }
+  return VBMC_OK;
+}
+
+// a13: c[i][j] = |a_i - b_j|^2 the way AbstractAcqFcn._sq_dist computes it
+// (acquisition_functions/abstract_acq_fcn.py:195-222); argmin_n (nullable) = np.argmin(c, axis=1)
+// (the nearest-neighbour lookup of _estimate_observation_noise, :244-252).
+extern "C" int vbmc_sq_dist(vbmc_ctx* ctx, int64_t n, int64_t m, int D, const double* a_nxD,
+                            const double* b_mxD, double* c_nxm, int64_t* argmin_n) {
+  if (!ctx || n < 0 || m < 0 || D < 1) return VBMC_E_ARG;
+  if (n > 0 && m > 0 && (!a_nxD || !b_mxD)) return VBMC_E_ARG;
+  NEED_DEVICE(ctx);
+  if (D > 32) return vbmc_fail(ctx, VBMC_E_UNSUP, "sq_dist: D=%d > 32 not supported", D);
+  if (m > (int64_t)1 << 24) return vbmc_fail(ctx, VBMC_E_UNSUP, "sq_dist: more than 2^24 columns");
+  if (argmin_n && m == 0 && n > 0)
+    return vbmc_fail(ctx, VBMC_E_ARG, "sq_dist: argmin of an empty row");
+  if (n == 0 || m == 0) return VBMC_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // mu = m/(n+m) mean(b) + n/(n+m) mean(a)   (:212-215)
+  std::vector<double> ma(D, 0.0), mbv(D, 0.0), cen(D);
+  for (int64_t i = 0; i < n; ++i)
+    for (int d = 0; d < D; ++d) ma[d] += a_nxD[i * D + d];
+  for (int64_t j = 0; j < m; ++j)
+    for (int d = 0; d < D; ++d) mbv[d] += b_mxD[j * D + d];
+  const double tot = (double)(n + m);
+  for (int d = 0; d < D; ++d) cen[d] = ((double)m / tot) * (mbv[d] / m) + ((double)n / tot) * (ma[d] / n);
+  const int ntiles = (int)((m + 63) / 64);
+  // rows per pass: keep the n x m block under ~256 MiB
+  int64_t nb = c_nxm ? ((int64_t)1 << 25) / (m > 0 ? m : 1) : ((int64_t)1 << 20);
+  nb = nb < 64 ? 64 : nb;
+  nb = nb > n ? n : nb;
+  const size_t n_c = c_nxm ? (size_t)nb * m : 0;
+  const size_t n_p = argmin_n ? 2 * (size_t)ntiles * nb + (size_t)nb : 0;  // tile minima/indices + int64 out
+  const size_t need = (size_t)D + (size_t)nb * D + (size_t)m * D + n_c + n_p;
+  int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, need);
+  if (rc) return rc;
+  double* d_cen = ctx->d_scratch;
+  double* d_a = d_cen + D;
+  double* d_b = d_a + (size_t)nb * D;
+  double* d_c = c_nxm ? d_b + (size_t)m * D : nullptr;
+  double* d_p = d_b + (size_t)m * D + n_c;
+  int64_t* d_am = argmin_n ? (int64_t*)(d_p + 2 * (size_t)ntiles * nb) : nullptr;
+  HIP_TRY(ctx, hipMemcpyAsync(d_cen, cen.data(), sizeof(double) * D, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_b, b_mxD, sizeof(double) * m * D, hipMemcpyHostToDevice, ctx->stream));
+  for (int64_t o = 0; o < n; o += nb) {
+    const int64_t cnt = (n - o) < nb ? (n - o) : nb;
+    HIP_TRY(ctx, hipMemcpyAsync(d_a, a_nxD + o * D, sizeof(double) * cnt * D, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_sq_dist(ctx, d_a, cnt, d_b, (int)m, D, d_cen, d_c, d_p, d_am);
+    if (rc) return rc;
+    if (c_nxm)
+      HIP_TRY(ctx, hipMemcpyAsync(c_nxm + o * m, d_c, sizeof(double) * cnt * m, hipMemcpyDeviceToHost, ctx->stream));
+    if (argmin_n)
+      HIP_TRY(ctx, hipMemcpyAsync(argmin_n + o, d_am, sizeof(int64_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return VBMC_OK;
+}

@@ -22,7 +22,7 @@ extern "C" int vbmc_set_gp(vbmc_ctx* ctx, int N, int D, int S, int P, int mean_k
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   GpState& g = ctx->gp;
-  double** bufs[] = {&g.d_X, &g.d_alpha, &g.d_L, &g.d_Linv, &g.d_sW, &g.d_hyp};
+  double** bufs[] = {&g.d_X, &g.d_alpha, &g.d_L, &g.d_Linv, &g.d_sW, &g.d_hyp, &g.d_xc};
   for (double** b : bufs)
     if (*b) {
       HIP_TRY(ctx, hipFree(*b));
@@ -51,6 +51,14 @@ extern "C" int vbmc_set_gp(vbmc_ctx* ctx, int N, int D, int S, int P, int mean_k
   HIP_TRY(ctx, hipMemcpyAsync(g.d_L, L_SxNxN, sizeof(double) * S * nn, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(g.d_sW, sW_SxN, sizeof(double) * S * N, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(g.d_hyp, hyp_SxP, sizeof(double) * S * P, hipMemcpyHostToDevice, ctx->stream));
+  // centre of the |a|^2 + |b|^2 - 2 a.b expansion in predict (cf. _sq_dist's mean shift,
+  // acquisition_functions/abstract_acq_fcn.py:212-217)
+  std::vector<double> xc(D, 0.0);
+  for (int n = 0; n < N; ++n)
+    for (int d = 0; d < D; ++d) xc[d] += X_NxD[(size_t)n * D + d];
+  for (int d = 0; d < D; ++d) xc[d] /= N;
+  HIP_TRY(ctx, hipMalloc((void**)&g.d_xc, sizeof(double) * D));
+  HIP_TRY(ctx, hipMemcpy(g.d_xc, xc.data(), sizeof(double) * D, hipMemcpyHostToDevice));
   // L^-1 of the Cholesky samples, once per GP update
   int rc = launch_trinv(ctx);
   if (rc) return rc;
@@ -273,17 +281,17 @@ extern "C" int vbmc_gp_predict(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, i
   const int ntiles = (N + 63) / 64;
   const int64_t BATCH = 1 << 16;
   const int64_t mb = M < BATCH ? M : BATCH;
-  // scratch: xs (mb*D) | Ks (mb*N) | part, fpart (2*ntiles*mb) | fmu (mb) | fs2 (mb)
-  const size_t need = (size_t)mb * D + (size_t)mb * N + 2 * (size_t)ntiles * mb + 2 * (size_t)mb;
+  // scratch: xs (mb*D) | Ks (mb*N) | part, fpart (2*ntiles*mb) | fmu [S][mb] | fs2 [S][mb]
+  const size_t need = (size_t)mb * D + (size_t)mb * N + 2 * (size_t)ntiles * mb + 2 * (size_t)S * mb;
   int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, need);
   if (rc) return rc;
-  rc = ensure_pinned(ctx, 2 * (size_t)mb);
+  rc = ensure_pinned(ctx, 2 * (size_t)S * mb);
   if (rc) return rc;
   double* d_xs = ctx->d_scratch;
   double* d_Ks = d_xs + (size_t)mb * D;
   double* d_part = d_Ks + (size_t)mb * N;
   double* d_fmu = d_part + 2 * (size_t)ntiles * mb;
-  double* d_fs2 = d_fmu + mb;
+  double* d_fs2 = d_fmu + (size_t)S * mb;
   std::vector<double> mu_s, s2_s;
   if (!separate_samples) {
     mu_s.resize((size_t)mb * S);
@@ -293,23 +301,23 @@ extern "C" int vbmc_gp_predict(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, i
     const int64_t m = (M - o) < mb ? (M - o) : mb;
     HIP_TRY(ctx, hipMemcpyAsync(d_xs, xs_MxD + o * D, sizeof(double) * m * D, hipMemcpyHostToDevice,
                                 ctx->stream));
+    // every hyper-parameter sample is enqueued before the one synchronisation of the batch
     for (int s = 0; s < S; ++s) {
       if (s == 0) HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
-      rc = launch_gp_predict_sample(ctx, s, m, d_xs, d_Ks, d_part, add_noise, d_fmu, d_fs2);
+      rc = launch_gp_predict_sample(ctx, s, m, d_xs, d_Ks, d_part, add_noise, d_fmu + (size_t)s * mb,
+                                    d_fs2 + (size_t)s * mb);
       if (rc) return rc;
       if (s == 0) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
         ctx->ev_valid[3] = true;
       }
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, d_fmu, sizeof(double) * 2 * m, hipMemcpyDeviceToHost,
-                                  ctx->stream));
-      // d_fs2 directly follows d_fmu only when m == mb; copy separately otherwise
-      if (m != mb)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned + m, d_fs2, sizeof(double) * m,
-                                    hipMemcpyDeviceToHost, ctx->stream));
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-      const double* hm = ctx->h_pinned;
-      const double* hv = ctx->h_pinned + m;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, d_fmu, sizeof(double) * 2 * S * mb, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int s = 0; s < S; ++s) {
+      const double* hm = ctx->h_pinned + (size_t)s * mb;
+      const double* hv = ctx->h_pinned + (size_t)(S + s) * mb;
       if (separate_samples) {
         for (int64_t i = 0; i < m; ++i) {
           fmu[(o + i) * S + s] = hm[i];

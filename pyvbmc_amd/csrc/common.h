@@ -58,6 +58,7 @@ struct GpState {
   double* d_Linv = nullptr;   // S x N x N : inverse of the upper Cholesky factor (L_chol samples)
   double* d_sW = nullptr;     // S x N
   double* d_hyp = nullptr;    // S x P
+  double* d_xc = nullptr;     // D : column means of X (centre of the pairwise-distance expansion)
 };
 
 struct vbmc_ctx {
@@ -183,6 +184,10 @@ int launch_gp_var(vbmc_ctx* ctx, const double* d_Z, double* d_V, double* d_Q);
 int launch_trinv(vbmc_ctx* ctx);
 int launch_gp_predict_sample(vbmc_ctx* ctx, int s, int64_t M, const double* d_xs, double* d_Ks,
                              double* d_part, int add_noise, double* d_fmu, double* d_fs2);
+// c[n][m] = |a_n - b_m|^2 (centred expansion, cross term on the FP64 matrix cores), optional
+// row-wise argmin; d_cen[D] = the centre subtracted from both sets
+int launch_sq_dist(vbmc_ctx* ctx, const double* d_a, int64_t n, const double* d_b, int m, int D,
+                   const double* d_cen, double* d_c, double* d_pmin, int64_t* d_argmin);
 
 // host finalisation of the GP expected log joint (api_gp.hip)
 struct GljHost {

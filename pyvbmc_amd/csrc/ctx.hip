@@ -118,7 +118,8 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   vbmc_comm_destroy(ctx);
   adam_free(ctx);
   double* bufs[] = {ctx->d_mix, ctx->d_eps, ctx->d_scratch, ctx->d_out, ctx->gp.d_X,
-                    ctx->gp.d_alpha, ctx->gp.d_L, ctx->gp.d_Linv, ctx->gp.d_sW, ctx->gp.d_hyp};
+                    ctx->gp.d_alpha, ctx->gp.d_L, ctx->gp.d_Linv, ctx->gp.d_sW, ctx->gp.d_hyp,
+                    ctx->gp.d_xc};
   for (double* b : bufs)
     if (b) (void)hipFree(b);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);

@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
                                                            int chunks, int stride,
                                                            const double* __restrict__ mix,
                                                            MixLayout ml, double inv_ns,
-                                                           int want_grad, double* __restrict__ raw) {
+                                                           int want_grad, int mu_from_w,
+                                                           double* __restrict__ raw) {
   const int D = ml.D, K = ml.K;
   const double* w = mix + ml.o_w;
   const double* sig = mix + ml.o_sig;
@@ -217,6 +218,17 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
     if (u < D * K) {
       const int j = u / D, d = u - j * D;
       for (int c = lane; c < chunks; c += 64) v += partial[((int64_t)j * chunks + c) * stride + 1 + d];
+      if (mu_from_w) {
+        // wave-split kernel: the Delta part of the mean gradient comes from the W sums,
+        //   sum_k w_k/sigma_k^2 (mu'_jd - mu'_kd) W_jk   (entropy_ws.hip, pass 2)
+        const double* mup = mix + ml.o_mup;
+        const double* is2 = mix + ml.o_is2;
+        for (int i = lane; i < K * chunks; i += 64) {
+          const int k = i / chunks, c = i - k * chunks;
+          const double Wjk = partial[((int64_t)j * chunks + c) * stride + 2 + 2 * D + k];
+          v = fma(w[k] * is2[k] * (mup[j * D + d] - mup[k * D + d]), Wjk, v);
+        }
+      }
       v = wave_sum(v) * w[j] * inv_ns * ilam[d];
     } else if ((u -= D * K) < K) {
       for (int c = lane; c < chunks; c += 64) v += partial[((int64_t)u * chunks + c) * stride + 1 + D];
@@ -500,7 +512,7 @@ int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out) {
   const int n_out = raw_len(ctx->D, ctx->K);
   hipLaunchKernelGGL(entmc_finish_kernel, dim3((n_out + 3) / 4), dim3(256), 0, ctx->stream,
                      p.a.partial, p.a.chunks, p.a.stride, ctx->d_mix, ctx->ml, p.inv_ns,
-                     p.a.want_grad, raw_out);
+                     p.a.want_grad, p.ws ? 1 : 0, raw_out);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }

@@ -23,8 +23,11 @@
 //     gradient accumulator is linear in the per-wave partial sums and is reduced once
 //     per workgroup;
 //   * exp is exp2 with log2(e), -1/(2 sigma_k^2) and log2 of the normalisation folded
-//     into one FMA; log is an atanh series (fastmath.h).
-// Output: the same per-workgroup partial rows as entropy.hip, reduced by its kernels.
+//     into one FMA; log is an atanh series (fastmath.h);
+//   * the Delta part of the mean gradient, summed over the rows, only needs the W sums
+//     the weight gradient already collects, so it is formed by the finish kernel.
+// Output: the same per-workgroup partial rows as entropy.hip, reduced by its kernels
+// (entmc_finish_kernel, mu_from_w = 1).
 #include "common.h"
 #include "entropy_args.h"
 #include "fastmath.h"
@@ -98,8 +101,8 @@ __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   const double sig_j = a.mix[a.ml.o_sig + j];
-  const double two_sj = 2.0 * sig_j;
   const double sj2 = sig_j * sig_j;
+  const double two_sj = 2.0 * sig_j;
   const double* Tj = T + (size_t)j * K4 * TS;
 
   double ec[11];
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double
     // Scalar loads return out of order, hence the explicit "wait, then issue" sequence.
     double qp = 0.0, qm = 0.0;
     double rp_[KTMAX], rm_[KTMAX];
-    constexpr int NR1 = DP + 4;  // Delta, a, c, lrc, w
+    constexpr int NR1 = DP + 4;  // Delta, |Delta|^2, a, lrc, w
     double cur[NR1], nxt[NR1];
     {
       const double* tr = Tw;
@@ -230,6 +233,10 @@ __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double
       //   lp_d = sum_k gp_k (Delta_dk + s e_d),  lm_d = sum_k gm_k (Delta_dk - s e_d),
       //   gp_k = w_k r+_k / (sigma_k^2 q+), gm_k likewise;
       //   mu  += lp + lm       = sum_k (gp+gm) Delta_dk + s e_d sum_k (gp-gm)
+      //          the first sum, added over the rows, is sum_k wis2_k Delta_dk W_jk with
+      //          W_jk = sum_rows (r+_k/q+ + r-_k/q-) -- exactly what Wacc collects for the
+      //          weight gradient, so the finish kernel forms it once per (j, d) and the
+      //          inner loop only keeps the e_d part
       //   lam += (lp - lm) e_d = e_d [ sum_k (gp-gm) Delta_dk + s e_d sum_k (gp+gm) ]
       const double ip = valid ? fm::rcp_fast(qp) : 0.0;
       const double im = valid ? fm::rcp_fast(qm) : 0.0;
@@ -258,16 +265,13 @@ __global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double
           }
           __builtin_amdgcn_sched_barrier(0);
           const double t1 = rp_[kk] * ip, t2 = rm_[kk] * im;  // norm_j1 / q
-          Wacc[kk] += t1 + t2;
-          const double gp = t1 * c2[DP + 4], gm = t2 * c2[DP + 4];
-          const double gs = gp + gm, gd = gp - gm;
-          sgs += gs;
+          const double ts = t1 + t2, td = t1 - t2;
+          Wacc[kk] += ts;
+          sgs = fma(ts, c2[DP + 4], sgs);  // sum_k (gp + gm),  g = w_k / sigma_k^2 * norm_j1 / q
+          const double gd = td * c2[DP + 4];
           sgd += gd;
 #pragma unroll
-          for (int d = 0; d < DP; ++d) {
-            mu_acc[d] = fma(gs, c2[d], mu_acc[d]);
-            Td[d] = fma(gd, c2[d], Td[d]);
-          }
+          for (int d = 0; d < DP; ++d) Td[d] = fma(gd, c2[d], Td[d]);
 #pragma unroll
           for (int d = 0; d < DP; ++d) c2[d] = n2[d];
           c2[DP + 4] = n2[DP + 4];

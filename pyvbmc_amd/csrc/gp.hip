@@ -211,13 +211,14 @@ __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __r
 // the cross term a . b is a 64 x 64 x D product on v_mfma_f64_16x16x4_f64 (D padded to a
 // multiple of 4), then Ks = sf^2 exp(-d2/2) (exp2 with folded constants), Ks * sW is stored
 // for stage 2 and the partial means sum_{n in tile} Ks alpha_n go to fpart[ntile][m].
-// Cancellation: |d2 error| <= ~1e-16 (|a|^2+|b|^2), i.e. a relative error of the same size
-// in Ks -- far inside the 1e-10 budget of the predictive variance.
+// Both sets are shifted by the column means of X first, as the reference's _sq_dist shifts by
+// a common mean.  Cancellation: |d2 error| <= ~1e-16 (|a|^2+|b|^2), i.e. a relative error of
+// the same size in Ks -- far inside the 1e-10 budget of the predictive variance.
 constexpr int KDP = 32 + 1;  // LDS row stride (max padded D = 32, +1 against bank conflicts)
 __global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
     const double* __restrict__ X, const double* __restrict__ xs, const double* __restrict__ alpha,
-    const double* __restrict__ sW, const double* __restrict__ hyp, int N, int D, int64_t M,
-    int scale_sw, double* __restrict__ Ks, double* __restrict__ fpart) {
+    const double* __restrict__ sW, const double* __restrict__ hyp, const double* __restrict__ cen,
+    int N, int D, int64_t M, int scale_sw, double* __restrict__ Ks, double* __restrict__ fpart) {
   __shared__ double sAm[TS * KDP];  // [64 m][d]
   __shared__ double sBn[TS * KDP];  // [64 n][d]
   __shared__ double sA2[TS], sB2[TS], sAl[TS], sSc[TS];
@@ -231,10 +232,11 @@ __global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
   for (int idx = tid; idx < TS * DQ * 4; idx += 256) {
     const int r = idx / (DQ * 4), d = idx - r * (DQ * 4);
     const double iell = (d < D) ? exp(-hyp[d]) : 0.0;
+    const double c0 = (d < D) ? cen[d] : 0.0;
     const int64_t m = m0 + r;
     const int n = n0 + r;
-    sAm[r * KDP + d] = (d < D && m < M) ? xs[m * D + d] * iell : 0.0;
-    sBn[r * KDP + d] = (d < D && n < N) ? X[(size_t)n * D + d] * iell : 0.0;
+    sAm[r * KDP + d] = (d < D && m < M) ? (xs[m * D + d] - c0) * iell : 0.0;
+    sBn[r * KDP + d] = (d < D && n < N) ? (X[(size_t)n * D + d] - c0) * iell : 0.0;
   }
   __syncthreads();
   if (tid < TS) {
@@ -292,6 +294,127 @@ __global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
     }
   __syncthreads();
   if (tid < TS && m0 + tid < M) fpart[(size_t)blockIdx.x * M + m0 + tid] = sF[tid][0] + sF[tid][1];
+}
+
+// a13: AbstractAcqFcn._sq_dist (acquisition_functions/abstract_acq_fcn.py:195-222):
+//   c[i][j] = max(|a_i - mu|^2 + |b_j - mu|^2 - 2 (a_i - mu).(b_j - mu), 0),
+// mu = the size-weighted mean of both sets (computed by the caller, `cen`).  Same tiling as
+// the kernel above; optional outputs: the matrix, and per row the (min, first argmin) of
+// each 64-column tile for the nearest-neighbour lookup (:244-252).
+__global__ __launch_bounds__(256) void sq_dist_mfma_kernel(
+    const double* __restrict__ A, const double* __restrict__ B, const double* __restrict__ cen,
+    int64_t NA, int NB, int D, double* __restrict__ C, double* __restrict__ pmin,
+    int* __restrict__ pidx) {
+  __shared__ double sAm[TS * KDP];
+  __shared__ double sBn[TS * KDP];
+  __shared__ double sA2[TS], sB2[TS];
+  __shared__ double sMin[TS][2];
+  __shared__ int sIdx[TS][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lk = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.y * TS;
+  const int n0 = blockIdx.x * TS;
+  const int DQ = (D + 3) / 4;
+  for (int idx = tid; idx < TS * DQ * 4; idx += 256) {
+    const int r = idx / (DQ * 4), d = idx - r * (DQ * 4);
+    const double c0 = (d < D) ? cen[d] : 0.0;
+    const int64_t m = m0 + r;
+    const int n = n0 + r;
+    sAm[r * KDP + d] = (d < D && m < NA) ? A[m * D + d] - c0 : 0.0;
+    sBn[r * KDP + d] = (d < D && n < NB) ? B[(size_t)n * D + d] - c0 : 0.0;
+  }
+  __syncthreads();
+  if (tid < TS) {
+    double a2 = 0.0, b2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+      a2 = fma(sAm[tid * KDP + d], sAm[tid * KDP + d], a2);
+      b2 = fma(sBn[tid * KDP + d], sBn[tid * KDP + d], b2);
+    }
+    sA2[tid] = a2;
+    sB2[tid] = b2;
+  }
+  __syncthreads();
+  double4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int kq = 0; kq < DQ; ++kq) {
+    const double a0 = sAm[(wm * 32 + li) * KDP + kq * 4 + lk];
+    const double a1 = sAm[(wm * 32 + 16 + li) * KDP + kq * 4 + lk];
+    const double b0 = sBn[(wn * 32 + li) * KDP + kq * 4 + lk];
+    const double b1 = sBn[(wn * 32 + 16 + li) * KDP + kq * 4 + lk];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wm * 32 + mt * 16 + lk + 4 * r;
+      const int64_t m = m0 + row;
+      double best = INFINITY;
+      int bidx = 0x7fffffff;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int col = wn * 32 + nt * 16 + li;
+        const int n = n0 + col;
+        // the reference's association: |a|^2 + (|b|^2 - 2 a.b)
+        const double d2 = fmax(sA2[row] + fma(-2.0, acc[mt][nt][r], sB2[col]), 0.0);
+        if (m < NA && n < NB) {
+          if (C) C[(size_t)m * NB + n] = d2;
+          if (d2 < best) {  // nt ascending: ties keep the smaller column
+            best = d2;
+            bidx = n;
+          }
+        }
+      }
+      // first minimum over the 16 lanes that share this row
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        const double ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bidx, off, 64);
+        if (ob < best || (ob == best && oi < bidx)) {
+          best = ob;
+          bidx = oi;
+        }
+      }
+      if (li == 0) {
+        sMin[row][wn] = best;
+        sIdx[row][wn] = bidx;
+      }
+    }
+  if (!pmin) return;
+  __syncthreads();
+  if (tid < TS && m0 + tid < NA) {
+    double best = sMin[tid][0];
+    int bidx = sIdx[tid][0];
+    if (sMin[tid][1] < best) {  // columns of wn = 1 are larger: ties keep wn = 0
+      best = sMin[tid][1];
+      bidx = sIdx[tid][1];
+    }
+    pmin[(size_t)blockIdx.x * NA + m0 + tid] = best;
+    pidx[(size_t)blockIdx.x * NA + m0 + tid] = bidx;
+  }
+}
+
+__global__ void sq_dist_argmin_kernel(const double* __restrict__ pmin, const int* __restrict__ pidx,
+                                      int ntiles, int64_t NA, int64_t* __restrict__ out) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= NA) return;
+  double best = pmin[m];
+  int bidx = pidx[m];
+  for (int t = 1; t < ntiles; ++t) {  // tiles ascending: ties keep the first (np.argmin)
+    const double v = pmin[(size_t)t * NA + m];
+    if (v < best) {
+      best = v;
+      bidx = pidx[(size_t)t * NA + m];
+    }
+  }
+  out[m] = bidx;
 }
 
 // predict, stage 3: fmu[m] = mean(x*_m) + sum of the stage-1 partial means,
@@ -394,8 +517,8 @@ int launch_gp_predict_sample(vbmc_ctx* ctx, int s, int64_t M, const double* d_xs
   double* d_fpart = d_part + (size_t)ntiles * M;  // caller provides 2 * ntiles * M doubles
   const dim3 grid(ntiles, (unsigned)((M + TS - 1) / TS));
   hipLaunchKernelGGL(predict_kstar_mfma_kernel, grid, dim3(256), 0, ctx->stream, g.d_X, d_xs,
-                     g.d_alpha + (size_t)s * N, g.d_sW + (size_t)s * N, g.d_hyp + (size_t)s * g.P, N, D,
-                     M, chol, d_Ks, d_fpart);
+                     g.d_alpha + (size_t)s * N, g.d_sW + (size_t)s * N, g.d_hyp + (size_t)s * g.P,
+                     (const double*)g.d_xc, N, D, M, chol, d_Ks, d_fpart);
   const double* Bm = (chol ? g.d_Linv : g.d_L) + (size_t)s * N * N;
   hipLaunchKernelGGL(predict_var_mfma_kernel, grid, dim3(256), 0, ctx->stream, d_Ks, Bm, M, N,
                      chol ? 0 : 1, d_part, (double*)nullptr);
@@ -404,6 +527,22 @@ int launch_gp_predict_sample(vbmc_ctx* ctx, int s, int64_t M, const double* d_xs
   hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
                      ctx->stream, d_part, (const double*)d_fpart, ntiles, M, D, g.mean_kind,
                      g.d_hyp + (size_t)s * g.P, d_xs, sf2, chol ? -1.0 : 1.0, add, d_fmu, d_fs2);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+// d_pmin: scratch of 2 * ntiles * n doubles (tile minima, then their int indices) when the
+// argmin is wanted.
+int launch_sq_dist(vbmc_ctx* ctx, const double* d_a, int64_t n, const double* d_b, int m, int D,
+                   const double* d_cen, double* d_c, double* d_pmin, int64_t* d_argmin) {
+  const int ntiles = (m + TS - 1) / TS;
+  int* d_pidx = d_argmin ? (int*)(d_pmin + (size_t)ntiles * n) : nullptr;
+  const dim3 grid(ntiles, (unsigned)((n + TS - 1) / TS));
+  hipLaunchKernelGGL(sq_dist_mfma_kernel, grid, dim3(256), 0, ctx->stream, d_a, d_b, d_cen, n, m, D,
+                     d_c, d_argmin ? d_pmin : (double*)nullptr, d_pidx);
+  if (d_argmin)
+    hipLaunchKernelGGL(sq_dist_argmin_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const double*)d_pmin, (const int*)d_pidx, ntiles, n, d_argmin);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }

@@ -18,7 +18,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .entropy import DEFAULT_RNG, _even_ns, draw_eps_half
+from .entropy import _even_ns, draw_eps_half
 from .gp import upload_gp
 
 BATCH_SIZE = 20  # minimize_adam.py:66
@@ -87,9 +87,10 @@ def minimize_adam_elbo(theta0, gp, vp, Ns, theta_bnd=None, beta=0.0, lb=None, ub
     theta0, lb, ub, ...)`` with the whole inner loop on the device.
 
     Same return tuple ``(x, y, x_tab, y_tab, iterations)``.  Differences from the host loop:
-    ``theta0`` is not modified; with ``rng="philox"`` (default) iteration ``i`` draws from
-    ``seed + i``; with ``rng="numpy"`` / ``eps_half`` one set of draws from the NumPy stream
-    is uploaded and reused by every iteration (common random numbers).  On return ``vp``
+    ``theta0`` is not modified; the draws come from the in-kernel Philox generator (iteration
+    ``i`` uses ``seed + i``) whatever ``VBMC_HIP_RNG`` says, because fresh NumPy draws would
+    have to be uploaded every iteration; ``rng="numpy"`` / ``eps_half`` upload ONE set of
+    draws from the NumPy stream that every iteration reuses (common random numbers).  On return ``vp``
     holds the parameters of the last iterate (the reference leaves those of the last
     *evaluated* iterate; its caller overwrites them right away, :283-300)."""
     if beta != 0 and np.isfinite(beta):
@@ -114,7 +115,7 @@ def minimize_adam_elbo(theta0, gp, vp, Ns, theta_bnd=None, beta=0.0, lb=None, ub
         opts.tol_con = float(theta_bnd["tol_con"])
         opts.weight_threshold = float(theta_bnd.get("weight_threshold", 0.0))
         opts.weight_penalty = float(theta_bnd.get("weight_penalty", 0.0))
-    mode = DEFAULT_RNG if rng is None else rng
+    mode = "philox" if rng is None else rng  # fresh draws per iteration need the in-kernel generator
     if eps_half is not None or mode == "numpy":
         if eps_half is None:
             eps_half = draw_eps_half(K, D, ns)

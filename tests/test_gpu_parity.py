@@ -437,7 +437,8 @@ def test_full_size_config3_against_oracle(ctx):
 def test_rccl_call_path_single_rank(golden):
     """A 1-rank RCCL communicator with the collective forced on: exercises
     ncclCommInitRank / ncclAllReduce(sum, f64) on the library stream and the
-    device-raw -> all-reduce -> copy-back branch of the fused objective."""
+    device-raw -> all-reduce -> copy-back branch of the fused objective, and the in-stream
+    all-reduce of the device-resident Adam loop."""
     import os
     import subprocess
     import sys
@@ -466,7 +467,10 @@ gp.update(X_new=wl.X, y_new=wl.y, hyp=wl.hyp)
 eps = synthetic.draw_eps_half(wl.K, wl.D, wl.NsK, 7)
 r = _neg_elcbo(wl.theta.copy(), gp, mk(), 0.0, wl.NsK, True, False, None, eps_half=eps)
 H, dH = entmc_vbmc(mk(), wl.NsK, eps_half=eps)
-print("RESULT", repr(r[0]), repr(r[3]), repr(H), repr(float(np.abs(dH).sum())))
+from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+ad = minimize_adam_elbo(wl.theta.copy(), gp, mk(), wl.NsK, synthetic.default_theta_bnd(wl), max_iter=25, seed=5, rng="philox")
+print("RESULT", repr(r[0]), repr(r[3]), repr(H), repr(float(np.abs(dH).sum())), repr(float(ad[3].sum())),
+      repr(float(np.abs(ad[2]).sum())))
 """ % (str(root), str(root / "tests"))
     outs = []
     for force in ("0", "1"):

@@ -182,6 +182,34 @@ def main():
     emit("8f-2 minimize_adam, device-resident loop (per iteration)", "vbmc/minimize_adam.py:84-105 + variational_optimization.py:238-249",
          f"NsK={wl1.NsK} K={K} N={N} iters={n_it}", t / n_it, tc_entmc_grad, "oracle entropy value+grad of one evaluation, scaled (the GP part and the update are negligible)",
          rel(out[3], oh[3]), {"host_loop_device_objective_ms_per_iter": 1e3 * th / n_it, "device_vs_host_loop": th / t})
+    # ---- 8f row 3: acquisition evaluation on the cached search batch (2^13 points) ------------
+    from types import SimpleNamespace
+    from oracle import acq_ref
+    from pyvbmc_amd import acquisition
+    M = 8192
+    g8, ogp8 = mkgp(wl8), gp_ref.make_gp(wl8.X, wl8.y, wl8.hyp, s2=wl8.s2, noise_user=wl8.s2 is not None)
+    comp = rng.integers(0, K, size=M)
+    Xs = wl8.mu.T[comp] + 1.5 * wl8.lambd * wl8.sigma[comp, None] * rng.standard_normal((M, D))
+    length = np.exp(wl8.hyp[0, :D])
+    state = dict(integer_vars=None, lb_eps_orig=wl8.X.min(0) - 2.0, ub_eps_orig=wl8.X.max(0) + 2.0,
+                 gp_length_scale=length, variance_regularized_acq_fcn=True, tol_gp_var=1e-4)
+    flog = SimpleNamespace(y_max=float(np.max(wl8.y)))
+    v8 = mkvp(wl8)
+    fn = acquisition.AcqFcnLog()
+    t, av = med(lambda: fn(Xs.copy(), g8, v8, flog, state), reps=5)
+    def composed():
+        fm, fs = g8.predict(Xs, separate_samples=True)
+        lp = v8.pdf(Xs, orig_flag=False, log_flag=True)
+        return fm, fs, lp
+    tcomp, _ = med(composed, reps=5)
+    ms = 512
+    with np.errstate(all="ignore"):
+        tc, ao = once(lambda: acq_ref.acq_call(acq_ref.LOG, Xs[:ms].copy(), ogp8, mix, flog.y_max, state))
+    fin = ~np.isinf(ao)
+    emit("8f-3 AcqFcnLog.__call__ (predict S=8 + log pdf + formula)", "acquisition_functions/abstract_acq_fcn.py:68-147",
+         f"M={M} N={N} D={D} K={K} S=8", t, tc * M / ms, f"oracle on {ms} points, scaled",
+         float(np.max(np.abs(av[:ms][fin] - ao[fin]) / np.maximum(1.0, np.abs(ao[fin])))),
+         {"separate_predict_plus_pdf_calls_ms": 1e3 * tcomp})
     ctx.close()
 
 
