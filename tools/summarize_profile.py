@@ -35,6 +35,8 @@ for k, v in acc.items():
     short = k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").strip() or k[:40]
     if "anonymous" in k and "::" in k:
         short = k.split("::")[1].split("(")[0].split("<")[0]
+    if "entmc_ws_kernel<" in k:  # keep <DP, KTMAX, GRAD, EXACT, PHILOX>: the draw source changes the traffic
+        short = "entmc_ws_kernel<" + k.split("entmc_ws_kernel<")[1].split(">")[0].replace(" ", "") + ">"
     summary.setdefault(short, {})
     for c, vals in v.items():
         m = sum(vals) / len(vals)
