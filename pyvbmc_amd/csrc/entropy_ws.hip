@@ -85,8 +85,20 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // The (j,k) table rows [Delta_jk (DP) | a | c | lrc | w | wis2 | pad] are written by prep.hip.
 // EXACT: ceil(K/4) == KTMAX (padding components have zero density): the per-component guards fold away.
+// Per-lane state is ~(4 DP + 3 KTMAX) doubles with gradients.  Up to ~95 it fits the 256
+// registers of 2 waves/SIMD; beyond that one wave per SIMD with the 512-register budget
+// (AGPRs as spill space) beats spilling to scratch memory.
+constexpr int ws_min_waves(int dp, int ktmax, bool grad) {
+#ifdef VBMC_WS_FORCE_WAVES
+  return VBMC_WS_FORCE_WAVES;
+#else
+  return (grad && 4 * dp + 3 * ktmax > 95) ? 1 : 2;
+#endif
+}
+
 template <int DP, int KTMAX, bool GRAD, bool EXACT, bool PHILOX>
-__global__ __launch_bounds__(WG, 2) void entmc_ws_kernel(EntArgs a, const double* __restrict__ T) {
+__global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_kernel(
+    EntArgs a, const double* __restrict__ T) {
   constexpr int TS = DP + 6;
   __shared__ double sQ[2][WAVES][2][64];          // q partials, double-buffered by batch parity
   constexpr int GB = 4;                           // Philox mode: batches generated per round
