@@ -300,6 +300,28 @@ int vbmc_acq_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int kind, doub
 int vbmc_sq_dist(vbmc_ctx* ctx, int64_t n, int64_t m, int D, const double* a_nxD,
                  const double* b_mxD, double* c_nxm, int64_t* argmin_n);
 
+/* ---- sampling and its Monte-Carlo consumers -------------- */
+
+/* VariationalPosterior.sample in transformed space, Gaussian components
+ * (variational_posterior/variational_posterior.py:241-363 with orig_flag=False, df=inf):
+ * x_n = mu_i + (lambda o z_n) sigma_i, i from the weights (np.random.choice, :316-319) or, with
+ * balance_flag, split exactly by floor(w N) plus remainder draws (:296-313).  Draws come from
+ * the counter-based Philox generator keyed by (seed, n) -- not NumPy's stream -- so sample n
+ * is reproducible on its own; unlike the reference the balanced samples are NOT shuffled
+ * (grouped by component).  x_NxD / comp_N nullable. */
+int vbmc_mixture_sample(vbmc_ctx* ctx, int64_t N, uint64_t seed, int balance_flag, double* x_NxD,
+                        int32_t* comp_N);
+
+/* VariationalPosterior.kl_div, Monte-Carlo branch (gauss_flag=False, :1107-1126), between
+ * the ctx mixture (vp1) and a second mixture over the same D: N balanced samples of each
+ * (seed, seed+1), both densities, the reference's zero-density replacement rules, and
+ * kl_out = max(0, [KL(vp1||vp2), KL(vp2||vp1)]).  Evaluated in transformed space, which equals
+ * the reference's original-space value when both posteriors share one parameter transformer
+ * (the Jacobians cancel in log q2 - log q1). */
+int vbmc_kl_div_mc(vbmc_ctx* ctx, int64_t N, uint64_t seed, int K2, const double* mu2_KxD,
+                   const double* sigma2_K, const double* lambd2_D, const double* w2_K,
+                   double kl_out[2]);
+
 /* ---- multi-GPU: one process per GPU, one collective ---------- */
 
 /* 128-byte RCCL unique id, created on rank 0 and shipped to the other ranks by

@@ -312,6 +312,40 @@ def acq():
     print("wrote acq:", len(out), "keys")
 
 
+def vpmc():
+    """The reference's RNG-bound VariationalPosterior methods under a seeded NumPy stream:
+    sample (plain / balanced), Monte-Carlo moments, kl_div (both branches) and kl_div_mvn."""
+    from pyvbmc.stats import kl_div_mvn
+
+    out = {}
+    for name, cfg, shrink in (("c1", 1, {}), ("c2s", 2, dict(Ns_total=20 * 100))):
+        wl = synthetic.make_workload(cfg, S=1, **shrink)
+        vp = ref_vp(wl)
+        vp2 = ref_vp(wl)
+        rng = np.random.default_rng(60 + cfg)
+        vp2.mu = vp2.mu + 0.2 * rng.standard_normal(vp2.mu.shape)
+        vp2.sigma = vp2.sigma * np.exp(0.1 * rng.standard_normal(vp2.sigma.shape))
+        w2 = vp2.w * np.exp(0.3 * rng.standard_normal(vp2.w.shape))
+        vp2.w = w2 / w2.sum()
+        out[f"{name}_mu2"], out[f"{name}_sigma2"], out[f"{name}_w2"] = vp2.mu, vp2.sigma.ravel(), vp2.w.ravel()
+        for bal in (False, True):
+            np.random.seed(7)
+            x, i = vp.sample(500, orig_flag=False, balance_flag=bal)
+            out[f"{name}_sample_x_{int(bal)}"], out[f"{name}_sample_i_{int(bal)}"] = x, i
+        np.random.seed(8)
+        m, c = vp.moments(20000, orig_flag=True, cov_flag=True)
+        out[f"{name}_mom_mc_mean"], out[f"{name}_mom_mc_cov"] = m, c
+        np.random.seed(9)
+        out[f"{name}_kl_mc"] = vp.kl_div(vp2, N=20000)
+        np.random.seed(10)
+        out[f"{name}_kl_gauss"] = vp.kl_div(vp2, N=20000, gauss_flag=True)
+        m1, c1 = vp.moments(orig_flag=False, cov_flag=True)
+        m2, c2 = vp2.moments(orig_flag=False, cov_flag=True)
+        out[f"{name}_kl_mvn"] = kl_div_mvn(m1, c1, m2, c2)
+    np.savez_compressed(OUT / "vpmc.npz", **out)
+    print("wrote vpmc:", len(out), "keys")
+
+
 if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
     jobs = {
@@ -323,6 +357,7 @@ if __name__ == "__main__":
         "misc": misc,
         "adam": adam,
         "acq": acq,
+        "vpmc": vpmc,
     }
     for name in sys.argv[1:] or list(jobs):  # no argument: rewrite everything
         jobs[name]()

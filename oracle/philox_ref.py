@@ -57,3 +57,38 @@ def eps_half(K, n_half, D, seed, row_begin=0, row_count=None):
         if 2 * p + 1 < D:
             out[:, :, 2 * p + 1] = rad * np.sin(2.0 * np.pi * u2)
     return out
+
+
+def _split(idx):
+    idx = np.asarray(idx, dtype=np.uint64)
+    return (idx & MASK).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32)
+
+
+def normals(idx, D, seed, c3):
+    """[len(idx)][D] standard normals for counter = (idx_lo, idx_hi, pair, c3): the
+    generator of csrc/philox.h with the stream word c3 free (csrc/sample.hip uses c3 = 2)."""
+    seed = int(seed)
+    lo, hi = _split(idx)
+    out = np.empty((lo.size, D))
+    for p in range((D + 1) // 2):
+        x0, x1, x2, x3 = philox4x32_10(lo, hi, np.full_like(lo, p), np.full_like(lo, c3),
+                                       seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+        a = ((x0.astype(np.uint64) << np.uint64(32)) | x1.astype(np.uint64)) >> np.uint64(11)
+        b = ((x2.astype(np.uint64) << np.uint64(32)) | x3.astype(np.uint64)) >> np.uint64(11)
+        u1 = (a + np.uint64(1)).astype(np.float64) * 2.0**-53
+        u2 = b.astype(np.float64) * 2.0**-53
+        rad = np.sqrt(-2.0 * np.log(u1))
+        out[:, 2 * p] = rad * np.cos(2.0 * np.pi * u2)
+        if 2 * p + 1 < D:
+            out[:, 2 * p + 1] = rad * np.sin(2.0 * np.pi * u2)
+    return out
+
+
+def uniform(idx, seed, c3):
+    """[len(idx)] uniforms in [0,1) for counter = (idx_lo, idx_hi, 0, c3)."""
+    seed = int(seed)
+    lo, hi = _split(idx)
+    x0, x1, _, _ = philox4x32_10(lo, hi, np.zeros_like(lo), np.full_like(lo, c3),
+                                 seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    a = ((x0.astype(np.uint64) << np.uint64(32)) | x1.astype(np.uint64)) >> np.uint64(11)
+    return a.astype(np.float64) * 2.0**-53

@@ -104,6 +104,8 @@ SIGNATURES = {
         [_vp, C.c_int64, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp, _dp],
     ),
     "vbmc_sq_dist": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, _dp, _dp, _dp, C.POINTER(C.c_int64)]),
+    "vbmc_mixture_sample": (C.c_int, [_vp, C.c_int64, C.c_uint64, C.c_int, _dp, C.POINTER(C.c_int32)]),
+    "vbmc_kl_div_mc": (C.c_int, [_vp, C.c_int64, C.c_uint64, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "vbmc_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "vbmc_comm_init": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
     "vbmc_comm_destroy": (C.c_int, [_vp]),

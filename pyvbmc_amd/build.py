@@ -26,6 +26,7 @@ SOURCES = [
     "api_batch.hip",
     "adam.hip",
     "api_acq.hip",
+    "sample.hip",
     "comm.hip",
 ]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

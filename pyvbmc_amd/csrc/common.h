@@ -178,6 +178,8 @@ int launch_entlb(vbmc_ctx* ctx, double* d_res);  // writes raw entlb terms
 // mixture pdf
 int launch_mixture_pdf(vbmc_ctx* ctx, int64_t n, const double* d_x, int log_flag,
                        int grad_flag, double df, double* d_y, double* d_dy);
+int launch_mixture_pdf_on(vbmc_ctx* ctx, const double* d_pack, const MixLayout& ml, int64_t n,
+                          const double* d_x, int log_flag, double* d_y);
 // gp
 int launch_gp_log_joint(vbmc_ctx* ctx, int want_grad, double* d_res, double* d_Z);
 int launch_gp_var(vbmc_ctx* ctx, const double* d_Z, double* d_V, double* d_Q);

@@ -154,6 +154,38 @@ int launch_mixture_pdf(vbmc_ctx* ctx, int64_t n, const double* d_x, int log_flag
   return 0;
 }
 
+// Gaussian-mode density of an arbitrary mixture pack (not necessarily the ctx mixture) at
+// device points: used by the Monte-Carlo KL divergence, which needs two mixtures at once.
+int launch_mixture_pdf_on(vbmc_ctx* ctx, const double* d_pack, const MixLayout& ml, int64_t n,
+                          const double* d_x, int log_flag, double* d_y) {
+  const int D = ml.D;
+  if (D > 32) return vbmc_fail(ctx, VBMC_E_UNSUP, "mixture_pdf: D=%d > 32 not supported", D);
+  PdfArgs a;
+  a.mix = d_pack;
+  a.ml = ml;
+  a.x = d_x;
+  a.n = n;
+  a.log_flag = log_flag;
+  a.grad_flag = 0;
+  a.y = d_y;
+  a.dy = nullptr;
+  a.df = 0.0;
+  a.nf = 0.0;
+  a.mode = 0;
+  if (D <= 2) launch_dp<2>(ctx, a);
+  else if (D <= 4) launch_dp<4>(ctx, a);
+  else if (D <= 6) launch_dp<6>(ctx, a);
+  else if (D <= 8) launch_dp<8>(ctx, a);
+  else if (D <= 10) launch_dp<10>(ctx, a);
+  else if (D <= 12) launch_dp<12>(ctx, a);
+  else if (D <= 16) launch_dp<16>(ctx, a);
+  else if (D <= 20) launch_dp<20>(ctx, a);
+  else if (D <= 24) launch_dp<24>(ctx, a);
+  else launch_dp<32>(ctx, a);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
 extern "C" int vbmc_mixture_pdf(vbmc_ctx* ctx, int64_t n, const double* x_nxD, int log_flag,
                                 int grad_flag, double df, double* y_n, double* dy_nxD) {
   if (!ctx || (n > 0 && (!x_nxD || !y_n))) return VBMC_E_ARG;

@@ -6,13 +6,22 @@ Mirrors /root/reference/pyvbmc/variational_posterior/variational_posterior.py
 methods on the ELBO path -- ``get_bounds`` (:140-239), ``sample`` (:241-363),
 ``pdf`` (:365-564), ``log_pdf`` (:566-621), ``get_parameters`` (:623-678),
 ``set_parameters`` (:680-759), ``moments`` (:761-808) -- with the same mutation
-side effects and exceptions.  ``mode``, ``mtv``, ``kl_div``, ``plot`` are host-side
-analysis outside the path and are not provided.
+side effects and exceptions -- plus ``kl_div`` (:1032-1127), the Monte-Carlo consumer
+SURVEY.md 8f row 4 names.  ``mode``, ``mtv``, ``plot`` are host-side analysis outside
+the path and are not provided.
 
 Where the arithmetic runs: ``pdf``/``log_pdf`` -> HIP kernel (vbmc_mixture_pdf).
-State bookkeeping (get/set_parameters, bounds), RNG-bound sampling and the
-closed-form K*D^2 moments are plain NumPy object state, as in the reference.
+State bookkeeping (get/set_parameters, bounds) and the closed-form K*D^2 moments are
+plain NumPy object state, as in the reference.  ``sample`` draws from NumPy's global
+stream exactly like the reference by default; ``rng="philox"`` (keyword-only, or env
+``VBMC_HIP_RNG=philox``) generates the samples on the device instead
+(vbmc_mixture_sample), which is what ``moments(orig_flag=True)`` and ``kl_div`` then use;
+with ``rng="philox"`` ``kl_div`` runs entirely on the device (vbmc_kl_div_mc).
 """
+import ctypes as C
+import os
+import sys
+
 import numpy as np
 
 from . import _lib
@@ -137,9 +146,32 @@ class VariationalPosterior:
         return theta_bnd
 
     # -- sampling (:241-363): RNG-bound, consumes np.random in the reference's order ----
-    def sample(self, N, orig_flag=True, balance_flag=False, df=np.inf):
+    def sample(self, N, orig_flag=True, balance_flag=False, df=np.inf, *, rng=None, seed=None,
+               shuffle=True):
+        """Reference signature; keyword-only extras: ``rng`` ("numpy": the reference's global
+        MT19937 stream, the default; "philox": the device generator), ``seed`` of the device
+        generator (drawn from ``np.random`` when omitted) and ``shuffle`` (the device returns
+        balanced samples grouped by component; ``True`` permutes them like the reference)."""
         if N < 1:
             return np.zeros((0, self.D)), np.zeros((0, 1))
+        mode = os.environ.get("VBMC_HIP_RNG", "numpy") if rng is None else rng
+        if mode == "philox" and not (np.isfinite(df) and df != 0):
+            N = int(N)
+            ctx = self._upload()
+            if seed is None:
+                seed = int(np.random.randint(0, 2**62, dtype=np.int64))
+            x = np.empty((N, self.D))
+            i = np.empty(N, dtype=np.int32)
+            ctx.check(ctx._lib.vbmc_mixture_sample(ctx._h, N, int(seed), int(bool(balance_flag)), _lib.ptr(x),
+                                                   i.ctypes.data_as(C.POINTER(C.c_int32))))
+            if balance_flag and shuffle and self.K > 1:
+                perm = np.random.permutation(N)
+                x, i = x[perm], i[perm]
+            if orig_flag:
+                x = self.parameter_transformer.inverse(x)
+            return x, (i.astype(np.int64) if self.K > 1 else np.zeros(N))
+        if mode not in ("numpy", "philox"):
+            raise ValueError(f"unknown rng {mode!r}")
         lam = self.lambd.reshape(1, -1)
         heavy = np.isfinite(df) and df != 0
         if self.K > 1:
@@ -273,9 +305,10 @@ class VariationalPosterior:
         self._mode = None
 
     # -- moments (:761-808) ----------------------------------------------------------------------
-    def moments(self, N=int(1e6), orig_flag=True, cov_flag=False):
+    def moments(self, N=int(1e6), orig_flag=True, cov_flag=False, *, rng=None, seed=None):
         if orig_flag:
-            x, _ = self.sample(int(N), orig_flag=True, balance_flag=True)
+            # mean / covariance do not depend on the order: skip the shuffle on the device path
+            x, _ = self.sample(int(N), orig_flag=True, balance_flag=True, rng=rng, seed=seed, shuffle=False)
             mubar = np.mean(x, axis=0)
             if cov_flag:
                 cov = np.cov(x.T)
@@ -286,3 +319,73 @@ class VariationalPosterior:
                 dev = self.mu - mubar[:, np.newaxis]
                 cov = cov + (self.w * dev) @ dev.T
         return (mubar.reshape(1, -1), cov) if cov_flag else mubar.reshape(1, -1)
+
+    # -- Kullback-Leibler divergence (:1032-1127) ------------------------------------------------
+    def kl_div(self, vp2=None, samples=None, N=int(1e5), gauss_flag=False, *, rng=None, seed=None):
+        """Forward and reverse KL divergence between two posteriors, reference signature.
+        With ``rng="philox"`` (or ``VBMC_HIP_RNG=philox``) and both posteriors sharing one
+        parameter transformer the Monte-Carlo branch runs in one device call."""
+        if samples is None and vp2 is None:
+            raise ValueError("Either vp2 or samples have to be not None")
+        if not gauss_flag and vp2 is None:
+            raise ValueError("Unless the KL divergence is gaussianized, VP2 is required.")
+        mode = os.environ.get("VBMC_HIP_RNG", "numpy") if rng is None else rng
+        if gauss_flag:
+            if N == 0:
+                raise ValueError("Analytical moments are available only for the transformed space.")
+            q1mu, q1sigma = self.moments(N, True, True, rng=rng, seed=seed)
+            if vp2 is not None:
+                q2mu, q2sigma = vp2.moments(N, True, True, rng=rng, seed=None if seed is None else seed + 1)
+            else:
+                q2mu = np.mean(samples)  # sic (:1103)
+                q2sigma = np.cov(samples.T)
+            kls = kl_div_mvn(q1mu, q1sigma, q2mu, q2sigma)
+        elif mode == "philox" and _same_transformer(self, vp2) and vp2.D == self.D:
+            ctx = self._upload()
+            if seed is None:
+                seed = int(np.random.randint(0, 2**62, dtype=np.int64))
+            mu2 = _lib.f64(np.asarray(vp2.mu, dtype=np.float64).reshape(vp2.D, vp2.K).T)
+            sg2, lm2, w2 = _lib.f64(np.ravel(vp2.sigma)), _lib.f64(np.ravel(vp2.lambd)), _lib.f64(np.ravel(vp2.w))
+            kls = np.empty(2)
+            ctx.check(ctx._lib.vbmc_kl_div_mc(ctx._h, int(N), int(seed), vp2.K, _lib.ptr(mu2), _lib.ptr(sg2),
+                                              _lib.ptr(lm2), _lib.ptr(w2), _lib.ptr(kls)))
+        else:
+            minp = sys.float_info.min
+            xx1, _ = self.sample(N, True, True, rng=rng, seed=seed, shuffle=False)
+            q1 = self.pdf(xx1, True)
+            q2 = vp2.pdf(xx1, True)
+            # the reference writes `q == 0 | np.isinf(q)`, which Python parses as
+            # q == (0 | isinf(q)): true exactly where q == 0 (:1113-1114)
+            q1[q1 == 0] = 1.0
+            q2[q2 == 0] = minp
+            kl1 = -np.mean(np.log(q2) - np.log(q1))
+            xx2, _ = vp2.sample(N, True, True, rng=rng, seed=None if seed is None else seed + 1, shuffle=False)
+            q1 = self.pdf(xx2, True)
+            q2 = vp2.pdf(xx2, True)
+            q1[q1 == 0] = minp
+            q2[q2 == 0] = 1.0
+            kl2 = -np.mean(np.log(q1) - np.log(q2))
+            kls = np.concatenate((kl1, kl2), axis=None)
+        return np.maximum(0, kls)  # correct for numerical errors (:1126)
+
+
+def _same_transformer(a, b):
+    ta, tb = a.parameter_transformer, b.parameter_transformer
+    return ta is tb or (isinstance(ta, IdentityTransformer) and isinstance(tb, IdentityTransformer))
+
+
+def kl_div_mvn(mu1, sigma1, mu2, sigma2):
+    """Analytical KL divergences between two multivariate normals, both directions
+    (reference pyvbmc/stats/kl_div_mvn.py:10-47)."""
+    D = mu1.size
+    dmu = mu2.reshape(-1, 1) - mu1.reshape(-1, 1)
+    det1, det2 = np.linalg.det(sigma1), np.linalg.det(sigma2)
+    if det1 == 0 or det2 == 0:
+        return np.array([np.inf, np.inf])
+    lndet = np.log(det2 / det1)
+    out = []
+    for S_to, S_from, sign in ((sigma2, sigma1, 1.0), (sigma1, sigma2, -1.0)):
+        a = np.linalg.lstsq(S_to, S_from, rcond=None)[0]
+        b = np.linalg.lstsq(S_to, dmu, rcond=None)[0]
+        out.append(0.5 * (np.trace(a) + dmu.T @ b - D + sign * lndet))
+    return np.concatenate(out, axis=None)

@@ -210,6 +210,26 @@ def main():
          f"M={M} N={N} D={D} K={K} S=8", t, tc * M / ms, f"oracle on {ms} points, scaled",
          float(np.max(np.abs(av[:ms][fin] - ao[fin]) / np.maximum(1.0, np.abs(ao[fin])))),
          {"separate_predict_plus_pdf_calls_ms": 1e3 * tcomp})
+    # ---- 8f row 4: vp.sample and kl_div ---------------------------------------------------------
+    from oracle import sample_ref
+    vpa = mkvp(wl1)
+    vpb = mkvp(wl1)
+    vpb.mu = vpb.mu + 0.2 * rng.standard_normal(vpb.mu.shape)
+    mix2 = mix.copy(); mix2.mu = vpb.mu.copy()
+    Nsmp = 1_000_000
+    t, (xs_, is_) = med(lambda: vpa.sample(Nsmp, orig_flag=False, balance_flag=True, rng="philox", seed=21, shuffle=False), reps=5)
+    tc, (xo_, io_) = once(lambda: vpa.sample(Nsmp, orig_flag=False, balance_flag=True, rng="numpy"))
+    nchk = 20000
+    xr, ir = sample_ref.sample(mix, nchk, 21, False)
+    xd, idd = vpa.sample(nchk, orig_flag=False, balance_flag=False, rng="philox", seed=21)
+    emit("8f-4 vp.sample(1e6, balance) on the device generator", "variational_posterior.py:241-363", f"N={Nsmp} D={D} K={K}",
+         t, tc, "the mirror's NumPy-stream path (reference arithmetic), full", float(np.max(np.abs(xd - xr)) / np.max(np.abs(xr))),
+         {"labels_equal": bool(np.array_equal(idd, ir)), "note": "device time includes the 80 MB D2H of the samples"})
+    Nkl = 100_000
+    t, kld = med(lambda: vpa.kl_div(vpb, N=Nkl, rng="philox", seed=31), reps=5)
+    tc, klo = once(lambda: sample_ref.kl_div_mc(mix, mix2, Nkl, 31))
+    emit("8f-4 vp.kl_div(vp2, N=1e5), Monte-Carlo branch, one device call", "variational_posterior.py:1107-1126", f"N={Nkl} D={D} K={K}",
+         t, tc, "oracle on the same draws, full", rel(kld, klo))
     ctx.close()
 
 
