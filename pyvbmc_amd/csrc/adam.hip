@@ -23,6 +23,7 @@
 
 #include "common.h"
 #include "entropy_args.h"
+#include "philox.h"
 
 namespace {
 
@@ -438,6 +439,28 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamDev a, int do_step) 
   }
 }
 
+// The draws of iteration i+1, generated while the entropy kernel of iteration i runs: the
+// same Philox/Box-Muller values the entropy kernel would generate in-line (counter = global
+// row, pair; key = seed + i + 1), written in its resident-draw layout [K][rows][D].  The
+// entropy kernel issues ~63 % of its FP64 slots at 2 waves/SIMD and leaves ~90 VGPRs per
+// SIMD unused; this small-footprint kernel, on a second low-priority stream, fills part of
+// the gap instead of adding its ~17 us to the critical path.
+__global__ __launch_bounds__(256) void eps_gen_kernel(double* __restrict__ eps, int K, int64_t rows, int D,
+                                                      int64_t n_half, int64_t row_begin, uint64_t seed) {
+  const int np = (D + 1) / 2;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)K * rows * np) return;
+  const int p = (int)(t % np);
+  const int64_t r = t / np;
+  const int64_t j = r / rows, i = r - j * rows;
+  const uint64_t grow = (uint64_t)j * (uint64_t)n_half + (uint64_t)(row_begin + i);
+  double z0, z1;
+  philox_normal_pair(grow, (uint32_t)p, seed, z0, z1);
+  double* dst = eps + r * D + 2 * p;
+  dst[0] = z0;
+  if (2 * p + 1 < D) dst[1] = z1;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -458,6 +481,14 @@ struct AdamState {
   int* d_status = nullptr;
   // carve of d_buf
   double *state = nullptr, *work = nullptr, *x_tab = nullptr, *y_tab = nullptr;
+  // draws generated one iteration ahead on a second stream (Philox mode)
+  bool pregen = false;
+  double* d_eps2[2] = {nullptr, nullptr};
+  size_t eps2_cap = 0;               // doubles per buffer
+  hipStream_t gen_stream = nullptr;
+  hipEvent_t ev_gen[2] = {nullptr, nullptr};  // buffer b holds the draws of its iteration
+  hipEvent_t ev_ent[2] = {nullptr, nullptr};  // the entropy kernel reading buffer b has finished
+  bool ent_recorded[2] = {false, false};
 };
 
 static AdamState* adam_of(vbmc_ctx* ctx) {
@@ -470,6 +501,12 @@ void adam_free(vbmc_ctx* ctx) {
   if (!st) return;
   if (st->d_buf) (void)hipFree(st->d_buf);
   if (st->d_status) (void)hipFree(st->d_status);
+  for (int b = 0; b < 2; ++b) {
+    if (st->d_eps2[b]) (void)hipFree(st->d_eps2[b]);
+    if (st->ev_gen[b]) (void)hipEventDestroy(st->ev_gen[b]);
+    if (st->ev_ent[b]) (void)hipEventDestroy(st->ev_ent[b]);
+  }
+  if (st->gen_stream) (void)hipStreamDestroy(st->gen_stream);
   delete st;
   ctx->adam = nullptr;
 }
@@ -503,6 +540,20 @@ static void fill_dev(const vbmc_ctx* ctx, const AdamState& st, AdamDev& a) {
   a.x_row = nullptr;
   a.y_out = nullptr;
   a.status = st.d_status;
+}
+
+// Enqueue the generation of iteration `iter`'s draws into buffer iter & 1 on the second stream.
+static int enqueue_gen(vbmc_ctx* ctx, AdamState* st, int iter) {
+  const int b = iter & 1;
+  if (st->ent_recorded[b]) HIP_TRY(ctx, hipStreamWaitEvent(st->gen_stream, st->ev_ent[b], 0));
+  const int D = ctx->D, K = ctx->K;
+  const int64_t total = (int64_t)K * st->row_count * ((D + 1) / 2);
+  if (total > 0)
+    hipLaunchKernelGGL(eps_gen_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st->gen_stream,
+                       st->d_eps2[b], K, st->row_count, D, st->ns / 2, st->row_begin,
+                       st->seed + (uint64_t)iter);
+  HIP_TRY(ctx, hipEventRecord(st->ev_gen[b], st->gen_stream));
+  return 0;
 }
 
 extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
@@ -629,6 +680,36 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
   fill_dev(ctx, *st, a);
   hipLaunchKernelGGL(adam_step_kernel, dim3(1), dim3(256), st->lds_bytes, sm, a, 0);
   HIP_TRY(ctx, hipGetLastError());
+  // draws one iteration ahead (Philox mode, unless switched off or too large)
+  {
+    const char* off = getenv("VBMC_ADAM_PREGEN");
+    const size_t n_eps = (size_t)K * (size_t)st->row_count * D;
+    st->pregen = st->eps_mode == VBMC_EPS_PHILOX && !(off && off[0] == '0') && n_eps > 0 &&
+                 n_eps <= ((size_t)1 << 28);  // <= 2 GiB per buffer
+    if (st->pregen) {
+      if (!st->gen_stream) {
+        int lo = 0, hi = 0;
+        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&st->gen_stream, hipStreamNonBlocking, lo));
+        for (int b = 0; b < 2; ++b) {
+          HIP_TRY(ctx, hipEventCreateWithFlags(&st->ev_gen[b], hipEventDisableTiming));
+          HIP_TRY(ctx, hipEventCreateWithFlags(&st->ev_ent[b], hipEventDisableTiming));
+        }
+      }
+      if (st->eps2_cap < n_eps) {
+        HIP_TRY(ctx, hipStreamSynchronize(st->gen_stream));
+        for (int b = 0; b < 2; ++b) {
+          if (st->d_eps2[b]) HIP_TRY(ctx, hipFree(st->d_eps2[b]));
+          st->d_eps2[b] = nullptr;
+          HIP_TRY(ctx, hipMalloc((void**)&st->d_eps2[b], sizeof(double) * n_eps));
+        }
+        st->eps2_cap = n_eps;
+      }
+      st->ent_recorded[0] = st->ent_recorded[1] = false;
+      rc = enqueue_gen(ctx, st, 0);
+      if (rc) return rc;
+    }
+  }
   st->active = true;
   return VBMC_OK;
 }
@@ -649,8 +730,12 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
     return e && e[0] == '1';
   }();
   const bool multi = ctx->comm != nullptr && (ctx->world > 1 || force_coll);
-  const bool timing = ctx->timing;
-  ctx->timing = false;  // no per-kernel event pairs inside the loop
+  struct TimingOff {  // no per-kernel event pairs inside the loop; restored on every exit path
+    vbmc_ctx* c;
+    bool was;
+    explicit TimingOff(vbmc_ctx* c_) : c(c_), was(c_->timing) { c->timing = false; }
+    ~TimingOff() { c->timing = was; }
+  } timing_off(ctx);
   AdamDev a;
   fill_dev(ctx, *st, a);
   const int i0 = st->iter;
@@ -660,13 +745,28 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
     PrepArgs pa;
     glj_fill_prep(ctx, 1, st->state + st->lay.o_res(), nullptr, pa);
     EntPlan plan;
-    rc = entmc_plan(ctx, st->ns, st->eps_mode, st->seed + (uint64_t)i, st->row_begin, st->row_count, 1, plan);
+    rc = entmc_plan(ctx, st->ns, st->pregen ? VBMC_EPS_RESIDENT : st->eps_mode, st->seed + (uint64_t)i,
+                    st->row_begin, st->row_count, 1, plan);
     if (rc) break;
+    const int b = i & 1;
+    if (st->pregen) {
+      plan.a.eps = st->d_eps2[b];
+      plan.a.eps_rows = st->row_count;
+    }
     entmc_fill_prep(ctx, plan, pa);
     rc = launch_prep(ctx, pa);
     if (rc) break;
+    if (st->pregen) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, st->ev_gen[b], 0));
     rc = entmc_launch_main(ctx, plan);
     if (rc) break;
+    if (st->pregen) {
+      HIP_TRY(ctx, hipEventRecord(st->ev_ent[b], ctx->stream));
+      st->ent_recorded[b] = true;
+      if (i + 1 < st->max_iter) {
+        rc = enqueue_gen(ctx, st, i + 1);  // overlaps the entropy kernel just launched
+        if (rc) break;
+      }
+    }
     rc = entmc_launch_finish(ctx, plan, st->state + st->lay.o_raw());
     if (rc) break;
     if (multi) {
@@ -681,7 +781,6 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
     a.y_out = st->y_tab + 3 * (size_t)i;
     hipLaunchKernelGGL(adam_step_kernel, dim3(1), dim3(256), st->lds_bytes, ctx->stream, a, 1);
   }
-  ctx->timing = timing;
   if (rc) return rc;
   HIP_TRY(ctx, hipGetLastError());
   st->iter = i0 + n_iters;
@@ -721,6 +820,7 @@ extern "C" int vbmc_adam_end(vbmc_ctx* ctx, double* theta_out, double* mu_KxD, d
   HIP_TRY(ctx, hipMemcpyAsync(aux.data(), st->state + st->lay.o_aux(), sizeof(double) * n_aux, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(th.data(), st->state + st->lay.o_theta(), sizeof(double) * st->n_theta, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (st->gen_stream) HIP_TRY(ctx, hipStreamSynchronize(st->gen_stream));
   // the device pack in d_mix is the mixture of the last iterate: make the host copies agree
   ctx->mu.assign(aux.begin(), aux.begin() + K * D);
   ctx->sigma.assign(aux.begin() + K * D, aux.begin() + K * D + K);

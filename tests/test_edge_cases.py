@@ -1,0 +1,206 @@
+"""Edge shapes of the hot path on the GPU, each against the oracle on the same inputs:
+smallest and largest supported (D, K), component counts around the 4-wave split and the
+128-component switch to the generic kernel, sample counts of one antithetic pair, GP sizes
+around the 64-wide matrix tiles, the L_chol=False posterior branch, degenerate mixtures
+(densities that underflow to exactly zero) and the loud failures (D > 32, non-finite input).
+"""
+import numpy as np
+import pytest
+from helpers import oracle_gp, oracle_mix, rel_err
+
+from oracle import elbo_ref, entropy_ref, gp_ref, mixture_ref, philox_ref
+from pyvbmc_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pyvbmc_amd import _lib
+
+    c = _lib.Context(0)
+    _lib.set_default_context(c)
+    yield c
+    _lib.set_default_context(None)
+    c.close()
+
+
+def case(D, K, N, NsK, cfg=2, S=1):
+    wl = synthetic.make_workload(cfg, S=S, D=D, K=K, N=N, Ns_total=NsK * K)
+    wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X,
+              y=wl.y, hyp=wl.hyp, s2=np.zeros(0))
+    return wl, wd
+
+
+def objects(wd, ctx):
+    from test_gpu_parity import make_gp, make_vp
+
+    return make_vp(wd, ctx), make_gp(wd, ctx)
+
+
+@pytest.mark.parametrize("D,K", [(1, 1), (1, 5), (2, 3), (3, 4), (5, 7), (7, 33), (11, 9), (13, 2), (17, 6),
+                                 (21, 5), (25, 3), (32, 4), (4, 128), (3, 129), (2, 140)])
+def test_entropy_shapes(ctx, D, K):
+    """entmc (Philox draws, value + all gradients) and entlb for awkward (D, K): padded D,
+    K not a multiple of the 4-wave split, K = 128 / 129 either side of the kernel switch."""
+    from pyvbmc_amd import entlb_vbmc, entmc_vbmc
+
+    NsK = 64 if K < 100 else 16
+    wl, wd = case(D, K, 20, NsK)
+    vp, _ = objects(wd, ctx)
+    mix = oracle_mix(wd)
+    H, dH = entmc_vbmc(vp, NsK, (True,) * 4, True, rng="philox", seed=17)
+    eps = philox_ref.eps_half(K, NsK // 2, D, 17)
+    Ho, dHo = entropy_ref.entmc(oracle_mix(wd), NsK, (True,) * 4, True, eps_half=eps)
+    assert abs(H - Ho) <= 1e-10 * max(1.0, abs(Ho)), (D, K, H, Ho)
+    assert dH.shape == dHo.shape and rel_err(dH, dHo) < 1e-8, (D, K, rel_err(dH, dHo))
+    Hl, dHl = entlb_vbmc(vp, (True,) * 4, True)
+    Hlo, dHlo = entropy_ref.entlb(mix, (True,) * 4, True)
+    assert abs(Hl - Hlo) <= 1e-10 * max(1.0, abs(Hlo))
+    assert rel_err(dHl, dHlo) < 1e-9
+
+
+@pytest.mark.parametrize("NsK", [2, 3, 7, 126, 130])
+def test_entropy_sample_counts(ctx, NsK):
+    """One antithetic pair, odd requests (the reference rounds Ns up to even,
+    entmc_vbmc.py:61), counts around the 64-row batch."""
+    from pyvbmc_amd import entmc_vbmc
+
+    wl, wd = case(3, 5, 20, 8)
+    vp, _ = objects(wd, ctx)
+    even = 2 * int(np.ceil(NsK / 2))
+    H, dH = entmc_vbmc(vp, NsK, (True,) * 4, True, rng="philox", seed=5)
+    eps = philox_ref.eps_half(5, even // 2, 3, 5)
+    Ho, dHo = entropy_ref.entmc(oracle_mix(wd), even, (True,) * 4, True, eps_half=eps)
+    assert abs(H - Ho) <= 1e-10 * max(1.0, abs(Ho))
+    assert rel_err(dH, dHo) < 1e-8
+
+
+def test_entropy_far_apart_components(ctx):
+    """Components hundreds of widths apart: cross densities underflow to exactly 0, sigma
+    ratios of 1e3; the value stays finite and equals the oracle's."""
+    from pyvbmc_amd import entmc_vbmc
+
+    wl, wd = case(4, 6, 20, 200)
+    wd["mu"] = wd["mu"] * 200.0
+    wd["sigma"] = wd["sigma"] * np.array([1e-2, 1.0, 10.0, 1e-1, 1.0, 3.0])
+    vp, _ = objects(wd, ctx)
+    H, dH = entmc_vbmc(vp, 200, (True,) * 4, True, rng="philox", seed=2)
+    eps = philox_ref.eps_half(6, 100, 4, 2)
+    Ho, dHo = entropy_ref.entmc(oracle_mix(wd), 200, (True,) * 4, True, eps_half=eps)
+    assert np.isfinite(H) and abs(H - Ho) <= 1e-9 * max(1.0, abs(Ho))
+    assert np.all(np.isfinite(dH)) and rel_err(dH, dHo) < 1e-7
+
+
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 129])
+def test_gp_sizes_around_the_tiles(ctx, N):
+    """_gp_log_joint (+variance), predict and the fused objective for N around the 64-wide
+    MFMA tiles, S = 2 hyper-samples."""
+    from pyvbmc_amd.variational_optimization import _gp_log_joint, _neg_elcbo
+
+    wl, wd = case(3, 5, N, 40, S=2)
+    vp, gp = objects(wd, ctx)
+    mix, ogp = oracle_mix(wd), oracle_gp(wd)
+    G, dG, _, _, _ = _gp_log_joint(vp, gp, True, True, True, False, False)
+    Go, dGo, _, _, _ = gp_ref.gp_log_joint(mix, ogp, True, True, True, False, False)
+    assert abs(G - Go) <= 1e-10 * max(1.0, abs(Go)) and rel_err(dG, dGo) < 1e-9
+    r = _gp_log_joint(vp, gp, False, True, True, True, True)
+    ro = gp_ref.gp_log_joint(mix, ogp, False, True, True, True, True)
+    scale = max(1.0, float(np.max(np.abs(ro[6]))))
+    assert np.max(np.abs(r[6] - ro[6])) <= 1e-9 * scale  # J_sjk
+    assert abs(np.ravel(r[2])[0] - np.ravel(ro[2])[0]) <= 1e-9 * max(1.0, abs(np.ravel(ro[2])[0]))
+    xs = np.random.default_rng(N).standard_normal((70, 3))
+    fmu, fs2 = gp.predict(xs, separate_samples=True)
+    omu, os2 = gp_ref.predict(ogp, xs, separate_samples=True)
+    sf2 = float(np.exp(2 * wl.hyp[0, 3]))
+    assert np.max(np.abs(fmu - omu)) <= 1e-10 * max(1.0, np.max(np.abs(omu)))
+    assert np.max(np.abs(fs2 - os2)) <= 1e-10 * max(1.0, sf2)
+    eps = synthetic.draw_eps_half(5, 3, 40, 3)
+    F = _neg_elcbo(wl.theta.copy(), gp, vp, 0.0, 40, True, False, None, eps_half=eps)
+    Fo = elbo_ref.neg_elcbo(wl.theta.copy(), ogp, oracle_mix(wd), 0.0, 40, True, False, None, eps_half=eps)
+    assert abs(F[0] - Fo[0]) <= 1e-10 * max(1.0, abs(Fo[0])) and rel_err(F[1], Fo[1]) < 1e-8
+
+
+def test_predict_batch_shapes(ctx):
+    wl, wd = case(3, 5, 50, 40, S=3)
+    _, gp = objects(wd, ctx)
+    ogp = oracle_gp(wd)
+    fmu, fs2 = gp.predict(np.zeros((0, 3)))
+    assert fmu.shape == (0, 1) and fs2.shape == (0, 1)
+    x1 = np.array([[0.1, -0.2, 0.3]])
+    for sep in (False, True):
+        fmu, fs2 = gp.predict(x1, separate_samples=sep)
+        omu, os2 = gp_ref.predict(ogp, x1, separate_samples=sep)
+        assert fmu.shape == omu.shape and np.allclose(fmu, omu, rtol=0, atol=1e-10 * max(1.0, np.abs(omu).max()))
+        assert np.allclose(fs2, os2, rtol=0, atol=1e-9)
+    fmu, fs2 = gp.predict(x1, add_noise=True)
+    omu, os2 = gp_ref.predict(ogp, x1, add_noise=True)
+    assert np.allclose(fs2, os2, rtol=0, atol=1e-9)
+
+
+def test_low_noise_posterior_branch(ctx):
+    """sn2 < 1e-6 switches the posterior to L = -(K + sn2 I)^-1 (L_chol = False): the variance
+    then uses z^T L z / K*^T L K* instead of triangular products."""
+    from pyvbmc_amd.variational_optimization import _gp_log_joint
+
+    wl, wd = case(3, 4, 40, 40)
+    hyp = wd["hyp"].copy()
+    hyp[:, 3 + 1] = np.log(3e-4)  # log sn -> sn2 = 9e-8
+    wd["hyp"] = hyp
+    vp, gp = objects(wd, ctx)
+    assert not gp.posteriors[0].L_chol
+    mix, ogp = oracle_mix(wd), oracle_gp(wd)
+    r = _gp_log_joint(vp, gp, False, True, True, True, True)
+    ro = gp_ref.gp_log_joint(mix, ogp, False, True, True, True, True)
+    assert abs(r[0] - ro[0]) <= 1e-9 * max(1.0, abs(ro[0]))
+    assert np.max(np.abs(r[6] - ro[6])) <= 1e-7 * max(1.0, float(np.max(np.abs(ro[6]))))
+    xs = np.random.default_rng(0).standard_normal((33, 3))
+    fmu, fs2 = gp.predict(xs, separate_samples=True)
+    omu, os2 = gp_ref.predict(ogp, xs, separate_samples=True)
+    sf2 = float(np.exp(2 * hyp[0, 3]))
+    assert np.max(np.abs(fmu - omu)) <= 1e-8 * max(1.0, np.max(np.abs(omu)))
+    assert np.max(np.abs(fs2 - os2)) <= 1e-8 * max(1.0, sf2)
+
+
+def test_pdf_underflow_and_extremes(ctx):
+    wl, wd = case(4, 6, 20, 40)
+    vp, _ = objects(wd, ctx)
+    mix = oracle_mix(wd)
+    x = np.vstack([wd["mu"].T, 1e3 * np.ones((2, 4)), -1e6 * np.ones((1, 4)), np.zeros((1, 4))])
+    with np.errstate(all="ignore"):
+        y = vp.pdf(x, orig_flag=False)
+        yo = mixture_ref.pdf(mix, x)
+        ly = vp.pdf(x, orig_flag=False, log_flag=True)
+        lyo = mixture_ref.pdf(mix, x, log_flag=True)
+    assert np.array_equal(y == 0, yo == 0) and rel_err(y, yo) < 1e-12
+    assert np.array_equal(np.isneginf(ly), np.isneginf(lyo))
+    fin = np.isfinite(lyo)
+    assert np.max(np.abs(ly[fin] - lyo[fin])) < 1e-11 * max(1.0, np.max(np.abs(lyo[fin])))
+
+
+def test_loud_failures(ctx):
+    from pyvbmc_amd import VariationalPosterior, entmc_vbmc
+    from pyvbmc_amd._lib import VbmcHipError
+    from pyvbmc_amd.variational_optimization import _neg_elcbo
+
+    big = VariationalPosterior(33, 2)
+    big.ctx = ctx
+    with pytest.raises(NotImplementedError):
+        entmc_vbmc(big, 10, rng="philox", seed=1)
+    with pytest.raises(NotImplementedError):
+        big.pdf(np.zeros((2, 33)), orig_flag=False)
+    wl, wd = case(3, 4, 20, 20)
+    vp, gp = objects(wd, ctx)
+    bad = wl.theta.copy()
+    bad[1] = np.inf
+    with pytest.raises((VbmcHipError, ValueError)):
+        _neg_elcbo(bad, gp, vp, 0.0, 20, True, False, None, rng="philox", seed=1)
+    with pytest.raises(ValueError):
+        _neg_elcbo(wl.theta[:-2].copy(), gp, vp, 0.0, 20, True, False, None, rng="philox", seed=1)
+    vp.sigma = np.zeros_like(vp.sigma)
+    with pytest.raises((VbmcHipError, ValueError)):
+        entmc_vbmc(vp, 10, rng="philox", seed=1)
+    # the context survives every one of them
+    vp2, _ = objects(wd, ctx)
+    H, _ = entmc_vbmc(vp2, 20, rng="philox", seed=1)
+    assert np.isfinite(H)
