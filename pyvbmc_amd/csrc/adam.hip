@@ -23,7 +23,6 @@
 
 #include "common.h"
 #include "entropy_args.h"
-#include "philox.h"
 
 namespace {
 
@@ -439,28 +438,6 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamDev a, int do_step) 
   }
 }
 
-// The draws of iteration i+1, generated while the entropy kernel of iteration i runs: the
-// same Philox/Box-Muller values the entropy kernel would generate in-line (counter = global
-// row, pair; key = seed + i + 1), written in its resident-draw layout [K][rows][D].  The
-// entropy kernel issues ~63 % of its FP64 slots at 2 waves/SIMD and leaves ~90 VGPRs per
-// SIMD unused; this small-footprint kernel, on a second low-priority stream, fills part of
-// the gap instead of adding its ~17 us to the critical path.
-__global__ __launch_bounds__(256) void eps_gen_kernel(double* __restrict__ eps, int K, int64_t rows, int D,
-                                                      int64_t n_half, int64_t row_begin, uint64_t seed) {
-  const int np = (D + 1) / 2;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)K * rows * np) return;
-  const int p = (int)(t % np);
-  const int64_t r = t / np;
-  const int64_t j = r / rows, i = r - j * rows;
-  const uint64_t grow = (uint64_t)j * (uint64_t)n_half + (uint64_t)(row_begin + i);
-  double z0, z1;
-  philox_normal_pair(grow, (uint32_t)p, seed, z0, z1);
-  double* dst = eps + r * D + 2 * p;
-  dst[0] = z0;
-  if (2 * p + 1 < D) dst[1] = z1;
-}
-
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -546,12 +523,13 @@ static void fill_dev(const vbmc_ctx* ctx, const AdamState& st, AdamDev& a) {
 static int enqueue_gen(vbmc_ctx* ctx, AdamState* st, int iter) {
   const int b = iter & 1;
   if (st->ent_recorded[b]) HIP_TRY(ctx, hipStreamWaitEvent(st->gen_stream, st->ev_ent[b], 0));
-  const int D = ctx->D, K = ctx->K;
-  const int64_t total = (int64_t)K * st->row_count * ((D + 1) / 2);
-  if (total > 0)
-    hipLaunchKernelGGL(eps_gen_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st->gen_stream,
-                       st->d_eps2[b], K, st->row_count, D, st->ns / 2, st->row_begin,
-                       st->seed + (uint64_t)iter);
+  // The draws of iteration `iter`, produced while the kernels of iteration iter - 1 run: the
+  // entropy kernel issues ~63 % of its FP64 slots and the finish / step / prep kernels leave the
+  // GPU almost idle; this small-footprint kernel fills that time instead of adding its ~20 us to
+  // the critical path.
+  int rc = launch_eps_gen(ctx, st->gen_stream, st->d_eps2[b], st->ns / 2, st->row_begin, st->row_count,
+                          st->seed + (uint64_t)iter);
+  if (rc) return rc;
   HIP_TRY(ctx, hipEventRecord(st->ev_gen[b], st->gen_stream));
   return 0;
 }

@@ -175,6 +175,10 @@ void glj_fill_prep(const vbmc_ctx* ctx, int want_grad, double* res, double* Z, P
 int launch_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed,
                  int64_t row_begin, int64_t row_count, int want_grad, double* d_raw);
 int launch_entlb(vbmc_ctx* ctx, double* d_res);  // writes raw entlb terms
+// the in-line Philox/Box-Muller draws of the entropy kernel, written to eps[K][rows][D] by a
+// kernel of their own on `st` (same values: counter = global row, pair; key = seed)
+int launch_eps_gen(vbmc_ctx* ctx, hipStream_t st, double* d_eps, int64_t n_half, int64_t row_begin,
+                   int64_t row_count, uint64_t seed);
 // mixture pdf
 int launch_mixture_pdf(vbmc_ctx* ctx, int64_t n, const double* d_x, int log_flag,
                        int grad_flag, double df, double* d_y, double* d_dy);

@@ -508,6 +508,35 @@ int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p) {
   return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void eps_gen_kernel(double* __restrict__ eps, int K, int64_t rows, int D,
+                                                      int64_t n_half, int64_t row_begin, uint64_t seed) {
+  const int np = (D + 1) / 2;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)K * rows * np) return;
+  const int p = (int)(t % np);
+  const int64_t r = t / np;
+  const int64_t j = r / rows, i = r - j * rows;
+  const uint64_t grow = (uint64_t)j * (uint64_t)n_half + (uint64_t)(row_begin + i);
+  double z0, z1;
+  philox_normal_pair(grow, (uint32_t)p, seed, z0, z1);
+  double* dst = eps + r * D + 2 * p;
+  dst[0] = z0;
+  if (2 * p + 1 < D) dst[1] = z1;
+}
+}  // namespace
+
+int launch_eps_gen(vbmc_ctx* ctx, hipStream_t st, double* d_eps, int64_t n_half, int64_t row_begin,
+                   int64_t row_count, uint64_t seed) {
+  const int D = ctx->D, K = ctx->K;
+  const int64_t total = (int64_t)K * row_count * ((D + 1) / 2);
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(eps_gen_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_eps, K,
+                     row_count, D, n_half, row_begin, seed);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
 int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out) {
   const int n_out = raw_len(ctx->D, ctx->K);
   hipLaunchKernelGGL(entmc_finish_kernel, dim3((n_out + 3) / 4), dim3(256), 0, ctx->stream,
