@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "fastmath.h"
 
 namespace {
 
@@ -25,7 +26,7 @@ struct PdfArgs {
   double* dy;   // n x D or null
 };
 
-template <int DP>
+template <int DP, int MODE, bool GRAD>
 __global__ __launch_bounds__(256) void mixture_pdf_kernel(PdfArgs a) {
   const int D = a.ml.D, K = a.ml.K;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void mixture_pdf_kernel(PdfArgs a) {
   for (int k = 0; k < K; ++k) {
     const double* mk = mup + k * D;
     double nn;
-    if (a.mode == 0) {
+    if (MODE == 0) {
       double d2 = 0.0;
 #pragma unroll
       for (int d = 0; d < DP; ++d)
@@ -56,14 +57,15 @@ __global__ __launch_bounds__(256) void mixture_pdf_kernel(PdfArgs a) {
           const double u = xs[d] - mk[d];
           d2 = fma(u, u, d2);
         }
-      nn = wc[k] * exp(-0.5 * d2 * is2[k]);
-      if (a.grad_flag) {
+      // exp(-d2 / (2 sigma_k^2)) as exp2 with log2(e) folded into the scale (fastmath.h, <= 1 ulp)
+      nn = wc[k] * fm::exp2_fast((-0.5 * 0x1.71547652b82fep+0 * is2[k]) * d2);
+      if (GRAD) {
         const double c = nn * is2[k];
 #pragma unroll
         for (int d = 0; d < DP; ++d)
           if (d < D) g[d] = fma(c, xs[d] - mk[d], g[d]);
       }
-    } else if (a.mode == 1) {
+    } else if (MODE == 1) {
       double d2 = 0.0;
 #pragma unroll
       for (int d = 0; d < DP; ++d)
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void mixture_pdf_kernel(PdfArgs a) {
     y += nn;
   }
   (void)rc;
-  if (a.grad_flag) {
+  if (GRAD) {
     // dy = -sum_k nn (x - mu_k)/(lambda^2 sigma_k^2); log: dy / y taken before the log (:464-469,532)
     const double s = a.log_flag ? -1.0 / y : -1.0;
 #pragma unroll
@@ -100,8 +102,15 @@ __global__ __launch_bounds__(256) void mixture_pdf_kernel(PdfArgs a) {
 
 template <int DP>
 void launch_dp(vbmc_ctx* ctx, const PdfArgs& a) {
-  const int64_t blocks = (a.n + 255) / 256;
-  hipLaunchKernelGGL(mixture_pdf_kernel<DP>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+  const dim3 grid((unsigned)((a.n + 255) / 256)), block(256);
+  if (a.mode == 0) {
+    if (a.grad_flag) hipLaunchKernelGGL((mixture_pdf_kernel<DP, 0, true>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((mixture_pdf_kernel<DP, 0, false>), grid, block, 0, ctx->stream, a);
+  } else if (a.mode == 1) {
+    hipLaunchKernelGGL((mixture_pdf_kernel<DP, 1, false>), grid, block, 0, ctx->stream, a);
+  } else {
+    hipLaunchKernelGGL((mixture_pdf_kernel<DP, 2, false>), grid, block, 0, ctx->stream, a);
+  }
 }
 
 }  // namespace
