@@ -21,6 +21,7 @@ done
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_SQ1 -o p -- $B --steps 10 --warmup 2 > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/pmc_SQ2 -o p -- $B --steps 10 --warmup 2 > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT/pmc_SQ3 -o p -- $B --steps 10 --warmup 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_adam -o s -- python $REPO/tools/adam_loop_profile.py > $OUT/adam_loop.txt 2>/dev/null
 # un-profiled bench lines of the same build
 cd $REPO
 python bench.py --steps 200 --warmup 20 > $OUT/bench_philox.json 2>/dev/null

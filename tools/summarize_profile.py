@@ -21,7 +21,7 @@ from pathlib import Path
 src, tag = Path(sys.argv[1]), sys.argv[2]
 out = Path(__file__).resolve().parent.parent / "profiles"
 out.mkdir(exist_ok=True)
-for mode, d in (("philox", "stats"), ("resident", "stats_res")):
+for mode, d in (("philox", "stats"), ("resident", "stats_res"), ("adam_loop", "stats_adam")):
     f = src / d / "s_kernel_stats.csv"
     if f.exists():
         shutil.copy(f, out / f"{tag}_kernel_stats_{mode}.csv")
