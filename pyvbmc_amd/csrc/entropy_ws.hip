@@ -32,27 +32,29 @@
 #include "entropy_args.h"
 #include "fastmath.h"
 
-// exp2 with its 11 polynomial coefficients held in VGPRs (frees 22 SGPRs for table rows)
-__device__ __forceinline__ double exp2_vc(double x, const double (&c)[11]) {
+// exp2 with its polynomial coefficients held in VGPRs (frees 20 SGPRs for table rows).  Degree
+// 10 here (fastmath.h uses 11): max relative error 4.1e-16 instead of 1.6e-16 in float64 Horner
+// evaluation (tools/fit_polys.py), one FMA less per density -- the entropy averages ~10^6 of them.
+__device__ __forceinline__ double exp2_vc(double x, const double (&c)[10]) {
   const double t = __builtin_rint(x);
   const double f = x - t;
   const int n = (int)t;
-  double p = c[10];
+  double p = c[9];
 #pragma unroll
-  for (int i = 9; i >= 0; --i) p = fma(p, f, c[i]);
+  for (int i = 8; i >= 0; --i) p = fma(p, f, c[i]);
   p = fma(p, f, 1.0);
   return __builtin_amdgcn_ldexp(p, n);
 }
 // two independent exp2 evaluations with their Horner chains interleaved step by step
 // (a dependent v_fma_f64 chain alone leaves the FP64 pipe half idle)
-__device__ __forceinline__ void exp2_vc2(double x1, double x2, const double (&c)[11], double& r1,
+__device__ __forceinline__ void exp2_vc2(double x1, double x2, const double (&c)[10], double& r1,
                                          double& r2) {
   const double t1 = __builtin_rint(x1), t2 = __builtin_rint(x2);
   const double f1 = x1 - t1, f2 = x2 - t2;
   const int n1 = (int)t1, n2 = (int)t2;
-  double p1 = c[10], p2 = c[10];
+  double p1 = c[9], p2 = c[9];
 #pragma unroll
-  for (int i = 9; i >= 0; --i) {
+  for (int i = 8; i >= 0; --i) {
     p1 = fma(p1, f1, c[i]);
     p2 = fma(p2, f2, c[i]);
   }
@@ -61,7 +63,7 @@ __device__ __forceinline__ void exp2_vc2(double x1, double x2, const double (&c)
   r1 = __builtin_amdgcn_ldexp(p1, n1);
   r2 = __builtin_amdgcn_ldexp(p2, n2);
 }
-__device__ const double kExp2C[11] = {0x1.62e42fefa39efp-1, 0x1.ebfbdff82c5aep-3, 0x1.c6b08d704a0c6p-5, 0x1.3b2ab6fb9f1a5p-7, 0x1.5d87fe78a3f9cp-10, 0x1.430913112c61bp-13, 0x1.ffcbfc6da6ed1p-17, 0x1.62bfc2c86d700p-20, 0x1.b524ebd13a55fp-24, 0x1.e6228acd1c6e5p-28, 0x1.e9ec1fcb69a7fp-32};
+__device__ const double kExp2C[10] = {0x1.62e42fefa3a19p-1, 0x1.ebfbdff82c598p-3, 0x1.c6b08d703ce49p-5, 0x1.3b2ab6fba1ddap-7, 0x1.5d87fe9d7a584p-10, 0x1.430913096fd9fp-13, 0x1.ffcb54062e698p-17, 0x1.62bfd47773353p-20, 0x1.b675bca4eeebbp-24, 0x1.e6063f7217bc6p-28};
 
 #include "philox.h"
 
@@ -117,12 +119,12 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   const double two_sj = 2.0 * sig_j;
   const double* Tj = T + (size_t)j * K4 * TS;
 
-  double ec[11];
+  double ec[10];
   {
     int vz;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vz));  // opaque per-lane zero: keeps the loads vector loads
 #pragma unroll
-    for (int i = 0; i < 11; ++i) ec[i] = kExp2C[i + vz];
+    for (int i = 0; i < 10; ++i) ec[i] = kExp2C[i + vz];
   }
   double slog_acc = 0.0;
   double mu_acc[DP], lam_acc[DP], Wacc[KTMAX];
