@@ -122,6 +122,7 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
                     ctx->gp.d_xc};
   for (double* b : bufs)
     if (b) (void)hipFree(b);
+  if (ctx->d_epsgen) (void)hipFree(ctx->d_epsgen);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
   for (int i = 0; i < 10; ++i)

@@ -477,6 +477,33 @@ void entmc_fill_prep(const vbmc_ctx* ctx, const EntPlan& p, PrepArgs& a) {
   }
 }
 
+// Philox mode: have extra blocks of the prep launch generate the draws (they fill the GPU while
+// its few table / GP blocks sit in latency chains) and run the entropy kernel in its
+// resident-draw form on the identical values.  Call after entmc_plan + entmc_fill_prep.
+// VBMC_ELBO_PREGEN=0 keeps the generation inside the entropy kernel.
+int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& pa) {
+  static const bool on = [] {
+    const char* e = getenv("VBMC_ELBO_PREGEN");
+    return !(e && e[0] == '0');
+  }();
+  const int D = ctx->D, K = ctx->K;
+  const size_t n_eps = (size_t)K * (size_t)p.a.row_count * D;
+  if (!on || p.a.eps_mode != VBMC_EPS_PHILOX || n_eps == 0 || n_eps > ((size_t)1 << 28)) return 0;
+  int rc = ensure_dev(ctx, &ctx->d_epsgen, &ctx->d_epsgen_cap, n_eps);
+  if (rc) return rc;
+  const int64_t items = (int64_t)K * p.a.row_count * ((D + 1) / 2);
+  pa.n_gen = (int)((items + 255) / 256);
+  pa.gen_eps = ctx->d_epsgen;
+  pa.gen_rows = p.a.row_count;
+  pa.gen_n_half = p.a.n_half;
+  pa.gen_row_begin = p.a.row_begin;
+  pa.gen_seed = p.a.seed;
+  p.a.eps_mode = VBMC_EPS_RESIDENT;
+  p.a.eps = ctx->d_epsgen;
+  p.a.eps_rows = p.a.row_count;
+  return 0;
+}
+
 int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p) {
   const EntArgs& a = p.a;
   if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
@@ -554,6 +581,8 @@ int launch_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed
   if (rc) return rc;
   PrepArgs pa;
   entmc_fill_prep(ctx, p, pa);
+  rc = entmc_pregen(ctx, p, pa);
+  if (rc) return rc;
   rc = launch_prep(ctx, pa);
   if (rc) return rc;
   rc = entmc_launch_main(ctx, p);

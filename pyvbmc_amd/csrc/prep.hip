@@ -11,6 +11,7 @@
 //        tau_dk = sqrt(sigma_k^2 lambda_d^2 + ell_d^2);  optionally Z[s][k][n] = z_n.
 //      The host turns these into G, dG (api_gp.hip: glj_finalize).
 #include "common.h"
+#include "philox.h"
 
 namespace {
 
@@ -53,6 +54,24 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
       }
       row[DP + 5] = 0.0;
     }
+    return;
+  }
+
+  if ((int)blockIdx.x >= a.n_table + a.n_glj) {
+    // ---- draw-generation block: 256 (row, pair) items, the entropy kernel's own values
+    // (counter = global antithetic-pair row, pair; key = seed; philox.h) ----
+    const int np = (D + 1) / 2;
+    const int64_t t = (int64_t)(blockIdx.x - a.n_table - a.n_glj) * 256 + tid;
+    if (t >= (int64_t)K * a.gen_rows * np) return;
+    const int p = (int)(t % np);
+    const int64_t r = t / np;
+    const int64_t j = r / a.gen_rows, i = r - j * a.gen_rows;
+    const uint64_t grow = (uint64_t)j * (uint64_t)a.gen_n_half + (uint64_t)(a.gen_row_begin + i);
+    double z0, z1;
+    philox_normal_pair(grow, (uint32_t)p, a.gen_seed, z0, z1);
+    double* dst = a.gen_eps + r * D + 2 * p;
+    dst[0] = z0;
+    if (2 * p + 1 < D) dst[1] = z1;
     return;
   }
 
@@ -130,7 +149,7 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
 int launch_prep(vbmc_ctx* ctx, const PrepArgs& a) {
   const int D = a.ml.D;
   const int gblocks = a.n_glj;
-  const int grid = a.n_table + gblocks;
+  const int grid = a.n_table + gblocks + a.n_gen;
   if (grid <= 0) return 0;
   size_t lds = 0;
   if (gblocks > 0) {
