@@ -194,7 +194,10 @@ def main():
     k_ms = float(np.mean(kern_ms))
     flops = algorithmic_flops(D, K, ns_job / world, grad=True)  # per launch (this rank's rows)
     achieved = flops / (k_ms * 1e-3) / 1e12
-    eps_bytes = (ns_job / world / 2) * D * 8 if a.rng == "resident" else 0.0
+    # the draws the entropy kernel reads: resident, or (Philox mode) generated into HBM by the prep
+    # launch -- unless VBMC_ELBO_PREGEN=0 keeps the generation inside the entropy kernel
+    inline_gen = a.rng == "philox" and os.environ.get("VBMC_ELBO_PREGEN", "1")[:1] == "0"
+    eps_bytes = 0.0 if inline_gen else (ns_job / world / 2) * D * 8
     traffic = None
     try:  # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc passes, see profiles/README.md)
         tj = json.load(open(ROOT / "profiles" / "traffic.json"))
