@@ -1,4 +1,4 @@
-// Kernel argument block shared by the entropy kernels (entropy.hip, entropy_quad.hip).
+// Kernel argument block shared by the entropy kernels (entropy.hip, entropy_ws.hip).
 #pragma once
 #include "common.h"
 

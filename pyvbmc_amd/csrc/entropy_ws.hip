@@ -70,9 +70,6 @@ __device__ const double kExp2C[10] = {0x1.62e42fefa3a19p-1, 0x1.ebfbdff82c598p-3
 #ifndef VBMC_DP
 #error "compile with -DVBMC_DP=<padded D>"
 #endif
-#ifndef VBMC_WS_PREFETCH
-#define VBMC_WS_PREFETCH 0
-#endif
 
 namespace {
 
