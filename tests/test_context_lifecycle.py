@@ -1,0 +1,74 @@
+"""Context plumbing on the GPU: several contexts in one process, one context fed alternating
+problem shapes (every scratch buffer regrows / is reused), objects pickled without their
+handles, and results that do not depend on any of it."""
+import pickle
+
+import numpy as np
+import pytest
+from helpers import oracle_gp, oracle_mix
+
+from oracle import elbo_ref, philox_ref
+from pyvbmc_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def make(wl, ctx):
+    from test_gpu_parity import make_gp, make_vp
+
+    wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X,
+              y=wl.y, hyp=wl.hyp, s2=np.zeros(0))
+    return wd, make_vp(wd, ctx), make_gp(wd, ctx)
+
+
+def objective(wl, vp, gp, seed):
+    from pyvbmc_amd.variational_optimization import _neg_elcbo
+
+    bnd = synthetic.default_theta_bnd(wl)
+    return _neg_elcbo(wl.theta.copy(), gp, vp, 0.0, wl.NsK, True, False, bnd, rng="philox", seed=seed)
+
+
+def oracle_objective(wl, wd, seed):
+    eps = philox_ref.eps_half(wl.K, wl.NsK // 2, wl.D, seed)
+    bnd = synthetic.default_theta_bnd(wl)
+    return elbo_ref.neg_elcbo(wl.theta.copy(), oracle_gp(wd), oracle_mix(wd), 0.0, wl.NsK, True, False, bnd,
+                              eps_half=eps)
+
+
+def test_alternating_shapes_two_contexts_and_pickling():
+    from pyvbmc_amd import _lib
+    from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+
+    a, b = _lib.Context(0), _lib.Context(0)
+    try:
+        shapes = [synthetic.make_workload(2, D=3, K=5, N=40, Ns_total=5 * 60),
+                  synthetic.make_workload(2, D=7, K=21, N=130, Ns_total=21 * 200),
+                  synthetic.make_workload(1),
+                  synthetic.make_workload(2, D=3, K=5, N=40, Ns_total=5 * 60)]
+        ref = [oracle_objective(wl, make(wl, a)[0], 11 + i) for i, wl in enumerate(shapes)]
+        for rep in range(2):
+            for i, wl in enumerate(shapes):
+                for ctx in (a, b):
+                    wd, vp, gp = make(wl, ctx)
+                    F = objective(wl, vp, gp, 11 + i)
+                    assert abs(F[0] - ref[i][0]) <= 1e-10 * max(1.0, abs(ref[i][0])), (rep, i)
+                    assert np.max(np.abs(F[1] - ref[i][1])) <= 1e-8 * max(1.0, np.max(np.abs(ref[i][1])))
+        # the device-resident loop leaves the context usable for a different shape
+        wd, vp, gp = make(shapes[1], a)
+        out = minimize_adam_elbo(shapes[1].theta.copy(), gp, vp, shapes[1].NsK, max_iter=20, seed=3)
+        assert np.all(np.isfinite(out[3]))
+        wd, vp, gp = make(shapes[0], a)
+        F = objective(shapes[0], vp, gp, 11)
+        assert abs(F[0] - ref[0][0]) <= 1e-10 * max(1.0, abs(ref[0][0]))
+        # objects travel without their device handle and pick up the default context again
+        vp2, gp2 = pickle.loads(pickle.dumps((vp, gp)))
+        assert vp2._ctx is None and gp2._ctx is None
+        _lib.set_default_context(b)
+        F2 = objective(shapes[0], vp2, gp2, 11)
+        assert F2[0] == F[0] and np.array_equal(F2[1], F[1])  # same kernels, same order: same bits
+    finally:
+        _lib.set_default_context(None)
+        a.close()
+        b.close()
+    with pytest.raises(Exception):
+        objective(shapes[0], *make(shapes[0], a)[1:], 1)  # a closed context refuses work
