@@ -117,7 +117,8 @@ def main():
 
         def step():
             step_no[0] += 1
-            return _neg_elcbo(theta, gp, vp, 0.0, nsk_job, True, False, bnd, rng="philox", seed=step_no[0])
+            th = theta + 1e-9 * (step_no[0] % 7)  # a different parameter vector every call, as in Adam
+            return _neg_elcbo(th, gp, vp, 0.0, nsk_job, True, False, bnd, rng="philox", seed=step_no[0])
 
     else:
         # HBM-resident draws, uploaded once and reused by every evaluation: the fused
@@ -143,8 +144,12 @@ def main():
         Fc, Gc, Hc = C.c_double(), C.c_double(), C.c_double()
         dF = np.empty(theta.size)
 
+        th = theta.copy()
+
         def step():
-            ctx.check(ctx._lib.vbmc_neg_elcbo(ctx._h, _lib.ptr(theta), theta.size, C.byref(opts),
+            step_no[0] += 1
+            th[:] = theta + 1e-9 * (step_no[0] % 7)  # a different parameter vector every call
+            ctx.check(ctx._lib.vbmc_neg_elcbo(ctx._h, _lib.ptr(th), th.size, C.byref(opts),
                                               C.byref(Fc), _lib.ptr(dF), C.byref(Gc), C.byref(Hc),
                                               None, None, None, None, None))
             return Fc.value, dF, Gc.value, Hc.value, 0

@@ -560,6 +560,7 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
     if (!std::isfinite(theta0[i])) return vbmc_fail(ctx, VBMC_E_NONFINITE, "theta has a non-finite entry");
   AdamState* st = adam_of(ctx);
   st->active = false;
+  ctx->pack_valid = false;  // the loop rewrites d_mix on the device; vbmc_adam_end re-syncs the host copies
   st->has_bnd = opts->bnd_lb && opts->bnd_ub;
   st->n_bnd = st->has_bnd ? opts->n_bnd : 0;
   if (st->has_bnd) {
@@ -805,6 +806,7 @@ extern "C" int vbmc_adam_end(vbmc_ctx* ctx, double* theta_out, double* mu_KxD, d
   ctx->lambd.assign(aux.begin() + K * D + K, aux.begin() + K * D + K + D);
   ctx->w.assign(aux.begin() + K * D + K + D, aux.begin() + K * D + 2 * K + D);
   ctx->eta.assign(aux.begin() + K * D + 2 * K + D, aux.end());
+  ctx->pack_valid = true;
   if (theta_out) memcpy(theta_out, th.data(), sizeof(double) * st->n_theta);
   if (mu_KxD) memcpy(mu_KxD, ctx->mu.data(), sizeof(double) * K * D);
   if (sigma_K) memcpy(sigma_K, ctx->sigma.data(), sizeof(double) * K);

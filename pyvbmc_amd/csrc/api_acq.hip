@@ -101,19 +101,20 @@ extern "C" int vbmc_acq_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int
   const int N = g.N, D = g.D, S = g.S;
   if (D > 32) return vbmc_fail(ctx, VBMC_E_UNSUP, "acq_eval: D=%d > 32 not supported", D);
   const int ntiles = (N + 63) / 64;
-  const int64_t BATCH = 1 << 16;
-  const int64_t mb = M < BATCH ? M : BATCH;
-  // scratch: xs | Ks | part,fpart | fmu[S] | fs2[S] | dens | sn2 | acq | f_bar | var_tot
-  const size_t need = (size_t)mb * D + (size_t)mb * N + 2 * (size_t)ntiles * mb + 2 * (size_t)S * mb +
-                      5 * (size_t)mb;
+  int64_t mb = ((int64_t)1 << 27) / ((int64_t)S * N);  // S kernel matrices of a batch under 1 GiB
+  mb = mb > 65536 ? 65536 : (mb < 64 ? 64 : (mb / 64) * 64);
+  if (M < mb) mb = M;
+  // scratch: xs | Ks [S] | part,fpart [S] | fmu[S] | fs2[S] | dens | sn2 | acq | f_bar | var_tot
+  const size_t need = (size_t)mb * D + (size_t)S * mb * N + 2 * (size_t)S * ntiles * mb +
+                      2 * (size_t)S * mb + 5 * (size_t)mb;
   int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, need);
   if (rc) return rc;
   rc = ensure_pinned(ctx, 3 * (size_t)mb);
   if (rc) return rc;
   double* d_xs = ctx->d_scratch;
   double* d_Ks = d_xs + (size_t)mb * D;
-  double* d_part = d_Ks + (size_t)mb * N;
-  double* d_fmu = d_part + 2 * (size_t)ntiles * mb;
+  double* d_part = d_Ks + (size_t)S * mb * N;
+  double* d_fmu = d_part + 2 * (size_t)S * ntiles * mb;
   double* d_fs2 = d_fmu + (size_t)S * mb;
   double* d_dens = d_fs2 + (size_t)S * mb;
   double* d_sn2 = d_dens + mb;
@@ -124,11 +125,8 @@ extern "C" int vbmc_acq_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int
                                 ctx->stream));
     if (kind == VBMC_ACQ_NOISY)
       HIP_TRY(ctx, hipMemcpyAsync(d_sn2, sn2_M + o, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
-    for (int s = 0; s < S; ++s) {
-      rc = launch_gp_predict_sample(ctx, s, m, d_xs, d_Ks, d_part, 0, d_fmu + (size_t)s * mb,
-                                    d_fs2 + (size_t)s * mb);
-      if (rc) return rc;
-    }
+    rc = launch_gp_predict_all(ctx, m, d_xs, d_Ks, d_part, 0, d_fmu, d_fs2, mb);
+    if (rc) return rc;
     rc = launch_mixture_pdf(ctx, m, d_xs, kind == VBMC_ACQ_LOG, 0, INFINITY, d_dens, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(acq_combine_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream,

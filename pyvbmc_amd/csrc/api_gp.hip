@@ -22,7 +22,7 @@ extern "C" int vbmc_set_gp(vbmc_ctx* ctx, int N, int D, int S, int P, int mean_k
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   GpState& g = ctx->gp;
-  double** bufs[] = {&g.d_X, &g.d_alpha, &g.d_L, &g.d_Linv, &g.d_sW, &g.d_hyp, &g.d_xc};
+  double** bufs[] = {&g.d_X, &g.d_alpha, &g.d_L, &g.d_Linv, &g.d_sW, &g.d_hyp, &g.d_xc, &g.d_smeta};
   for (double** b : bufs)
     if (*b) {
       HIP_TRY(ctx, hipFree(*b));
@@ -59,6 +59,13 @@ extern "C" int vbmc_set_gp(vbmc_ctx* ctx, int N, int D, int S, int P, int mean_k
   for (int d = 0; d < D; ++d) xc[d] /= N;
   HIP_TRY(ctx, hipMalloc((void**)&g.d_xc, sizeof(double) * D));
   HIP_TRY(ctx, hipMemcpy(g.d_xc, xc.data(), sizeof(double) * D, hipMemcpyHostToDevice));
+  std::vector<double> smeta(2 * (size_t)S);
+  for (int s = 0; s < S; ++s) {
+    smeta[2 * s] = g.L_chol[s] ? 1.0 : 0.0;
+    smeta[2 * s + 1] = g.sn2_mult[s];
+  }
+  HIP_TRY(ctx, hipMalloc((void**)&g.d_smeta, sizeof(double) * 2 * S));
+  HIP_TRY(ctx, hipMemcpy(g.d_smeta, smeta.data(), sizeof(double) * 2 * S, hipMemcpyHostToDevice));
   // L^-1 of the Cholesky samples, once per GP update
   int rc = launch_trinv(ctx);
   if (rc) return rc;
@@ -279,18 +286,20 @@ extern "C" int vbmc_gp_predict(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, i
   const int N = g.N, D = g.D, S = g.S;
   if (D > 32) return vbmc_fail(ctx, VBMC_E_UNSUP, "gp_predict: D=%d > 32 not supported", D);
   const int ntiles = (N + 63) / 64;
-  const int64_t BATCH = 1 << 16;
-  const int64_t mb = M < BATCH ? M : BATCH;
-  // scratch: xs (mb*D) | Ks (mb*N) | part, fpart (2*ntiles*mb) | fmu [S][mb] | fs2 [S][mb]
-  const size_t need = (size_t)mb * D + (size_t)mb * N + 2 * (size_t)ntiles * mb + 2 * (size_t)S * mb;
+  // batch so that the S kernel matrices of a batch stay under 1 GiB
+  int64_t mb = ((int64_t)1 << 27) / ((int64_t)S * N);
+  mb = mb > 65536 ? 65536 : (mb < 64 ? 64 : (mb / 64) * 64);
+  if (M < mb) mb = M;
+  // scratch: xs (mb*D) | Ks [S](mb*N) | part, fpart [S](2*ntiles*mb) | fmu [S][mb] | fs2 [S][mb]
+  const size_t need = (size_t)mb * D + (size_t)S * mb * N + 2 * (size_t)S * ntiles * mb + 2 * (size_t)S * mb;
   int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, need);
   if (rc) return rc;
   rc = ensure_pinned(ctx, 2 * (size_t)S * mb);
   if (rc) return rc;
   double* d_xs = ctx->d_scratch;
   double* d_Ks = d_xs + (size_t)mb * D;
-  double* d_part = d_Ks + (size_t)mb * N;
-  double* d_fmu = d_part + 2 * (size_t)ntiles * mb;
+  double* d_part = d_Ks + (size_t)S * mb * N;
+  double* d_fmu = d_part + 2 * (size_t)S * ntiles * mb;
   double* d_fs2 = d_fmu + (size_t)S * mb;
   std::vector<double> mu_s, s2_s;
   if (!separate_samples) {
@@ -301,17 +310,12 @@ extern "C" int vbmc_gp_predict(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, i
     const int64_t m = (M - o) < mb ? (M - o) : mb;
     HIP_TRY(ctx, hipMemcpyAsync(d_xs, xs_MxD + o * D, sizeof(double) * m * D, hipMemcpyHostToDevice,
                                 ctx->stream));
-    // every hyper-parameter sample is enqueued before the one synchronisation of the batch
-    for (int s = 0; s < S; ++s) {
-      if (s == 0) HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
-      rc = launch_gp_predict_sample(ctx, s, m, d_xs, d_Ks, d_part, add_noise, d_fmu + (size_t)s * mb,
-                                    d_fs2 + (size_t)s * mb);
-      if (rc) return rc;
-      if (s == 0) {
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
-        ctx->ev_valid[3] = true;
-      }
-    }
+    // every hyper-parameter sample in the same three launches (grid.z = sample)
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    rc = launch_gp_predict_all(ctx, m, d_xs, d_Ks, d_part, add_noise, d_fmu, d_fs2, mb);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+    ctx->ev_valid[3] = true;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, d_fmu, sizeof(double) * 2 * S * mb, hipMemcpyDeviceToHost,
                                 ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -119,7 +119,7 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   adam_free(ctx);
   double* bufs[] = {ctx->d_mix, ctx->d_eps, ctx->d_scratch, ctx->d_out, ctx->gp.d_X,
                     ctx->gp.d_alpha, ctx->gp.d_L, ctx->gp.d_Linv, ctx->gp.d_sW, ctx->gp.d_hyp,
-                    ctx->gp.d_xc};
+                    ctx->gp.d_xc, ctx->gp.d_smeta};
   for (double* b : bufs)
     if (b) (void)hipFree(b);
   if (ctx->d_epsgen) (void)hipFree(ctx->d_epsgen);
@@ -273,12 +273,26 @@ static int upload_mixture(vbmc_ctx* ctx) {
                               ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->pack_ev, ctx->stream));
   ctx->pack_in_flight = true;
+  ctx->pack_valid = true;
   return 0;
 }
 
 int set_mixture_host(vbmc_ctx* ctx, int D, int K, const double* mu_KxD, const double* sigma_K,
-                     const double* lambd_D, const double* w_K, const double* eta_K) {
+                     const double* lambd_D, const double* w_K, const double* eta_K, bool skip_if_same) {
   if (D < 1 || K < 1) return vbmc_fail(ctx, VBMC_E_ARG, "set_mixture: bad D=%d K=%d", D, K);
+  // The same mixture as the one already on the device (thousands of acquisition / pdf calls
+  // between two updates of the posterior): nothing to pack or upload.  Only for the explicit
+  // vbmc_set_mixture; the optimiser path (theta -> mixture) always packs and uploads, a new
+  // theta every call being its normal case.
+  if (skip_if_same && ctx->mix_set && ctx->pack_valid && ctx->D == D && ctx->K == K &&
+      memcmp(ctx->mu.data(), mu_KxD, sizeof(double) * K * D) == 0 &&
+      memcmp(ctx->sigma.data(), sigma_K, sizeof(double) * K) == 0 &&
+      memcmp(ctx->lambd.data(), lambd_D, sizeof(double) * D) == 0 &&
+      memcmp(ctx->w.data(), w_K, sizeof(double) * K) == 0) {
+    if (eta_K) ctx->eta.assign(eta_K, eta_K + K);
+    return 0;
+  }
+  ctx->pack_valid = false;
   ctx->D = D;
   ctx->K = K;
   ctx->mu.assign(mu_KxD, mu_KxD + (size_t)K * D);
@@ -307,7 +321,7 @@ int vbmc_set_mixture(vbmc_ctx* ctx, int D, int K, const double* mu_KxD, const do
                      const double* lambd_D, const double* w_K, const double* eta_K) {
   if (!ctx || !mu_KxD || !sigma_K || !lambd_D || !w_K) return VBMC_E_ARG;
   if (ctx->device >= 0) HIP_TRY(ctx, hipSetDevice(ctx->device));
-  return set_mixture_host(ctx, D, K, mu_KxD, sigma_K, lambd_D, w_K, eta_K);
+  return set_mixture_host(ctx, D, K, mu_KxD, sigma_K, lambd_D, w_K, eta_K, true);
 }
 
 int vbmc_theta_to_mixture(vbmc_ctx* ctx, const double* theta, int n_theta, int optimize_mask,
@@ -324,7 +338,7 @@ int vbmc_theta_to_mixture(vbmc_ctx* ctx, const double* theta, int n_theta, int o
     return vbmc_fail(ctx, VBMC_E_ARG, "theta length %d does not match D=%d K=%d mask=%d", n_theta, D, K,
                      optimize_mask);
   if (st == -2) return vbmc_fail(ctx, VBMC_E_NONFINITE, "theta has a non-finite entry");
-  int rc = set_mixture_host(ctx, D, K, mu.data(), sg.data(), lm.data(), w.data(), eta.data());
+  int rc = set_mixture_host(ctx, D, K, mu.data(), sg.data(), lm.data(), w.data(), eta.data(), false);
   if (rc) return rc;
   if (mu_KxD) memcpy(mu_KxD, mu.data(), sizeof(double) * D * K);
   if (sigma_K) memcpy(sigma_K, sg.data(), sizeof(double) * K);

@@ -101,11 +101,24 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ U,
 // matrix instruction buys here is issue efficiency: 1024 FMAs per instruction and no
 // per-FMA operand traffic.
 constexpr int TS = 64, TKD = 16, LDA = TKD + 1, LDB = TS + 16;
+// blockIdx.z (predict only): GP sample -- A, part advance by their strides, B is the sample's
+// L^-1 or L according to smeta[2z] (smeta == null: single problem, B and mode as given).
 __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __restrict__ A,
                                                                const double* __restrict__ B,
                                                                int64_t M, int N, int mode,
                                                                double* __restrict__ part,
-                                                               double* __restrict__ Cout) {
+                                                               double* __restrict__ Cout,
+                                                               const double* __restrict__ Bfull,
+                                                               const double* __restrict__ smeta,
+                                                               int64_t part_stride) {
+  if (smeta) {
+    const int z = blockIdx.z;
+    const bool chol = smeta[2 * z] != 0.0;
+    A += (size_t)z * M * N;
+    B = (chol ? B : Bfull) + (size_t)z * N * N;
+    mode = chol ? 0 : 1;
+    part += (size_t)z * part_stride;
+  }
   __shared__ double sA[TS * LDA];
   __shared__ double sB[TKD * LDB];
   __shared__ double sRow[TS][2];
@@ -218,7 +231,18 @@ constexpr int KDP = 32 + 1;  // LDS row stride (max padded D = 32, +1 against ba
 __global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
     const double* __restrict__ X, const double* __restrict__ xs, const double* __restrict__ alpha,
     const double* __restrict__ sW, const double* __restrict__ hyp, const double* __restrict__ cen,
-    int N, int D, int64_t M, int scale_sw, double* __restrict__ Ks, double* __restrict__ fpart) {
+    const double* __restrict__ smeta, int P, int N, int D, int64_t M, double* __restrict__ Ks,
+    double* __restrict__ fpart, int64_t part_stride) {
+  // blockIdx.z = GP hyper-parameter sample: all S samples in one launch
+  {
+    const int s = blockIdx.z;
+    alpha += (size_t)s * N;
+    sW += (size_t)s * N;
+    hyp += (size_t)s * P;
+    Ks += (size_t)s * M * N;
+    fpart += (size_t)s * part_stride;
+  }
+  const int scale_sw = smeta[2 * blockIdx.z] != 0.0;  // L_chol sample: stage 2 wants sW o K*
   __shared__ double sAm[TS * KDP];  // [64 m][d]
   __shared__ double sBn[TS * KDP];  // [64 n][d]
   __shared__ double sA2[TS], sB2[TS], sAl[TS], sSc[TS];
@@ -419,19 +443,26 @@ __global__ void sq_dist_argmin_kernel(const double* __restrict__ pmin, const int
 
 // predict, stage 3: fmu[m] = mean(x*_m) + sum of the stage-1 partial means,
 // fs2[m] = max(0, sf^2 -/+ sum of the stage-2 partial row sums) (+ noise).
-__global__ void predict_finish_kernel(const double* __restrict__ part, const double* __restrict__ fpart,
-                                      int ntiles, int64_t M, int D, int mean_kind,
-                                      const double* __restrict__ hyp, const double* __restrict__ xs,
-                                      double sf2, double sign, double add, double* __restrict__ fmu,
-                                      double* __restrict__ fs2) {
+__global__ void predict_finish_kernel(const double* __restrict__ part_all, int64_t part_stride, int ntiles,
+                                      int64_t M, int D, int P, int mean_kind, const double* __restrict__ hyp_all,
+                                      const double* __restrict__ smeta, const double* __restrict__ xs,
+                                      int add_noise, double* __restrict__ fmu, double* __restrict__ fs2,
+                                      int64_t ld) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
+  const int smp = blockIdx.y;  // GP sample
+  const double* part = part_all + (size_t)smp * part_stride;
+  const double* fpart = part + (size_t)ntiles * M;
+  const double* hyp = hyp_all + (size_t)smp * P;
+  const bool chol = smeta[2 * smp] != 0.0;
+  const double sf2 = exp(2.0 * hyp[D]);
+  const double add = add_noise ? exp(2.0 * hyp[D + 1]) * smeta[2 * smp + 1] : 0.0;
   double s = 0.0, f = 0.0;
   for (int t = 0; t < ntiles; ++t) {
     s += part[(size_t)t * M + m];
     f += fpart[(size_t)t * M + m];
   }
-  fs2[m] = fmax(sf2 + sign * s, 0.0) + add;
+  fs2[(size_t)smp * ld + m] = fmax(chol ? sf2 - s : sf2 + s, 0.0) + add;
   // mean function at x* (variational_optimization.py:1383-1392 layout)
   double mean = 0.0;
   const double* hm = hyp + D + 2;
@@ -443,7 +474,7 @@ __global__ void predict_finish_kernel(const double* __restrict__ part, const dou
       mean -= 0.5 * t * t;
     }
   }
-  fmu[m] = mean + f;
+  fmu[(size_t)smp * ld + m] = mean + f;
 }
 
 }  // namespace
@@ -487,7 +518,8 @@ int launch_gp_var(vbmc_ctx* ctx, const double* d_Z, double* d_V, double* d_Q) {
     // V = Z L^-1 (upper-triangular skip) or Z L, on the FP64 matrix cores
     hipLaunchKernelGGL(predict_var_mfma_kernel, dim3((N + TS - 1) / TS, (K + TS - 1) / TS), dim3(256),
                        0, ctx->stream, d_Z + (size_t)s * K * N, Bm, (int64_t)K, N, chol ? 0 : 1,
-                       (double*)nullptr, d_V + (size_t)s * K * N);
+                       (double*)nullptr, d_V + (size_t)s * K * N, (const double*)nullptr,
+                       (const double*)nullptr, (int64_t)0);
     const double* U = chol ? d_V + (size_t)s * K * N : d_Z + (size_t)s * K * N;
     hipLaunchKernelGGL(gram_kernel, dim3((K * K + WAVES - 1) / WAVES, 1), dim3(256), 0, ctx->stream,
                        U, (const double*)(d_V + (size_t)s * K * N), (const double*)ctx->d_mix,
@@ -506,27 +538,26 @@ int launch_trinv(vbmc_ctx* ctx) {
   return 0;
 }
 
-// One GP sample s, one batch of M points already on the device.
-int launch_gp_predict_sample(vbmc_ctx* ctx, int s, int64_t M, const double* d_xs, double* d_Ks,
-                             double* d_part, int add_noise, double* d_fmu, double* d_fs2) {
+// All S GP samples, one batch of M points already on the device: three launches in total
+// (grid.z / grid.y = sample).  d_Ks: S * M * N doubles; d_part: S * 2 * ntiles * M doubles;
+// d_fmu / d_fs2: [S][ld].
+int launch_gp_predict_all(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* d_Ks, double* d_part,
+                          int add_noise, double* d_fmu, double* d_fs2, int64_t ld) {
   const GpState& g = ctx->gp;
-  const int N = g.N, D = g.D;
-  const double* h = g.hyp.data() + (size_t)s * g.P;
-  const int chol = g.L_chol[s];
+  const int N = g.N, D = g.D, S = g.S;
   const int ntiles = (N + TS - 1) / TS;
-  double* d_fpart = d_part + (size_t)ntiles * M;  // caller provides 2 * ntiles * M doubles
-  const dim3 grid(ntiles, (unsigned)((M + TS - 1) / TS));
+  const int64_t pstride = 2 * (int64_t)ntiles * M;
+  const dim3 grid(ntiles, (unsigned)((M + TS - 1) / TS), S);
   hipLaunchKernelGGL(predict_kstar_mfma_kernel, grid, dim3(256), 0, ctx->stream, g.d_X, d_xs,
-                     g.d_alpha + (size_t)s * N, g.d_sW + (size_t)s * N, g.d_hyp + (size_t)s * g.P,
-                     (const double*)g.d_xc, N, D, M, chol, d_Ks, d_fpart);
-  const double* Bm = (chol ? g.d_Linv : g.d_L) + (size_t)s * N * N;
-  hipLaunchKernelGGL(predict_var_mfma_kernel, grid, dim3(256), 0, ctx->stream, d_Ks, Bm, M, N,
-                     chol ? 0 : 1, d_part, (double*)nullptr);
-  const double sf2 = std::exp(2.0 * h[D]);
-  const double add = add_noise ? std::exp(2.0 * h[D + 1]) * g.sn2_mult[s] : 0.0;
-  hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
-                     ctx->stream, d_part, (const double*)d_fpart, ntiles, M, D, g.mean_kind,
-                     g.d_hyp + (size_t)s * g.P, d_xs, sf2, chol ? -1.0 : 1.0, add, d_fmu, d_fs2);
+                     (const double*)g.d_alpha, (const double*)g.d_sW, (const double*)g.d_hyp,
+                     (const double*)g.d_xc, (const double*)g.d_smeta, g.P, N, D, M, d_Ks,
+                     d_part + (size_t)ntiles * M, pstride);
+  hipLaunchKernelGGL(predict_var_mfma_kernel, grid, dim3(256), 0, ctx->stream, (const double*)d_Ks,
+                     (const double*)g.d_Linv, M, N, 0, d_part, (double*)nullptr, (const double*)g.d_L,
+                     (const double*)g.d_smeta, pstride);
+  hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((M + 255) / 256), S), dim3(256), 0, ctx->stream,
+                     (const double*)d_part, pstride, ntiles, M, D, g.P, g.mean_kind, (const double*)g.d_hyp,
+                     (const double*)g.d_smeta, d_xs, add_noise, d_fmu, d_fs2, ld);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
