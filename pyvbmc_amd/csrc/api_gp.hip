@@ -59,13 +59,14 @@ extern "C" int vbmc_set_gp(vbmc_ctx* ctx, int N, int D, int S, int P, int mean_k
   for (int d = 0; d < D; ++d) xc[d] /= N;
   HIP_TRY(ctx, hipMalloc((void**)&g.d_xc, sizeof(double) * D));
   HIP_TRY(ctx, hipMemcpy(g.d_xc, xc.data(), sizeof(double) * D, hipMemcpyHostToDevice));
-  std::vector<double> smeta(2 * (size_t)S);
+  std::vector<double> smeta(3 * (size_t)S);
   for (int s = 0; s < S; ++s) {
-    smeta[2 * s] = g.L_chol[s] ? 1.0 : 0.0;
-    smeta[2 * s + 1] = g.sn2_mult[s];
+    smeta[3 * s] = g.L_chol[s] ? 1.0 : 0.0;
+    smeta[3 * s + 1] = g.sn2_mult[s];
+    smeta[3 * s + 2] = 1.0 / g.sn2_eff[s];
   }
-  HIP_TRY(ctx, hipMalloc((void**)&g.d_smeta, sizeof(double) * 2 * S));
-  HIP_TRY(ctx, hipMemcpy(g.d_smeta, smeta.data(), sizeof(double) * 2 * S, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMalloc((void**)&g.d_smeta, sizeof(double) * 3 * S));
+  HIP_TRY(ctx, hipMemcpy(g.d_smeta, smeta.data(), sizeof(double) * 3 * S, hipMemcpyHostToDevice));
   // L^-1 of the Cholesky samples, once per GP update
   int rc = launch_trinv(ctx);
   if (rc) return rc;

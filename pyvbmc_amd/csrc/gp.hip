@@ -52,18 +52,26 @@ __global__ void trinv_upper_kernel(const double* __restrict__ L, int N, double* 
 //   J_jk = exp(lnnf_jk - 1/2 sum_d delta_jk_d^2)  -/+  sum_c U[j][c] V[k][c] (/ sn2_eff),
 //   tau_jk_d = sqrt((sigma_j^2+sigma_k^2) lambda_d^2 + ell_d^2), delta = (mu_j - mu_k)/tau,
 //   lnnf_jk = 2 hyp[D] + sum_d hyp[d] - sum_d log tau_jk_d.   Writes both triangles.
-__global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ U,
+// blockIdx.y = GP sample: U = V (L_chol sample: rows of Z L^-1) or Z (rows of z, V = Z L).
+__global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Z,
                                                    const double* __restrict__ V,
                                                    const double* __restrict__ mix, MixLayout ml,
-                                                   const double* __restrict__ hyp, int N, int chol,
-                                                   double inv_sn2, double* __restrict__ J) {
+                                                   const double* __restrict__ hyp, int P, int N,
+                                                   const double* __restrict__ smeta,
+                                                   double* __restrict__ J) {
   const int D = ml.D, K = ml.K;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pair = blockIdx.x * WAVES + wave;
   if (pair >= K * K) return;
   const int j = pair / K, k = pair - j * K;
   if (j > k) return;
-  const double* u = U + (size_t)j * N;
+  const int smp = blockIdx.y;
+  const bool chol = smeta[3 * smp] != 0.0;
+  const double inv_sn2 = smeta[3 * smp + 2];
+  hyp += (size_t)smp * P;
+  J += (size_t)smp * K * K;
+  V += (size_t)smp * K * N;
+  const double* u = (chol ? V : Z + (size_t)smp * K * N) + (size_t)j * N;
   const double* v = V + (size_t)k * N;
   double acc = 0.0;
   for (int c = lane; c < N; c += 64) acc = fma(u[c], v[c], acc);
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ U,
 // per-FMA operand traffic.
 constexpr int TS = 64, TKD = 16, LDA = TKD + 1, LDB = TS + 16;
 // blockIdx.z (predict only): GP sample -- A, part advance by their strides, B is the sample's
-// L^-1 or L according to smeta[2z] (smeta == null: single problem, B and mode as given).
+// L^-1 or L according to smeta[3z] (smeta == null: single problem, B and mode as given).
 __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __restrict__ A,
                                                                const double* __restrict__ B,
                                                                int64_t M, int N, int mode,
@@ -113,8 +121,9 @@ __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __r
                                                                int64_t part_stride) {
   if (smeta) {
     const int z = blockIdx.z;
-    const bool chol = smeta[2 * z] != 0.0;
+    const bool chol = smeta[3 * z] != 0.0;
     A += (size_t)z * M * N;
+    if (Cout) Cout += (size_t)z * M * N;
     B = (chol ? B : Bfull) + (size_t)z * N * N;
     mode = chol ? 0 : 1;
     part += (size_t)z * part_stride;
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
     Ks += (size_t)s * M * N;
     fpart += (size_t)s * part_stride;
   }
-  const int scale_sw = smeta[2 * blockIdx.z] != 0.0;  // L_chol sample: stage 2 wants sW o K*
+  const int scale_sw = smeta[3 * blockIdx.z] != 0.0;  // L_chol sample: stage 2 wants sW o K*
   __shared__ double sAm[TS * KDP];  // [64 m][d]
   __shared__ double sBn[TS * KDP];  // [64 n][d]
   __shared__ double sA2[TS], sB2[TS], sAl[TS], sSc[TS];
@@ -454,9 +463,9 @@ __global__ void predict_finish_kernel(const double* __restrict__ part_all, int64
   const double* part = part_all + (size_t)smp * part_stride;
   const double* fpart = part + (size_t)ntiles * M;
   const double* hyp = hyp_all + (size_t)smp * P;
-  const bool chol = smeta[2 * smp] != 0.0;
+  const bool chol = smeta[3 * smp] != 0.0;
   const double sf2 = exp(2.0 * hyp[D]);
-  const double add = add_noise ? exp(2.0 * hyp[D + 1]) * smeta[2 * smp + 1] : 0.0;
+  const double add = add_noise ? exp(2.0 * hyp[D + 1]) * smeta[3 * smp + 1] : 0.0;
   double s = 0.0, f = 0.0;
   for (int t = 0; t < ntiles; ++t) {
     s += part[(size_t)t * M + m];
@@ -511,21 +520,15 @@ int launch_gp_log_joint(vbmc_ctx* ctx, int want_grad, double* d_res, double* d_Z
 // Q[s][j][k] = z_j^T (L^T L)^-1 z_k (L_chol)  or  z_j^T L z_k (otherwise), from Z.
 int launch_gp_var(vbmc_ctx* ctx, const double* d_Z, double* d_V, double* d_Q) {
   const GpState& g = ctx->gp;
-  const int K = ctx->K, N = g.N;
-  for (int s = 0; s < g.S; ++s) {
-    const int chol = g.L_chol[s];
-    const double* Bm = (chol ? g.d_Linv : g.d_L) + (size_t)s * N * N;
-    // V = Z L^-1 (upper-triangular skip) or Z L, on the FP64 matrix cores
-    hipLaunchKernelGGL(predict_var_mfma_kernel, dim3((N + TS - 1) / TS, (K + TS - 1) / TS), dim3(256),
-                       0, ctx->stream, d_Z + (size_t)s * K * N, Bm, (int64_t)K, N, chol ? 0 : 1,
-                       (double*)nullptr, d_V + (size_t)s * K * N, (const double*)nullptr,
-                       (const double*)nullptr, (int64_t)0);
-    const double* U = chol ? d_V + (size_t)s * K * N : d_Z + (size_t)s * K * N;
-    hipLaunchKernelGGL(gram_kernel, dim3((K * K + WAVES - 1) / WAVES, 1), dim3(256), 0, ctx->stream,
-                       U, (const double*)(d_V + (size_t)s * K * N), (const double*)ctx->d_mix,
-                       ctx->ml, (const double*)(g.d_hyp + (size_t)s * g.P), N, chol,
-                       1.0 / g.sn2_eff[s], d_Q + (size_t)s * K * K);
-  }
+  const int K = ctx->K, N = g.N, S = g.S;
+  // V = Z L^-1 (upper-triangular skip) or Z L on the FP64 matrix cores, then the K x K Gram
+  // matrix; every GP sample in the same two launches
+  hipLaunchKernelGGL(predict_var_mfma_kernel, dim3((N + TS - 1) / TS, (K + TS - 1) / TS, S), dim3(256), 0,
+                     ctx->stream, d_Z, (const double*)g.d_Linv, (int64_t)K, N, 0, (double*)nullptr, d_V,
+                     (const double*)g.d_L, (const double*)g.d_smeta, (int64_t)0);
+  hipLaunchKernelGGL(gram_kernel, dim3((K * K + WAVES - 1) / WAVES, S), dim3(256), 0, ctx->stream, d_Z,
+                     (const double*)d_V, (const double*)ctx->d_mix, ctx->ml, (const double*)g.d_hyp, g.P, N,
+                     (const double*)g.d_smeta, d_Q);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
