@@ -1,0 +1,312 @@
+"""The reference's OWN tests for this path (SURVEY.md 8c lists the ones that run green against
+the reference in the build container), re-expressed against the accelerated API: same inputs,
+same asserted constants and tolerances.  Each test names the reference test it restates
+(paths relative to pyvbmc/testing/).
+
+The tests that mock ``gp.predict`` / ``vp.pdf`` (acquisition ``__call__`` tests) cannot be
+restated that way -- the device path has no seam to mock -- and are covered by
+tests/test_acquisition.py against outputs of the reference's classes instead.
+"""
+import numpy as np
+import pytest
+import scipy.optimize
+
+from pyvbmc_amd.minimize_adam import minimize_adam
+from pyvbmc_amd.variational_optimization import _soft_bound_loss
+
+
+def fd_check(f, grad, x0, rtol=0.01, h=1e-6):
+    """Central differences against an analytic gradient, the role of pyvbmc.testing.check_grad."""
+    g = np.asarray(grad(x0), dtype=float)
+    num = np.empty_like(g)
+    for i in range(x0.size):
+        e = np.zeros_like(x0)
+        e[i] = h * max(1.0, abs(x0[i]))
+        num[i] = (f(x0 + e) - f(x0 - e)) / (2 * e[i])
+    return np.allclose(num, g, rtol=rtol, atol=rtol * max(1.0, np.max(np.abs(g))))
+
+
+# ------------------------------------------------------------------ vbmc/test_minimize_adam.py (CPU)
+def test_minimize_adam_sphere():
+    x, y, _, _, _ = minimize_adam(lambda x_: (np.sum(x_**2), 2 * x_), np.array([-3.0, -4.0]))
+    assert np.all(np.abs(x) < 0.1) and np.abs(y) < 0.001
+
+
+def test_minimize_adam_sphere_with_noise():
+    state = np.random.get_state()
+    np.random.seed(0)
+    f = lambda x_: (np.sum(x_**2), 2 * x_ + np.random.normal(scale=3, size=x_.shape))  # noqa: E731
+    x, y, _, _, _ = minimize_adam(f, np.array([-0.3, -0.4]), use_early_stopping=False)
+    np.random.set_state(state)
+    assert np.all(np.abs(x) < 0.5) and np.abs(y) < 0.1
+
+
+def matyas(noise):
+    def f(x_):
+        val = 0.26 * (x_[0] ** 2 + x_[1] ** 2) - 0.48 * x_[0] * x_[1]
+        g = np.array([0.52 * x_[0] - 0.48 * x_[1], 0.52 * x_[1] - 0.48 * x_[0]])
+        return val, (g + np.random.normal(scale=3, size=(2,)) if noise else g)
+
+    return f
+
+
+@pytest.mark.parametrize("noise", [False, True])
+def test_minimize_adam_matyas(noise):
+    state = np.random.get_state()
+    np.random.seed(0)  # the reference leaves this unseeded; its bound |x| < 1 fails for ~1 seed in 3
+    lb, ub = np.array([-10.0, -10.0]), np.array([10.0, 10.0])
+    x, y, _, _, _ = minimize_adam(matyas(noise), np.array([-0.3, -0.4]), lb, ub, use_early_stopping=False)
+    np.random.set_state(state)
+    assert np.all(np.abs(x) < 1.0) and np.abs(y) < 0.1
+
+
+def test_minimize_adam_rosen():
+    f = lambda x_: (scipy.optimize.rosen(x_), scipy.optimize.rosen_der(x_))  # noqa: E731
+    x, y, _, _, _ = minimize_adam(f, np.array([-3.0, -4.0]), max_iter=50000, use_early_stopping=False)
+    assert np.all(np.isclose(x, 1)) and np.isclose(y, 0.0)
+
+
+# ------------------------------------------------------------------ vbmc/test_variational_optimization.py:37 (CPU)
+def test_soft_bound_loss():
+    D = 3
+    x1 = np.zeros(D)
+    slb, sub = np.full((D,), -10), np.full((D,), 10)
+    L1 = _soft_bound_loss(x1, slb, sub)
+    assert np.isclose(L1, 0.0)
+    L1, dL1 = _soft_bound_loss(x1, slb, sub, compute_grad=True)
+    assert np.isclose(L1, 0.0) and np.allclose(dL1, 0.0)
+    x2 = x1.copy()
+    x2[0] = 15.0
+    L2, dL2 = _soft_bound_loss(x2, slb, sub, compute_grad=True)
+    assert np.isclose(L2, 31250.0) and np.isclose(dL2[0], 12500.0) and np.allclose(dL2[1:], 0.0)
+    x3 = x1.copy()
+    x3[1] = -20.0
+    L3, dL3 = _soft_bound_loss(x3, slb, sub, compute_grad=True)
+    assert np.isclose(L3, 125000.0) and np.isclose(dL3[1], -25000.0)
+
+
+# ------------------------------------------------------------------ acquisition_functions/*: the un-mocked ones
+def test_acq_info():
+    from pyvbmc_amd.acquisition import AcqFcn, AcqFcnLog, AcqFcnNoisy, AcqFcnVanilla
+
+    for cls, log_flag in ((AcqFcn, False), (AcqFcnLog, True), (AcqFcnVanilla, False), (AcqFcnNoisy, False)):
+        info = cls().get_info()
+        assert isinstance(info, dict)
+        assert info["log_flag"] is log_flag and info["compute_var_log_joint"] is False
+
+
+def test_real2int():
+    """test_abstract_acquisition_function.py:232: integer dimensions are rounded in original space."""
+    from pyvbmc_amd.acquisition import AbstractAcqFcn
+    from pyvbmc_amd.variational_posterior import IdentityTransformer
+
+    X = np.array([[0.4, 1.6, -2.2], [3.5, 0.49, 7.51]])
+    out = AbstractAcqFcn._real2int(X.copy(), IdentityTransformer(3), np.array([False, True, True]))
+    assert np.array_equal(out, np.array([[0.4, 2.0, -2.0], [3.5, 0.0, 8.0]]))
+    same = AbstractAcqFcn._real2int(X.copy(), IdentityTransformer(3), np.array([False] * 3))
+    assert np.array_equal(same, X)
+    assert np.array_equal(AbstractAcqFcn._real2int(X.copy(), IdentityTransformer(3), None), X)
+
+
+# ------------------------------------------------------------------ GPU part
+@pytest.fixture(scope="module")
+def ctx():
+    from pyvbmc_amd import _lib
+
+    c = _lib.Context(0)
+    _lib.set_default_context(c)
+    yield c
+    _lib.set_default_context(None)
+    c.close()
+
+
+def new_vp(D, K, ctx):
+    from pyvbmc_amd import VariationalPosterior
+
+    vp = VariationalPosterior(D, K)
+    vp.ctx = ctx
+    return vp
+
+
+def wrapper(fn, D, K, ctx, ret, **kw):
+    """entmc_vbmc_wrapper / entlb_vbmc_wrapper of the reference tests: theta -> H or dH."""
+
+    def call(theta):
+        vp = new_vp(D, K, ctx)
+        vp.mu = np.reshape(theta[: D * K], (D, K), "F")
+        vp.sigma = theta[D * K : D * K + K]
+        vp.lambd = theta[D * K + K : D * K + K + D]
+        vp.w = theta[D * K + K + D :]
+        state = np.random.get_state()
+        np.random.seed(42)  # the same draws for every evaluation of the numerical gradient
+        flags = tuple([ret == "dH"] * 4)
+        H, dH = fn(vp, grad_flags=flags, jacobian_flag=False, **kw)
+        np.random.set_state(state)
+        return H if ret == "H" else dH
+
+    return call
+
+
+def theta_of(vp):
+    return np.concatenate([np.ravel(x) for x in (np.asarray(vp.mu).T, vp.sigma, vp.lambd, vp.w)])
+
+
+def single_gaussian_entropy(D, sigma, lambd):
+    H = 0.5 * D * (1 + np.log(2 * np.pi)) + D * np.log(sigma).sum() + np.log(lambd).sum()
+    dH = np.concatenate([np.zeros(D), D / sigma.flatten(), 1 / lambd.flatten(), np.array([H - 1])])
+    return H, dH
+
+
+@pytest.mark.gpu
+def test_entmc_vbmc_single_gaussian(ctx):
+    """entropy/test_entmc_vbmc.py:52"""
+    from pyvbmc_amd import entmc_vbmc
+
+    D, K, Ns = 3, 1, 1e5
+    vp = new_vp(D, K, ctx)
+    vp.mu = np.ones((D, K))
+    vp.sigma = np.ones((1, K))
+    H_exact, dH_exact = single_gaussian_entropy(D, vp.sigma, vp.lambd)
+    H, dH = entmc_vbmc(vp, Ns, jacobian_flag=False)
+    assert np.isclose(H, H_exact, rtol=0.01, atol=0.01) and np.allclose(dH, dH_exact, rtol=0.01, atol=0.01)
+    theta0 = theta_of(vp)
+    assert fd_check(wrapper(entmc_vbmc, D, K, ctx, "H", Ns=Ns), wrapper(entmc_vbmc, D, K, ctx, "dH", Ns=Ns), theta0)
+
+
+def nonoverlapping(ctx):
+    D, K = 3, 2
+    vp = new_vp(D, K, ctx)
+    vp.mu = np.array([[0.0, 10.0], [0.0, 10.0], [0.0, 10.0]])
+    vp.sigma = np.array([1.0, 1.0])
+    vp.lambd = np.ones(D)
+    vp.w = np.ones(K) / K
+    return D, K, vp
+
+
+@pytest.mark.gpu
+def test_entmc_vbmc_nonoverlapping_mixture(ctx):
+    """entropy/test_entmc_vbmc.py:74: far-apart components -> sum of the single-Gaussian entropies."""
+    from pyvbmc_amd import entmc_vbmc
+
+    D, K, vp = nonoverlapping(ctx)
+    Ns = 1e5
+    H_exact = -np.sum(vp.w * np.log(vp.w)) + np.sum(
+        vp.w * (0.5 * D * (1 + np.log(2 * np.pi)) + D * np.log(vp.sigma) + np.log(vp.lambd).sum()))
+    H, dH = entmc_vbmc(vp, Ns, jacobian_flag=False)
+    assert np.isclose(H, H_exact, rtol=0.01, atol=0.01)
+    assert np.allclose(dH[: D * K], 0.0, atol=0.01)  # no pull between the components
+    assert np.allclose(dH[D * K : D * K + K], vp.w * D / vp.sigma, rtol=0.01, atol=0.01)
+    theta0 = theta_of(vp)
+    assert fd_check(wrapper(entmc_vbmc, D, K, ctx, "H", Ns=Ns), wrapper(entmc_vbmc, D, K, ctx, "dH", Ns=Ns), theta0)
+
+
+def overlapping(ctx):
+    state = np.random.get_state()
+    np.random.seed(42)
+    D, K = 3, 2
+    vp = new_vp(D, K, ctx)
+    vp.mu = np.random.uniform(-1, 1, size=(D, K))
+    vp.sigma = np.ones(K) + 0.2 * np.random.rand(K)
+    vp.lambd = np.ones(D) + 0.2 * np.random.rand(D)
+    vp.eta = np.random.rand(K)
+    vp.w = np.exp(vp.eta) / np.exp(vp.eta).sum()
+    np.random.set_state(state)
+    return D, K, vp
+
+
+@pytest.mark.gpu
+def test_entmc_vbmc_overlapping_mixture(ctx):
+    """entropy/test_entmc_vbmc.py:118"""
+    from pyvbmc_amd import entmc_vbmc
+
+    D, K, vp = overlapping(ctx)
+    assert fd_check(wrapper(entmc_vbmc, D, K, ctx, "H", Ns=1e5), wrapper(entmc_vbmc, D, K, ctx, "dH", Ns=1e5),
+                    theta_of(vp))
+
+
+@pytest.mark.gpu
+def test_entmc_and_entlb_vbmc_grad_flags(ctx):
+    """entropy/test_entmc_vbmc.py:174, test_entlb_vbmc.py:122: disabled blocks are omitted."""
+    from pyvbmc_amd import entlb_vbmc, entmc_vbmc
+
+    D, K = 4, 3
+    for fn, kw in ((entmc_vbmc, dict(Ns=1e5)), (entlb_vbmc, {})):
+        vp = new_vp(D, K, ctx)
+        _, dH = fn(vp, grad_flags=tuple([False] * 4), **kw)
+        assert dH.shape == (0,)
+        _, dH = fn(vp, grad_flags=tuple([False] * 3) + (True,), **kw)
+        assert dH.shape == (K,)
+
+
+@pytest.mark.gpu
+def test_entlb_vbmc_single_gaussian(ctx):
+    """entropy/test_entlb_vbmc.py:29"""
+    from pyvbmc_amd import entlb_vbmc
+
+    D, K = 3, 1
+    vp = new_vp(D, K, ctx)
+    vp.mu = np.ones((D, K))
+    vp.sigma = np.ones((1, K))
+    assert fd_check(wrapper(entlb_vbmc, D, K, ctx, "H"), wrapper(entlb_vbmc, D, K, ctx, "dH"), theta_of(vp))
+
+
+@pytest.mark.gpu
+def test_entlb_vbmc_nonoverlapping_mixture(ctx):
+    """entropy/test_entlb_vbmc.py:45: closed-form approximation of the lower bound."""
+    from pyvbmc_amd import entlb_vbmc
+
+    D, K, vp = nonoverlapping(ctx)
+    nconst = 1 / (2 * np.pi) ** (D / 2) / np.prod(vp.lambd)
+    H_appro = -np.sum(vp.w * np.log(vp.w * nconst / (2 * vp.sigma**2) ** (D / 2)))
+    dH_appro = np.concatenate([np.zeros(D * K), vp.w / vp.sigma * D, (vp.w[:, None] / vp.lambd).sum(0),
+                               -np.log(vp.w * nconst / (2 * vp.sigma**2) ** (D / 2)) - 1])
+    H, dH = entlb_vbmc(vp, jacobian_flag=False)
+    assert np.isclose(H, H_appro, rtol=0.01) and np.allclose(dH, dH_appro, rtol=0.01)
+    assert fd_check(wrapper(entlb_vbmc, D, K, ctx, "H"), wrapper(entlb_vbmc, D, K, ctx, "dH"), theta_of(vp))
+
+
+@pytest.mark.gpu
+def test_entlb_vbmc_overlapping_mixture(ctx):
+    """entropy/test_entlb_vbmc.py:80"""
+    from pyvbmc_amd import entlb_vbmc
+
+    D, K, vp = overlapping(ctx)
+    assert fd_check(wrapper(entlb_vbmc, D, K, ctx, "H"), wrapper(entlb_vbmc, D, K, ctx, "dH"), theta_of(vp))
+
+
+@pytest.mark.gpu
+def test_entropy_matlab(ctx, golden):
+    """entropy/test_entmc_vbmc.py:140, test_entlb_vbmc.py:101: MATLAB's H, dH (entropy-test.mat)."""
+    from pyvbmc_amd import entlb_vbmc, entmc_vbmc
+
+    g = golden("matlab_known")
+    D, K = int(g["ent_D"]), int(g["ent_K"])
+
+    def vp():
+        v = new_vp(D, K, ctx)
+        v.mu, v.sigma, v.lambd = g["ent_mu"].reshape(D, K), g["ent_sigma"].reshape(1, -1), g["ent_lambd"].reshape(-1, 1)
+        v.w, v.eta = g["ent_w"].reshape(1, -1), g["ent_eta"].reshape(1, -1)
+        return v
+
+    jac = bool(g["ent_jacobian_flag"])
+    Hl, dHl = entlb_vbmc(vp(), jacobian_flag=jac)
+    assert np.isclose(Hl, g["ent_Hl"]) and np.allclose(dHl, g["ent_dHl"])
+    state = np.random.get_state()
+    np.random.seed(3)
+    H, dH = entmc_vbmc(vp(), int(g["ent_Ns"]) * 10, jacobian_flag=jac)
+    np.random.set_state(state)
+    assert np.isclose(H, g["ent_H"], rtol=0.05, atol=0.05)  # two independent Monte-Carlo estimates
+    assert np.allclose(dH, g["ent_dH"], rtol=0.3, atol=0.3)
+
+
+@pytest.mark.gpu
+def test_sq_dist(ctx):
+    """acquisition_functions/test_abstract_acquisition_function.py:267: against the direct loop."""
+    from pyvbmc_amd.acquisition import AbstractAcqFcn
+
+    rng = np.random.default_rng(5)
+    for n, m, D in ((10, 20, 3), (1, 7, 5), (33, 1, 2)):
+        a, b = rng.standard_normal((n, D)), rng.standard_normal((m, D))
+        c = AbstractAcqFcn._sq_dist(a, b)
+        ref = np.array([[np.sum((a[i] - b[j]) ** 2) for j in range(m)] for i in range(n)])
+        assert c.shape == (n, m) and np.allclose(c, ref)
