@@ -310,3 +310,86 @@ def test_sq_dist(ctx):
         c = AbstractAcqFcn._sq_dist(a, b)
         ref = np.array([[np.sum((a[i] - b[j]) ** 2) for j in range(m)] for i in range(n)])
         assert c.shape == (n, m) and np.allclose(c, ref)
+
+
+def matlab_gp_and_points(ctx):
+    """The GP / test points shared by test_fess and test_active_sample_proposal_pdf
+    (vbmc/test_active_importance_sampling.py:120-163, :185-228)."""
+    from pyvbmc_amd import gp as gpm
+
+    D = 3
+    X = np.arange(-7, 8).reshape((5, 3), order="F").astype(float)
+    y = (-0.5 * np.sum(X**2, axis=1) - 0.5 * D * np.log(2 * np.pi)).reshape(-1, 1)  # MVN(0, I) log pdf
+    hyp = np.array([-2.0, -3.0, -4.0, 1.0, 0.0, -(D / 2) * np.log(2 * np.pi), 0.0, 0.25, 0.5, -0.5, 0.0, 0.5])
+    gp = gpm.GP(D, gpm.SquaredExponential(), gpm.NegativeQuadratic(), gpm.GaussianNoise(constant_add=True))
+    gp.ctx = ctx
+    gp.update(X_new=X, y_new=y, hyp=np.vstack([hyp, 2 * hyp]))
+    Xa = 2 * np.arange(-4, 5).reshape((3, 3), order="F") / np.pi
+    return D, X, gp, Xa
+
+
+@pytest.mark.gpu
+def test_fess(ctx, golden):
+    """vbmc/test_active_importance_sampling.py:113: MATLAB's fractional effective sample sizes."""
+    from pyvbmc_amd.active_importance_sampling import fess
+
+    m = golden("matlab_known")
+    D, X, gp, Xa = matlab_gp_and_points(ctx)
+    vp = new_vp(D, 2, ctx)
+    vp.mu = np.array([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]).T
+    vp.w = np.array([[0.7, 0.3]])
+    vp.lambd = np.ones(vp.lambd.shape)
+    gp_means = np.arange(-5, 5).reshape((5, 2), order="F") * np.pi
+    fess_means, fess_gp = fess(vp, gp_means, X), fess(vp, gp, Xa)
+    assert np.isscalar(fess_means) and np.isscalar(fess_gp)
+    assert np.isclose(fess_means, m["fess_fess_means"]) and np.isclose(fess_gp, m["fess_fess_gp"])
+    with pytest.raises(ValueError):
+        fess(vp, gp_means[:3], X)
+    assert 0.0 < fess(vp, gp, 200) <= 1.0  # the sampling form (the reference's own crashes on its tuple)
+
+
+@pytest.mark.gpu
+def test_active_sample_proposal_pdf(ctx, golden):
+    """vbmc/test_active_importance_sampling.py:178: MATLAB's log importance weights, VIQR and IMIQR."""
+    from pyvbmc_amd.active_importance_sampling import AcqFcnIMIQR, AcqFcnVIQR, active_sample_proposal_pdf
+
+    m = golden("matlab_known")
+    D, X, gp, Xa = matlab_gp_and_points(ctx)
+    vp = new_vp(D, 2, ctx)
+    vp.mu = np.array([[-1.0, -2.0, -3.0], [3.0, 2.0, 1.0]]).T
+    vp.w = np.array([[0.7, 0.3]])
+    vp.sigma = np.ones(vp.sigma.shape)
+    vp.lambd = np.ones(vp.lambd.shape)
+    rect_delta = 2 * np.std(gp.X, ddof=1, axis=0)
+    lw_v, s2_v = active_sample_proposal_pdf(Xa, gp, vp, 0.5, rect_delta, AcqFcnVIQR())
+    lw_i, s2_i = active_sample_proposal_pdf(Xa, gp, vp, 0.5, rect_delta, AcqFcnIMIQR())
+    assert lw_v.shape == lw_i.shape == (D, 2) and s2_v.shape == s2_i.shape == (D, 2)
+    assert np.allclose(lw_v, m["activesample_proposalpdf_ln_weights_viqr"])
+    assert np.allclose(s2_v, m["activesample_proposalpdf_f_s2_viqr"])
+    assert np.allclose(lw_i, m["activesample_proposalpdf_ln_weights_imiqr"])
+    assert np.allclose(s2_i, m["activesample_proposalpdf_f_s2_imiqr"])
+    # pure-VP proposal (w_vp = 1) has a single mixture column
+    lw1, _ = active_sample_proposal_pdf(Xa, gp, vp, 1.0, rect_delta, AcqFcnVIQR())
+    assert lw1.shape == (D, 2) and np.all(np.isfinite(lw1))
+
+
+def test_is_log_densities_and_weights():
+    """acq_fcn_viqr.py:159-247 / acq_fcn_imiqr.py:173-260 log densities; renormalize_weights :481."""
+    from scipy.stats import norm
+
+    from pyvbmc_amd.active_importance_sampling import AcqFcnIMIQR, AcqFcnVIQR, get_mcmc_opts, renormalize_weights
+
+    v, i = AcqFcnVIQR(), AcqFcnIMIQR(quantile=0.9)
+    assert np.isclose(v.u, norm.ppf(0.75)) and np.isclose(i.u, norm.ppf(0.9))
+    assert v.get_info()["log_flag"] and v.get_info()["importance_sampling"]
+    f_s2, f_mu = np.array([[0.5, 2.0]]), np.array([[1.0, -1.0]])
+    s = np.sqrt(f_s2)
+    assert np.allclose(v.is_log_full(None, f_s2=f_s2), np.log(np.sinh(v.u * s)) + np.log(2.0))
+    assert np.allclose(i.is_log_full(None, f_mu=f_mu, f_s2=f_s2), f_mu + np.log(np.sinh(i.u * s)) + np.log(2.0))
+    assert np.array_equal(v.is_log_base(None, f_mu=f_mu, f_s2=f_s2), np.zeros((1, 2)))
+    with pytest.raises(ValueError):
+        v.is_log_full(np.zeros(3))
+    w = renormalize_weights(np.array([0.0, 1.0, 2.0]))
+    assert np.isclose(np.sum(np.exp(w)), 1.0)
+    assert get_mcmc_opts(100) == ({"display": "off", "diagnostics": False}, 1, 50)
+    assert get_mcmc_opts(10, thin=3)[2] == 15
