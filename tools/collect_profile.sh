@@ -2,6 +2,7 @@
 # Collect the rocprofv3 evidence profiles/README.md describes, on a GPU box:
 #     gpurun -- 'bash tools/collect_profile.sh r01c'
 # then locally:  python tools/summarize_profile.py gpurun_out/r01c r01c
+#                python tools/summarize_rows_pmc.py gpurun_out/r01c r01c
 set -u
 TAG=${1:-prof}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
@@ -22,6 +23,8 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-tr
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/pmc_SQ2 -o p -- $B --steps 10 --warmup 2 > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT/pmc_SQ3 -o p -- $B --steps 10 --warmup 2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_adam -o s -- python $REPO/tools/adam_loop_profile.py > $OUT/adam_loop.txt 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_rows -o s -- python $REPO/tools/bench_rows.py > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_rows_mfma -o p -- python $REPO/tools/bench_rows.py > /dev/null 2>&1
 # un-profiled bench lines of the same build
 cd $REPO
 python bench.py --steps 200 --warmup 20 > $OUT/bench_philox.json 2>/dev/null
