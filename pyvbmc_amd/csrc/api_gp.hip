@@ -116,11 +116,12 @@ void glj_finalize(const vbmc_ctx* ctx, const double* res, int want_grad, GljHost
       for (int d = 0; d < D; ++d) {
         const double lam = ctx->lambd[d];
         const double tau2 = sg * sg * lam * lam + ell2[d];
-        const double tau = std::sqrt(tau2);
+        const double itau2 = 1.0 / tau2;            // the only division of this (k, d)
+        const double itau = std::sqrt(tau2) * itau2;  // 1 / tau
         const double U = r[1 + d], T = r[1 + D + d] - r[0];
-        double gm = wk * (-U / tau);
-        double gl = wk * (sg * sg / tau2) * lam * T;
-        gs += (lam * lam / tau2) * T;
+        double gm = wk * (-U * itau);
+        double gl = wk * (sg * sg * itau2) * lam * T;
+        gs += (lam * lam * itau2) * T;
         if (quad) {
           gm -= wk * iom2[d] * (ctx->mu[(size_t)k * D + d] - xm[d]);
           gl -= wk * sg * sg * iom2[d] * lam;
