@@ -119,8 +119,28 @@ __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __r
                                                                const double* __restrict__ Bfull,
                                                                const double* __restrict__ smeta,
                                                                int64_t part_stride) {
+  // XCD-aware tile order: the dispatcher places workgroup b (x fastest, then y, z) on XCD b % 8
+  // (MI355X_MICROARCH.md, workgroup dispatch), each XCD has its own 4 MiB L2, and the nct column
+  // tiles of one row tile all re-read the same rows of A.  Remap the linear id (bijectively) so
+  // that one XCD runs all column tiles of a row tile back to back: A then comes from that XCD's L2
+  // instead of nct times from the Infinity Cache.
+  const int nct = gridDim.x;
+  int tile_c, tile_z;
+  int64_t tile_r;
+  {
+    const int64_t per_z = (int64_t)gridDim.x * gridDim.y;
+    const int64_t nwg = per_z * gridDim.z;
+    const int64_t orig = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int64_t q = nwg / 8, r = nwg % 8;
+    const int64_t xcd = orig % 8;
+    int64_t wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+    tile_z = (int)(wgid / per_z);
+    wgid -= (int64_t)tile_z * per_z;
+    tile_r = wgid / nct;
+    tile_c = (int)(wgid - tile_r * nct);
+  }
   if (smeta) {
-    const int z = blockIdx.z;
+    const int z = tile_z;
     const bool chol = smeta[3 * z] != 0.0;
     A += (size_t)z * M * N;
     if (Cout) Cout += (size_t)z * M * N;
@@ -134,8 +154,8 @@ __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wc = wave & 1;
   const int li = lane & 15, lk = lane >> 4;
-  const int64_t m0 = (int64_t)blockIdx.y * TS;
-  const int c0 = blockIdx.x * TS;
+  const int64_t m0 = tile_r * TS;
+  const int c0 = tile_c * TS;
   double4_t acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -224,7 +244,7 @@ __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __r
       if (li == 0) sRow[row][wc] = v;
     }
   __syncthreads();
-  if (tid < TS && m0 + tid < M) part[(size_t)blockIdx.x * M + m0 + tid] = sRow[tid][0] + sRow[tid][1];
+  if (tid < TS && m0 + tid < M) part[(size_t)tile_c * M + m0 + tid] = sRow[tid][0] + sRow[tid][1];
 }
 
 // predict, stage 1 on the FP64 matrix cores: the dense pairwise-squared-distance block.
