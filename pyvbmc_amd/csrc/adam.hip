@@ -172,6 +172,11 @@ __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, do
   }
 }
 
+// MODE 2: the whole state block and the scratch are in LDS; MODE 0: everything in global memory;
+// MODE 1: a prefix tier in LDS.  Compile-time for modes 0 and 2 so that every access is a true
+// LDS (ds_*) or global access: a pointer that may be either one at run time makes the compiler
+// emit flat_* instructions, whose LDS latency is several times that of ds_*.
+template <int MODE>
 __global__ __launch_bounds__(256) void adam_step_kernel(AdamDev a, int do_step) {
   extern __shared__ double sh[];
   __shared__ double red[16];
@@ -200,10 +205,14 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamDev a, int do_step) 
     }
     if (cnt > 0) __syncthreads();
   }
-  auto at = [&](int off) -> double* { return off < a.n_stage ? sh + off : a.state + off; };
+  auto at = [&](int off) -> double* {
+    if (MODE == 2) return sh + off;
+    if (MODE == 0) return a.state + off;
+    return off < a.n_stage ? sh + off : a.state + off;
+  };
   double* theta = at(L.o_theta());
   double* aux = at(L.o_aux());
-  double* work = a.work_lds ? sh + a.n_stage : a.work;
+  double* work = MODE == 2 ? sh + a.n_stage : MODE == 0 ? a.work : (a.work_lds ? sh + a.n_stage : a.work);
   const double* raw = at(L.o_raw());
   const double* res = at(L.o_res());
   const double* hyp = at(L.o_hyp());
@@ -488,6 +497,13 @@ void adam_free(vbmc_ctx* ctx) {
   ctx->adam = nullptr;
 }
 
+static void launch_step(const AdamState& st, hipStream_t sm, const AdamDev& a, int do_step) {
+  const int mode = st.n_stage == 0 ? 0 : (st.n_stage == st.lay.end() ? 2 : 1);
+  if (mode == 2) hipLaunchKernelGGL(adam_step_kernel<2>, dim3(1), dim3(256), st.lds_bytes, sm, a, do_step);
+  else if (mode == 1) hipLaunchKernelGGL(adam_step_kernel<1>, dim3(1), dim3(256), st.lds_bytes, sm, a, do_step);
+  else hipLaunchKernelGGL(adam_step_kernel<0>, dim3(1), dim3(256), st.lds_bytes, sm, a, do_step);
+}
+
 static void fill_dev(const vbmc_ctx* ctx, const AdamState& st, AdamDev& a) {
   const GpState& g = ctx->gp;
   a.ml = ctx->ml;
@@ -619,8 +635,12 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
     st->work_lds = st->n_stage > 0;
     st->lds_bytes = st->work_lds ? sizeof(double) * ((size_t)st->n_stage + n_work) : 0;
     if (st->lds_bytes > 64 * 1024)
-      HIP_TRY(ctx, hipFuncSetAttribute((const void*)adam_step_kernel,
+    {
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)adam_step_kernel<1>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)st->lds_bytes));
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)adam_step_kernel<2>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)st->lds_bytes));
+    }
   }
   const size_t total = (size_t)L.end() + n_work + (size_t)max_iter * n_theta + 3 * (size_t)max_iter + 64;
   int rc = ensure_dev(ctx, &st->d_buf, &st->d_cap, total);
@@ -657,7 +677,7 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
   ctx->pack_in_flight = false;
   AdamDev a;
   fill_dev(ctx, *st, a);
-  hipLaunchKernelGGL(adam_step_kernel, dim3(1), dim3(256), st->lds_bytes, sm, a, 0);
+  launch_step(*st, sm, a, 0);
   HIP_TRY(ctx, hipGetLastError());
   // draws one iteration ahead (Philox mode, unless switched off or too large)
   {
@@ -758,7 +778,7 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
     a.step = st->master_min + (st->master_max - st->master_min) * std::exp(-(double)(i + 1) / st->master_decay);
     a.x_row = st->x_tab + (size_t)i * n;
     a.y_out = st->y_tab + 3 * (size_t)i;
-    hipLaunchKernelGGL(adam_step_kernel, dim3(1), dim3(256), st->lds_bytes, ctx->stream, a, 1);
+    launch_step(*st, ctx->stream, a, 1);
   }
   if (rc) return rc;
   HIP_TRY(ctx, hipGetLastError());
