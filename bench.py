@@ -174,6 +174,26 @@ def main():
         "evals_per_s": (n_loop / dt_loop) * (ns_job / 1e6),
         "F_first_last": [float(loop[3][0]), float(loop[3][-1])],
     }
+    # Secondary roofline (third way): gp.predict at the acquisition batch size,
+    # its GEMM flops against the FP64 matrix-core peak.  Timed with HIP events around the three
+    # predict launches (K* on MFMA, variance GEMM on MFMA, finish), so `frac` is a lower bound
+    # for the GEMM alone.
+    M_pred = 8192
+    xs_pred = np.random.default_rng(7).standard_normal((M_pred, D))
+    gp.predict(xs_pred, separate_samples=True)
+    pm = []
+    for _ in range(5):
+        gp.predict(xs_pred, separate_samples=True)
+        pm.append(ctx.last_kernel_ms(3))
+    nt = (wl.N + 63) // 64
+    gemm_flops = 2.0 * M_pred * 64 * sum(min((c + 1) * 64, wl.N) for c in range(nt))  # triangular skip
+    pred_ms = float(np.median(pm))
+    predict_roofline = {
+        "kernel": "predict_kstar_mfma + predict_var_mfma + predict_finish (S=1, M=8192)",
+        "bound": "mfma", "achieved": gemm_flops / (pred_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
+        "unit": "TFLOP/s", "frac": gemm_flops / (pred_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+        "kernels_ms": pred_ms, "gemm_flops": gemm_flops,
+    }
     for _ in range(a.warmup):
         out = step()
     ctx.comm_barrier()
@@ -246,6 +266,7 @@ def main():
             "hbm_achieved_GBs": (eps_bytes / (k_ms * 1e-3) / 1e9) if eps_bytes else 0.0,
             "hbm_peak_GBs": HBM_PEAK_GBS,
         },
+        "predict_roofline": predict_roofline,
         "device_resident_adam_loop": adam_loop,
         "F": F,
         "host_us_per_step": dict(zip(["pack_upload", "launch", "wait_device", "finalize", "c_total"],
