@@ -16,7 +16,7 @@
 //                 lane = antithetic-pair row (64 rows per batch),
 //                 wave w owns components k = w, w+4, w+8, ...  (KT = ceil(K/4)).
 //     Everything indexed by k is therefore wave-uniform: the per-(j,k) constants
-//     (Delta_jk row, |Delta|^2, exponent scale, log2 normaliser, weights) come from a
+//     (Delta_jk row, log2 density at the component mean, exponent scale, weights) come from a
 //     small precomputed table through SCALAR loads and feed the FMAs as SGPR operands
 //     -- the inner loop issues no vector-memory or LDS instruction at all;
 //   * only q+ and q- cross waves (one LDS exchange + barrier per 64-row batch); every
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
     // Scalar loads return out of order, hence the explicit "wait, then issue" sequence.
     double qp = 0.0, qm = 0.0;
     double rp_[KTMAX], rm_[KTMAX];
-    constexpr int NR1 = DP + 4;  // Delta, |Delta|^2, a, lrc, w
+    constexpr int NR1 = DP + 3;  // Delta, c0, a, w
     double cur[NR1], nxt[NR1];
     {
       const double* tr = Tw;
@@ -212,15 +212,14 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
         double c = 0.0;
 #pragma unroll
         for (int d = 0; d < DP; ++d) c = fma(cur[d], e[d], c);
-        const double ab = cur[DP + 0] + b;
-        const double sp = fma(two_sj, c, ab);
-        const double sm = fma(-two_sj, c, ab);
+        const double sp = fma(two_sj, c, b);   // sigma_j^2 |eps|^2 +- 2 sigma_j Delta.eps
+        const double sm = fma(-two_sj, c, b);
         double rp, rm;  // norm_j1 of the reference for the + and - sample
-        exp2_vc2(fma(cur[DP + 1], sp, cur[DP + 2]), fma(cur[DP + 1], sm, cur[DP + 2]), ec, rp, rm);
+        exp2_vc2(fma(cur[DP + 1], sp, cur[DP + 0]), fma(cur[DP + 1], sm, cur[DP + 0]), ec, rp, rm);
         rp_[kk] = rp;
         rm_[kk] = rm;
-        qp = fma(cur[DP + 3], rp, qp);
-        qm = fma(cur[DP + 3], rm, qm);
+        qp = fma(cur[DP + 2], rp, qp);
+        qm = fma(cur[DP + 2], rm, qm);
 #pragma unroll
         for (int i = 0; i < NR1; ++i) cur[i] = nxt[i];
       }
@@ -255,13 +254,13 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
       double Td[DP];
 #pragma unroll
       for (int d = 0; d < DP; ++d) Td[d] = 0.0;
-      constexpr int NR2 = DP + 5;  // Delta, (a, c, lrc, w skipped), wis2
+      constexpr int NR2 = DP + 4;  // Delta, (c0, a, w skipped), wis2
       double c2[NR2], n2[NR2];
       {
         const double* tr = Tw;
 #pragma unroll
         for (int d = 0; d < DP; ++d) c2[d] = tr[d];
-        c2[DP + 4] = tr[DP + 4];
+        c2[DP + 3] = tr[DP + 3];
       }
 #pragma unroll
       for (int kk = 0; kk < KTMAX; ++kk) {
@@ -272,20 +271,20 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
             const double* tn = Tw + (size_t)(4 * (kk + 1)) * TS;
 #pragma unroll
             for (int d = 0; d < DP; ++d) n2[d] = tn[d];
-            n2[DP + 4] = tn[DP + 4];
+            n2[DP + 3] = tn[DP + 3];
           }
           __builtin_amdgcn_sched_barrier(0);
           const double t1 = rp_[kk] * ip, t2 = rm_[kk] * im;  // norm_j1 / q
           const double ts = t1 + t2, td = t1 - t2;
           Wacc[kk] += ts;
-          sgs = fma(ts, c2[DP + 4], sgs);  // sum_k (gp + gm),  g = w_k / sigma_k^2 * norm_j1 / q
-          const double gd = td * c2[DP + 4];
+          sgs = fma(ts, c2[DP + 3], sgs);  // sum_k (gp + gm),  g = w_k / sigma_k^2 * norm_j1 / q
+          const double gd = td * c2[DP + 3];
           sgd += gd;
 #pragma unroll
           for (int d = 0; d < DP; ++d) Td[d] = fma(gd, c2[d], Td[d]);
 #pragma unroll
           for (int d = 0; d < DP; ++d) c2[d] = n2[d];
-          c2[DP + 4] = n2[DP + 4];
+          c2[DP + 3] = n2[DP + 3];
         }
       }
       const double cs = sig_j * sgs, cd = sig_j * sgd;

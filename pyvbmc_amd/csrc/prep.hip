@@ -29,7 +29,9 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
   a.res += (size_t)blockIdx.y * a.res_stride;
 
   if ((int)blockIdx.x < a.n_table) {
-    // ---- table row block: T[j][k] = [Delta_jk (DP) | a | c | lrc | w | wis2 | pad] ----
+    // ---- table row block: T[j][k] = [Delta_jk (DP) | c0 | a | w | w/sigma_k^2 | pad pad], where
+    // c0 + a (sigma_j^2 |eps|^2 +- 2 sigma_j Delta.eps) is the log2 density of component k at
+    // mu_j +- sigma_j lambda eps:  a = -log2(e)/(2 sigma_k^2),  c0 = a |Delta|^2 + log2 c_k ----
     const int j = blockIdx.x;
     const int DP = a.DP, TS = a.DP + 6, K4 = a.K4;
     const double* mup = a.mix + a.ml.o_mup;
@@ -44,14 +46,15 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
       if (k < K) {
         const double is2 = a.mix[a.ml.o_is2 + k];
         const double w = a.mix[a.ml.o_w + k];
-        row[DP + 0] = s;
-        row[DP + 1] = -0.5 * 0x1.71547652b82fep+0 * is2;  // -log2(e) / (2 sigma_k^2)
-        row[DP + 2] = a.mix[a.ml.o_lrc + k];
-        row[DP + 3] = w;
-        row[DP + 4] = w * is2;
+        const double ak = -0.5 * 0x1.71547652b82fep+0 * is2;  // -log2(e) / (2 sigma_k^2)
+        row[DP + 0] = fma(ak, s, a.mix[a.ml.o_lrc + k]);      // log2 density of component k at mu_j
+        row[DP + 1] = ak;
+        row[DP + 2] = w;
+        row[DP + 3] = w * is2;
       } else {  // padding component: density exactly 0
-        row[DP + 0] = 0.0; row[DP + 1] = 0.0; row[DP + 2] = -2000.0; row[DP + 3] = 0.0; row[DP + 4] = 0.0;
+        row[DP + 0] = -2000.0; row[DP + 1] = 0.0; row[DP + 2] = 0.0; row[DP + 3] = 0.0;
       }
+      row[DP + 4] = 0.0;
       row[DP + 5] = 0.0;
     }
     return;
