@@ -53,8 +53,10 @@ enum { VBMC_MEAN_ZERO = 0, VBMC_MEAN_CONST = 1, VBMC_MEAN_NEGQUAD = 2 };
 enum {
   VBMC_EPS_RESIDENT = 0, /* draws uploaded with vbmc_set_eps (parity mode: the
                             reference's np.random.randn stream, entmc_vbmc.py:67) */
-  VBMC_EPS_PHILOX = 1    /* Philox4x32-10 + Box-Muller generated in-kernel,
-                            fresh per call from `seed` (throughput mode)        */
+  VBMC_EPS_PHILOX = 1    /* Philox4x32-10 + Box-Muller generated on the device, fresh
+                            per call from `seed` (throughput mode): by extra blocks
+                            of the prep launch, one iteration ahead in the optimiser
+                            loop, or inside the entropy kernel -- the same values  */
 };
 
 /* ---- library / context ------------------------------------------------- */
@@ -102,7 +104,9 @@ int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
 
 /* Upload the mixture (variational_posterior.py:106-138: mu (D,K), sigma (1,K),
  * lambd (D,1), w (1,K), eta (1,K)).  Values are taken as given (no
- * renormalisation: that is set_parameters' job, see vbmc_theta_to_mixture). */
+ * renormalisation: that is set_parameters' job, see vbmc_theta_to_mixture).
+ * Giving the values the device already holds is a no-op (no pack, no upload): pdf,
+ * acquisition and sampling calls between two updates of the posterior pay nothing. */
 int vbmc_set_mixture(vbmc_ctx* ctx, int D, int K, const double* mu_KxD,
                      const double* sigma_K, const double* lambd_D, const double* w_K,
                      const double* eta_K);
