@@ -21,76 +21,13 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "adam_dev.h"
 #include "common.h"
 #include "entropy_args.h"
 
+using namespace adam_dev;
+
 namespace {
-
-// One contiguous block of doubles holds everything the step kernel reads; the kernel
-// mirrors a prefix of it (a tier boundary) into LDS with one deep batch of loads.
-struct AdamLayout {
-  int n = 0, n_aux = 0, n_hyp = 0, n_raw = 0, n_res = 0, n_bnd = 0;
-  __host__ __device__ int o_theta() const { return 0; }               // [n] current x
-  __host__ __device__ int o_aux() const { return n; }                 // mu K*D | sigma K | lambd D | w K | eta K
-  __host__ __device__ int o_hyp() const { return o_aux() + n_aux; }   // [S][P]
-  __host__ __device__ int o_raw() const { return o_hyp() + n_hyp; }   // normalised entropy accumulator
-  __host__ __device__ int o_res() const { return o_raw() + n_raw; }   // [S][K][1+2D] GP sums     (tier 1 ends)
-  __host__ __device__ int o_m() const { return o_res() + n_res; }     // Adam first moment        (tier 2 ends)
-  __host__ __device__ int o_v() const { return o_m() + n; }
-  __host__ __device__ int o_blb() const { return o_v() + n; }         // soft bounds
-  __host__ __device__ int o_bub() const { return o_blb() + n_bnd; }
-  __host__ __device__ int o_xlb() const { return o_bub() + n_bnd; }   // box
-  __host__ __device__ int o_xub() const { return o_xlb() + n; }
-  __host__ __device__ int end() const { return o_xub() + n; }         //                          (tier 3 ends)
-};
-
-struct AdamDev {
-  MixLayout ml;
-  AdamLayout lay;
-  int D, K, S, P, mean_kind, mask, n_theta, n_bnd, has_box, has_bnd;
-  int n_stage;    // doubles of `state` mirrored in LDS (0, or a tier boundary of AdamLayout)
-  int work_lds;   // scratch arrays in LDS (after the mirror) instead of `work`
-  double* mix;    // mixture pack of the current iterate (rewritten for the next one)
-  double* state;  // AdamLayout block
-  double* work;   // scratch when it does not fit the LDS: see work_len()
-  double tol_con, w_thresh, w_pen;
-  double step, c1, c2, fudge, beta1, beta2;  // step size and 1/(1-beta^(i+1)) of this iteration
-  double* x_row;  // [n_theta] row i of x_tab
-  double* y_out;  // y_tab[i], then G, H (3 doubles per iteration)
-  int* status;    // != 0: a non-finite iterate was produced
-};
-
-__host__ __device__ inline size_t aux_len(int D, int K) { return (size_t)K * D + 3 * (size_t)K + D; }
-// scratch: ell2, iom2 [S][D] | gmu, tgs, tnu [K][D] | gsg, gw, ee [K] | glm, bl [D] | dL [n_bnd] | dF [n]
-__host__ __device__ inline size_t work_len(int D, int K, int S, int n_bnd, int n) {
-  return 2 * (size_t)S * D + 3 * (size_t)K * D + 3 * (size_t)K + 2 * (size_t)D + (size_t)n_bnd + (size_t)n;
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
-// all four waves get the sum; red[0..3] is scratch (barriers on both sides)
-__device__ double block_sum(double v, double* red) {
-  const int tid = threadIdx.x;
-  v = wave_sum(v);
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
-}
-
-__device__ double block_max(double v, double* red) {
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-}
 
 // set_parameters(theta) + eta max-shift + mixture pack; theta's eta tail is shifted in
 // place.  theta / aux may live in LDS; the pack goes to a.mix.
@@ -172,205 +109,81 @@ __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, do
   }
 }
 
-// MODE 2: the whole state block and the scratch are in LDS; MODE 0: everything in global memory;
-// MODE 1: a prefix tier in LDS.  Compile-time for modes 0 and 2 so that every access is a true
-// LDS (ds_*) or global access: a pointer that may be either one at run time makes the compiler
-// emit flat_* instructions, whose LDS latency is several times that of ds_*.
-template <int MODE>
+// stand-alone launch of the pre workgroup, for entropy kernels without the extra row
+template <bool LDS>
+__global__ __launch_bounds__(256) void adam_pre_kernel(AdamDev a) {
+  extern __shared__ double sh[];
+  __shared__ double red[16];
+  adam_pre_body<LDS>(a, sh, red);
+}
+
+// ---------------------------------------------------------------------------
+// adam_step_kernel (one workgroup, main stream): the only work between the entropy reduction and
+// the next iteration's table launch.  dF = pre + Jacobian(entropy gradient) (entmc_vbmc.py:114-130),
+// the Adam update with the box clamp (minimize_adam.py:89-105), then set_parameters + mixture pack
+// of the new iterate.  Every array that is read exactly once (entropy sums, pre, m, v, box) goes
+// from global memory straight to registers in one batch of independent loads; only theta and the
+// mixture attributes, which the pack re-reads across barriers, live in LDS.
+template <bool LDS>
 __global__ __launch_bounds__(256) void adam_step_kernel(AdamDev a, int do_step) {
   extern __shared__ double sh[];
   __shared__ double red[16];
-  const int D = a.D, K = a.K, S = a.S, tid = threadIdx.x, n = a.n_theta;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int st = 1 + 2 * D;
-  
-  // ---- mirror the state block (or a prefix) in LDS: one deep batch of loads, then every
-  // later access is an LDS access instead of a ~1 us global round trip ----
+  const int D = a.D, K = a.K, tid = threadIdx.x, n = a.n_theta;
   const AdamLayout& L = a.lay;
-  {
-    const int cnt = do_step ? a.n_stage : min(a.n_stage, L.o_hyp());
-    constexpr int U = 16;
-    for (int base = 0; base < cnt; base += 256 * U) {
-      double r[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = base + u * 256 + tid;
-        r[u] = i < cnt ? a.state[i] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = base + u * 256 + tid;
-        if (i < cnt) sh[i] = r[u];
-      }
-    }
-    if (cnt > 0) __syncthreads();
+  double* theta = LDS ? sh : a.state + L.o_theta();
+  double* aux = LDS ? sh + n : a.state + L.o_aux();
+  double* ee = LDS ? sh + n + L.n_aux : a.ee;
+  const double* raw = a.state + L.o_raw();
+  const bool o_mu = a.mask & 1, o_sg = a.mask & 2, o_lm = a.mask & 4, o_w = a.mask & 8;
+  const int p_sg = o_mu ? D * K : 0, p_lm = p_sg + (o_sg ? K : 0), p_w = n - K;
+  const int f_w = 1 + D * K + K + D;  // weight block of the entropy accumulator
+
+  constexpr int U = 4;
+  double r_raw[U], r_pre[U], r_m[U], r_v[U], r_lo[U], r_hi[U];
+  double rw = 0.0;
+  int iter = 0;
+  if (do_step) {
+    iter = a.iter_base[0] + a.it_off;
+    if (o_w && tid < K) rw = raw[f_w + tid];  // K <= 256 per pass below
   }
-  auto at = [&](int off) -> double* {
-    if (MODE == 2) return sh + off;
-    if (MODE == 0) return a.state + off;
-    return off < a.n_stage ? sh + off : a.state + off;
+  if (LDS) {
+    const int cnt = L.o_hyp();  // theta | aux
+    for (int i = tid; i < cnt; i += 256) sh[i] = a.state[i];
+  }
+  // which accumulator entry / Jacobian scale belongs to theta index i
+  auto raw_index = [&](int i) -> int {
+    if (o_mu && i < D * K) return 1 + i;
+    if (o_sg && i >= p_sg && i < p_sg + K) return 1 + D * K + (i - p_sg);
+    if (o_lm && i >= p_lm && i < p_lm + D) return 1 + D * K + K + (i - p_lm);
+    return f_w + (i - p_w);
   };
-  double* theta = at(L.o_theta());
-  double* aux = at(L.o_aux());
-  double* work = MODE == 2 ? sh + a.n_stage : MODE == 0 ? a.work : (a.work_lds ? sh + a.n_stage : a.work);
-  const double* raw = at(L.o_raw());
-  const double* res = at(L.o_res());
-  const double* hyp = at(L.o_hyp());
-  double* am = at(L.o_m());
-  double* av = at(L.o_v());
-  const double* bnd_lb = at(L.o_blb());
-  const double* bnd_ub = at(L.o_bub());
-  const double* box_lb = at(L.o_xlb());
-  const double* box_ub = at(L.o_xub());
+  auto load_chunk = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * 256 + tid;
+      const bool in = i < n;
+      r_raw[u] = in ? raw[raw_index(i)] : 0.0;
+      r_pre[u] = in ? a.pre[i] : 0.0;
+      r_m[u] = in ? a.state[L.o_m() + i] : 0.0;
+      r_v[u] = in ? a.state[L.o_v() + i] : 0.0;
+      r_lo[u] = (in && a.has_box) ? a.state[L.o_xlb() + i] : 0.0;
+      r_hi[u] = (in && a.has_box) ? a.state[L.o_xub() + i] : 0.0;
+    }
+  };
+  if (do_step) load_chunk(0);
+  // minimize_adam.py:92-98 (evaluated while the loads above are in flight)
+  const double c1 = 1.0 / (1.0 - pow(a.beta1, (double)(iter + 1)));
+  const double c2 = 1.0 / (1.0 - pow(a.beta2, (double)(iter + 1)));
+  const double step = a.master_min + (a.master_max - a.master_min) * exp(-(double)(iter + 1) / a.master_decay);
+  double* x_row = a.x_tab + (size_t)iter * n;
+  double* y_out = a.y_tab + 3 * (size_t)iter;
+  __syncthreads();
 
   if (do_step) {
-    const bool o_mu = a.mask & 1, o_sg = a.mask & 2, o_lm = a.mask & 4, o_w = a.mask & 8;
-    const int p_sg = o_mu ? D * K : 0, p_lm = p_sg + (o_sg ? K : 0), p_w = n - K;
-    const double* mu = aux;
-    const double* sg = mu + K * D;
+    const double* sg = aux + K * D;
     const double* lm = sg + K;
-    const double* w = lm + D;
-    const double* eta = w + K;
-    double* ell2 = work;              // [S][D]
-    double* iom2 = ell2 + S * D;      // [S][D]
-    double* gmu = iom2 + S * D;       // [K][D]  d G / d mu   (averaged over s)
-    double* gsg = gmu + K * D;        // [K]     d G / d sigma (pre-Jacobian)
-    double* glm = gsg + K;            // [D]
-    double* gw = glm + D;             // [K]     combined pre-Jacobian weight gradient of F
-    double* ee = gw + K;              // [K]
-    double* tgs = ee + K;             // [K][D]  per-(k,d) terms of d G / d sigma
-    double* tnu = tgs + K * D;        // [K][D]  per-(k,d) terms of the quadratic-mean part
-    double* bl = tnu + K * D;         // [D]     soft-bound gradient folded onto lambda
-    double* dL = bl + D;              // [n_bnd]
-    double* dF = dL + a.n_bnd;        // [n_theta]
-    const bool quad = a.mean_kind == VBMC_MEAN_NEGQUAD;
-
-    for (int i = tid; i < S * D; i += 256) {
-      const int s = i / D, d = i - s * D;
-      const double* h = hyp + (size_t)s * a.P;
-      ell2[i] = exp(2.0 * h[d]);
-      iom2[i] = quad ? exp(-2.0 * h[2 * D + 3 + d]) : 0.0;
-    }
-    __syncthreads();
-
-    // ---- GP expected log joint (host twin: api_gp.hip glj_finalize), in two steps so that
-    // all 256 lanes work: per (k, d) term first, per component after the barrier ----
-    for (int idx = tid; idx < K * D; idx += 256) {
-      const int k = idx / D, d = idx - k * D;
-      const double sgk = sg[k], wk = w[k], lam = lm[d], m = mu[idx];
-      double gm_acc = 0.0, gs_acc = 0.0, nu_acc = 0.0;
-      for (int s = 0; s < S; ++s) {
-        const double* h = hyp + (size_t)s * a.P;
-        const double* r = res + ((size_t)s * K + k) * st;
-        const double tau2 = sgk * sgk * lam * lam + ell2[s * D + d];
-        const double tau = sqrt(tau2);
-        const double U = r[1 + d], T = r[1 + D + d] - r[0];
-        double gm = wk * (-U / tau);
-        gs_acc += (lam * lam / tau2) * T / S;
-        if (quad) {
-          const double xm = h[D + 3 + d], io = iom2[s * D + d];
-          gm -= wk * io * (m - xm);
-          nu_acc += io * (m * m + sgk * sgk * lam * lam - 2.0 * m * xm + xm * xm) / S;
-        }
-        gm_acc += gm / S;
-      }
-      gmu[idx] = gm_acc;
-      tgs[idx] = gs_acc;
-      tnu[idx] = nu_acc;
-    }
-    __syncthreads();
-    double gpart = 0.0;
-    for (int k = tid; k < K; k += 256) {
-      const double sgk = sg[k], wk = w[k];
-      double gs = 0.0, nu = 0.0, base = 0.0, qbar = 0.0;
-      for (int d = 0; d < D; ++d) {
-        gs += tgs[k * D + d];
-        nu += tnu[k * D + d];
-      }
-      for (int s = 0; s < S; ++s) {
-        const double* h = hyp + (size_t)s * a.P;
-        base += (res[((size_t)s * K + k) * st] + (a.mean_kind == VBMC_MEAN_ZERO ? 0.0 : h[D + 2])) / S;
-        if (quad)
-          for (int d = 0; d < D; ++d) qbar += iom2[s * D + d] * lm[d] * lm[d] / S;
-      }
-      const double wI = base - 0.5 * nu;  // mean over s of I_sk
-      gpart += wk * wI;
-      gsg[k] = wk * sgk * (gs - qbar);
-      // pre-Jacobian weight gradient of F = -G - H (+ penalty below)
-      gw[k] = -wI - raw[1 + D * K + K + D + k];
-    }
-    // ---- lambda gradient: one wave per dimension, lanes over the (s, k) terms ----
-    for (int d = wave; d < D; d += 4) {
-      const double lam = lm[d];
-      double acc = 0.0;
-      for (int idx = lane; idx < S * K; idx += 64) {
-        const int s = idx / K, k = idx - s * K;
-        const double* r = res + (size_t)idx * st;
-        const double sgk = sg[k], wk = w[k];
-        const double tau2 = sgk * sgk * lam * lam + ell2[s * D + d];
-        const double T = r[1 + D + d] - r[0];
-        double gl = wk * (sgk * sgk / tau2) * lam * T;
-        if (quad) gl -= wk * sgk * sgk * iom2[s * D + d] * lam;
-        acc += gl / S;
-      }
-      acc = wave_sum(acc);
-      if (lane == 0) glm[d] = acc;
-    }
-    const double G = block_sum(gpart, red);
-
-    // ---- soft bounds (_vp_bound_loss :537-606) and weight penalty (:1211-1229) ----
-    double loss = 0.0;
-    if (a.has_bnd) {
-      const int n_mu = o_mu ? D * K : 0, n_sc = (o_sg || o_lm) ? D * K : 0;
-      for (int i = tid; i < a.n_bnd; i += 256) {
-        double x;
-        if (i < n_mu) {
-          x = theta[i];
-        } else if (i < n_mu + n_sc) {
-          const int q = i - n_mu, k = q / D, d = q - k * D;  // ravel('F') of the (D,K) array
-          const double ls = o_sg ? theta[p_sg + k] : log(sg[k]);
-          const double ll = o_lm ? theta[p_lm + d] : log(lm[d]);
-          x = ll + ls;
-        } else {
-          x = theta[p_w + (i - n_mu - n_sc)];
-        }
-        const double lb = bnd_lb[i], ub = bnd_ub[i];
-        const double ell = (ub - lb) * a.tol_con;
-        double g = 0.0;
-        if (x < lb) {
-          const double t = (lb - x) / ell;
-          loss += 0.5 * t * t;
-          g = (x - lb) / (ell * ell);
-        }
-        if (x > ub) {
-          const double t = (x - ub) / ell;
-          loss += 0.5 * t * t;
-          g = (x - ub) / (ell * ell);
-        }
-        dL[i] = g;
-      }
-      if (o_w) {
-        for (int k = tid; k < K; k += 256) {  // same thread wrote gw[k] above
-          const bool small = w[k] < a.w_thresh;
-          loss += (small ? w[k] : a.w_thresh) * a.w_pen;
-          if (small) gw[k] += a.w_pen;
-        }
-      }
-    }
-    loss = block_sum(loss, red);  // its barriers also order the writes above before the reads below
-    if (a.has_bnd && o_lm) {
-      // the reference reshapes the scale block C-order (D,K) (:585-587); restated as-is
-      const int sc0 = o_mu ? D * K : 0;
-      for (int d = wave; d < D; d += 4) {
-        double acc = 0.0;
-        for (int k = lane; k < K; k += 64) acc += dL[sc0 + d * K + k];
-        acc = wave_sum(acc);
-        if (lane == 0) bl[d] = acc;
-      }
-    }
-    __syncthreads();
-
-    // ---- softmax Jacobian of the combined weight gradient (entmc_vbmc.py:122-130) ----
+    const double* eta = lm + D + K;
+    // ---- softmax Jacobian of the entropy's weight gradient: needs two sums over k ----
     double sm_s = 1.0, sm_dot = 0.0;
     if (o_w) {
       double ps = 0.0, pd = 0.0;
@@ -378,74 +191,58 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamDev a, int do_step) 
         const double e = exp(eta[k]);
         ee[k] = e;
         ps += e;
-        pd += e * gw[k];
+        pd += e * (k == tid ? rw : raw[f_w + k]);
       }
       sm_s = block_sum(ps, red);
       sm_dot = block_sum(pd, red);
     }
-
-    // ---- assemble dF ----
-    const double* rmu = raw + 1;
-    const double* rsg = rmu + D * K;
-    const double* rlm = rsg + K;
-    const int sc0 = o_mu ? D * K : 0;
-    for (int i = tid; i < n; i += 256) {
-      double g;
-      if (o_mu && i < D * K) {
-        g = -gmu[i] - rmu[i];
-        if (a.has_bnd) g += dL[i];
-      } else if (o_sg && i >= p_sg && i < p_sg + K) {
-        const int k = i - p_sg;
-        g = -gsg[k] * sg[k] - rsg[k] * sg[k];
-        if (a.has_bnd) {
-          // the reference reshapes this block C-order (D,K) (:585-587); restated as-is
-          double acc = 0.0;
-          for (int d = 0; d < D; ++d) acc += dL[sc0 + d * K + k];
-          g += acc;
-        }
-      } else if (o_lm && i >= p_lm && i < p_lm + D) {
-        const int d = i - p_lm;
-        g = -glm[d] * lm[d] - rlm[d] * lm[d];
-        if (a.has_bnd) g += bl[d];
-      } else {
-        const int k = i - p_w;
-        g = -ee[k] * sm_dot / (sm_s * sm_s) + ee[k] * gw[k] / sm_s;
-        if (a.has_bnd) g += dL[a.n_bnd - K + k];
-      }
-      dF[i] = g;
-    }
     if (tid == 0) {
-      const double H = raw[0];
-      a.y_out[0] = -G - H + loss;
-      a.y_out[1] = G;
-      a.y_out[2] = H;
+      const double G = a.pre[n], loss = a.pre[n + 1], H = raw[0];
+      y_out[0] = -G - H + loss;
+      y_out[1] = G;
+      y_out[2] = H;
     }
-    __syncthreads();
-
-    // ---- Adam update (minimize_adam.py:89-105) ----
-    for (int i = tid; i < n; i += 256) {
-      const double g = dF[i];
-      const double m = a.beta1 * am[i] + (1.0 - a.beta1) * g;
-      const double v = a.beta2 * av[i] + (1.0 - a.beta2) * (g * g);
-      am[i] = m;
-      av[i] = v;
-      const double m_hat = m * a.c1, v_hat = v * a.c2;
-      double x = theta[i] - a.step * m_hat / (sqrt(v_hat) + a.fudge);
-      if (a.has_box) x = fmin(box_ub[i], fmax(box_lb[i], x));
-      theta[i] = x;
-      a.x_row[i] = x;
+    for (int base = 0; base < n; base += 256 * U) {
+      if (base > 0) load_chunk(base);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * 256 + tid;
+        if (i >= n) continue;
+        // ---- dF: pre + Jacobian of the entropy part of F = -G - H ----
+        double g;
+        if (o_mu && i < D * K) {
+          g = r_pre[u] - r_raw[u];
+        } else if (o_sg && i >= p_sg && i < p_sg + K) {
+          g = r_pre[u] - r_raw[u] * sg[i - p_sg];
+        } else if (o_lm && i >= p_lm && i < p_lm + D) {
+          g = r_pre[u] - r_raw[u] * lm[i - p_lm];
+        } else {
+          const double e = ee[i - p_w];
+          g = r_pre[u] + (e * sm_dot / (sm_s * sm_s) - e * r_raw[u] / sm_s);
+        }
+        // ---- Adam update (minimize_adam.py:89-105) ----
+        const double m = a.beta1 * r_m[u] + (1.0 - a.beta1) * g;
+        const double v = a.beta2 * r_v[u] + (1.0 - a.beta2) * (g * g);
+        a.state[L.o_m() + i] = m;
+        a.state[L.o_v() + i] = v;
+        const double m_hat = m * c1, v_hat = v * c2;
+        double x = theta[i] - step * m_hat / (sqrt(v_hat) + a.fudge);
+        if (a.has_box) x = fmin(r_hi[u], fmax(r_lo[u], x));
+        theta[i] = x;
+        x_row[i] = x;
+      }
     }
     __syncthreads();
   }
 
   pack_from_theta(a, theta, aux, red);
-  if (a.n_stage > 0) {  // write the mirrored, modified arrays back
+  if (LDS) {  // write the mirrored, modified arrays back
     __syncthreads();
     for (int i = tid; i < L.o_hyp(); i += 256) a.state[i] = sh[i];  // theta | aux
-    if (do_step && a.n_stage > L.o_m())
-      for (int i = L.o_m() + tid; i < L.o_blb(); i += 256) a.state[i] = sh[i];  // m | v
   }
 }
+
+__global__ void set_int_kernel(int* p, int v) { *p = v; }
 
 }  // namespace
 
@@ -460,21 +257,33 @@ struct AdamState {
   double tol_con = 0, w_thresh = 0, w_pen = 0;
   bool has_box = false, has_bnd = false;
   AdamLayout lay;
-  int n_stage = 0, work_lds = 0;  // what the step kernel keeps in LDS
-  size_t lds_bytes = 0;
+  bool pre_lds = false, step_lds = false;  // which kernels keep their working set in LDS
+  size_t pre_lds_bytes = 0, step_lds_bytes = 0;
   double* d_buf = nullptr;
   size_t d_cap = 0;
   int* d_status = nullptr;
   // carve of d_buf
-  double *state = nullptr, *work = nullptr, *x_tab = nullptr, *y_tab = nullptr;
-  // draws generated one iteration ahead on a second stream (Philox mode)
+  double *state = nullptr, *work = nullptr, *ee = nullptr, *pre = nullptr, *x_tab = nullptr, *y_tab = nullptr;
+  AdamDev* d_args = nullptr;  // the argument block in device memory, for the entropy launch's pre row
+  // Philox mode: the draws of a whole vbmc_adam_run batch are generated on a second, low-priority
+  // stream into one buffer per iteration.  That stream runs ahead on its own; the main stream only
+  // WAITS on its events (free once signalled) and never records one per iteration -- a record
+  // between two dependent kernels opens a 6 us gap on MI355X, a cross-queue wait up to 13 us.
   bool pregen = false;
-  double* d_eps2[2] = {nullptr, nullptr};
-  size_t eps2_cap = 0;               // doubles per buffer
+  size_t n_eps = 0;         // doubles per iteration
+  double* d_epsN = nullptr; // [iterations of a batch][n_eps]
+  size_t eps_cap = 0;       // doubles allocated
   hipStream_t gen_stream = nullptr;
-  hipEvent_t ev_gen[2] = {nullptr, nullptr};  // buffer b holds the draws of its iteration
-  hipEvent_t ev_ent[2] = {nullptr, nullptr};  // the entropy kernel reading buffer b has finished
-  bool ent_recorded[2] = {false, false};
+  // two sets of events: [0] for direct launches, [1] for the captured batch (an event recorded
+  // inside a stream capture must not be mixed with ordinary use)
+  struct Events {
+    hipEvent_t fork = nullptr;     // the batch's first iterate is packed (start of the gen stream's work)
+    std::vector<hipEvent_t> gen;   // buffer `it` holds the draws of iteration i0 + it
+  } ev[2];
+  // a captured batch of graph_len iterations, replayed by vbmc_adam_run calls of that length
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_len = 0;
+  int runs = 0;  // vbmc_adam_run calls since vbmc_adam_begin
 };
 
 static AdamState* adam_of(vbmc_ctx* ctx) {
@@ -487,10 +296,12 @@ void adam_free(vbmc_ctx* ctx) {
   if (!st) return;
   if (st->d_buf) (void)hipFree(st->d_buf);
   if (st->d_status) (void)hipFree(st->d_status);
+  if (st->graph_exec) (void)hipGraphExecDestroy(st->graph_exec);
+  if (st->d_epsN) (void)hipFree(st->d_epsN);
+  if (st->d_args) (void)hipFree(st->d_args);
   for (int b = 0; b < 2; ++b) {
-    if (st->d_eps2[b]) (void)hipFree(st->d_eps2[b]);
-    if (st->ev_gen[b]) (void)hipEventDestroy(st->ev_gen[b]);
-    if (st->ev_ent[b]) (void)hipEventDestroy(st->ev_ent[b]);
+    if (st->ev[b].fork) (void)hipEventDestroy(st->ev[b].fork);
+    for (hipEvent_t e : st->ev[b].gen) (void)hipEventDestroy(e);
   }
   if (st->gen_stream) (void)hipStreamDestroy(st->gen_stream);
   delete st;
@@ -498,10 +309,13 @@ void adam_free(vbmc_ctx* ctx) {
 }
 
 static void launch_step(const AdamState& st, hipStream_t sm, const AdamDev& a, int do_step) {
-  const int mode = st.n_stage == 0 ? 0 : (st.n_stage == st.lay.end() ? 2 : 1);
-  if (mode == 2) hipLaunchKernelGGL(adam_step_kernel<2>, dim3(1), dim3(256), st.lds_bytes, sm, a, do_step);
-  else if (mode == 1) hipLaunchKernelGGL(adam_step_kernel<1>, dim3(1), dim3(256), st.lds_bytes, sm, a, do_step);
-  else hipLaunchKernelGGL(adam_step_kernel<0>, dim3(1), dim3(256), st.lds_bytes, sm, a, do_step);
+  if (st.step_lds) hipLaunchKernelGGL(adam_step_kernel<true>, dim3(1), dim3(256), st.step_lds_bytes, sm, a, do_step);
+  else hipLaunchKernelGGL(adam_step_kernel<false>, dim3(1), dim3(256), 0, sm, a, do_step);
+}
+
+static void launch_pre(const AdamState& st, hipStream_t sm, const AdamDev& a) {
+  if (st.pre_lds) hipLaunchKernelGGL(adam_pre_kernel<true>, dim3(1), dim3(256), st.pre_lds_bytes, sm, a);
+  else hipLaunchKernelGGL(adam_pre_kernel<false>, dim3(1), dim3(256), 0, sm, a);
 }
 
 static void fill_dev(const vbmc_ctx* ctx, const AdamState& st, AdamDev& a) {
@@ -518,36 +332,25 @@ static void fill_dev(const vbmc_ctx* ctx, const AdamState& st, AdamDev& a) {
   a.has_box = st.has_box;
   a.has_bnd = st.has_bnd;
   a.lay = st.lay;
-  a.n_stage = st.n_stage;
-  a.work_lds = st.work_lds;
   a.mix = ctx->d_mix;
   a.state = st.state;
   a.work = st.work;
+  a.ee = st.ee;
+  a.pre = st.pre;
   a.tol_con = st.tol_con;
   a.w_thresh = st.w_thresh;
   a.w_pen = st.w_pen;
-  a.step = a.c1 = a.c2 = 0.0;
   a.fudge = std::sqrt(2.220446049250313e-16);  // sqrt(np.spacing(1))
   a.beta1 = 0.9;
   a.beta2 = 0.999;
-  a.x_row = nullptr;
-  a.y_out = nullptr;
+  a.master_min = st.master_min;
+  a.master_max = st.master_max;
+  a.master_decay = st.master_decay;
+  a.iter_base = st.d_status + 1;
+  a.it_off = 0;
+  a.x_tab = st.x_tab;
+  a.y_tab = st.y_tab;
   a.status = st.d_status;
-}
-
-// Enqueue the generation of iteration `iter`'s draws into buffer iter & 1 on the second stream.
-static int enqueue_gen(vbmc_ctx* ctx, AdamState* st, int iter) {
-  const int b = iter & 1;
-  if (st->ent_recorded[b]) HIP_TRY(ctx, hipStreamWaitEvent(st->gen_stream, st->ev_ent[b], 0));
-  // The draws of iteration `iter`, produced while the kernels of iteration iter - 1 run: the
-  // entropy kernel issues ~63 % of its FP64 slots and the finish / step / prep kernels leave the
-  // GPU almost idle; this small-footprint kernel fills that time instead of adding its ~20 us to
-  // the critical path.
-  int rc = launch_eps_gen(ctx, st->gen_stream, st->d_eps2[b], st->ns / 2, st->row_begin, st->row_count,
-                          st->seed + (uint64_t)iter);
-  if (rc) return rc;
-  HIP_TRY(ctx, hipEventRecord(st->ev_gen[b], st->gen_stream));
-  return 0;
 }
 
 extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
@@ -620,42 +423,52 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
   L.n_raw = raw_len(D, K);
   L.n_res = S * K * (1 + 2 * D);
   L.n_bnd = st->n_bnd;
-  const size_t n_work = work_len(D, K, S, st->n_bnd, n_theta);
+  const size_t n_work = work_len(D, K, S, st->n_bnd);
   {
-    // LDS plan of the step kernel: the largest tier of the state block that fits next to
-    // the scratch arrays
+    // LDS plan: each kernel keeps its working set in LDS when it fits
     const char* no_lds = getenv("VBMC_ADAM_NO_LDS");  // test hook: force the global-memory path
     const size_t cap = (no_lds && no_lds[0] == '1') ? 0 : 150 * 1024 / sizeof(double);
-    st->n_stage = 0;
-    for (int tier : {L.end(), L.o_m(), L.o_res()})
-      if ((size_t)tier + n_work <= cap) {
-        st->n_stage = tier;
-        break;
-      }
-    st->work_lds = st->n_stage > 0;
-    st->lds_bytes = st->work_lds ? sizeof(double) * ((size_t)st->n_stage + n_work) : 0;
-    if (st->lds_bytes > 64 * 1024)
-    {
-      HIP_TRY(ctx, hipFuncSetAttribute((const void*)adam_step_kernel<1>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)st->lds_bytes));
-      HIP_TRY(ctx, hipFuncSetAttribute((const void*)adam_step_kernel<2>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)st->lds_bytes));
-    }
+    const size_t n_pre = (size_t)L.o_raw() + n_work, n_step = (size_t)L.o_hyp() + K;
+    st->pre_lds = n_pre <= cap;
+    st->step_lds = n_step <= cap;
+    st->pre_lds_bytes = sizeof(double) * n_pre;
+    st->step_lds_bytes = sizeof(double) * n_step;
+    if (st->pre_lds && st->pre_lds_bytes > 64 * 1024)
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)adam_pre_kernel<true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)st->pre_lds_bytes));
+    if (st->step_lds && st->step_lds_bytes > 64 * 1024)
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)adam_step_kernel<true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)st->step_lds_bytes));
   }
-  const size_t total = (size_t)L.end() + n_work + (size_t)max_iter * n_theta + 3 * (size_t)max_iter + 64;
+  const size_t total = (size_t)L.end() + n_work + (size_t)K + (size_t)n_theta + 2 +
+                       (size_t)max_iter * n_theta + 3 * (size_t)max_iter + 64;
   int rc = ensure_dev(ctx, &st->d_buf, &st->d_cap, total);
   if (rc) return rc;
-  if (!st->d_status) HIP_TRY(ctx, hipMalloc((void**)&st->d_status, sizeof(int)));
+  if (!st->d_status) HIP_TRY(ctx, hipMalloc((void**)&st->d_status, 2 * sizeof(int)));  // flag, iteration base
+  if (!st->d_args) HIP_TRY(ctx, hipMalloc((void**)&st->d_args, sizeof(AdamDev)));
+  if (!st->gen_stream) {
+    int lo = 0, hi = 0;
+    HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(ctx, hipStreamCreateWithPriority(&st->gen_stream, hipStreamNonBlocking, lo));
+    for (int b = 0; b < 2; ++b) HIP_TRY(ctx, hipEventCreateWithFlags(&st->ev[b].fork, hipEventDisableTiming));
+  }
+  if (st->graph_exec) {  // captured for the previous problem
+    HIP_TRY(ctx, hipGraphExecDestroy(st->graph_exec));
+    st->graph_exec = nullptr;
+  }
+  st->runs = 0;
   st->state = st->d_buf;
   st->work = st->state + L.end();
-  st->x_tab = st->work + n_work;
+  st->ee = st->work + n_work;
+  st->pre = st->ee + K;
+  st->x_tab = st->pre + n_theta + 2;
   st->y_tab = st->x_tab + (size_t)max_iter * n_theta;
 
   hipStream_t sm = ctx->stream;
   double* sb = st->state;
   HIP_TRY(ctx, hipMemsetAsync(sb, 0, sizeof(double) * L.end(), sm));  // m = v = 0
   HIP_TRY(ctx, hipMemcpyAsync(sb + L.o_theta(), theta0, sizeof(double) * n_theta, hipMemcpyHostToDevice, sm));
-  HIP_TRY(ctx, hipMemsetAsync(st->d_status, 0, sizeof(int), sm));
+  HIP_TRY(ctx, hipMemsetAsync(st->d_status, 0, 2 * sizeof(int), sm));
   // attributes of the blocks theta does not carry start from the ctx mixture
   std::vector<double> aux(L.n_aux);
   memcpy(aux.data(), ctx->mu.data(), sizeof(double) * K * D);
@@ -677,40 +490,85 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
   ctx->pack_in_flight = false;
   AdamDev a;
   fill_dev(ctx, *st, a);
+  HIP_TRY(ctx, hipMemcpyAsync(st->d_args, &a, sizeof(AdamDev), hipMemcpyHostToDevice, sm));
+  HIP_TRY(ctx, hipStreamSynchronize(sm));  // `a` is a stack object
   launch_step(*st, sm, a, 0);
   HIP_TRY(ctx, hipGetLastError());
-  // draws one iteration ahead (Philox mode, unless switched off or too large)
+  // draws generated ahead on the second stream (Philox mode, unless switched off)
   {
     const char* off = getenv("VBMC_ADAM_PREGEN");
-    const size_t n_eps = (size_t)K * (size_t)st->row_count * D;
-    st->pregen = st->eps_mode == VBMC_EPS_PHILOX && !(off && off[0] == '0') && n_eps > 0 &&
-                 n_eps <= ((size_t)1 << 28);  // <= 2 GiB per buffer
-    if (st->pregen) {
-      if (!st->gen_stream) {
-        int lo = 0, hi = 0;
-        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIP_TRY(ctx, hipStreamCreateWithPriority(&st->gen_stream, hipStreamNonBlocking, lo));
-        for (int b = 0; b < 2; ++b) {
-          HIP_TRY(ctx, hipEventCreateWithFlags(&st->ev_gen[b], hipEventDisableTiming));
-          HIP_TRY(ctx, hipEventCreateWithFlags(&st->ev_ent[b], hipEventDisableTiming));
-        }
-      }
-      if (st->eps2_cap < n_eps) {
-        HIP_TRY(ctx, hipStreamSynchronize(st->gen_stream));
-        for (int b = 0; b < 2; ++b) {
-          if (st->d_eps2[b]) HIP_TRY(ctx, hipFree(st->d_eps2[b]));
-          st->d_eps2[b] = nullptr;
-          HIP_TRY(ctx, hipMalloc((void**)&st->d_eps2[b], sizeof(double) * n_eps));
-        }
-        st->eps2_cap = n_eps;
-      }
-      st->ent_recorded[0] = st->ent_recorded[1] = false;
-      rc = enqueue_gen(ctx, st, 0);
-      if (rc) return rc;
-    }
+    st->n_eps = (size_t)K * (size_t)st->row_count * D;
+    st->pregen = st->eps_mode == VBMC_EPS_PHILOX && !(off && off[0] == '0') && st->n_eps > 0;
   }
   st->active = true;
   return VBMC_OK;
+}
+
+// One batch of iterations [i0, i0 + n_iters): four launches per iteration on the main stream,
+//   prep (table rows + GP sums) -> entropy (+ the pre row) -> finish [-> all-reduce] -> step,
+// ordered by the stream alone.  With `use_gen` the Philox draws of the whole batch are generated
+// on the second stream, one buffer per iteration.  Self-contained (every wait is on an event
+// recorded inside the batch), so the same sequence can be launched directly or captured.
+static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool multi, bool use_gen,
+                         AdamState::Events& ev) {
+  hipStream_t sm = ctx->stream;
+  AdamDev a;
+  fill_dev(ctx, *st, a);
+  if (use_gen && n_iters > 0) {
+    // The entropy kernel issues ~63 % of its FP64 slots and the finish / step / prep kernels leave
+    // the GPU almost idle; these small-footprint kernels fill that time.  Only the first
+    // iteration's draws are not hidden.
+    HIP_TRY(ctx, hipEventRecord(ev.fork, sm));
+    HIP_TRY(ctx, hipStreamWaitEvent(st->gen_stream, ev.fork, 0));
+    while ((int)ev.gen.size() < n_iters) {
+      hipEvent_t e = nullptr;
+      HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ev.gen.push_back(e);
+    }
+    for (int it = 0; it < n_iters; ++it) {
+      int rc = launch_eps_gen(ctx, st->gen_stream, st->d_epsN + (size_t)it * st->n_eps, st->ns / 2, st->row_begin,
+                              st->row_count, st->seed + (uint64_t)it, st->d_status + 1);
+      if (rc) return rc;
+      HIP_TRY(ctx, hipEventRecord(ev.gen[it], st->gen_stream));
+    }
+  }
+  for (int it = 0; it < n_iters; ++it) {
+    PrepArgs pa;
+    glj_fill_prep(ctx, 1, st->state + st->lay.o_res(), nullptr, pa);
+    EntPlan plan;
+    int rc = entmc_plan(ctx, st->ns, use_gen ? VBMC_EPS_RESIDENT : st->eps_mode, st->seed + (uint64_t)(i0 + it),
+                        st->row_begin, st->row_count, 1, plan);
+    if (rc) return rc;
+    if (use_gen) {
+      plan.a.eps = st->d_epsN + (size_t)it * st->n_eps;
+      plan.a.eps_rows = st->row_count;
+    }
+    entmc_fill_prep(ctx, plan, pa);
+    rc = launch_prep(ctx, pa);
+    if (rc) return rc;
+    // the entropy-free part of dF: an extra row of the entropy launch when that kernel has one
+    // (wave-split, draws from memory), otherwise a launch of its own in front of it
+    static const bool pre_row_on = [] {
+      const char* e = getenv("VBMC_ADAM_PREROW");  // test hook: 0 = always the stand-alone launch
+      return !(e && e[0] == '0');
+    }();
+    const bool pre_row = pre_row_on && plan.ws && plan.a.eps_mode != VBMC_EPS_PHILOX;
+    if (pre_row) plan.a.extra = st->d_args;
+    else launch_pre(*st, sm, a);
+    if (use_gen) HIP_TRY(ctx, hipStreamWaitEvent(sm, ev.gen[it], 0));
+    rc = entmc_launch_main(ctx, plan);
+    if (rc) return rc;
+    rc = entmc_launch_finish(ctx, plan, st->state + st->lay.o_raw());
+    if (rc) return rc;
+    if (multi) {
+      rc = comm_allreduce_sum(ctx, st->state + st->lay.o_raw(), raw_len(ctx->D, ctx->K));
+      if (rc) return rc;
+    }
+    a.it_off = it;
+    launch_step(*st, sm, a, 1);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
 }
 
 extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, double* x_tab_out,
@@ -735,50 +593,67 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
     explicit TimingOff(vbmc_ctx* c_) : c(c_), was(c_->timing) { c->timing = false; }
     ~TimingOff() { c->timing = was; }
   } timing_off(ctx);
-  AdamDev a;
-  fill_dev(ctx, *st, a);
   const int i0 = st->iter;
   int rc = 0;
-  for (int it = 0; it < n_iters && rc == 0; ++it) {
-    const int i = i0 + it;
-    PrepArgs pa;
-    glj_fill_prep(ctx, 1, st->state + st->lay.o_res(), nullptr, pa);
-    EntPlan plan;
-    rc = entmc_plan(ctx, st->ns, st->pregen ? VBMC_EPS_RESIDENT : st->eps_mode, st->seed + (uint64_t)i,
-                    st->row_begin, st->row_count, 1, plan);
-    if (rc) break;
-    const int b = i & 1;
-    if (st->pregen) {
-      plan.a.eps = st->d_eps2[b];
-      plan.a.eps_rows = st->row_count;
-    }
-    entmc_fill_prep(ctx, plan, pa);
-    rc = launch_prep(ctx, pa);
-    if (rc) break;
-    if (st->pregen) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, st->ev_gen[b], 0));
-    rc = entmc_launch_main(ctx, plan);
-    if (rc) break;
-    if (st->pregen) {
-      HIP_TRY(ctx, hipEventRecord(st->ev_ent[b], ctx->stream));
-      st->ent_recorded[b] = true;
-      if (i + 1 < st->max_iter) {
-        rc = enqueue_gen(ctx, st, i + 1);  // overlaps the entropy kernel just launched
-        if (rc) break;
+  // the iteration base every kernel of this call adds its launch-constant offset to
+  hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, ctx->stream, st->d_status + 1, i0);
+  // A batch whose draws are resident or generated ahead contains no per-iteration host value, so
+  // it can be captured once and replayed.  The first call after vbmc_adam_begin always launches
+  // directly (it sizes every scratch buffer); so does a multi-rank loop (the collective stays an
+  // ordinary RCCL call) and any call of a different length.
+  static const bool graphs_on = [] {
+    const char* e = getenv("VBMC_ADAM_GRAPH");
+    return !(e && e[0] == '0');
+  }();
+  // one draw buffer per iteration of the batch (288 GB of HBM: 20 x 40 MB at BASELINE config 3);
+  // beyond 32 GiB the draws are generated inside the entropy kernel instead
+  bool use_gen = st->pregen && n_iters > 0;
+  if (use_gen && st->eps_cap < st->n_eps * (size_t)n_iters) {
+    const size_t bytes = sizeof(double) * st->n_eps * (size_t)n_iters;
+    if (bytes > ((size_t)32 << 30)) {
+      use_gen = false;
+    } else {
+      HIP_TRY(ctx, hipStreamSynchronize(st->gen_stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      if (st->d_epsN) HIP_TRY(ctx, hipFree(st->d_epsN));
+      st->d_epsN = nullptr;
+      st->eps_cap = 0;
+      HIP_TRY(ctx, hipMalloc((void**)&st->d_epsN, bytes));
+      st->eps_cap = st->n_eps * (size_t)n_iters;
+      if (st->graph_exec) {  // captured with the old buffer
+        HIP_TRY(ctx, hipGraphExecDestroy(st->graph_exec));
+        st->graph_exec = nullptr;
       }
     }
-    rc = entmc_launch_finish(ctx, plan, st->state + st->lay.o_raw());
-    if (rc) break;
-    if (multi) {
-      rc = comm_allreduce_sum(ctx, st->state + st->lay.o_raw(), raw_len(ctx->D, ctx->K));
-      if (rc) break;
+  }
+  const bool graphable = graphs_on && !multi && n_iters >= 4 && st->runs >= 1 &&
+                         (use_gen || st->eps_mode == VBMC_EPS_RESIDENT);
+  st->runs++;
+  if (graphable && st->graph_exec && st->graph_len != n_iters) {
+    HIP_TRY(ctx, hipGraphExecDestroy(st->graph_exec));
+    st->graph_exec = nullptr;
+  }
+  if (graphable && !st->graph_exec) {
+    hipGraph_t graph = nullptr;
+    HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+    rc = enqueue_batch(ctx, st, i0, n_iters, false, use_gen, st->ev[1]);
+    const hipError_t e_end = hipStreamEndCapture(ctx->stream, &graph);  // also ends a failed capture
+    if (rc == 0 && e_end != hipSuccess) rc = vbmc_fail(ctx, VBMC_E_HIP, "adam_run: stream capture: %s", hipGetErrorString(e_end));
+    if (rc == 0) {
+      const hipError_t e_inst = hipGraphInstantiate(&st->graph_exec, graph, nullptr, nullptr, 0);
+      if (e_inst != hipSuccess) {
+        st->graph_exec = nullptr;
+        rc = vbmc_fail(ctx, VBMC_E_HIP, "adam_run: graph instantiate: %s", hipGetErrorString(e_inst));
+      }
     }
-    // minimize_adam.py:92-98
-    a.c1 = 1.0 / (1.0 - std::pow(a.beta1, (double)(i + 1)));
-    a.c2 = 1.0 / (1.0 - std::pow(a.beta2, (double)(i + 1)));
-    a.step = st->master_min + (st->master_max - st->master_min) * std::exp(-(double)(i + 1) / st->master_decay);
-    a.x_row = st->x_tab + (size_t)i * n;
-    a.y_out = st->y_tab + 3 * (size_t)i;
-    launch_step(*st, ctx->stream, a, 1);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (rc) return rc;
+    st->graph_len = n_iters;
+  }
+  if (graphable) {
+    HIP_TRY(ctx, hipGraphLaunch(st->graph_exec, ctx->stream));
+  } else {
+    rc = enqueue_batch(ctx, st, i0, n_iters, multi, use_gen, st->ev[0]);
   }
   if (rc) return rc;
   HIP_TRY(ctx, hipGetLastError());

@@ -1,0 +1,318 @@
+// Device-side pieces of the Adam loop (adam.hip) that other translation units need: the state
+// layout, the argument block, and the body of the "pre" workgroup, which the wave-split entropy
+// kernel (entropy_ws.hip) runs as an extra row of its own launch.
+#pragma once
+#include "common.h"
+
+namespace adam_dev {
+
+// One contiguous block of doubles holds the optimiser state.  The prefix up to o_raw() is what the
+// side-stream kernel (adam_pre_kernel) reads and mirrors into LDS with one deep batch of loads.
+struct AdamLayout {
+  int n = 0, n_aux = 0, n_hyp = 0, n_raw = 0, n_res = 0, n_bnd = 0;
+  __host__ __device__ int o_theta() const { return 0; }               // [n] current x
+  __host__ __device__ int o_aux() const { return n; }                 // mu K*D | sigma K | lambd D | w K | eta K
+  __host__ __device__ int o_hyp() const { return o_aux() + n_aux; }   // [S][P]
+  __host__ __device__ int o_res() const { return o_hyp() + n_hyp; }   // [S][K][1+2D] GP sums
+  __host__ __device__ int o_blb() const { return o_res() + n_res; }   // soft bounds
+  __host__ __device__ int o_bub() const { return o_blb() + n_bnd; }
+  __host__ __device__ int o_raw() const { return o_bub() + n_bnd; }   // normalised entropy accumulator
+  __host__ __device__ int o_m() const { return o_raw() + n_raw; }     // Adam first moment
+  __host__ __device__ int o_v() const { return o_m() + n; }
+  __host__ __device__ int o_xlb() const { return o_v() + n; }         // box
+  __host__ __device__ int o_xub() const { return o_xlb() + n; }
+  __host__ __device__ int end() const { return o_xub() + n; }
+};
+
+struct AdamDev {
+  MixLayout ml;
+  AdamLayout lay;
+  int D, K, S, P, mean_kind, mask, n_theta, n_bnd, has_box, has_bnd;
+  double* mix;    // mixture pack of the current iterate (rewritten for the next one)
+  double* state;  // AdamLayout block
+  double* work;   // adam_pre_kernel scratch when it does not fit the LDS: see work_len()
+  double* ee;     // [K] adam_step_kernel scratch when it does not use the LDS
+  double* pre;    // [n_theta + 2]: the part of dF that does not depend on the entropy, then G, loss
+  double tol_con, w_thresh, w_pen;
+  double fudge, beta1, beta2;
+  double master_min, master_max, master_decay;  // step-size schedule (minimize_adam.py:92-98)
+  // The iteration index is iter_base[0] + it_off: the base lives in device memory (set once per
+  // vbmc_adam_run call) and the offset is a launch constant, so that a captured batch of
+  // iterations (hipGraph) can be replayed unchanged for every batch.
+  const int* iter_base;
+  int it_off;
+  double* x_tab;  // [max_iter][n_theta]
+  double* y_tab;  // [max_iter][3]: y, G, H
+  int* status;    // != 0: a non-finite iterate was produced
+};
+
+__host__ __device__ inline size_t aux_len(int D, int K) { return (size_t)K * D + 3 * (size_t)K + D; }
+// scratch: ell2, iom2 [S][D] | gmu, tgs, tnu [K][D] | gsg, gw, ee [K] | glm, bl [D] | dL [n_bnd]
+__host__ __device__ inline size_t work_len(int D, int K, int S, int n_bnd) {
+  return 2 * (size_t)S * D + 3 * (size_t)K * D + 3 * (size_t)K + 2 * (size_t)D + (size_t)n_bnd;
+}
+
+static __device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// all four waves get the sum; red[0..3] is scratch (barriers on both sides)
+static __device__ double block_sum(double v, double* red) {
+  const int tid = threadIdx.x;
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+static __device__ double block_max(double v, double* red) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// ---------------------------------------------------------------------------
+// The "pre" workgroup: everything of one iteration's dF that does NOT depend on the Monte-Carlo
+// entropy.  It runs as an extra row of the entropy launch (entropy_ws.hip), i.e. beside the entropy
+// workgroups and ordered after the GP sums by the stream alone -- no second stream and no events,
+// whose cross-queue latency (6-13 us each on MI355X) would cost more than the work itself.  Only
+// the short adam_step_kernel (adam.hip) then sits between two entropy launches.
+//   GP-sum finalisation (host twin: api_gp.hip glj_finalize), soft bounds + weight penalty
+//   (api_elbo.hip), their Jacobians, and the softmax Jacobian of the entropy-free part of the
+//   weight gradient (the Jacobian is linear, so the entropy part is added by the step kernel).
+// LDS = true: the state prefix [theta | aux | hyp | res | bounds] and the scratch live in LDS;
+// compile-time so that every access is a true ds_* or global access (a pointer that may be
+// either at run time makes the compiler emit flat_* instructions, several times slower on LDS).
+template <bool LDS>
+static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red) {
+  const int D = a.D, K = a.K, S = a.S, tid = threadIdx.x, n = a.n_theta;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int st = 1 + 2 * D;
+  const AdamLayout& L = a.lay;
+  if (LDS) {
+    const int cnt = L.o_raw();
+    constexpr int U = 16;
+    for (int base = 0; base < cnt; base += 256 * U) {
+      double r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * 256 + tid;
+        r[u] = i < cnt ? a.state[i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * 256 + tid;
+        if (i < cnt) sh[i] = r[u];
+      }
+    }
+    __syncthreads();
+  }
+  const double* base = LDS ? sh : a.state;
+  const double* theta = base + L.o_theta();
+  const double* aux = base + L.o_aux();
+  const double* hyp = base + L.o_hyp();
+  const double* res = base + L.o_res();
+  const double* bnd_lb = base + L.o_blb();
+  const double* bnd_ub = base + L.o_bub();
+  double* work = LDS ? sh + L.o_raw() : a.work;
+
+  const bool o_mu = a.mask & 1, o_sg = a.mask & 2, o_lm = a.mask & 4, o_w = a.mask & 8;
+  const int p_sg = o_mu ? D * K : 0, p_lm = p_sg + (o_sg ? K : 0), p_w = n - K;
+  const double* mu = aux;
+  const double* sg = mu + K * D;
+  const double* lm = sg + K;
+  const double* w = lm + D;
+  const double* eta = w + K;
+  double* ell2 = work;              // [S][D]
+  double* iom2 = ell2 + S * D;      // [S][D]
+  double* gmu = iom2 + S * D;       // [K][D]  d G / d mu   (averaged over s)
+  double* gsg = gmu + K * D;        // [K]     d G / d sigma (pre-Jacobian)
+  double* glm = gsg + K;            // [D]
+  double* gw = glm + D;             // [K]     entropy-free pre-Jacobian weight gradient of F
+  double* ee = gw + K;              // [K]
+  double* tgs = ee + K;             // [K][D]  per-(k,d) terms of d G / d sigma
+  double* tnu = tgs + K * D;        // [K][D]  per-(k,d) terms of the quadratic-mean part
+  double* bl = tnu + K * D;         // [D]     soft-bound gradient folded onto lambda
+  double* dL = bl + D;              // [n_bnd]
+  const bool quad = a.mean_kind == VBMC_MEAN_NEGQUAD;
+
+  for (int i = tid; i < S * D; i += 256) {
+    const int s = i / D, d = i - s * D;
+    const double* h = hyp + (size_t)s * a.P;
+    ell2[i] = exp(2.0 * h[d]);
+    iom2[i] = quad ? exp(-2.0 * h[2 * D + 3 + d]) : 0.0;
+  }
+  __syncthreads();
+
+  // ---- GP expected log joint, in two steps so that all 256 lanes work: per (k, d) term
+  // first, per component after the barrier ----
+  for (int idx = tid; idx < K * D; idx += 256) {
+    const int k = idx / D, d = idx - k * D;
+    const double sgk = sg[k], wk = w[k], lam = lm[d], m = mu[idx];
+    double gm_acc = 0.0, gs_acc = 0.0, nu_acc = 0.0;
+    for (int s = 0; s < S; ++s) {
+      const double* h = hyp + (size_t)s * a.P;
+      const double* r = res + ((size_t)s * K + k) * st;
+      const double tau2 = sgk * sgk * lam * lam + ell2[s * D + d];
+      const double tau = sqrt(tau2);
+      const double U = r[1 + d], T = r[1 + D + d] - r[0];
+      double gm = wk * (-U / tau);
+      gs_acc += (lam * lam / tau2) * T / S;
+      if (quad) {
+        const double xm = h[D + 3 + d], io = iom2[s * D + d];
+        gm -= wk * io * (m - xm);
+        nu_acc += io * (m * m + sgk * sgk * lam * lam - 2.0 * m * xm + xm * xm) / S;
+      }
+      gm_acc += gm / S;
+    }
+    gmu[idx] = gm_acc;
+    tgs[idx] = gs_acc;
+    tnu[idx] = nu_acc;
+  }
+  __syncthreads();
+  double gpart = 0.0;
+  for (int k = tid; k < K; k += 256) {
+    const double sgk = sg[k], wk = w[k];
+    double gs = 0.0, nu = 0.0, b0 = 0.0, qbar = 0.0;
+    for (int d = 0; d < D; ++d) {
+      gs += tgs[k * D + d];
+      nu += tnu[k * D + d];
+    }
+    for (int s = 0; s < S; ++s) {
+      const double* h = hyp + (size_t)s * a.P;
+      b0 += (res[((size_t)s * K + k) * st] + (a.mean_kind == VBMC_MEAN_ZERO ? 0.0 : h[D + 2])) / S;
+      if (quad)
+        for (int d = 0; d < D; ++d) qbar += iom2[s * D + d] * lm[d] * lm[d] / S;
+    }
+    const double wI = b0 - 0.5 * nu;  // mean over s of I_sk
+    gpart += wk * wI;
+    gsg[k] = wk * sgk * (gs - qbar);
+    gw[k] = -wI;  // d(-G)/dw_k; the entropy part is the step kernel's, the penalty comes below
+  }
+  // ---- lambda gradient: one wave per dimension, lanes over the (s, k) terms ----
+  for (int d = wave; d < D; d += 4) {
+    const double lam = lm[d];
+    double acc = 0.0;
+    for (int idx = lane; idx < S * K; idx += 64) {
+      const int s = idx / K, k = idx - s * K;
+      const double* r = res + (size_t)idx * st;
+      const double sgk = sg[k], wk = w[k];
+      const double tau2 = sgk * sgk * lam * lam + ell2[s * D + d];
+      const double T = r[1 + D + d] - r[0];
+      double gl = wk * (sgk * sgk / tau2) * lam * T;
+      if (quad) gl -= wk * sgk * sgk * iom2[s * D + d] * lam;
+      acc += gl / S;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) glm[d] = acc;
+  }
+  const double G = block_sum(gpart, red);
+
+  // ---- soft bounds (_vp_bound_loss :537-606) and weight penalty (:1211-1229) ----
+  double loss = 0.0;
+  if (a.has_bnd) {
+    const int n_mu = o_mu ? D * K : 0, n_sc = (o_sg || o_lm) ? D * K : 0;
+    for (int i = tid; i < a.n_bnd; i += 256) {
+      double x;
+      if (i < n_mu) {
+        x = theta[i];
+      } else if (i < n_mu + n_sc) {
+        const int q = i - n_mu, k = q / D, d = q - k * D;  // ravel('F') of the (D,K) array
+        const double ls = o_sg ? theta[p_sg + k] : log(sg[k]);
+        const double ll = o_lm ? theta[p_lm + d] : log(lm[d]);
+        x = ll + ls;
+      } else {
+        x = theta[p_w + (i - n_mu - n_sc)];
+      }
+      const double lb = bnd_lb[i], ub = bnd_ub[i];
+      const double ell = (ub - lb) * a.tol_con;
+      double g = 0.0;
+      if (x < lb) {
+        const double t = (lb - x) / ell;
+        loss += 0.5 * t * t;
+        g = (x - lb) / (ell * ell);
+      }
+      if (x > ub) {
+        const double t = (x - ub) / ell;
+        loss += 0.5 * t * t;
+        g = (x - ub) / (ell * ell);
+      }
+      dL[i] = g;
+    }
+    if (o_w) {
+      for (int k = tid; k < K; k += 256) {  // same thread wrote gw[k] above
+        const bool small = w[k] < a.w_thresh;
+        loss += (small ? w[k] : a.w_thresh) * a.w_pen;
+        if (small) gw[k] += a.w_pen;
+      }
+    }
+  }
+  loss = block_sum(loss, red);  // its barriers also order the writes above before the reads below
+  if (a.has_bnd && o_lm) {
+    // the reference reshapes the scale block C-order (D,K) (:585-587); restated as-is
+    const int sc0 = o_mu ? D * K : 0;
+    for (int d = wave; d < D; d += 4) {
+      double acc = 0.0;
+      for (int k = lane; k < K; k += 64) acc += dL[sc0 + d * K + k];
+      acc = wave_sum(acc);
+      if (lane == 0) bl[d] = acc;
+    }
+  }
+  __syncthreads();
+
+  // ---- softmax Jacobian of the entropy-free weight gradient (entmc_vbmc.py:122-130) ----
+  double sm_s = 1.0, sm_dot = 0.0;
+  if (o_w) {
+    double ps = 0.0, pd = 0.0;
+    for (int k = tid; k < K; k += 256) {
+      const double e = exp(eta[k]);
+      ee[k] = e;
+      ps += e;
+      pd += e * gw[k];
+    }
+    sm_s = block_sum(ps, red);
+    sm_dot = block_sum(pd, red);
+  }
+
+  // ---- the entropy-free part of dF ----
+  const int sc0 = o_mu ? D * K : 0;
+  for (int i = tid; i < n; i += 256) {
+    double g;
+    if (o_mu && i < D * K) {
+      g = -gmu[i];
+      if (a.has_bnd) g += dL[i];
+    } else if (o_sg && i >= p_sg && i < p_sg + K) {
+      const int k = i - p_sg;
+      g = -gsg[k] * sg[k];
+      if (a.has_bnd) {
+        // the reference reshapes this block C-order (D,K) (:585-587); restated as-is
+        double acc = 0.0;
+        for (int d = 0; d < D; ++d) acc += dL[sc0 + d * K + k];
+        g += acc;
+      }
+    } else if (o_lm && i >= p_lm && i < p_lm + D) {
+      const int d = i - p_lm;
+      g = -glm[d] * lm[d];
+      if (a.has_bnd) g += bl[d];
+    } else {
+      const int k = i - p_w;
+      g = -ee[k] * sm_dot / (sm_s * sm_s) + ee[k] * gw[k] / sm_s;
+      if (a.has_bnd) g += dL[a.n_bnd - K + k];
+    }
+    a.pre[i] = g;
+  }
+  if (tid == 0) {
+    a.pre[n] = G;
+    a.pre[n + 1] = loss;
+  }
+}
+
+
+}  // namespace adam_dev

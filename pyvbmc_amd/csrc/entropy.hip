@@ -537,7 +537,9 @@ int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p) {
 
 namespace {
 __global__ __launch_bounds__(256) void eps_gen_kernel(double* __restrict__ eps, int K, int64_t rows, int D,
-                                                      int64_t n_half, int64_t row_begin, uint64_t seed) {
+                                                      int64_t n_half, int64_t row_begin, uint64_t seed,
+                                                      const int* __restrict__ seed_add) {
+  if (seed_add) seed += (uint64_t)seed_add[0];  // device-side iteration index (adam.hip)
   const int np = (D + 1) / 2;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)K * rows * np) return;
@@ -554,12 +556,12 @@ __global__ __launch_bounds__(256) void eps_gen_kernel(double* __restrict__ eps, 
 }  // namespace
 
 int launch_eps_gen(vbmc_ctx* ctx, hipStream_t st, double* d_eps, int64_t n_half, int64_t row_begin,
-                   int64_t row_count, uint64_t seed) {
+                   int64_t row_count, uint64_t seed, const int* seed_add) {
   const int D = ctx->D, K = ctx->K;
   const int64_t total = (int64_t)K * row_count * ((D + 1) / 2);
   if (total <= 0) return 0;
   hipLaunchKernelGGL(eps_gen_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_eps, K,
-                     row_count, D, n_half, row_begin, seed);
+                     row_count, D, n_half, row_begin, seed, seed_add);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }

@@ -17,6 +17,9 @@ struct EntArgs {
   int chunks;          // workgroups per component
   int stride;          // 2 + 2D + K : [Slog | mu(D) | sig | lam(D) | W(K)]
   int rg;              // wave-split kernel: 64-row batches per workgroup
+  // wave-split kernel only: when set, the launch gets one extra grid row whose first workgroup
+  // runs adam_dev::adam_pre_body on this argument block (device memory) -- see adam_dev.h
+  const void* extra = nullptr;
 };
 
 struct EntPlan {

@@ -28,6 +28,7 @@
 //     the weight gradient already collects, so it is formed by the finish kernel.
 // Output: the same per-workgroup partial rows as entropy.hip, reduced by its kernels
 // (entmc_finish_kernel, mu_from_w = 1).
+#include "adam_dev.h"
 #include "common.h"
 #include "entropy_args.h"
 #include "fastmath.h"
@@ -105,9 +106,19 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   __shared__ double sRed[WAVES][2 * DP + 1];
   extern __shared__ double sW[];                  // [K4]
 
+  // Adam loop (adam.hip): grid row 0 is not an entropy row -- its first workgroup computes the
+  // entropy-free part of the iteration's gradient beside the entropy workgroups (adam_dev.h)
+  constexpr bool EXTRA_ROW = GRAD && !PHILOX;
+  if constexpr (EXTRA_ROW) {
+    if (a.extra != nullptr && blockIdx.y == 0) {
+      if (blockIdx.x == 0)
+        adam_dev::adam_pre_body<false>(*(const adam_dev::AdamDev*)a.extra, nullptr, &sRed[0][0]);
+      return;
+    }
+  }
   const int D = a.ml.D, K = a.ml.K;
   const int KT = EXACT ? KTMAX : ((K + 3) >> 2), K4 = KT * 4;
-  const int j = blockIdx.y, chunk = blockIdx.x;
+  const int j = (EXTRA_ROW && a.extra != nullptr) ? blockIdx.y - 1 : blockIdx.y, chunk = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -351,7 +362,8 @@ void launch_one(hipStream_t st, const EntArgs& a, const double* d_table) {
   // variant applies whenever ceil(K/4) == KTMAX
   const bool exact = ((K + 3) / 4 == KTMAX);
   const bool philox = a.eps_mode == VBMC_EPS_PHILOX;
-  const dim3 grid(a.chunks, K), block(WG);
+  const bool extra_row = a.extra != nullptr && a.want_grad && !philox;  // see EXTRA_ROW in the kernel
+  const dim3 grid(a.chunks, K + (extra_row ? 1 : 0)), block(WG);
 #define VBMC_LAUNCH_WS(G, E, P) \
   hipLaunchKernelGGL((entmc_ws_kernel<DP, KTMAX, G, E, P>), grid, block, lds, st, a, d_table)
   if (a.want_grad) {

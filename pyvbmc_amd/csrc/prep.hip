@@ -149,7 +149,9 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
 
 }  // namespace
 
-int launch_prep(vbmc_ctx* ctx, const PrepArgs& a) {
+int launch_prep(vbmc_ctx* ctx, const PrepArgs& a) { return launch_prep_on(ctx, ctx->stream, a); }
+
+int launch_prep_on(vbmc_ctx* ctx, hipStream_t stream, const PrepArgs& a) {
   const int D = a.ml.D;
   const int gblocks = a.n_glj;
   const int grid = a.n_table + gblocks + a.n_gen;
@@ -159,7 +161,7 @@ int launch_prep(vbmc_ctx* ctx, const PrepArgs& a) {
     lds = sizeof(double) * ((size_t)2 * D + a.N + 4 * (2 * D + 1) + 1);
     if (lds > 150 * 1024) return vbmc_fail(ctx, VBMC_E_UNSUP, "gp_log_joint: N=%d too large", a.N);
   }
-  hipLaunchKernelGGL(elbo_prep_kernel, dim3(grid, a.batch), dim3(256), lds, ctx->stream, a);
+  hipLaunchKernelGGL(elbo_prep_kernel, dim3(grid, a.batch), dim3(256), lds, stream, a);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
