@@ -162,9 +162,11 @@ def main():
     xs_pred = np.random.default_rng(7).standard_normal((M_pred, D))
     gp.predict(xs_pred, separate_samples=True)
     pm = []
+    ctx.set_timing(True)
     for _ in range(5):
         gp.predict(xs_pred, separate_samples=True)
         pm.append(ctx.last_kernel_ms(3))
+    ctx.set_timing(False)
     nt = (wl.N + 63) // 64
     gemm_flops = 2.0 * M_pred * 64 * sum(min((c + 1) * 64, wl.N) for c in range(nt))  # triangular skip
     pred_ms = float(np.median(pm))
@@ -198,13 +200,21 @@ def main():
         out = step()
     ctx.comm_barrier()
     ctx.synchronize()
+    # HIP events on the ctx stream bracket the main kernel on every TIMED_EVERY-th step of the
+    # timed region: each record puts a barrier packet between dependent kernels (~6 us on this
+    # stack, ~12 us per evaluation), which no production caller pays
+    TIMED_EVERY = 4
     kern_ms = []
     host_us = np.zeros(5)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
+        timed = i % TIMED_EVERY == 0
+        ctx.set_timing(timed)
         out = step()
-        kern_ms.append(ctx.last_kernel_ms(0))  # HIP events on the ctx stream around the main kernel
+        if timed:
+            kern_ms.append(ctx.last_kernel_ms(0))
         host_us += ctx.last_host_us()
+    ctx.set_timing(False)
     ctx.synchronize()
     ctx.comm_barrier()
     dt = time.perf_counter() - t0
@@ -261,6 +271,8 @@ def main():
             "frac": achieved / FP64_PEAK_TFLOPS,
             "traffic": traffic,
             "kernel_ms": k_ms,
+            "kernel_ms_from": f"HIP events around the kernel on every {TIMED_EVERY}th of the {a.steps} timed steps "
+                              f"({len(kern_ms)} launches)",
             "algorithmic_flops_per_launch": flops,
             "hbm_bytes_per_launch_algorithmic": eps_bytes,
             "hbm_achieved_GBs": (eps_bytes / (k_ms * 1e-3) / 1e9) if eps_bytes else 0.0,

@@ -88,8 +88,14 @@ int vbmc_device_info(const vbmc_ctx* ctx, char* name, int name_len, int* cu_coun
 /* Block until everything queued on the ctx has finished (bench bracketing). */
 int vbmc_synchronize(vbmc_ctx* ctx);
 
-/* Duration in milliseconds of the most recent launch of the dominant kernel of
- * the given entry point, measured with HIP events on the ctx's own stream.
+/* Switch the HIP event pair around the dominant kernels on or off (default: off).
+ * A record between two dependent kernels puts a barrier packet into the queue, which
+ * costs ~6 us per record on MI355X -- measurement harnesses switch it on for the
+ * launches they want timed, production callers leave it off. */
+int vbmc_set_timing(vbmc_ctx* ctx, int on);
+
+/* Duration in milliseconds of the most recent TIMED launch (vbmc_set_timing) of the
+ * dominant kernel of the given entry point, from HIP events on the ctx's own stream.
  * which: 0 = entmc main kernel, 1 = gp_log_joint, 2 = mixture pdf,
  *        3 = gp_predict, 4 = whole last vbmc_neg_elcbo device section. */
 int vbmc_last_kernel_ms(vbmc_ctx* ctx, int which, double* ms_out);

@@ -63,6 +63,7 @@ SIGNATURES = {
         [_vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)],
     ),
     "vbmc_synchronize": (C.c_int, [_vp]),
+    "vbmc_set_timing": (C.c_int, [_vp, C.c_int]),
     "vbmc_last_kernel_ms": (C.c_int, [_vp, C.c_int, _dp]),
     "vbmc_last_host_us": (C.c_int, [_vp, _dp]),
     "vbmc_set_mixture": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
@@ -212,6 +213,10 @@ class Context:
 
     def synchronize(self):
         self.check(self._lib.vbmc_synchronize(self._h))
+
+    def set_timing(self, on):
+        """HIP event pair around the dominant kernels (off by default: each record costs ~6 us)."""
+        self.check(self._lib.vbmc_set_timing(self._h, 1 if on else 0))
 
     def last_kernel_ms(self, which=0):
         v = C.c_double()

@@ -24,6 +24,7 @@
 #include "adam_dev.h"
 #include "common.h"
 #include "entropy_args.h"
+#include "philox.h"
 
 using namespace adam_dev;
 
@@ -125,9 +126,15 @@ __global__ __launch_bounds__(256) void adam_pre_kernel(AdamDev a) {
 // from global memory straight to registers in one batch of independent loads; only theta and the
 // mixture attributes, which the pack re-reads across barriers, live in LDS.
 template <bool LDS>
-__global__ __launch_bounds__(256) void adam_step_kernel(AdamDev a, int do_step) {
+__global__ __launch_bounds__(256) void adam_step_kernel(AdamDev a, int do_step, GenSlice gen) {
   extern __shared__ double sh[];
   __shared__ double red[16];
+  if (blockIdx.x > 0) {
+    // this kernel is one workgroup of latency chains on an otherwise idle GPU: the spare
+    // workgroups of its launch generate a slice of the next iteration's draws meanwhile
+    gen_slice_block(gen, blockIdx.x - 1, threadIdx.x);
+    return;
+  }
   const int D = a.D, K = a.K, tid = threadIdx.x, n = a.n_theta;
   const AdamLayout& L = a.lay;
   double* theta = LDS ? sh : a.state + L.o_theta();
@@ -265,21 +272,17 @@ struct AdamState {
   // carve of d_buf
   double *state = nullptr, *work = nullptr, *ee = nullptr, *pre = nullptr, *x_tab = nullptr, *y_tab = nullptr;
   AdamDev* d_args = nullptr;  // the argument block in device memory, for the entropy launch's pre row
-  // Philox mode: the draws of a whole vbmc_adam_run batch are generated on a second, low-priority
-  // stream into one buffer per iteration.  That stream runs ahead on its own; the main stream only
-  // WAITS on its events (free once signalled) and never records one per iteration -- a record
-  // between two dependent kernels opens a 6 us gap on MI355X, a cross-queue wait up to 13 us.
+  // Philox mode: the draws of iteration i + 1 are generated by spare workgroups of iteration i's
+  // finish and step launches and of iteration i + 1's prep launch -- the three short launches
+  // during which the GPU is otherwise idle (~26 us per iteration at BASELINE config 3, about what
+  // generating 5e6 normals takes).  One buffer suffices: the entropy kernel that reads it runs
+  // between prep and finish.  No second stream, no events: a record between two dependent
+  // kernels opens a ~6 us gap on MI355X and a cross-queue wait up to 13 us.
   bool pregen = false;
-  size_t n_eps = 0;         // doubles per iteration
-  double* d_epsN = nullptr; // [iterations of a batch][n_eps]
-  size_t eps_cap = 0;       // doubles allocated
-  hipStream_t gen_stream = nullptr;
-  // two sets of events: [0] for direct launches, [1] for the captured batch (an event recorded
-  // inside a stream capture must not be mixed with ordinary use)
-  struct Events {
-    hipEvent_t fork = nullptr;     // the batch's first iterate is packed (start of the gen stream's work)
-    std::vector<hipEvent_t> gen;   // buffer `it` holds the draws of iteration i0 + it
-  } ev[2];
+  size_t n_eps = 0;          // doubles per iteration
+  double* d_eps1 = nullptr;  // [K][row_count][D]
+  size_t eps_cap = 0;        // doubles allocated
+  bool eps_started = false;  // the buffer already holds the finish/step slices of the next iteration
   // a captured batch of graph_len iterations, replayed by vbmc_adam_run calls of that length
   hipGraphExec_t graph_exec = nullptr;
   int graph_len = 0;
@@ -297,20 +300,16 @@ void adam_free(vbmc_ctx* ctx) {
   if (st->d_buf) (void)hipFree(st->d_buf);
   if (st->d_status) (void)hipFree(st->d_status);
   if (st->graph_exec) (void)hipGraphExecDestroy(st->graph_exec);
-  if (st->d_epsN) (void)hipFree(st->d_epsN);
+  if (st->d_eps1) (void)hipFree(st->d_eps1);
   if (st->d_args) (void)hipFree(st->d_args);
-  for (int b = 0; b < 2; ++b) {
-    if (st->ev[b].fork) (void)hipEventDestroy(st->ev[b].fork);
-    for (hipEvent_t e : st->ev[b].gen) (void)hipEventDestroy(e);
-  }
-  if (st->gen_stream) (void)hipStreamDestroy(st->gen_stream);
   delete st;
   ctx->adam = nullptr;
 }
 
-static void launch_step(const AdamState& st, hipStream_t sm, const AdamDev& a, int do_step) {
-  if (st.step_lds) hipLaunchKernelGGL(adam_step_kernel<true>, dim3(1), dim3(256), st.step_lds_bytes, sm, a, do_step);
-  else hipLaunchKernelGGL(adam_step_kernel<false>, dim3(1), dim3(256), 0, sm, a, do_step);
+static void launch_step(const AdamState& st, hipStream_t sm, const AdamDev& a, int do_step, const GenSlice& gen) {
+  const dim3 grid(1 + gen.n_blocks);
+  if (st.step_lds) hipLaunchKernelGGL(adam_step_kernel<true>, grid, dim3(256), st.step_lds_bytes, sm, a, do_step, gen);
+  else hipLaunchKernelGGL(adam_step_kernel<false>, grid, dim3(256), 0, sm, a, do_step, gen);
 }
 
 static void launch_pre(const AdamState& st, hipStream_t sm, const AdamDev& a) {
@@ -446,12 +445,6 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
   if (rc) return rc;
   if (!st->d_status) HIP_TRY(ctx, hipMalloc((void**)&st->d_status, 2 * sizeof(int)));  // flag, iteration base
   if (!st->d_args) HIP_TRY(ctx, hipMalloc((void**)&st->d_args, sizeof(AdamDev)));
-  if (!st->gen_stream) {
-    int lo = 0, hi = 0;
-    HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIP_TRY(ctx, hipStreamCreateWithPriority(&st->gen_stream, hipStreamNonBlocking, lo));
-    for (int b = 0; b < 2; ++b) HIP_TRY(ctx, hipEventCreateWithFlags(&st->ev[b].fork, hipEventDisableTiming));
-  }
   if (st->graph_exec) {  // captured for the previous problem
     HIP_TRY(ctx, hipGraphExecDestroy(st->graph_exec));
     st->graph_exec = nullptr;
@@ -492,46 +485,47 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
   fill_dev(ctx, *st, a);
   HIP_TRY(ctx, hipMemcpyAsync(st->d_args, &a, sizeof(AdamDev), hipMemcpyHostToDevice, sm));
   HIP_TRY(ctx, hipStreamSynchronize(sm));  // `a` is a stack object
-  launch_step(*st, sm, a, 0);
+  launch_step(*st, sm, a, 0, GenSlice());
   HIP_TRY(ctx, hipGetLastError());
-  // draws generated ahead on the second stream (Philox mode, unless switched off)
+  // draws generated ahead by spare workgroups (Philox mode, unless switched off or > 32 GiB)
   {
     const char* off = getenv("VBMC_ADAM_PREGEN");
     st->n_eps = (size_t)K * (size_t)st->row_count * D;
-    st->pregen = st->eps_mode == VBMC_EPS_PHILOX && !(off && off[0] == '0') && st->n_eps > 0;
+    st->pregen = st->eps_mode == VBMC_EPS_PHILOX && !(off && off[0] == '0') && st->n_eps > 0 &&
+                 st->n_eps <= ((size_t)1 << 32);
+    st->eps_started = false;
+    if (st->pregen && st->eps_cap < st->n_eps) {
+      if (st->d_eps1) HIP_TRY(ctx, hipFree(st->d_eps1));
+      st->d_eps1 = nullptr;
+      st->eps_cap = 0;
+      HIP_TRY(ctx, hipMalloc((void**)&st->d_eps1, sizeof(double) * st->n_eps));
+      st->eps_cap = st->n_eps;
+    }
   }
   st->active = true;
   return VBMC_OK;
 }
 
-// One batch of iterations [i0, i0 + n_iters): four launches per iteration on the main stream,
+static double env_frac(const char* name, double dflt) {
+  const char* e = getenv(name);
+  return e ? atof(e) : dflt;
+}
+
+// One batch of iterations [i0, i0 + n_iters): four launches per iteration on one stream,
 //   prep (table rows + GP sums) -> entropy (+ the pre row) -> finish [-> all-reduce] -> step,
-// ordered by the stream alone.  With `use_gen` the Philox draws of the whole batch are generated
-// on the second stream, one buffer per iteration.  Self-contained (every wait is on an event
-// recorded inside the batch), so the same sequence can be launched directly or captured.
-static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool multi, bool use_gen,
-                         AdamState::Events& ev) {
+// ordered by the stream alone, so the same sequence can be launched directly or captured.
+static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool multi) {
   hipStream_t sm = ctx->stream;
   AdamDev a;
   fill_dev(ctx, *st, a);
-  if (use_gen && n_iters > 0) {
-    // The entropy kernel issues ~63 % of its FP64 slots and the finish / step / prep kernels leave
-    // the GPU almost idle; these small-footprint kernels fill that time.  Only the first
-    // iteration's draws are not hidden.
-    HIP_TRY(ctx, hipEventRecord(ev.fork, sm));
-    HIP_TRY(ctx, hipStreamWaitEvent(st->gen_stream, ev.fork, 0));
-    while ((int)ev.gen.size() < n_iters) {
-      hipEvent_t e = nullptr;
-      HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      ev.gen.push_back(e);
-    }
-    for (int it = 0; it < n_iters; ++it) {
-      int rc = launch_eps_gen(ctx, st->gen_stream, st->d_epsN + (size_t)it * st->n_eps, st->ns / 2, st->row_begin,
-                              st->row_count, st->seed + (uint64_t)it, st->d_status + 1);
-      if (rc) return rc;
-      HIP_TRY(ctx, hipEventRecord(ev.gen[it], st->gen_stream));
-    }
-  }
+  const bool use_gen = st->pregen;
+  // shares of the next iteration's draws given to the finish / step / prep launches, about
+  // proportional to how long each of them leaves the GPU idle (5.5 / 12 / 8.5 us)
+  const double f_fin = env_frac("VBMC_F_FIN", 0.20), f_step = env_frac("VBMC_F_STEP", 0.67);
+  auto slice = [&](int seed_off, double f0, double f1) {
+    return make_gen_slice(st->d_eps1, ctx->K, ctx->D, st->row_count, st->ns / 2, st->row_begin,
+                          st->seed + (uint64_t)seed_off, st->d_status + 1, f0, f1);
+  };
   for (int it = 0; it < n_iters; ++it) {
     PrepArgs pa;
     glj_fill_prep(ctx, 1, st->state + st->lay.o_res(), nullptr, pa);
@@ -540,8 +534,11 @@ static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool
                         st->row_begin, st->row_count, 1, plan);
     if (rc) return rc;
     if (use_gen) {
-      plan.a.eps = st->d_epsN + (size_t)it * st->n_eps;
+      plan.a.eps = st->d_eps1;
       plan.a.eps_rows = st->row_count;
+      // this iteration's remaining draws (all of them when no earlier launch began the buffer)
+      pa.gen = slice(it, st->eps_started ? f_step : 0.0, 1.0);
+      st->eps_started = true;
     }
     entmc_fill_prep(ctx, plan, pa);
     rc = launch_prep(ctx, pa);
@@ -555,17 +552,17 @@ static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool
     const bool pre_row = pre_row_on && plan.ws && plan.a.eps_mode != VBMC_EPS_PHILOX;
     if (pre_row) plan.a.extra = st->d_args;
     else launch_pre(*st, sm, a);
-    if (use_gen) HIP_TRY(ctx, hipStreamWaitEvent(sm, ev.gen[it], 0));
     rc = entmc_launch_main(ctx, plan);
     if (rc) return rc;
-    rc = entmc_launch_finish(ctx, plan, st->state + st->lay.o_raw());
+    const GenSlice g_fin = use_gen ? slice(it + 1, 0.0, f_fin) : GenSlice();
+    rc = entmc_launch_finish(ctx, plan, st->state + st->lay.o_raw(), &g_fin);
     if (rc) return rc;
     if (multi) {
       rc = comm_allreduce_sum(ctx, st->state + st->lay.o_raw(), raw_len(ctx->D, ctx->K));
       if (rc) return rc;
     }
     a.it_off = it;
-    launch_step(*st, sm, a, 1);
+    launch_step(*st, sm, a, 1, use_gen ? slice(it + 1, f_fin, f_step) : GenSlice());
   }
   HIP_TRY(ctx, hipGetLastError());
   return 0;
@@ -605,29 +602,8 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
     const char* e = getenv("VBMC_ADAM_GRAPH");
     return !(e && e[0] == '0');
   }();
-  // one draw buffer per iteration of the batch (288 GB of HBM: 20 x 40 MB at BASELINE config 3);
-  // beyond 32 GiB the draws are generated inside the entropy kernel instead
-  bool use_gen = st->pregen && n_iters > 0;
-  if (use_gen && st->eps_cap < st->n_eps * (size_t)n_iters) {
-    const size_t bytes = sizeof(double) * st->n_eps * (size_t)n_iters;
-    if (bytes > ((size_t)32 << 30)) {
-      use_gen = false;
-    } else {
-      HIP_TRY(ctx, hipStreamSynchronize(st->gen_stream));
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-      if (st->d_epsN) HIP_TRY(ctx, hipFree(st->d_epsN));
-      st->d_epsN = nullptr;
-      st->eps_cap = 0;
-      HIP_TRY(ctx, hipMalloc((void**)&st->d_epsN, bytes));
-      st->eps_cap = st->n_eps * (size_t)n_iters;
-      if (st->graph_exec) {  // captured with the old buffer
-        HIP_TRY(ctx, hipGraphExecDestroy(st->graph_exec));
-        st->graph_exec = nullptr;
-      }
-    }
-  }
   const bool graphable = graphs_on && !multi && n_iters >= 4 && st->runs >= 1 &&
-                         (use_gen || st->eps_mode == VBMC_EPS_RESIDENT);
+                         (st->pregen || st->eps_mode == VBMC_EPS_RESIDENT);
   st->runs++;
   if (graphable && st->graph_exec && st->graph_len != n_iters) {
     HIP_TRY(ctx, hipGraphExecDestroy(st->graph_exec));
@@ -636,7 +612,7 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
   if (graphable && !st->graph_exec) {
     hipGraph_t graph = nullptr;
     HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
-    rc = enqueue_batch(ctx, st, i0, n_iters, false, use_gen, st->ev[1]);
+    rc = enqueue_batch(ctx, st, i0, n_iters, false);
     const hipError_t e_end = hipStreamEndCapture(ctx->stream, &graph);  // also ends a failed capture
     if (rc == 0 && e_end != hipSuccess) rc = vbmc_fail(ctx, VBMC_E_HIP, "adam_run: stream capture: %s", hipGetErrorString(e_end));
     if (rc == 0) {
@@ -653,7 +629,7 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
   if (graphable) {
     HIP_TRY(ctx, hipGraphLaunch(st->graph_exec, ctx->stream));
   } else {
-    rc = enqueue_batch(ctx, st, i0, n_iters, multi, use_gen, st->ev[0]);
+    rc = enqueue_batch(ctx, st, i0, n_iters, multi);
   }
   if (rc) return rc;
   HIP_TRY(ctx, hipGetLastError());
@@ -694,7 +670,6 @@ extern "C" int vbmc_adam_end(vbmc_ctx* ctx, double* theta_out, double* mu_KxD, d
   HIP_TRY(ctx, hipMemcpyAsync(aux.data(), st->state + st->lay.o_aux(), sizeof(double) * n_aux, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(th.data(), st->state + st->lay.o_theta(), sizeof(double) * st->n_theta, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (st->gen_stream) HIP_TRY(ctx, hipStreamSynchronize(st->gen_stream));
   // the device pack in d_mix is the mixture of the last iterate: make the host copies agree
   ctx->mu.assign(aux.begin(), aux.begin() + K * D);
   ctx->sigma.assign(aux.begin() + K * D, aux.begin() + K * D + K);

@@ -157,6 +157,12 @@ int vbmc_synchronize(vbmc_ctx* ctx) {
   return VBMC_OK;
 }
 
+int vbmc_set_timing(vbmc_ctx* ctx, int on) {
+  if (!ctx) return VBMC_E_ARG;
+  ctx->timing = on != 0;
+  return VBMC_OK;
+}
+
 int vbmc_last_kernel_ms(vbmc_ctx* ctx, int which, double* ms_out) {
   if (!ctx || which < 0 || which > 4 || !ms_out) return VBMC_E_ARG;
   NEED_DEVICE(ctx);

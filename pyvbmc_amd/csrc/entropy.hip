@@ -200,8 +200,16 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
                                                            const double* __restrict__ mix,
                                                            MixLayout ml, double inv_ns,
                                                            int want_grad, int mu_from_w,
-                                                           double* __restrict__ raw) {
+                                                           double* __restrict__ raw, GenSlice gen) {
   const int D = ml.D, K = ml.K;
+  {
+    // spare workgroups after the reduction's own: a slice of the next draws (Adam loop)
+    const int n_main = (1 + D * K + 2 * K + D + 3) / 4;
+    if ((int)blockIdx.x >= n_main) {
+      gen_slice_block(gen, blockIdx.x - n_main, threadIdx.x);
+      return;
+    }
+  }
   const double* w = mix + ml.o_w;
   const double* sig = mix + ml.o_sig;
   const double* ilam = mix + ml.o_ilam;
@@ -491,13 +499,7 @@ int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& pa) {
   if (!on || p.a.eps_mode != VBMC_EPS_PHILOX || n_eps == 0 || n_eps > ((size_t)1 << 28)) return 0;
   int rc = ensure_dev(ctx, &ctx->d_epsgen, &ctx->d_epsgen_cap, n_eps);
   if (rc) return rc;
-  const int64_t items = (int64_t)K * p.a.row_count * ((D + 1) / 2);
-  pa.n_gen = (int)((items + 255) / 256);
-  pa.gen_eps = ctx->d_epsgen;
-  pa.gen_rows = p.a.row_count;
-  pa.gen_n_half = p.a.n_half;
-  pa.gen_row_begin = p.a.row_begin;
-  pa.gen_seed = p.a.seed;
+  pa.gen = make_gen_slice(ctx->d_epsgen, K, D, p.a.row_count, p.a.n_half, p.a.row_begin, p.a.seed, nullptr, 0.0, 1.0);
   p.a.eps_mode = VBMC_EPS_RESIDENT;
   p.a.eps = ctx->d_epsgen;
   p.a.eps_rows = p.a.row_count;
@@ -506,10 +508,13 @@ int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& pa) {
 
 int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p) {
   const EntArgs& a = p.a;
-  if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  // timing: the wave-split launch carries the event pair on its own dispatch packet; the generic
+  // kernel is bracketed by two records (each a barrier packet, ~6 us between dependent kernels)
+  hipEvent_t e0 = ctx->timing ? ctx->ev[0] : nullptr, e1 = ctx->timing ? ctx->ev[1] : nullptr;
+  if (ctx->timing && !p.ws) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   if (p.ws) {
     switch (p.DP) {
-#define VBMC_CASE_WS(dp) case dp: launch_entmc_ws_dp##dp(ctx->stream, a, p.table); break;
+#define VBMC_CASE_WS(dp) case dp: launch_entmc_ws_dp##dp(ctx->stream, a, p.table, e0, e1); break;
       VBMC_WS_DPS(VBMC_CASE_WS)
 #undef VBMC_CASE_WS
     }
@@ -528,7 +533,7 @@ int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p) {
     }
   }
   if (ctx->timing) {
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (!p.ws) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     ctx->ev_valid[0] = true;
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -536,41 +541,41 @@ int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p) {
 }
 
 namespace {
-__global__ __launch_bounds__(256) void eps_gen_kernel(double* __restrict__ eps, int K, int64_t rows, int D,
-                                                      int64_t n_half, int64_t row_begin, uint64_t seed,
-                                                      const int* __restrict__ seed_add) {
-  if (seed_add) seed += (uint64_t)seed_add[0];  // device-side iteration index (adam.hip)
-  const int np = (D + 1) / 2;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)K * rows * np) return;
-  const int p = (int)(t % np);
-  const int64_t r = t / np;
-  const int64_t j = r / rows, i = r - j * rows;
-  const uint64_t grow = (uint64_t)j * (uint64_t)n_half + (uint64_t)(row_begin + i);
-  double z0, z1;
-  philox_normal_pair(grow, (uint32_t)p, seed, z0, z1);
-  double* dst = eps + r * D + 2 * p;
-  dst[0] = z0;
-  if (2 * p + 1 < D) dst[1] = z1;
-}
+__global__ __launch_bounds__(256) void eps_gen_kernel(GenSlice g) { gen_slice_block(g, blockIdx.x, threadIdx.x); }
 }  // namespace
 
-int launch_eps_gen(vbmc_ctx* ctx, hipStream_t st, double* d_eps, int64_t n_half, int64_t row_begin,
-                   int64_t row_count, uint64_t seed, const int* seed_add) {
-  const int D = ctx->D, K = ctx->K;
-  const int64_t total = (int64_t)K * row_count * ((D + 1) / 2);
-  if (total <= 0) return 0;
-  hipLaunchKernelGGL(eps_gen_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_eps, K,
-                     row_count, D, n_half, row_begin, seed, seed_add);
+GenSlice make_gen_slice(double* eps, int K, int D, int64_t rows, int64_t n_half, int64_t row_begin,
+                        uint64_t seed, const int* seed_add, double frac_begin, double frac_end) {
+  GenSlice g;
+  g.eps = eps;
+  g.K = K;
+  g.D = D;
+  g.rows = rows;
+  g.n_half = n_half;
+  g.row_begin = row_begin;
+  g.seed = seed;
+  g.seed_add = seed_add;
+  const int64_t total = (int64_t)K * rows * ((D + 1) / 2);
+  const int64_t b = (int64_t)(frac_begin * (double)total), e = frac_end >= 1.0 ? total : (int64_t)(frac_end * (double)total);
+  g.item_begin = b;
+  g.item_count = e > b ? e - b : 0;
+  g.n_blocks = (int)((g.item_count + 255) / 256);
+  return g;
+}
+
+int launch_eps_gen(vbmc_ctx* ctx, hipStream_t st, const GenSlice& g) {
+  if (g.n_blocks <= 0) return 0;
+  hipLaunchKernelGGL(eps_gen_kernel, dim3((unsigned)g.n_blocks), dim3(256), 0, st, g);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
 
-int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out) {
+int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out, const GenSlice* gen) {
   const int n_out = raw_len(ctx->D, ctx->K);
-  hipLaunchKernelGGL(entmc_finish_kernel, dim3((n_out + 3) / 4), dim3(256), 0, ctx->stream,
+  const GenSlice g = gen ? *gen : GenSlice();
+  hipLaunchKernelGGL(entmc_finish_kernel, dim3((n_out + 3) / 4 + g.n_blocks), dim3(256), 0, ctx->stream,
                      p.a.partial, p.a.chunks, p.a.stride, ctx->d_mix, ctx->ml, p.inv_ns,
-                     p.a.want_grad, p.ws ? 1 : 0, raw_out);
+                     p.a.want_grad, p.ws ? 1 : 0, raw_out, g);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }

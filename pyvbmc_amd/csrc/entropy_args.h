@@ -33,6 +33,9 @@ struct EntPlan {
 // padded-D instantiations of the wave-split kernel (entropy_ws.hip), one translation
 // unit each; d_table: K * 4*ceil(K/4) * (dp+6) doubles of scratch for the (j,k) table
 #define VBMC_WS_DPS(X) X(2) X(4) X(6) X(8) X(10) X(12) X(16) X(20) X(24) X(32)
-#define VBMC_DECL_WS(dp) void launch_entmc_ws_dp##dp(hipStream_t st, const EntArgs& a, const double* d_table);
+// e0 / e1 (may be null): HIP events that take the start / stop timestamps of the dispatch itself
+// (hipExtLaunchKernel) -- unlike hipEventRecord they put no barrier packet between dependent kernels
+#define VBMC_DECL_WS(dp) \
+  void launch_entmc_ws_dp##dp(hipStream_t st, const EntArgs& a, const double* d_table, hipEvent_t e0, hipEvent_t e1);
 VBMC_WS_DPS(VBMC_DECL_WS)
 #undef VBMC_DECL_WS

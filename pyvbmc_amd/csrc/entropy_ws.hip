@@ -28,6 +28,8 @@
 //     the weight gradient already collects, so it is formed by the finish kernel.
 // Output: the same per-workgroup partial rows as entropy.hip, reduced by its kernels
 // (entmc_finish_kernel, mu_from_w = 1).
+#include <hip/hip_ext.h>
+
 #include "adam_dev.h"
 #include "common.h"
 #include "entropy_args.h"
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
 }
 
 template <int DP, int KTMAX>
-void launch_one(hipStream_t st, const EntArgs& a, const double* d_table) {
+void launch_one(hipStream_t st, const EntArgs& a, const double* d_table, hipEvent_t e0, hipEvent_t e1) {
   const int K = a.ml.K;
   const int K4 = ((K + 3) / 4) * 4;
   const size_t lds = sizeof(double) * (size_t)K4;
@@ -365,7 +367,7 @@ void launch_one(hipStream_t st, const EntArgs& a, const double* d_table) {
   const bool extra_row = a.extra != nullptr && a.want_grad && !philox;  // see EXTRA_ROW in the kernel
   const dim3 grid(a.chunks, K + (extra_row ? 1 : 0)), block(WG);
 #define VBMC_LAUNCH_WS(G, E, P) \
-  hipLaunchKernelGGL((entmc_ws_kernel<DP, KTMAX, G, E, P>), grid, block, lds, st, a, d_table)
+  hipExtLaunchKernelGGL((entmc_ws_kernel<DP, KTMAX, G, E, P>), grid, block, (std::uint32_t)lds, st, e0, e1, 0u, a, d_table)
   if (a.want_grad) {
     if (exact) { if (philox) VBMC_LAUNCH_WS(true, true, true); else VBMC_LAUNCH_WS(true, true, false); }
     else       { if (philox) VBMC_LAUNCH_WS(true, false, true); else VBMC_LAUNCH_WS(true, false, false); }
@@ -383,11 +385,12 @@ void launch_one(hipStream_t st, const EntArgs& a, const double* d_table) {
 
 // one exported launcher per padded D; picks the smallest register-array size that holds KT.
 // d_table must hold K * 4*ceil(K/4) * (DP+6) doubles.
-void VBMC_CAT(launch_entmc_ws_dp, VBMC_DP)(hipStream_t st, const EntArgs& a, const double* d_table) {
+void VBMC_CAT(launch_entmc_ws_dp, VBMC_DP)(hipStream_t st, const EntArgs& a, const double* d_table, hipEvent_t e0,
+                                            hipEvent_t e1) {
   const int KT = (a.ml.K + 3) / 4;
-  if (KT <= 8) launch_one<VBMC_DP, 8>(st, a, d_table);
-  else if (KT <= 13) launch_one<VBMC_DP, 13>(st, a, d_table);
-  else if (KT <= 16) launch_one<VBMC_DP, 16>(st, a, d_table);
-  else if (KT <= 25) launch_one<VBMC_DP, 25>(st, a, d_table);
-  else launch_one<VBMC_DP, 32>(st, a, d_table);
+  if (KT <= 8) launch_one<VBMC_DP, 8>(st, a, d_table, e0, e1);
+  else if (KT <= 13) launch_one<VBMC_DP, 13>(st, a, d_table, e0, e1);
+  else if (KT <= 16) launch_one<VBMC_DP, 16>(st, a, d_table, e0, e1);
+  else if (KT <= 25) launch_one<VBMC_DP, 25>(st, a, d_table, e0, e1);
+  else launch_one<VBMC_DP, 32>(st, a, d_table, e0, e1);
 }

@@ -14,6 +14,7 @@
 
 #include <cstdint>
 
+#include "common.h"
 #include "fastmath.h"
 
 struct Philox4 {
@@ -38,6 +39,26 @@ __host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
   Philox4 o;
   o.x[0] = c0; o.x[1] = c1; o.x[2] = c2; o.x[3] = c3;
   return o;
+}
+
+__device__ inline void philox_normal_pair(uint64_t row, uint32_t pair, uint64_t seed, double& z0, double& z1);
+
+// workgroup `block` (0-based among the slice's n_blocks) of a 256-thread launch
+__device__ inline void gen_slice_block(const GenSlice& g, int block, int tid) {
+  const int64_t local = (int64_t)block * 256 + tid;
+  if (local >= g.item_count) return;
+  const int64_t t = g.item_begin + local;
+  const int np = (g.D + 1) / 2;
+  const int p = (int)(t % np);
+  const int64_t r = t / np;
+  const int64_t j = r / g.rows, i = r - j * g.rows;
+  const uint64_t grow = (uint64_t)j * (uint64_t)g.n_half + (uint64_t)(g.row_begin + i);
+  const uint64_t seed = g.seed + (g.seed_add ? (uint64_t)g.seed_add[0] : 0);
+  double z0, z1;
+  philox_normal_pair(grow, (uint32_t)p, seed, z0, z1);
+  double* dst = g.eps + r * g.D + 2 * p;
+  dst[0] = z0;
+  if (2 * p + 1 < g.D) dst[1] = z1;
 }
 
 __device__ inline void philox_normal_pair(uint64_t row, uint32_t pair, uint64_t seed,

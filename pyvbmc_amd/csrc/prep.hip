@@ -35,14 +35,19 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
     const int j = blockIdx.x;
     const int DP = a.DP, TS = a.DP + 6, K4 = a.K4;
     const double* mup = a.mix + a.ml.o_mup;
+    // all lanes on the (k, d) differences (coalesced row writes), then one lane per k on the tail
+    double* sV2 = lds;  // [K4][DP] squared differences
+    for (int idx = tid; idx < K4 * DP; idx += 256) {
+      const int k = idx / DP, d = idx - k * DP;
+      const double v = (d < D && k < K) ? (mup[j * D + d] - mup[k * D + d]) : 0.0;
+      a.table[((size_t)j * K4 + k) * TS + d] = v;
+      sV2[idx] = v * v;
+    }
+    __syncthreads();
     for (int k = tid; k < K4; k += 256) {
       double* row = a.table + ((size_t)j * K4 + k) * TS;
       double s = 0.0;
-      for (int d = 0; d < DP; ++d) {
-        const double v = (d < D && k < K) ? (mup[j * D + d] - mup[k * D + d]) : 0.0;
-        row[d] = v;
-        s = fma(v, v, s);
-      }
+      for (int d = 0; d < DP; ++d) s += sV2[k * DP + d];
       if (k < K) {
         const double is2 = a.mix[a.ml.o_is2 + k];
         const double w = a.mix[a.ml.o_w + k];
@@ -61,20 +66,8 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
   }
 
   if ((int)blockIdx.x >= a.n_table + a.n_glj) {
-    // ---- draw-generation block: 256 (row, pair) items, the entropy kernel's own values
-    // (counter = global antithetic-pair row, pair; key = seed; philox.h) ----
-    const int np = (D + 1) / 2;
-    const int64_t t = (int64_t)(blockIdx.x - a.n_table - a.n_glj) * 256 + tid;
-    if (t >= (int64_t)K * a.gen_rows * np) return;
-    const int p = (int)(t % np);
-    const int64_t r = t / np;
-    const int64_t j = r / a.gen_rows, i = r - j * a.gen_rows;
-    const uint64_t grow = (uint64_t)j * (uint64_t)a.gen_n_half + (uint64_t)(a.gen_row_begin + i);
-    double z0, z1;
-    philox_normal_pair(grow, (uint32_t)p, a.gen_seed, z0, z1);
-    double* dst = a.gen_eps + r * D + 2 * p;
-    dst[0] = z0;
-    if (2 * p + 1 < D) dst[1] = z1;
+    // ---- draw-generation block (philox.h) ----
+    gen_slice_block(a.gen, blockIdx.x - a.n_table - a.n_glj, tid);
     return;
   }
 
@@ -85,8 +78,8 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
   double* sItau = lds;             // [D]
   double* sMu = sItau + D;         // [D]
   double* sZa = sMu + D;           // [N]
-  double* sPart = sZa + N;         // [4][2D+1]
-  double* sMisc = sPart + 4 * (2 * D + 1);  // [1]
+  double* sPart = sZa + N;         // [4]
+  double* sMisc = sPart + 4;       // [1]
   const double* h = a.hyp + (size_t)s * a.P;
   const double sigk = a.mix[a.ml.o_sig + k];
   if (tid < 64) {
@@ -116,35 +109,40 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
     if (a.Z) a.Z[((size_t)s * K + k) * N + n] = z;
   }
   __syncthreads();
-  const int items = a.want_grad ? 1 + 2 * D : 1;
+  double* out = a.res + ((size_t)s * K + k) * (1 + 2 * D);
   {
     double acc = 0.0;
     for (int n = tid; n < N; n += 256) acc += sZa[n];
     acc = wave_sum(acc);
-    if (lane == 0) sPart[wave * (2 * D + 1)] = acc;
+    if (lane == 0) sPart[wave] = acc;
   }
   if (a.want_grad) {
-    for (int d = 0; d < D; ++d) {
+    // thread = (slice ns of the points, dimension slot ds): every dimension's two sums advance
+    // side by side (independent loads, one short shuffle reduction over the 16 slices) instead
+    // of one block-wide reduction per dimension
+    const int ns = tid & 15, ds = tid >> 4;
+    for (int d = ds; d < D; d += 16) {
+      const double m = sMu[d], itau = sItau[d];
       double au = 0.0, at = 0.0;
-      for (int n = tid; n < N; n += 256) {
-        const double dl = (sMu[d] - a.X[(size_t)n * D + d]) * sItau[d];
+      for (int n = ns; n < N; n += 16) {
+        const double dl = (m - a.X[(size_t)n * D + d]) * itau;
         const double t = dl * sZa[n];
         au += t;
         at = fma(dl, t, at);
       }
-      au = wave_sum(au);
-      at = wave_sum(at);
-      if (lane == 0) {
-        sPart[wave * (2 * D + 1) + 1 + d] = au;
-        sPart[wave * (2 * D + 1) + 1 + D + d] = at;
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        au += __shfl_xor(au, off, 64);
+        at += __shfl_xor(at, off, 64);
+      }
+      if (ns == 0) {
+        out[1 + d] = au;
+        out[1 + D + d] = at;
       }
     }
   }
   __syncthreads();
-  for (int it = tid; it < items; it += 256) {
-    const double v = (sPart[it] + sPart[(2 * D + 1) + it]) + (sPart[2 * (2 * D + 1) + it] + sPart[3 * (2 * D + 1) + it]);
-    a.res[((size_t)s * K + k) * (1 + 2 * D) + it] = v;
-  }
+  if (tid == 0) out[0] = (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]);
 }
 
 }  // namespace
@@ -154,13 +152,20 @@ int launch_prep(vbmc_ctx* ctx, const PrepArgs& a) { return launch_prep_on(ctx, c
 int launch_prep_on(vbmc_ctx* ctx, hipStream_t stream, const PrepArgs& a) {
   const int D = a.ml.D;
   const int gblocks = a.n_glj;
-  const int grid = a.n_table + gblocks + a.n_gen;
+  const int grid = a.n_table + gblocks + a.gen.n_blocks;
   if (grid <= 0) return 0;
   size_t lds = 0;
   if (gblocks > 0) {
-    lds = sizeof(double) * ((size_t)2 * D + a.N + 4 * (2 * D + 1) + 1);
+    lds = sizeof(double) * ((size_t)2 * D + a.N + 4 + 1);
     if (lds > 150 * 1024) return vbmc_fail(ctx, VBMC_E_UNSUP, "gp_log_joint: N=%d too large", a.N);
   }
+  if (a.n_table > 0) {
+    const size_t lt = sizeof(double) * (size_t)a.K4 * a.DP;
+    if (lt > 150 * 1024) return vbmc_fail(ctx, VBMC_E_UNSUP, "entropy table: K=%d D=%d too large", a.ml.K, D);
+    lds = lt > lds ? lt : lds;
+  }
+  if (lds > 64 * 1024)
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)elbo_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(elbo_prep_kernel, dim3(grid, a.batch), dim3(256), lds, stream, a);
   HIP_TRY(ctx, hipGetLastError());
   return 0;

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--config", type=int, default=3)
     a = ap.parse_args()
     ctx = _lib.Context(0)
+    ctx.set_timing(True)
     _lib.set_default_context(ctx)
     wl1 = synthetic.make_workload(a.config, S=1)
     wl8 = synthetic.make_workload(a.config, S=8)
