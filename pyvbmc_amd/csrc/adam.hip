@@ -4,19 +4,25 @@
 // _neg_elcbo(theta, gp, vp, beta, NsK, compute_grad=True, theta_bnd=...)
 // (vbmc/variational_optimization.py:238-249) once per iteration and updates theta on the
 // host: one host<->device round trip, one synchronisation and ~50 us of host arithmetic
-// per iteration.  Here one iteration is four launches on one stream and no
-// synchronisation:
-//     elbo_prep_kernel -> entmc_ws_kernel -> entmc_finish_kernel [-> all-reduce] ->
-//     adam_step_kernel
-// adam_step_kernel (one workgroup) does everything the host did between two entropy
-// launches: GP-sum finalisation (api_gp.hip glj_finalize), entropy Jacobians
-// (api_entropy.hip entropy_pack), soft bounds + weight penalty (api_elbo.hip), the Adam
-// update with the box clamp, the in-place max-shift of the eta tail
-// (variational_optimization.py:1082-1085 -- minimize_adam's x IS the array _neg_elcbo
-// shifts), set_parameters with the lambda renormalisation
-// (variational_posterior.py:680-759) and the mixture pack of the next iterate.
-// The host only decides when to stop (every batch_size = 20 iterations, as the reference
-// does) from the y_tab / x_tab rows it copies back.
+// per iteration.  Here one iteration is four launches on ONE stream and no
+// synchronisation, ordered by the stream alone (no events: a record between two dependent
+// kernels opens a ~6 us gap on MI355X, a cross-queue wait up to 13 us):
+//     elbo_prep_kernel      entropy table rows + GP sums        (+ last third of the draws)
+//  -> entmc_ws_kernel       Monte-Carlo entropy sums, and as one extra grid row the "pre"
+//                           workgroup (adam_dev.h): everything of dF that does not need the
+//                           entropy -- GP-sum finalisation (host twin: api_gp.hip glj_finalize),
+//                           soft bounds + weight penalty (api_elbo.hip), their Jacobians
+//  -> entmc_finish_kernel   reduction of the entropy partials   (+ first fifth of the next draws)
+//  [-> all-reduce]          multi-rank only
+//  -> adam_step_kernel      entropy Jacobians (api_entropy.hip entropy_pack), Adam update with
+//                           the box clamp, the in-place max-shift of the eta tail
+//                           (variational_optimization.py:1082-1085 -- minimize_adam's x IS the
+//                           array _neg_elcbo shifts), set_parameters with the lambda
+//                           renormalisation (variational_posterior.py:680-759) and the mixture
+//                           pack of the next iterate           (+ about half of the next draws)
+// The Philox draws of iteration i + 1 are produced by spare workgroups of the three short
+// launches, during which the GPU is otherwise idle.  The host only decides when to stop (every
+// batch_size = 20 iterations, as the reference does) from the y_tab / x_tab rows it copies back.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -31,9 +37,11 @@ using namespace adam_dev;
 namespace {
 
 // set_parameters(theta) + eta max-shift + mixture pack; theta's eta tail is shifted in
-// place.  theta / aux may live in LDS; the pack goes to a.mix.
+// place.  theta / aux may live in LDS; the pack goes to a.mix.  Two reduction rounds:
+// (sum lambda^2, max eta), then (sum exp(eta - max), prod lambda); red needs 16 doubles.
 __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, double* red) {
   const int D = a.D, K = a.K, tid = threadIdx.x, n = a.n_theta;
+  const int lane = tid & 63, wave = tid >> 6;
   const bool o_mu = a.mask & 1, o_sg = a.mask & 2, o_lm = a.mask & 4, o_w = a.mask & 8;
   const int p_sg = o_mu ? D * K : 0, p_lm = p_sg + (o_sg ? K : 0), p_w = n - K;
   double* mu = aux;
@@ -44,69 +52,84 @@ __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, do
   int bad = 0;
   for (int i = tid; i < n; i += 256) bad |= !isfinite(theta[i]);
   if (bad) atomicOr(a.status, 1);
-  if (o_mu)
-    for (int i = tid; i < D * K; i += 256) mu[i] = theta[i];
-  if (o_sg)
-    for (int k = tid; k < K; k += 256) sg[k] = exp(theta[p_sg + k]);
-  if (o_lm)
-    for (int d = tid; d < D; d += 256) lm[d] = exp(theta[p_lm + d]);
-  if (o_w) {
-    double mx = -INFINITY;
+  // ---- round 1: raw lambda and its sum of squares; max of the eta tail ----
+  double s2 = 0.0, mx = -INFINITY;
+  for (int d = tid; d < D; d += 256) {
+    const double l = o_lm ? exp(theta[p_lm + d]) : lm[d];
+    lm[d] = l;
+    s2 = fma(l, l, s2);
+  }
+  if (o_w)
     for (int k = tid; k < K; k += 256) mx = fmax(mx, theta[p_w + k]);
-    mx = block_max(mx, red);
+  s2 = wave_sum(s2);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+  __syncthreads();
+  if (lane == 0) {
+    red[wave] = s2;
+    red[4 + wave] = mx;
+  }
+  __syncthreads();
+  s2 = (red[0] + red[1]) + (red[2] + red[3]);
+  mx = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+  const double nl = sqrt(s2 / D);  // lambda -> unit RMS, sigma absorbs it
+  // ---- round 2: unnormalised weights and their sum; product of the normalised lambdas ----
+  double wsum = 0.0, pr = 1.0;
+  if (o_w)
     for (int k = tid; k < K; k += 256) {
       const double e = theta[p_w + k] - mx;
       theta[p_w + k] = e;
       eta[k] = e;
-      w[k] = exp(e);
+      const double we = exp(e);
+      w[k] = we;
+      wsum += we;
     }
-  }
-  __syncthreads();
-  // lambda -> unit RMS, sigma absorbs it; weights normalised
-  double s2 = 0.0, wsum = 0.0;
-  for (int d = tid; d < D; d += 256) s2 += lm[d] * lm[d];
-  if (o_w)
-    for (int k = tid; k < K; k += 256) wsum += w[k];
-  s2 = block_sum(s2, red);
-  wsum = block_sum(wsum, red);
-  const double nl = sqrt(s2 / D);
-  __syncthreads();
-  for (int d = tid; d < D; d += 256) lm[d] /= nl;
-  for (int k = tid; k < K; k += 256) {
-    sg[k] *= nl;
-    if (o_w) w[k] /= wsum;
-  }
-  __syncthreads();
-  if (tid < 64) {
-    double pr = 1.0;
-    for (int d = tid; d < D; d += 64) pr *= lm[d];
+  for (int d = tid; d < D; d += 256) pr *= lm[d] / nl;  // this thread's own entries of round 1
+  wsum = wave_sum(wsum);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) pr *= __shfl_xor(pr, off, 64);
-    if (tid == 0) red[8] = 1.0 / pow(2.0 * M_PI, 0.5 * D) / pr;
+  for (int off = 32; off > 0; off >>= 1) pr *= __shfl_xor(pr, off, 64);
+  if (lane == 0) {
+    red[8 + wave] = wsum;
+    red[12 + wave] = pr;
   }
   __syncthreads();
-  const double nconst = red[8];
+  wsum = (red[8] + red[9]) + (red[10] + red[11]);
+  pr = (red[12] * red[13]) * (red[14] * red[15]);
+  const double nconst = a.c_norm / pr;  // 1 / (2 pi)^(D/2) / prod(lambda)   (entmc_vbmc.py:54-56)
   const double l2n = log2(nconst);
+  // ---- the pack and the final attributes (lm stays raw until every reader is through) ----
   const MixLayout& ml = a.ml;
   double* p = a.mix;
   for (int i = tid; i < K * D; i += 256) {
     const int d = i % D;
-    p[ml.o_mu + i] = mu[i];
-    p[ml.o_mup + i] = mu[i] / lm[d];
+    const double m = o_mu ? theta[i] : mu[i];
+    mu[i] = m;
+    p[ml.o_mu + i] = m;
+    p[ml.o_mup + i] = m / (lm[d] / nl);
   }
   for (int k = tid; k < K; k += 256) {
-    const double s = sg[k];
-    const double sD = pow(s, (double)D);
+    const double s = (o_sg ? exp(theta[p_sg + k]) : sg[k]) * nl;
+    const double wk = o_w ? w[k] / wsum : w[k];
+    double sD = 1.0, b = s;  // sigma^D by repeated squaring, as the host pack (ctx.hip)
+    for (int e = D; e > 0; e >>= 1) {
+      if (e & 1) sD *= b;
+      b *= b;
+    }
+    sg[k] = s;
+    w[k] = wk;
     p[ml.o_is2 + k] = 1.0 / (s * s);
     p[ml.o_rc + k] = nconst / sD;
     p[ml.o_lrc + k] = l2n - D * log2(s);
-    p[ml.o_wc + k] = w[k] * nconst / sD;
+    p[ml.o_wc + k] = wk * nconst / sD;
     p[ml.o_sig + k] = s;
-    p[ml.o_w + k] = w[k];
+    p[ml.o_w + k] = wk;
   }
+  __syncthreads();
   for (int d = tid; d < D; d += 256) {
-    p[ml.o_lam + d] = lm[d];
-    p[ml.o_ilam + d] = 1.0 / lm[d];
+    const double l = lm[d] / nl;
+    lm[d] = l;
+    p[ml.o_lam + d] = l;
+    p[ml.o_ilam + d] = 1.0 / l;
   }
 }
 
@@ -200,8 +223,15 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamDev a, int do_step, 
         ps += e;
         pd += e * (k == tid ? rw : raw[f_w + k]);
       }
-      sm_s = block_sum(ps, red);
-      sm_dot = block_sum(pd, red);
+      ps = wave_sum(ps);
+      pd = wave_sum(pd);
+      if ((tid & 63) == 0) {
+        red[tid >> 6] = ps;
+        red[4 + (tid >> 6)] = pd;
+      }
+      __syncthreads();
+      sm_s = (red[0] + red[1]) + (red[2] + red[3]);
+      sm_dot = (red[4] + red[5]) + (red[6] + red[7]);
     }
     if (tid == 0) {
       const double G = a.pre[n], loss = a.pre[n + 1], H = raw[0];
@@ -283,10 +313,6 @@ struct AdamState {
   double* d_eps1 = nullptr;  // [K][row_count][D]
   size_t eps_cap = 0;        // doubles allocated
   bool eps_started = false;  // the buffer already holds the finish/step slices of the next iteration
-  // a captured batch of graph_len iterations, replayed by vbmc_adam_run calls of that length
-  hipGraphExec_t graph_exec = nullptr;
-  int graph_len = 0;
-  int runs = 0;  // vbmc_adam_run calls since vbmc_adam_begin
 };
 
 static AdamState* adam_of(vbmc_ctx* ctx) {
@@ -299,7 +325,6 @@ void adam_free(vbmc_ctx* ctx) {
   if (!st) return;
   if (st->d_buf) (void)hipFree(st->d_buf);
   if (st->d_status) (void)hipFree(st->d_status);
-  if (st->graph_exec) (void)hipGraphExecDestroy(st->graph_exec);
   if (st->d_eps1) (void)hipFree(st->d_eps1);
   if (st->d_args) (void)hipFree(st->d_args);
   delete st;
@@ -342,6 +367,7 @@ static void fill_dev(const vbmc_ctx* ctx, const AdamState& st, AdamDev& a) {
   a.fudge = std::sqrt(2.220446049250313e-16);  // sqrt(np.spacing(1))
   a.beta1 = 0.9;
   a.beta2 = 0.999;
+  a.c_norm = 1.0 / std::pow(2.0 * M_PI, 0.5 * ctx->D);
   a.master_min = st.master_min;
   a.master_max = st.master_max;
   a.master_decay = st.master_decay;
@@ -445,11 +471,6 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
   if (rc) return rc;
   if (!st->d_status) HIP_TRY(ctx, hipMalloc((void**)&st->d_status, 2 * sizeof(int)));  // flag, iteration base
   if (!st->d_args) HIP_TRY(ctx, hipMalloc((void**)&st->d_args, sizeof(AdamDev)));
-  if (st->graph_exec) {  // captured for the previous problem
-    HIP_TRY(ctx, hipGraphExecDestroy(st->graph_exec));
-    st->graph_exec = nullptr;
-  }
-  st->runs = 0;
   st->state = st->d_buf;
   st->work = st->state + L.end();
   st->ee = st->work + n_work;
@@ -513,7 +534,7 @@ static double env_frac(const char* name, double dflt) {
 
 // One batch of iterations [i0, i0 + n_iters): four launches per iteration on one stream,
 //   prep (table rows + GP sums) -> entropy (+ the pre row) -> finish [-> all-reduce] -> step,
-// ordered by the stream alone, so the same sequence can be launched directly or captured.
+// ordered by the stream alone.
 static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool multi) {
   hipStream_t sm = ctx->stream;
   AdamDev a;
@@ -594,43 +615,7 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
   int rc = 0;
   // the iteration base every kernel of this call adds its launch-constant offset to
   hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, ctx->stream, st->d_status + 1, i0);
-  // A batch whose draws are resident or generated ahead contains no per-iteration host value, so
-  // it can be captured once and replayed.  The first call after vbmc_adam_begin always launches
-  // directly (it sizes every scratch buffer); so does a multi-rank loop (the collective stays an
-  // ordinary RCCL call) and any call of a different length.
-  static const bool graphs_on = [] {
-    const char* e = getenv("VBMC_ADAM_GRAPH");
-    return !(e && e[0] == '0');
-  }();
-  const bool graphable = graphs_on && !multi && n_iters >= 4 && st->runs >= 1 &&
-                         (st->pregen || st->eps_mode == VBMC_EPS_RESIDENT);
-  st->runs++;
-  if (graphable && st->graph_exec && st->graph_len != n_iters) {
-    HIP_TRY(ctx, hipGraphExecDestroy(st->graph_exec));
-    st->graph_exec = nullptr;
-  }
-  if (graphable && !st->graph_exec) {
-    hipGraph_t graph = nullptr;
-    HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
-    rc = enqueue_batch(ctx, st, i0, n_iters, false);
-    const hipError_t e_end = hipStreamEndCapture(ctx->stream, &graph);  // also ends a failed capture
-    if (rc == 0 && e_end != hipSuccess) rc = vbmc_fail(ctx, VBMC_E_HIP, "adam_run: stream capture: %s", hipGetErrorString(e_end));
-    if (rc == 0) {
-      const hipError_t e_inst = hipGraphInstantiate(&st->graph_exec, graph, nullptr, nullptr, 0);
-      if (e_inst != hipSuccess) {
-        st->graph_exec = nullptr;
-        rc = vbmc_fail(ctx, VBMC_E_HIP, "adam_run: graph instantiate: %s", hipGetErrorString(e_inst));
-      }
-    }
-    if (graph) (void)hipGraphDestroy(graph);
-    if (rc) return rc;
-    st->graph_len = n_iters;
-  }
-  if (graphable) {
-    HIP_TRY(ctx, hipGraphLaunch(st->graph_exec, ctx->stream));
-  } else {
-    rc = enqueue_batch(ctx, st, i0, n_iters, multi);
-  }
+  rc = enqueue_batch(ctx, st, i0, n_iters, multi);
   if (rc) return rc;
   HIP_TRY(ctx, hipGetLastError());
   st->iter = i0 + n_iters;
@@ -644,7 +629,7 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
                                   hipMemcpyDeviceToHost, ctx->stream));
   }
   HIP_TRY(ctx, hipMemcpyAsync(&status, st->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
   for (int it = 0; it < n_iters; ++it) {
     if (y_tab_out) y_tab_out[it] = y3[3 * (size_t)it];
     if (G_out) G_out[it] = y3[3 * (size_t)it + 1];
@@ -669,7 +654,7 @@ extern "C" int vbmc_adam_end(vbmc_ctx* ctx, double* theta_out, double* mu_KxD, d
   std::vector<double> aux(n_aux), th(st->n_theta);
   HIP_TRY(ctx, hipMemcpyAsync(aux.data(), st->state + st->lay.o_aux(), sizeof(double) * n_aux, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(th.data(), st->state + st->lay.o_theta(), sizeof(double) * st->n_theta, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
   // the device pack in d_mix is the mixture of the last iterate: make the host copies agree
   ctx->mu.assign(aux.begin(), aux.begin() + K * D);
   ctx->sigma.assign(aux.begin() + K * D, aux.begin() + K * D + K);

@@ -35,10 +35,13 @@ struct AdamDev {
   double* pre;    // [n_theta + 2]: the part of dF that does not depend on the entropy, then G, loss
   double tol_con, w_thresh, w_pen;
   double fudge, beta1, beta2;
+  double c_norm;  // 1 / (2 pi)^(D/2)
   double master_min, master_max, master_decay;  // step-size schedule (minimize_adam.py:92-98)
   // The iteration index is iter_base[0] + it_off: the base lives in device memory (set once per
-  // vbmc_adam_run call) and the offset is a launch constant, so that a captured batch of
-  // iterations (hipGraph) can be replayed unchanged for every batch.
+  // vbmc_adam_run call) and the offset is a launch constant, so the launch arguments of a batch
+  // do not depend on where in the optimisation it starts.  (That makes a batch replayable as a
+  // hipGraph; measured, the replay gains nothing -- 4 launches cost the host ~20 us against
+  // >= 50 us of device time per iteration -- so batches are launched directly.)
   const int* iter_base;
   int it_off;
   double* x_tab;  // [max_iter][n_theta]

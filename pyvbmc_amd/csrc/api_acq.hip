@@ -141,7 +141,7 @@ extern "C" int vbmc_acq_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int
     if (var_tot_M)
       HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned + 2 * mb, d_acq + 2 * mb, sizeof(double) * m,
                                   hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx));
     memcpy(acq_M + o, ctx->h_pinned, sizeof(double) * m);
     if (f_bar_M) memcpy(f_bar_M + o, ctx->h_pinned + mb, sizeof(double) * m);
     if (var_tot_M) memcpy(var_tot_M + o, ctx->h_pinned + 2 * mb, sizeof(double) * m);
@@ -198,7 +198,7 @@ extern "C" int vbmc_sq_dist(vbmc_ctx* ctx, int64_t n, int64_t m, int D, const do
       HIP_TRY(ctx, hipMemcpyAsync(c_nxm + o * m, d_c, sizeof(double) * cnt * m, hipMemcpyDeviceToHost, ctx->stream));
     if (argmin_n)
       HIP_TRY(ctx, hipMemcpyAsync(argmin_n + o, d_am, sizeof(int64_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx));
   }
   return VBMC_OK;
 }

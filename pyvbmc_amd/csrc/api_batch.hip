@@ -124,7 +124,7 @@ extern "C" int vbmc_neg_elcbo_batch(vbmc_ctx* ctx, const double* thetas_BxN, int
   }
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, d_res, sizeof(double) * (n_res * (1 + 2 * D) + n_H),
                               hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
 
   // ---- host finalisation per candidate (glj_finalize's value part + bound losses) ---------------
   const GpState& g = ctx->gp;

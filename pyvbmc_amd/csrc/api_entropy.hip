@@ -103,7 +103,7 @@ int vbmc_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
   }
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_out, sizeof(double) * n, hipMemcpyDeviceToHost,
                               ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
   if (raw_out) memcpy(raw_out, ctx->h_pinned, sizeof(double) * n);
   return vbmc_entmc_finalize(ctx, ctx->h_pinned, grad_flags, jacobian_flag, H, dH);
 }
@@ -133,7 +133,7 @@ int vbmc_entlb(vbmc_ctx* ctx, int grad_flags, int jacobian_flag, double* H, doub
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_out, sizeof(double) * n, hipMemcpyDeviceToHost,
                               ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
   const double* r = ctx->h_pinned;
   entropy_pack(ctx, r[0], r + 1, r + 1 + D * K, r + 1 + D * K + K, r + 1 + D * K + K + D,
                grad_flags, jacobian_flag, H, dH);

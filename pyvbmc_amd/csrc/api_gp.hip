@@ -20,7 +20,7 @@ extern "C" int vbmc_set_gp(vbmc_ctx* ctx, int N, int D, int S, int P, int mean_k
                      D + 2 + mean_n);
   NEED_DEVICE(ctx);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
   GpState& g = ctx->gp;
   double** bufs[] = {&g.d_X, &g.d_alpha, &g.d_L, &g.d_Linv, &g.d_sW, &g.d_hyp, &g.d_xc, &g.d_smeta};
   for (double** b : bufs)
@@ -70,7 +70,7 @@ extern "C" int vbmc_set_gp(vbmc_ctx* ctx, int N, int D, int S, int P, int mean_k
   // L^-1 of the Cholesky samples, once per GP update
   int rc = launch_trinv(ctx);
   if (rc) return rc;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
   g.set = true;
   return VBMC_OK;
 }
@@ -207,7 +207,7 @@ extern "C" int vbmc_gp_log_joint(vbmc_ctx* ctx, int grad_flags, int avg_flag, in
   }
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, d_res, sizeof(double) * n_res, hipMemcpyDeviceToHost,
                               ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
 
   GljHost o;
   glj_finalize(ctx, ctx->h_pinned, grad_flags != 0, o);
@@ -320,7 +320,7 @@ extern "C" int vbmc_gp_predict(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, i
     ctx->ev_valid[3] = true;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, d_fmu, sizeof(double) * 2 * S * mb, hipMemcpyDeviceToHost,
                                 ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx));
     for (int s = 0; s < S; ++s) {
       const double* hm = ctx->h_pinned + (size_t)s * mb;
       const double* hv = ctx->h_pinned + (size_t)(S + s) * mb;

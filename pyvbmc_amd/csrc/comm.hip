@@ -125,7 +125,7 @@ int vbmc_comm_allreduce_max(vbmc_ctx* ctx, double* value_inout) {
                                  (ncclComm_t)ctx->comm, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(value_inout, ctx->d_out, sizeof(double), hipMemcpyDeviceToHost,
                               ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
   return VBMC_OK;
 }
 

@@ -24,7 +24,7 @@ int ensure_dev(vbmc_ctx* ctx, double** p, size_t* cap, size_t n) {
   if (*cap >= n && *p) return 0;
   // never free under a running kernel: the stream is in-order, sync first
   if (*p) {
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx));
     HIP_TRY(ctx, hipFree(*p));
     *p = nullptr;
     *cap = 0;
@@ -38,7 +38,7 @@ int ensure_dev(vbmc_ctx* ctx, double** p, size_t* cap, size_t n) {
 int ensure_pinned(vbmc_ctx* ctx, size_t n) {
   if (ctx->h_pinned_cap >= n && ctx->h_pinned) return 0;
   if (ctx->h_pinned) {
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx));
     HIP_TRY(ctx, hipHostFree(ctx->h_pinned));
     ctx->h_pinned = nullptr;
     ctx->h_pinned_cap = 0;
@@ -91,7 +91,6 @@ int vbmc_ctx_create(int device_id, vbmc_ctx** out) {
   if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_id);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   for (int i = 0; i < 10 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pack_ev, hipEventDisableTiming);
   if (e != hipSuccess) {
     int rc = vbmc_fail(nullptr, VBMC_E_HIP, "context setup failed: %s", hipGetErrorString(e));
     delete ctx;
@@ -127,7 +126,6 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
   for (int i = 0; i < 10; ++i)
     if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
-  if (ctx->pack_ev) (void)hipEventDestroy(ctx->pack_ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -153,7 +151,7 @@ int vbmc_synchronize(vbmc_ctx* ctx) {
   if (!ctx) return VBMC_E_ARG;
   if (ctx->device < 0) return VBMC_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
   return VBMC_OK;
 }
 
@@ -264,7 +262,7 @@ static int upload_mixture(vbmc_ctx* ctx) {
   if (ctx->device < 0) return 0;  // host-only context keeps just the host copies
   if (ctx->h_pack_cap < (size_t)ml.total) {
     if (ctx->h_pack) {
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      HIP_TRY(ctx, stream_wait(ctx));
       HIP_TRY(ctx, hipHostFree(ctx->h_pack));
       ctx->h_pack = nullptr;
     }
@@ -273,18 +271,19 @@ static int upload_mixture(vbmc_ctx* ctx) {
     ctx->h_pack_cap = want;
   }
   if (ctx->pack_in_flight) {
-    // the pinned pack may still be the source of the previous asynchronous upload
-    HIP_TRY(ctx, hipEventSynchronize(ctx->pack_ev));
+    // The pinned pack may still be the source of the previous asynchronous upload.  Entry points
+    // that wait for the stream anyway clear the flag (every ELBO evaluation does); this wait is
+    // for back-to-back uploads only.  (No event: a record in front of the prep launch costs ~6 us.)
+    HIP_TRY(ctx, stream_wait(ctx));
     ctx->pack_in_flight = false;
   }
   double* p = ctx->h_pack;
   write_mixture_pack(ml, ctx->mu.data(), ctx->sigma.data(), ctx->lambd.data(), ctx->w.data(), p);
   int rc = ensure_dev(ctx, &ctx->d_mix, &ctx->d_mix_cap, (size_t)ml.total);
   if (rc) return rc;
-  // pinned source: a true asynchronous copy (pack_ev guards the buffer's reuse)
+  // pinned source: a true asynchronous copy (pack_in_flight guards the buffer's reuse)
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mix, p, sizeof(double) * ml.total, hipMemcpyHostToDevice,
                               ctx->stream));
-  HIP_TRY(ctx, hipEventRecord(ctx->pack_ev, ctx->stream));
   ctx->pack_in_flight = true;
   ctx->pack_valid = true;
   return 0;
@@ -378,7 +377,7 @@ int vbmc_set_eps(vbmc_ctx* ctx, int K, int64_t n_half, int D, const double* eps_
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)row_count * D,
                                 hipMemcpyHostToDevice, ctx->stream));
   }
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
   ctx->eps_K = K;
   ctx->eps_D = D;
   ctx->eps_rows = row_count;

@@ -225,7 +225,7 @@ extern "C" int vbmc_mixture_pdf(vbmc_ctx* ctx, int64_t n, const double* x_nxD, i
     if (grad_flag)
       HIP_TRY(ctx, hipMemcpyAsync(dy_nxD + o * D, d_dy, sizeof(double) * m * D,
                                   hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx));
   }
   return VBMC_OK;
 }

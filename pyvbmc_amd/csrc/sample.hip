@@ -153,7 +153,7 @@ int launch_sample(vbmc_ctx* ctx, const double* d_pack, const MixLayout& ml, cons
   double* d_cdf = (double*)(d_cum + K + 1);
   HIP_TRY(ctx, hipMemcpyAsync(d_cum, s.cum.data(), sizeof(int64_t) * (K + 1), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d_cdf, s.cdf.data(), sizeof(double) * K, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the selector vectors are locals
+  HIP_TRY(ctx, stream_wait(ctx));  // the selector vectors are locals
   SampleArgs a;
   a.mix = d_pack;
   a.ml = ml;
@@ -197,7 +197,7 @@ extern "C" int vbmc_mixture_sample(vbmc_ctx* ctx, int64_t N, uint64_t seed, int 
     HIP_TRY(ctx, hipMemcpyAsync(x_NxD, d_x, sizeof(double) * n_x, hipMemcpyDeviceToHost, ctx->stream));
   if (comp_N)
     HIP_TRY(ctx, hipMemcpyAsync(comp_N, d_c, sizeof(int32_t) * N, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
   return VBMC_OK;
 }
 
@@ -228,7 +228,7 @@ extern "C" int vbmc_kl_div_mc(vbmc_ctx* ctx, int64_t N, uint64_t seed, int K2, c
   void* d_sel = (void*)(d_y2 + N);
   double* d_part = (double*)d_sel + 2 * Kmax + 2;
   HIP_TRY(ctx, hipMemcpyAsync(d_pack2, pack2.data(), sizeof(double) * ml2.total, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
   std::vector<double> part(2 * (size_t)nblk);
   for (int dir = 0; dir < 2; ++dir) {
     // dir 0: samples of this mixture (xx1, :1110); dir 1: samples of vp2 (xx2, :1117)
@@ -247,7 +247,7 @@ extern "C" int vbmc_kl_div_mc(vbmc_ctx* ctx, int64_t N, uint64_t seed, int K2, c
     HIP_TRY(ctx, hipGetLastError());
   }
   HIP_TRY(ctx, hipMemcpyAsync(part.data(), d_part, sizeof(double) * 2 * nblk, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
   for (int dir = 0; dir < 2; ++dir) {
     double s = 0.0;
     for (int b = 0; b < nblk; ++b) s += part[(size_t)dir * nblk + b];
