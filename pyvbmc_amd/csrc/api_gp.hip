@@ -313,11 +313,13 @@ extern "C" int vbmc_gp_predict(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, i
     HIP_TRY(ctx, hipMemcpyAsync(d_xs, xs_MxD + o * D, sizeof(double) * m * D, hipMemcpyHostToDevice,
                                 ctx->stream));
     // every hyper-parameter sample in the same three launches (grid.z = sample)
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     rc = launch_gp_predict_all(ctx, m, d_xs, d_Ks, d_part, add_noise, d_fmu, d_fs2, mb);
     if (rc) return rc;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
-    ctx->ev_valid[3] = true;
+    if (ctx->timing) {
+      HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+      ctx->ev_valid[3] = true;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, d_fmu, sizeof(double) * 2 * S * mb, hipMemcpyDeviceToHost,
                                 ctx->stream));
     HIP_TRY(ctx, stream_wait(ctx));

@@ -146,7 +146,7 @@ int launch_mixture_pdf(vbmc_ctx* ctx, int64_t n, const double* d_x, int log_flag
                     (double)D) /
            prod_lam;
   }
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
   if (D <= 2) launch_dp<2>(ctx, a);
   else if (D <= 4) launch_dp<4>(ctx, a);
   else if (D <= 6) launch_dp<6>(ctx, a);
@@ -157,8 +157,10 @@ int launch_mixture_pdf(vbmc_ctx* ctx, int64_t n, const double* d_x, int log_flag
   else if (D <= 20) launch_dp<20>(ctx, a);
   else if (D <= 24) launch_dp<24>(ctx, a);
   else launch_dp<32>(ctx, a);
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
-  ctx->ev_valid[2] = true;
+  if (ctx->timing) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    ctx->ev_valid[2] = true;
+  }
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }

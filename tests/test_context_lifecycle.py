@@ -72,3 +72,27 @@ def test_alternating_shapes_two_contexts_and_pickling():
         b.close()
     with pytest.raises(Exception):
         objective(shapes[0], *make(shapes[0], a)[1:], 1)  # a closed context refuses work
+
+
+@pytest.mark.gpu
+def test_kernel_timing_is_opt_in():
+    """The HIP event pair around the dominant kernels is off by default (each record costs a
+    barrier packet between dependent kernels); vbmc_set_timing switches it on per context."""
+    from pyvbmc_amd import _lib, synthetic
+    from pyvbmc_amd.entropy import entmc_vbmc
+    from test_gpu_parity import make_vp
+
+    ctx = _lib.Context(0)
+    wl = synthetic.make_workload(1)
+    wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta)
+    vp = make_vp(wd, ctx)
+    entmc_vbmc(vp, wl.NsK, (True,) * 4, True, rng="philox", seed=1, ctx=ctx)
+    with pytest.raises(ValueError):
+        ctx.last_kernel_ms(0)  # nothing was timed
+    ctx.set_timing(True)
+    H1 = entmc_vbmc(vp, wl.NsK, (True,) * 4, True, rng="philox", seed=1, ctx=ctx)[0]
+    assert 0.0 < ctx.last_kernel_ms(0) < 100.0
+    ctx.set_timing(False)
+    H2 = entmc_vbmc(vp, wl.NsK, (True,) * 4, True, rng="philox", seed=1, ctx=ctx)[0]
+    assert H1 == H2
+    ctx.close()

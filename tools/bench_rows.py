@@ -52,7 +52,17 @@ def main():
     ap.add_argument("--config", type=int, default=3)
     a = ap.parse_args()
     ctx = _lib.Context(0)
-    ctx.set_timing(True)
+
+    def kernel_ms(fn, which):
+        """One extra call with the HIP event pair around the dominant kernel switched on (the rows'
+        wall times are taken with it off: each record costs ~6 us)."""
+        ctx.set_timing(True)
+        try:
+            fn()
+            return ctx.last_kernel_ms(which)
+        finally:
+            ctx.set_timing(False)
+
     _lib.set_default_context(ctx)
     wl1 = synthetic.make_workload(a.config, S=1)
     wl8 = synthetic.make_workload(a.config, S=8)
@@ -92,10 +102,10 @@ def main():
         t, y = med(lambda: vp.pdf(x, orig_flag=False, log_flag=True), reps=5)
         ns = min(n, 20000)
         tc, yo = once(lambda: mixture_ref.pdf(mix, x[:ns], log_flag=True))
-        ctx.last_kernel_ms(2)
         emit("a3 vp.pdf(log)", "variational_posterior.py:365-564", f"n={n} D={D} K={K}", t, tc * n / ns,
              f"oracle on {ns} points, scaled", rel(y[:ns], yo),
-             {"kernel_ms": ctx.last_kernel_ms(2), "algorithmic_bytes": 8.0 * n * (D + 1)})
+             {"kernel_ms": kernel_ms(lambda: vp.pdf(x, orig_flag=False, log_flag=True), 2),
+              "algorithmic_bytes": 8.0 * n * (D + 1)})
     t, (y, dy) = med(lambda: vp.pdf(x[:8192], orig_flag=False, log_flag=True, grad_flag=True), reps=5)
     tc, (yo, dyo) = once(lambda: mixture_ref.pdf(mix, x[:8192], log_flag=True, grad_flag=True))
     emit("a3 vp.pdf(log,grad)", "variational_posterior.py:464-469,532", f"n=8192 D={D} K={K}", t, tc, "full", rel(dy, dyo))
@@ -113,7 +123,8 @@ def main():
         Hd, dHd = entmc_vbmc(mkvp(wl1), nsk, gf, True, eps_half=eps)
         err = rel(Hd, Ho) if not dHo.size else max(rel(Hd, Ho), rel(dHd, dHo))
         emit(f"a6 entmc_vbmc {tag}", "entropy/entmc_vbmc.py:6-134", f"D={D} K={K} NsK={wl1.NsK}", t,
-             tc * wl1.NsK / nsk, f"oracle at NsK={nsk}, scaled", err, {"kernel_ms": ctx.last_kernel_ms(0)})
+             tc * wl1.NsK / nsk, f"oracle at NsK={nsk}, scaled", err,
+             {"kernel_ms": kernel_ms(lambda: entmc_vbmc(vpp, wl1.NsK, gf, True, rng="philox", seed=5), 0)})
         tc_entmc_grad = tc * wl1.NsK / nsk  # the gradient pass (last) stands in for one Adam objective
     # ---- a8: _gp_log_joint -------------------------------------------------------
     for wl, tag in ((wl1, "S=1"), (wl8, "S=8")):
@@ -139,7 +150,8 @@ def main():
         err = max(np.max(np.abs(fmu[:ms] - omu)) / max(1.0, np.max(np.abs(omu))), np.max(np.abs(fs2[:ms] - os2)) / max(1.0, sf2))
         emit(f"a12 gp.predict {tag}", "gpyreg GP.predict (third party; SURVEY App. A)", f"M={M} N={N} D={D} {tag}",
              t, tc * M / ms, f"oracle on {ms} points, scaled", float(err),
-             {"kernel_ms_first_sample": ctx.last_kernel_ms(3), "gemm_flops": 1.0 * M * N * N})
+             {"kernel_ms_first_sample": kernel_ms(lambda: g.predict(xs, separate_samples=True), 3),
+              "gemm_flops": 1.0 * M * N * N})
     # ---- a9 secondary: _eval_full_elcbo call (value, variance, separate_K) -------------
     g, ogp = mkgp(wl1), gp_ref.make_gp(wl1.X, wl1.y, wl1.hyp)
     nsk = 4096
