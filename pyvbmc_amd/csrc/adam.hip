@@ -571,8 +571,13 @@ static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool
       return !(e && e[0] == '0');
     }();
     const bool pre_row = pre_row_on && plan.ws && plan.a.eps_mode != VBMC_EPS_PHILOX;
-    if (pre_row) plan.a.extra = st->d_args;
-    else launch_pre(*st, sm, a);
+    if (pre_row) {
+      plan.a.extra = st->d_args;
+      // its working set in LDS when two entropy workgroups per CU still fit beside it
+      plan.a.extra_lds = (st->pre_lds && st->pre_lds_bytes <= 60 * 1024) ? (int)(st->pre_lds_bytes / sizeof(double)) : 0;
+    } else {
+      launch_pre(*st, sm, a);
+    }
     rc = entmc_launch_main(ctx, plan);
     if (rc) return rc;
     const GenSlice g_fin = use_gen ? slice(it + 1, 0.0, f_fin) : GenSlice();

@@ -61,26 +61,6 @@ static __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// all four waves get the sum; red[0..3] is scratch (barriers on both sides)
-static __device__ double block_sum(double v, double* red) {
-  const int tid = threadIdx.x;
-  v = wave_sum(v);
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
-}
-
-static __device__ double block_max(double v, double* red) {
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-}
-
 // ---------------------------------------------------------------------------
 // The "pre" workgroup: everything of one iteration's dF that does NOT depend on the Monte-Carlo
 // entropy.  It runs as an extra row of the entropy launch (entropy_ws.hip), i.e. beside the entropy
@@ -101,7 +81,7 @@ static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red) 
   const AdamLayout& L = a.lay;
   if (LDS) {
     const int cnt = L.o_raw();
-    constexpr int U = 16;
+    constexpr int U = 24;  // BASELINE config 3 (4 493 doubles) in one batch of loads
     for (int base = 0; base < cnt; base += 256 * U) {
       double r[U];
 #pragma unroll
@@ -154,8 +134,9 @@ static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red) 
   }
   __syncthreads();
 
-  // ---- GP expected log joint, in two steps so that all 256 lanes work: per (k, d) term
-  // first, per component after the barrier ----
+  // ---- phase 1 (all 256 lanes, two independent jobs):
+  //  * GP expected log joint, per (k, d) term (host twin: api_gp.hip glj_finalize)
+  //  * soft bounds (_vp_bound_loss :537-606): gradient dL and this thread's share of the loss
   for (int idx = tid; idx < K * D; idx += 256) {
     const int k = idx / D, d = idx - k * D;
     const double sgk = sg[k], wk = w[k], lam = lm[d], m = mu[idx];
@@ -179,46 +160,6 @@ static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red) 
     tgs[idx] = gs_acc;
     tnu[idx] = nu_acc;
   }
-  __syncthreads();
-  double gpart = 0.0;
-  for (int k = tid; k < K; k += 256) {
-    const double sgk = sg[k], wk = w[k];
-    double gs = 0.0, nu = 0.0, b0 = 0.0, qbar = 0.0;
-    for (int d = 0; d < D; ++d) {
-      gs += tgs[k * D + d];
-      nu += tnu[k * D + d];
-    }
-    for (int s = 0; s < S; ++s) {
-      const double* h = hyp + (size_t)s * a.P;
-      b0 += (res[((size_t)s * K + k) * st] + (a.mean_kind == VBMC_MEAN_ZERO ? 0.0 : h[D + 2])) / S;
-      if (quad)
-        for (int d = 0; d < D; ++d) qbar += iom2[s * D + d] * lm[d] * lm[d] / S;
-    }
-    const double wI = b0 - 0.5 * nu;  // mean over s of I_sk
-    gpart += wk * wI;
-    gsg[k] = wk * sgk * (gs - qbar);
-    gw[k] = -wI;  // d(-G)/dw_k; the entropy part is the step kernel's, the penalty comes below
-  }
-  // ---- lambda gradient: one wave per dimension, lanes over the (s, k) terms ----
-  for (int d = wave; d < D; d += 4) {
-    const double lam = lm[d];
-    double acc = 0.0;
-    for (int idx = lane; idx < S * K; idx += 64) {
-      const int s = idx / K, k = idx - s * K;
-      const double* r = res + (size_t)idx * st;
-      const double sgk = sg[k], wk = w[k];
-      const double tau2 = sgk * sgk * lam * lam + ell2[s * D + d];
-      const double T = r[1 + D + d] - r[0];
-      double gl = wk * (sgk * sgk / tau2) * lam * T;
-      if (quad) gl -= wk * sgk * sgk * iom2[s * D + d] * lam;
-      acc += gl / S;
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) glm[d] = acc;
-  }
-  const double G = block_sum(gpart, red);
-
-  // ---- soft bounds (_vp_bound_loss :537-606) and weight penalty (:1211-1229) ----
   double loss = 0.0;
   if (a.has_bnd) {
     const int n_mu = o_mu ? D * K : 0, n_sc = (o_sg || o_lm) ? D * K : 0;
@@ -249,40 +190,89 @@ static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red) 
       }
       dL[i] = g;
     }
-    if (o_w) {
-      for (int k = tid; k < K; k += 256) {  // same thread wrote gw[k] above
-        const bool small = w[k] < a.w_thresh;
-        loss += (small ? w[k] : a.w_thresh) * a.w_pen;
-        if (small) gw[k] += a.w_pen;
-      }
-    }
-  }
-  loss = block_sum(loss, red);  // its barriers also order the writes above before the reads below
-  if (a.has_bnd && o_lm) {
-    // the reference reshapes the scale block C-order (D,K) (:585-587); restated as-is
-    const int sc0 = o_mu ? D * K : 0;
-    for (int d = wave; d < D; d += 4) {
-      double acc = 0.0;
-      for (int k = lane; k < K; k += 64) acc += dL[sc0 + d * K + k];
-      acc = wave_sum(acc);
-      if (lane == 0) bl[d] = acc;
-    }
   }
   __syncthreads();
 
-  // ---- softmax Jacobian of the entropy-free weight gradient (entmc_vbmc.py:122-130) ----
-  double sm_s = 1.0, sm_dot = 0.0;
-  if (o_w) {
-    double ps = 0.0, pd = 0.0;
-    for (int k = tid; k < K; k += 256) {
+  // ---- phase 2: per component (lanes k), then per dimension in 16-lane groups ----
+  double gpart = 0.0, ps = 0.0, pd = 0.0;
+  for (int k = tid; k < K; k += 256) {
+    const double sgk = sg[k], wk = w[k];
+    double gs = 0.0, nu = 0.0, b0 = 0.0, qbar = 0.0;
+    for (int d = 0; d < D; ++d) {
+      gs += tgs[k * D + d];
+      nu += tnu[k * D + d];
+    }
+    for (int s = 0; s < S; ++s) {
+      const double* h = hyp + (size_t)s * a.P;
+      b0 += (res[((size_t)s * K + k) * st] + (a.mean_kind == VBMC_MEAN_ZERO ? 0.0 : h[D + 2])) / S;
+      if (quad)
+        for (int d = 0; d < D; ++d) qbar += iom2[s * D + d] * lm[d] * lm[d] / S;
+    }
+    const double wI = b0 - 0.5 * nu;  // mean over s of I_sk
+    gpart += wk * wI;
+    gsg[k] = wk * sgk * (gs - qbar);
+    double g = -wI;  // d(-G)/dw_k; the entropy part is the step kernel's
+    if (a.has_bnd && o_w) {  // weight penalty (:1211-1229)
+      const bool small = wk < a.w_thresh;
+      loss += (small ? wk : a.w_thresh) * a.w_pen;
+      if (small) g += a.w_pen;
+    }
+    gw[k] = g;
+    if (o_w) {  // softmax Jacobian of the entropy-free weight gradient (entmc_vbmc.py:122-130)
       const double e = exp(eta[k]);
       ee[k] = e;
       ps += e;
-      pd += e * gw[k];
+      pd += e * g;
     }
-    sm_s = block_sum(ps, red);
-    sm_dot = block_sum(pd, red);
   }
+  {
+    // 16 groups of 16 lanes, one dimension per group and round: the lambda gradient over the
+    // (s, k) terms and the soft-bound gradient folded onto lambda (the reference reshapes the
+    // scale block C-order (D,K), :585-587; restated as-is)
+    const int ns = tid & 15, g16 = tid >> 4;
+    const int sc0 = o_mu ? D * K : 0;
+    for (int d = g16; d < D; d += 16) {
+      const double lam = lm[d];
+      double acc = 0.0, accb = 0.0;
+      for (int idx = ns; idx < S * K; idx += 16) {
+        const int s = idx / K, k = idx - s * K;
+        const double* r = res + (size_t)idx * st;
+        const double sgk = sg[k], wk = w[k];
+        const double tau2 = sgk * sgk * lam * lam + ell2[s * D + d];
+        const double T = r[1 + D + d] - r[0];
+        double gl = wk * (sgk * sgk / tau2) * lam * T;
+        if (quad) gl -= wk * sgk * sgk * iom2[s * D + d] * lam;
+        acc += gl / S;
+      }
+      if (a.has_bnd && o_lm)
+        for (int k = ns; k < K; k += 16) accb += dL[sc0 + d * K + k];
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        acc += __shfl_xor(acc, off, 64);
+        accb += __shfl_xor(accb, off, 64);
+      }
+      if (ns == 0) {
+        glm[d] = acc;
+        bl[d] = accb;
+      }
+    }
+  }
+  // one reduction round for the four block sums
+  gpart = wave_sum(gpart);
+  loss = wave_sum(loss);
+  ps = wave_sum(ps);
+  pd = wave_sum(pd);
+  if (lane == 0) {
+    red[wave] = gpart;
+    red[4 + wave] = loss;
+    red[8 + wave] = ps;
+    red[12 + wave] = pd;
+  }
+  __syncthreads();  // also orders gsg / gw / ee / glm / bl before the reads below
+  const double G = (red[0] + red[1]) + (red[2] + red[3]);
+  loss = (red[4] + red[5]) + (red[6] + red[7]);
+  const double sm_s = o_w ? (red[8] + red[9]) + (red[10] + red[11]) : 1.0;
+  const double sm_dot = o_w ? (red[12] + red[13]) + (red[14] + red[15]) : 0.0;
 
   // ---- the entropy-free part of dF ----
   const int sc0 = o_mu ? D * K : 0;

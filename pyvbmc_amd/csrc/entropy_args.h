@@ -20,6 +20,7 @@ struct EntArgs {
   // wave-split kernel only: when set, the launch gets one extra grid row whose first workgroup
   // runs adam_dev::adam_pre_body on this argument block (device memory) -- see adam_dev.h
   const void* extra = nullptr;
+  int extra_lds = 0;  // doubles of dynamic LDS that workgroup may use (0: it works from global memory)
 };
 
 struct EntPlan {

@@ -113,8 +113,11 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   constexpr bool EXTRA_ROW = GRAD && !PHILOX;
   if constexpr (EXTRA_ROW) {
     if (a.extra != nullptr && blockIdx.y == 0) {
-      if (blockIdx.x == 0)
-        adam_dev::adam_pre_body<false>(*(const adam_dev::AdamDev*)a.extra, nullptr, &sRed[0][0]);
+      if (blockIdx.x == 0) {
+        const adam_dev::AdamDev& pa = *(const adam_dev::AdamDev*)a.extra;
+        if (a.extra_lds > 0) adam_dev::adam_pre_body<true>(pa, sW, &sRed[0][0]);
+        else adam_dev::adam_pre_body<false>(pa, nullptr, &sRed[0][0]);
+      }
       return;
     }
   }
@@ -359,15 +362,25 @@ template <int DP, int KTMAX>
 void launch_one(hipStream_t st, const EntArgs& a, const double* d_table, hipEvent_t e0, hipEvent_t e1) {
   const int K = a.ml.K;
   const int K4 = ((K + 3) / 4) * 4;
-  const size_t lds = sizeof(double) * (size_t)K4;
+  size_t lds = sizeof(double) * (size_t)K4;
   // the table carries zero-density padding rows up to 4*ceil(K/4), so the guard-free
   // variant applies whenever ceil(K/4) == KTMAX
   const bool exact = ((K + 3) / 4 == KTMAX);
   const bool philox = a.eps_mode == VBMC_EPS_PHILOX;
   const bool extra_row = a.extra != nullptr && a.want_grad && !philox;  // see EXTRA_ROW in the kernel
   const dim3 grid(a.chunks, K + (extra_row ? 1 : 0)), block(WG);
-#define VBMC_LAUNCH_WS(G, E, P) \
-  hipExtLaunchKernelGGL((entmc_ws_kernel<DP, KTMAX, G, E, P>), grid, block, (std::uint32_t)lds, st, e0, e1, 0u, a, d_table)
+  if (extra_row && sizeof(double) * (size_t)a.extra_lds > lds) lds = sizeof(double) * (size_t)a.extra_lds;
+  // (the raised dynamic-LDS limit is set once per instantiation and size)
+#define VBMC_LAUNCH_WS(G, E, P)                                                                           \
+  do {                                                                                                    \
+    auto kern = entmc_ws_kernel<DP, KTMAX, G, E, P>;                                                      \
+    static size_t lds_limit = 32 * 1024;                                                                  \
+    if (lds > lds_limit) {                                                                                \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      lds_limit = lds;                                                                                    \
+    }                                                                                                     \
+    hipExtLaunchKernelGGL(kern, grid, block, (std::uint32_t)lds, st, e0, e1, 0u, a, d_table);             \
+  } while (0)
   if (a.want_grad) {
     if (exact) { if (philox) VBMC_LAUNCH_WS(true, true, true); else VBMC_LAUNCH_WS(true, true, false); }
     else       { if (philox) VBMC_LAUNCH_WS(true, false, true); else VBMC_LAUNCH_WS(true, false, false); }
