@@ -301,3 +301,30 @@ for cfg, kw in ((2, dict(Ns_total=20 * 600)), (3, dict(Ns_total=50 * 200))):
             assert r[:2] == r0[:2], tag  # same configuration, same number of iterations
             a, b = np.array(r[2:], dtype=float), np.array(r0[2:], dtype=float)
             assert rel_err(a, b) < 1e-11, (tag, rel_err(a, b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [dict(D=20, K=12, N=60, S=3, NsK=40), dict(D=3, K=70, N=90, S=2, NsK=28),
+                                   dict(D=17, K=5, N=40, S=1, NsK=130)],
+                         ids=["D20-S3", "K70-S2", "D17"])
+def test_device_loop_other_shapes(ctx, shape):
+    """Shapes away from the BASELINE configurations: more than 16 dimensions (the 16-lane
+    dimension groups of the pre workgroup and of the GP sums take a second round), several GP
+    hyper-parameter samples, a component count that is not a multiple of four, and the
+    optimiser's default sample count (ns_ent = 100 K^(2/3), advanced_vbmc_options.ini:43)."""
+    from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+
+    wl = synthetic.make_workload(5, S=shape["S"], D=shape["D"], K=shape["K"], N=shape["N"],
+                                 Ns_total=shape["NsK"] * shape["K"])
+    wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,
+              hyp=wl.hyp, s2=wl.s2)  # config 5: user-provided noise
+    vp, gp = device_objects(wd, ctx)
+    bnd = synthetic.default_theta_bnd(wl)
+    theta0 = wl.theta.copy()
+    theta0[1] += 4.0  # one coordinate outside its soft bound
+    kw = dict(tol_fun=0.05, master_min=0.001, master_max=0.1, master_decay=200)
+    ref = oracle_philox_run(wl, wd, theta0, bnd, 31, 30, **kw)
+    got = minimize_adam_elbo(theta0, gp, vp, wl.NsK, bnd, max_iter=30, seed=31, rng="philox", **kw)
+    assert got[4] == ref[4]
+    assert rel_err(got[2], ref[2]) < 1e-7, rel_err(got[2], ref[2])
+    assert rel_err(got[3], ref[3]) < 1e-7, rel_err(got[3], ref[3])
