@@ -247,6 +247,61 @@ __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __r
   if (tid < TS && m0 + tid < M) part[(size_t)tile_c * M + m0 + tid] = sRow[tid][0] + sRow[tid][1];
 }
 
+// The same partial sums for a handful of points (a CMA-ES population, a single candidate): with
+// M <= 16 the 64-row MFMA tile above is almost all padding and its ~25 sequential LDS panels are
+// pure latency (30 us for one point).  Here a workgroup owns 64 columns of one sample; lane =
+// column, the four waves split the rows n of the triangular product, A (M x N) sits in LDS and
+// every B row is one coalesced 512-byte load.  Same outputs: part[tile_c * M + m].
+template <int MT>
+__global__ __launch_bounds__(256) void predict_var_small_kernel(const double* __restrict__ A,
+                                                                const double* __restrict__ B,
+                                                                int M, int N, double* __restrict__ part,
+                                                                const double* __restrict__ Bfull,
+                                                                const double* __restrict__ smeta,
+                                                                int64_t part_stride) {
+  extern __shared__ double sm[];  // A [M][N], then the cross-wave partials [4][MT][64]
+  const int z = blockIdx.z, tile_c = blockIdx.x;
+  const bool chol = smeta[3 * z] != 0.0;
+  A += (size_t)z * M * N;
+  B = (chol ? B : Bfull) + (size_t)z * N * N;
+  part += (size_t)z * part_stride;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = tile_c * TS, c = c0 + lane;
+  double* sA = sm;
+  double* sT = sm + (size_t)M * N;
+  for (int i = tid; i < M * N; i += 256) sA[i] = A[i];
+  __syncthreads();
+  const int nmax = chol ? min(N, c0 + TS) : N;  // upper-triangular L^-1: rows n <= c only
+  double acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = 0.0;
+  if (c < N) {
+    for (int n = wave; n < nmax; n += 4) {
+      const double b = B[(size_t)n * N + c];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        if (m < M) acc[m] = fma(sA[m * N + n], b, acc[m]);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) sT[(wave * MT + m) * 64 + lane] = acc[m];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m < M) {  // uniform
+        const double t = (sT[(0 * MT + m) * 64 + lane] + sT[(1 * MT + m) * 64 + lane]) +
+                         (sT[(2 * MT + m) * 64 + lane] + sT[(3 * MT + m) * 64 + lane]);
+        double v = 0.0;
+        if (c < N) v = chol ? t * t : sA[m * N + c] * t;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) part[(size_t)tile_c * M + m] = v;
+      }
+    }
+  }
+}
+
 // predict, stage 1 on the FP64 matrix cores: the dense pairwise-squared-distance block.
 //   d2[m][n] = |a_m|^2 + |b_n|^2 - 2 a_m . b_n,   a = x*/ell, b = X/ell
 // (the reference's own centred form, acquisition_functions/abstract_acq_fcn.py:195-222);
@@ -575,9 +630,26 @@ int launch_gp_predict_all(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* 
                      (const double*)g.d_alpha, (const double*)g.d_sW, (const double*)g.d_hyp,
                      (const double*)g.d_xc, (const double*)g.d_smeta, g.P, N, D, M, d_Ks,
                      d_part + (size_t)ntiles * M, pstride);
-  hipLaunchKernelGGL(predict_var_mfma_kernel, grid, dim3(256), 0, ctx->stream, (const double*)d_Ks,
-                     (const double*)g.d_Linv, M, N, 0, d_part, (double*)nullptr, (const double*)g.d_L,
-                     (const double*)g.d_smeta, pstride);
+  if (M <= 16 && (size_t)M * N <= 6144) {  // a handful of points: see predict_var_small_kernel
+    const dim3 sgrid(ntiles, 1, S);
+    if (M <= 4) {
+      const size_t lds = sizeof(double) * ((size_t)M * N + 4 * 4 * 64);
+      hipLaunchKernelGGL(predict_var_small_kernel<4>, sgrid, dim3(256), lds, ctx->stream, (const double*)d_Ks,
+                         (const double*)g.d_Linv, (int)M, N, d_part, (const double*)g.d_L,
+                         (const double*)g.d_smeta, pstride);
+    } else {
+      const size_t lds = sizeof(double) * ((size_t)M * N + 4 * 16 * 64);
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)predict_var_small_kernel<16>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      hipLaunchKernelGGL(predict_var_small_kernel<16>, sgrid, dim3(256), lds, ctx->stream, (const double*)d_Ks,
+                         (const double*)g.d_Linv, (int)M, N, d_part, (const double*)g.d_L,
+                         (const double*)g.d_smeta, pstride);
+    }
+  } else {
+    hipLaunchKernelGGL(predict_var_mfma_kernel, grid, dim3(256), 0, ctx->stream, (const double*)d_Ks,
+                       (const double*)g.d_Linv, M, N, 0, d_part, (double*)nullptr, (const double*)g.d_L,
+                       (const double*)g.d_smeta, pstride);
+  }
   hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((M + 255) / 256), S), dim3(256), 0, ctx->stream,
                      (const double*)d_part, pstride, ntiles, M, D, g.P, g.mean_kind, (const double*)g.d_hyp,
                      (const double*)g.d_smeta, d_xs, add_noise, d_fmu, d_fs2, ld);

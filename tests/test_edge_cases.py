@@ -204,3 +204,38 @@ def test_loud_failures(ctx):
     vp2, _ = objects(wd, ctx)
     H, _ = entmc_vbmc(vp2, 20, rng="philox", seed=1)
     assert np.isfinite(H)
+
+
+@pytest.mark.parametrize("low_noise", [False, True], ids=["chol", "no-chol"])
+def test_small_batches_take_the_small_kernels(ctx, low_noise):
+    """A handful of points (a CMA-ES population, one candidate) goes through kernels of its own --
+    predict_var_small_kernel (M <= 16) and mixture_pdf_wave_kernel (n <= 2^16) -- which must agree
+    with the oracle exactly as the large-batch kernels do, on both posterior branches, for several
+    GP samples, and for N not a multiple of the 64-column tile."""
+    wl, wd = case(5, 9, 150, 40, S=3)
+    if low_noise:
+        hyp = wd["hyp"].copy()
+        hyp[:, 5 + 1] = np.log(3e-4)
+        wd["hyp"] = hyp
+    vp, gp = objects(wd, ctx)
+    assert gp.posteriors[0].L_chol != low_noise
+    mix, ogp = oracle_mix(wd), oracle_gp(wd)
+    sf2 = float(np.exp(2 * wd["hyp"][0, 5]))
+    rng = np.random.default_rng(3)
+    for M in (1, 3, 4, 5, 16, 17, 70):
+        xs = rng.standard_normal((M, 5))
+        for sep in (True, False):
+            fmu, fs2 = gp.predict(xs, separate_samples=sep)
+            omu, os2 = gp_ref.predict(ogp, xs, separate_samples=sep)
+            assert fmu.shape == omu.shape and fs2.shape == os2.shape
+            assert np.max(np.abs(fmu - omu)) <= 1e-8 * max(1.0, np.max(np.abs(omu))), M
+            assert np.max(np.abs(fs2 - os2)) <= 1e-8 * max(1.0, sf2), M
+        for log_flag in (False, True):
+            y, dy = vp.pdf(xs, orig_flag=False, log_flag=log_flag, grad_flag=True)
+            yo, dyo = mixture_ref.pdf(mix, xs, log_flag=log_flag, grad_flag=True)
+            assert rel_err(y, yo) < 1e-12 and rel_err(dy, dyo) < 1e-11, (M, log_flag)
+    # the same points through both pdf kernels: a large batch containing the small one
+    big = rng.standard_normal((70000, 5))
+    yb = vp.pdf(big, orig_flag=False, log_flag=True)
+    ys = vp.pdf(big[:1000], orig_flag=False, log_flag=True)
+    assert rel_err(ys, yb[:1000]) < 1e-13
