@@ -250,16 +250,17 @@ __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __r
 // The same partial sums for a handful of points (a CMA-ES population, a single candidate): with
 // M <= 16 the 64-row MFMA tile above is almost all padding and its ~25 sequential LDS panels are
 // pure latency (30 us for one point).  Here a workgroup owns 64 columns of one sample; lane =
-// column, the four waves split the rows n of the triangular product, A (M x N) sits in LDS and
-// every B row is one coalesced 512-byte load.  Same outputs: part[tile_c * M + m].
-template <int MT>
-__global__ __launch_bounds__(256) void predict_var_small_kernel(const double* __restrict__ A,
+// column, its NW waves split the rows n of the triangular product (eight loads in flight each),
+// A (M x N) sits in LDS and every B row is one coalesced 512-byte load.  Same outputs:
+// part[tile_c * M + m].
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void predict_var_small_kernel(const double* __restrict__ A,
                                                                 const double* __restrict__ B,
                                                                 int M, int N, double* __restrict__ part,
                                                                 const double* __restrict__ Bfull,
                                                                 const double* __restrict__ smeta,
                                                                 int64_t part_stride) {
-  extern __shared__ double sm[];  // A [M][N], then the cross-wave partials [4][MT][64]
+  extern __shared__ double sm[];  // A [M][N], then the cross-wave partials [NW][MT][64]
   const int z = blockIdx.z, tile_c = blockIdx.x;
   const bool chol = smeta[3 * z] != 0.0;
   A += (size_t)z * M * N;
@@ -269,18 +270,30 @@ __global__ __launch_bounds__(256) void predict_var_small_kernel(const double* __
   const int c0 = tile_c * TS, c = c0 + lane;
   double* sA = sm;
   double* sT = sm + (size_t)M * N;
-  for (int i = tid; i < M * N; i += 256) sA[i] = A[i];
+  for (int i = tid; i < M * N; i += 64 * NW) sA[i] = A[i];
   __syncthreads();
   const int nmax = chol ? min(N, c0 + TS) : N;  // upper-triangular L^-1: rows n <= c only
   double acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = 0.0;
   if (c < N) {
-    for (int n = wave; n < nmax; n += 4) {
-      const double b = B[(size_t)n * N + c];
+    constexpr int UB = 8;
+    for (int n0 = wave; n0 < nmax; n0 += NW * UB) {
+      double b[UB];
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
-        if (m < M) acc[m] = fma(sA[m * N + n], b, acc[m]);
+      for (int u = 0; u < UB; ++u) {
+        const int n = n0 + u * NW;
+        b[u] = n < nmax ? B[(size_t)n * N + c] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int n = n0 + u * NW;
+        if (n < nmax) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            if (m < M) acc[m] = fma(sA[m * N + n], b[u], acc[m]);
+        }
+      }
     }
   }
 #pragma unroll
@@ -290,8 +303,9 @@ __global__ __launch_bounds__(256) void predict_var_small_kernel(const double* __
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       if (m < M) {  // uniform
-        const double t = (sT[(0 * MT + m) * 64 + lane] + sT[(1 * MT + m) * 64 + lane]) +
-                         (sT[(2 * MT + m) * 64 + lane] + sT[(3 * MT + m) * 64 + lane]);
+        double t = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) t += sT[(wv * MT + m) * 64 + lane];
         double v = 0.0;
         if (c < N) v = chol ? t * t : sA[m * N + c] * t;
 #pragma unroll
@@ -633,16 +647,16 @@ int launch_gp_predict_all(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* 
   if (M <= 16 && (size_t)M * N <= 6144) {  // a handful of points: see predict_var_small_kernel
     const dim3 sgrid(ntiles, 1, S);
     if (M <= 4) {
-      const size_t lds = sizeof(double) * ((size_t)M * N + 4 * 4 * 64);
-      hipLaunchKernelGGL(predict_var_small_kernel<4>, sgrid, dim3(256), lds, ctx->stream, (const double*)d_Ks,
-                         (const double*)g.d_Linv, (int)M, N, d_part, (const double*)g.d_L,
+      const size_t lds = sizeof(double) * ((size_t)M * N + 16 * 4 * 64);
+      hipLaunchKernelGGL((predict_var_small_kernel<4, 16>), sgrid, dim3(1024), lds, ctx->stream,
+                         (const double*)d_Ks, (const double*)g.d_Linv, (int)M, N, d_part, (const double*)g.d_L,
                          (const double*)g.d_smeta, pstride);
     } else {
-      const size_t lds = sizeof(double) * ((size_t)M * N + 4 * 16 * 64);
-      HIP_TRY(ctx, hipFuncSetAttribute((const void*)predict_var_small_kernel<16>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      hipLaunchKernelGGL(predict_var_small_kernel<16>, sgrid, dim3(256), lds, ctx->stream, (const double*)d_Ks,
-                         (const double*)g.d_Linv, (int)M, N, d_part, (const double*)g.d_L,
+      const size_t lds = sizeof(double) * ((size_t)M * N + 8 * 16 * 64);
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)predict_var_small_kernel<16, 8>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      hipLaunchKernelGGL((predict_var_small_kernel<16, 8>), sgrid, dim3(512), lds, ctx->stream,
+                         (const double*)d_Ks, (const double*)g.d_Linv, (int)M, N, d_part, (const double*)g.d_L,
                          (const double*)g.d_smeta, pstride);
     }
   } else {
