@@ -248,11 +248,11 @@ __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __r
 }
 
 // The same partial sums for a handful of points (a CMA-ES population, a single candidate): with
-// M <= 16 the 64-row MFMA tile above is almost all padding and its ~25 sequential LDS panels are
-// pure latency (30 us for one point).  Here a workgroup owns 64 columns of one sample; lane =
-// column, its NW waves split the rows n of the triangular product (eight loads in flight each),
-// A (M x N) sits in LDS and every B row is one coalesced 512-byte load.  Same outputs:
-// part[tile_c * M + m].
+// M <= 32 the 64-row MFMA tile above is mostly padding and its ~25 sequential LDS panels are pure
+// latency (30 us for one point).  Here a workgroup owns 64 columns of one sample and a group of
+// MT points (blockIdx.y); lane = column, its NW waves split the rows n of the triangular product
+// (eight loads in flight each), the group's A rows sit in LDS and every B row is one coalesced
+// 512-byte load.  Same outputs: part[tile_c * M + m].
 template <int MT, int NW>
 __global__ __launch_bounds__(64 * NW) void predict_var_small_kernel(const double* __restrict__ A,
                                                                 const double* __restrict__ B,
@@ -260,10 +260,13 @@ __global__ __launch_bounds__(64 * NW) void predict_var_small_kernel(const double
                                                                 const double* __restrict__ Bfull,
                                                                 const double* __restrict__ smeta,
                                                                 int64_t part_stride) {
-  extern __shared__ double sm[];  // A [M][N], then the cross-wave partials [NW][MT][64]
+  extern __shared__ double sm[];  // the group's A rows [<= MT][N], then the cross-wave partials [NW][MT][64]
   const int z = blockIdx.z, tile_c = blockIdx.x;
+  const int mg0 = blockIdx.y * MT;          // first point of this group
+  const int Mtot = M;                       // part rows are indexed by the global point number
   const bool chol = smeta[3 * z] != 0.0;
-  A += (size_t)z * M * N;
+  A += ((size_t)z * Mtot + mg0) * N;
+  M = min(MT, Mtot - mg0);                  // points in this group
   B = (chol ? B : Bfull) + (size_t)z * N * N;
   part += (size_t)z * part_stride;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(64 * NW) void predict_var_small_kernel(const double
         if (c < N) v = chol ? t * t : sA[m * N + c] * t;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) part[(size_t)tile_c * M + m] = v;
+        if (lane == 0) part[(size_t)tile_c * Mtot + mg0 + m] = v;
       }
     }
   }
@@ -644,21 +647,15 @@ int launch_gp_predict_all(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* 
                      (const double*)g.d_alpha, (const double*)g.d_sW, (const double*)g.d_hyp,
                      (const double*)g.d_xc, (const double*)g.d_smeta, g.P, N, D, M, d_Ks,
                      d_part + (size_t)ntiles * M, pstride);
-  if (M <= 16 && (size_t)M * N <= 6144) {  // a handful of points: see predict_var_small_kernel
-    const dim3 sgrid(ntiles, 1, S);
-    if (M <= 4) {
-      const size_t lds = sizeof(double) * ((size_t)M * N + 16 * 4 * 64);
-      hipLaunchKernelGGL((predict_var_small_kernel<4, 16>), sgrid, dim3(1024), lds, ctx->stream,
-                         (const double*)d_Ks, (const double*)g.d_Linv, (int)M, N, d_part, (const double*)g.d_L,
-                         (const double*)g.d_smeta, pstride);
-    } else {
-      const size_t lds = sizeof(double) * ((size_t)M * N + 8 * 16 * 64);
-      HIP_TRY(ctx, hipFuncSetAttribute((const void*)predict_var_small_kernel<16, 8>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      hipLaunchKernelGGL((predict_var_small_kernel<16, 8>), sgrid, dim3(512), lds, ctx->stream,
-                         (const double*)d_Ks, (const double*)g.d_Linv, (int)M, N, d_part, (const double*)g.d_L,
-                         (const double*)g.d_smeta, pstride);
-    }
+  if (M <= 32 && N <= 3000) {  // a handful of points: see predict_var_small_kernel (LDS <= 128 KB)
+    const dim3 sgrid(ntiles, (unsigned)((M + 3) / 4), S);
+    const size_t lds = sizeof(double) * ((size_t)4 * N + 16 * 4 * 64);
+    if (lds > 64 * 1024)
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)predict_var_small_kernel<4, 16>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    hipLaunchKernelGGL((predict_var_small_kernel<4, 16>), sgrid, dim3(1024), lds, ctx->stream,
+                       (const double*)d_Ks, (const double*)g.d_Linv, (int)M, N, d_part, (const double*)g.d_L,
+                       (const double*)g.d_smeta, pstride);
   } else {
     hipLaunchKernelGGL(predict_var_mfma_kernel, grid, dim3(256), 0, ctx->stream, (const double*)d_Ks,
                        (const double*)g.d_Linv, M, N, 0, d_part, (double*)nullptr, (const double*)g.d_L,

@@ -209,7 +209,7 @@ def test_loud_failures(ctx):
 @pytest.mark.parametrize("low_noise", [False, True], ids=["chol", "no-chol"])
 def test_small_batches_take_the_small_kernels(ctx, low_noise):
     """A handful of points (a CMA-ES population, one candidate) goes through kernels of its own --
-    predict_var_small_kernel (M <= 16) and mixture_pdf_wave_kernel (n <= 2^16) -- which must agree
+    predict_var_small_kernel (M <= 32) and mixture_pdf_wave_kernel (n <= 2^16) -- which must agree
     with the oracle exactly as the large-batch kernels do, on both posterior branches, for several
     GP samples, and for N not a multiple of the 64-column tile."""
     wl, wd = case(5, 9, 150, 40, S=3)
@@ -222,7 +222,7 @@ def test_small_batches_take_the_small_kernels(ctx, low_noise):
     mix, ogp = oracle_mix(wd), oracle_gp(wd)
     sf2 = float(np.exp(2 * wd["hyp"][0, 5]))
     rng = np.random.default_rng(3)
-    for M in (1, 3, 4, 5, 16, 17, 70):
+    for M in (1, 3, 4, 5, 16, 17, 32, 33, 70):
         xs = rng.standard_normal((M, 5))
         for sep in (True, False):
             fmu, fs2 = gp.predict(xs, separate_samples=sep)
