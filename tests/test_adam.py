@@ -328,3 +328,31 @@ def test_device_loop_other_shapes(ctx, shape):
     assert got[4] == ref[4]
     assert rel_err(got[2], ref[2]) < 1e-7, rel_err(got[2], ref[2])
     assert rel_err(got[3], ref[3]) < 1e-7, rel_err(got[3], ref[3])
+
+
+@pytest.mark.gpu
+def test_device_loop_random_shapes(ctx):
+    """A seeded sweep over (D, K, N, S, NsK, iterations): the device loop against the oracle loop
+    on the same Philox draws, whatever the shape does to the kernels' tiling (padded D, K not a
+    multiple of 4, one antithetic pair per component, batches that end mid-window)."""
+    from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+
+    rng = np.random.default_rng(2024)
+    for t in range(12):
+        D, K = int(rng.integers(1, 25)), int(rng.integers(1, 60))
+        N, S = int(rng.integers(5, 130)), int(rng.integers(1, 4))
+        nsk, cfg = 2 * int(rng.integers(1, 90)), int(rng.choice([2, 3, 5]))
+        wl = synthetic.make_workload(cfg, S=S, D=D, K=K, N=N, Ns_total=nsk * K)
+        wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,
+                  hyp=wl.hyp, s2=np.zeros(0) if wl.s2 is None else wl.s2)
+        vp, gp = device_objects(wd, ctx)
+        bnd = synthetic.default_theta_bnd(wl)
+        theta0 = wl.theta.copy()
+        theta0[0] += 3.0
+        kw = dict(tol_fun=0.05, master_min=0.001, master_max=0.1, master_decay=200)
+        n_it = int(rng.choice([7, 20, 23, 41]))
+        ref = oracle_philox_run(wl, wd, theta0, bnd, 5 + t, n_it, **kw)
+        got = minimize_adam_elbo(theta0, gp, vp, wl.NsK, bnd, max_iter=n_it, seed=5 + t, rng="philox", **kw)
+        shape = dict(D=D, K=K, N=N, S=S, NsK=wl.NsK, cfg=cfg, it=n_it)
+        assert got[4] == ref[4], shape
+        assert rel_err(got[2], ref[2]) < 1e-8 and rel_err(got[3], ref[3]) < 1e-8, shape
