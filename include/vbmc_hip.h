@@ -55,8 +55,9 @@ enum {
                             reference's np.random.randn stream, entmc_vbmc.py:67) */
   VBMC_EPS_PHILOX = 1    /* Philox4x32-10 + Box-Muller generated on the device, fresh
                             per call from `seed` (throughput mode): by extra blocks
-                            of the prep launch, one iteration ahead in the optimiser
-                            loop, or inside the entropy kernel -- the same values  */
+                            of the prep launch, by spare workgroups of the optimiser
+                            loop's short launches one iteration ahead, or inside the
+                            entropy kernel -- the same values                        */
 };
 
 /* ---- library / context ------------------------------------------------- */
