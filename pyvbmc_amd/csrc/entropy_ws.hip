@@ -370,14 +370,16 @@ void launch_one(hipStream_t st, const EntArgs& a, const double* d_table, hipEven
   const bool extra_row = a.extra != nullptr && a.want_grad && !philox;  // see EXTRA_ROW in the kernel
   const dim3 grid(a.chunks, K + (extra_row ? 1 : 0)), block(WG);
   if (extra_row && sizeof(double) * (size_t)a.extra_lds > lds) lds = sizeof(double) * (size_t)a.extra_lds;
+  int dev = 0;
+  if (lds > 32 * 1024) (void)hipGetDevice(&dev);
   // (the raised dynamic-LDS limit is set once per instantiation and size)
 #define VBMC_LAUNCH_WS(G, E, P)                                                                           \
   do {                                                                                                    \
     auto kern = entmc_ws_kernel<DP, KTMAX, G, E, P>;                                                      \
-    static size_t lds_limit = 32 * 1024;                                                                  \
-    if (lds > lds_limit) {                                                                                \
+    static size_t lds_limit[64] = {};  /* per device: function attributes are per device */              \
+    if (lds > 32 * 1024 && lds > lds_limit[dev & 63]) {                                                   \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      lds_limit = lds;                                                                                    \
+      lds_limit[dev & 63] = lds;                                                                          \
     }                                                                                                     \
     hipExtLaunchKernelGGL(kern, grid, block, (std::uint32_t)lds, st, e0, e1, 0u, a, d_table);             \
   } while (0)
