@@ -17,6 +17,7 @@ LIB = HERE / "libvbmc_hip.so"
 SOURCES = [
     "ctx.hip",
     "entropy.hip",
+    "entropy_small.hip",
     "prep.hip",
     "api_entropy.hip",
     "mixture.hip",

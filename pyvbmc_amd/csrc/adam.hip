@@ -29,6 +29,7 @@
 
 #include "adam_dev.h"
 #include "common.h"
+#include "fastmath.h"
 #include "entropy_args.h"
 #include "philox.h"
 
@@ -62,8 +63,7 @@ __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, do
   if (o_w)
     for (int k = tid; k < K; k += 256) mx = fmax(mx, theta[p_w + k]);
   s2 = wave_sum(s2);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+  mx = fm::wave_max_dpp(mx);
   __syncthreads();
   if (lane == 0) {
     red[wave] = s2;
@@ -86,8 +86,7 @@ __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, do
     }
   for (int d = tid; d < D; d += 256) pr *= lm[d] / nl;  // this thread's own entries of round 1
   wsum = wave_sum(wsum);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) pr *= __shfl_xor(pr, off, 64);
+  pr = fm::wave_prod_dpp(pr);
   if (lane == 0) {
     red[8 + wave] = wsum;
     red[12 + wave] = pr;

@@ -3,6 +3,7 @@
 // kernel (entropy_ws.hip) runs as an extra row of its own launch.
 #pragma once
 #include "common.h"
+#include "fastmath.h"
 
 namespace adam_dev {
 
@@ -56,9 +57,7 @@ __host__ __device__ inline size_t work_len(int D, int K, int S, int n_bnd) {
 }
 
 static __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  return fm::wave_sum_dpp(v);
 }
 
 // ---------------------------------------------------------------------------
@@ -246,11 +245,8 @@ static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red) 
       }
       if (a.has_bnd && o_lm)
         for (int k = ns; k < K; k += 16) accb += dL[sc0 + d * K + k];
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) {
-        acc += __shfl_xor(acc, off, 64);
-        accb += __shfl_xor(accb, off, 64);
-      }
+      acc = fm::row16_sum_dpp(acc);
+      accb = fm::row16_sum_dpp(accb);
       if (ns == 0) {
         glm[d] = acc;
         bl[d] = accb;

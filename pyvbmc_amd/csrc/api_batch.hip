@@ -9,13 +9,12 @@
 #include <cstring>
 
 #include "common.h"
+#include "fastmath.h"
 
 namespace {
 
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  return fm::wave_sum_dpp(v);
 }
 
 // H_b = -sum_i w_i log( sum_j w_j gamma_ij )   (entlb_vbmc.py:84-97), value only.

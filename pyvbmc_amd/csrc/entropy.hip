@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "fastmath.h"
 #include "entropy_args.h"
 #include "philox.h"
 
@@ -23,9 +24,7 @@ constexpr int WG = 256;
 constexpr int WAVES = WG / 64;
 
 __device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  return fm::wave_sum_dpp(v);
 }
 
 
@@ -511,8 +510,12 @@ int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p) {
   // timing: the wave-split launch carries the event pair on its own dispatch packet; the generic
   // kernel is bracketed by two records (each a barrier packet, ~6 us between dependent kernels)
   hipEvent_t e0 = ctx->timing ? ctx->ev[0] : nullptr, e1 = ctx->timing ? ctx->ev[1] : nullptr;
-  if (ctx->timing && !p.ws) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  if (p.ws) {
+  const bool small = p.ws && entmc_small_applies(a, p.DP);
+  const bool bracket = ctx->timing && (!p.ws || small);
+  if (bracket) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  if (small) {
+    launch_entmc_small(ctx->stream, a, p.DP, p.table);
+  } else if (p.ws) {
     switch (p.DP) {
 #define VBMC_CASE_WS(dp) case dp: launch_entmc_ws_dp##dp(ctx->stream, a, p.table, e0, e1); break;
       VBMC_WS_DPS(VBMC_CASE_WS)
@@ -533,7 +536,7 @@ int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p) {
     }
   }
   if (ctx->timing) {
-    if (!p.ws) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (bracket) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     ctx->ev_valid[0] = true;
   }
   HIP_TRY(ctx, hipGetLastError());

@@ -40,3 +40,7 @@ struct EntPlan {
   void launch_entmc_ws_dp##dp(hipStream_t st, const EntArgs& a, const double* d_table, hipEvent_t e0, hipEvent_t e1);
 VBMC_WS_DPS(VBMC_DECL_WS)
 #undef VBMC_DECL_WS
+
+// small sample counts: lane = component (entropy_small.hip); same table, same partial rows
+bool entmc_small_applies(const EntArgs& a, int DP);
+void launch_entmc_small(hipStream_t st, const EntArgs& a, int DP, const double* d_table);

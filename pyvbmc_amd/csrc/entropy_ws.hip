@@ -79,11 +79,7 @@ namespace {
 constexpr int WG = 256;
 constexpr int WAVES = WG / 64;
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return fm::wave_sum_dpp(v); }
 
 // The (j,k) table rows [Delta_jk (DP) | a | c | lrc | w | wis2 | pad] are written by prep.hip.
 // EXACT: ceil(K/4) == KTMAX (padding components have zero density): the per-component guards fold away.

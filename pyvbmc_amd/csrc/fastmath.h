@@ -96,4 +96,67 @@ __device__ __forceinline__ void sincospi_fast(double y, double& s, double& c) {
   c = ((q + 1) & 2) ? -cc : cc;
 }
 
+// Sum over the 64 lanes of a wave, result in every lane.  DPP row operations (no LDS traffic):
+// __shfl_xor compiles to ds_bpermute_b32 pairs with a wait after each step (~100 cycles per
+// step and double), this is 6 steps of two v_mov_dpp + one v_add_f64.
+//   quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: every lane of a 16-lane
+//   row holds its row's sum; row_bcast15 (rows 1, 3) and row_bcast31 (rows 2, 3) carry the row
+//   sums upwards, lane 63 ends with the total, v_readlane broadcasts it.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_get(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// the value of lane 63 in every lane
+__device__ __forceinline__ double wave_last(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_get<0xB1, 0xf>(v);
+  v += dpp_get<0x4E, 0xf>(v);
+  v += dpp_get<0x141, 0xf>(v);
+  v += dpp_get<0x140, 0xf>(v);
+  v += dpp_get<0x142, 0xa>(v);
+  v += dpp_get<0x143, 0xc>(v);
+  return wave_last(v);
+}
+// sum over each aligned group of 16 lanes (a DPP row), result in all 16 lanes
+__device__ __forceinline__ double row16_sum_dpp(double v) {
+  v += dpp_get<0xB1, 0xf>(v);
+  v += dpp_get<0x4E, 0xf>(v);
+  v += dpp_get<0x141, 0xf>(v);
+  v += dpp_get<0x140, 0xf>(v);
+  return v;
+}
+// max / product over the 64 lanes.  The masked row_bcast steps leave 0 in the rows they skip,
+// which is the identity of + only: here those steps are guarded by the lane's row instead.
+__device__ __forceinline__ double wave_max_dpp(double v) {
+  v = fmax(v, dpp_get<0xB1, 0xf>(v));
+  v = fmax(v, dpp_get<0x4E, 0xf>(v));
+  v = fmax(v, dpp_get<0x141, 0xf>(v));
+  v = fmax(v, dpp_get<0x140, 0xf>(v));
+  const int row = (threadIdx.x & 63) >> 4;
+  const double b15 = dpp_get<0x142, 0xa>(v);
+  v = (row & 1) ? fmax(v, b15) : v;
+  const double b31 = dpp_get<0x143, 0xc>(v);
+  v = (row & 2) ? fmax(v, b31) : v;
+  return wave_last(v);
+}
+__device__ __forceinline__ double wave_prod_dpp(double v) {
+  v *= dpp_get<0xB1, 0xf>(v);
+  v *= dpp_get<0x4E, 0xf>(v);
+  v *= dpp_get<0x141, 0xf>(v);
+  v *= dpp_get<0x140, 0xf>(v);
+  const int row = (threadIdx.x & 63) >> 4;
+  const double b15 = dpp_get<0x142, 0xa>(v);
+  v = (row & 1) ? v * b15 : v;
+  const double b31 = dpp_get<0x143, 0xc>(v);
+  v = (row & 2) ? v * b31 : v;
+  return wave_last(v);
+}
+
 }  // namespace fm

@@ -141,16 +141,13 @@ __global__ __launch_bounds__(256) void mixture_pdf_wave_kernel(PdfArgs a) {
         if (d < D) g[d] = fma(c, xs[d] - mk[d], g[d]);
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) y += __shfl_xor(y, off, 64);
+  y = fm::wave_sum_dpp(y);
   if (GRAD) {
     const double s = a.log_flag ? -1.0 / y : -1.0;
 #pragma unroll
     for (int d = 0; d < DP; ++d)
       if (d < D) {
-        double gd = g[d];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) gd += __shfl_xor(gd, off, 64);
+        const double gd = fm::wave_sum_dpp(g[d]);
         if (lane == 0) a.dy[i * D + d] = s * gd * ilam[d];
       }
   }

@@ -11,14 +11,13 @@
 //        tau_dk = sqrt(sigma_k^2 lambda_d^2 + ell_d^2);  optionally Z[s][k][n] = z_n.
 //      The host turns these into G, dG (api_gp.hip: glj_finalize).
 #include "common.h"
+#include "fastmath.h"
 #include "philox.h"
 
 namespace {
 
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  return fm::wave_sum_dpp(v);
 }
 
 __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
@@ -130,11 +129,8 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
         au += t;
         at = fma(dl, t, at);
       }
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) {
-        au += __shfl_xor(au, off, 64);
-        at += __shfl_xor(at, off, 64);
-      }
+      au = fm::row16_sum_dpp(au);
+      at = fm::row16_sum_dpp(at);
       if (ns == 0) {
         out[1 + d] = au;
         out[1 + D + d] = at;

@@ -20,6 +20,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "fastmath.h"
 #include "philox.h"
 
 namespace {
@@ -94,8 +95,7 @@ __global__ __launch_bounds__(256) void kl_terms_kernel(const double* __restrict_
     if (qx == 0.0) qx = 2.2250738585072014e-308;
     acc += log(qx) - log(qo);
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  acc = fm::wave_sum_dpp(acc);
   if ((tid & 63) == 0) red[tid >> 6] = acc;
   __syncthreads();
   if (tid == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
