@@ -19,9 +19,7 @@ constexpr int WAVES = 4;
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  return fm::wave_sum_dpp(v);
 }
 
 // Inverse of an upper-triangular matrix, one thread per column (back substitution);
@@ -237,10 +235,7 @@ __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __r
           v += (mode == 0) ? t * t : A[(size_t)m * N + c] * t;
         }
       }
-      v += __shfl_xor(v, 1, 64);
-      v += __shfl_xor(v, 2, 64);
-      v += __shfl_xor(v, 4, 64);
-      v += __shfl_xor(v, 8, 64);
+      v = fm::row16_sum_dpp(v);
       if (li == 0) sRow[row][wc] = v;
     }
   __syncthreads();
@@ -311,8 +306,7 @@ __global__ __launch_bounds__(64 * NW) void predict_var_small_kernel(const double
         for (int wv = 0; wv < NW; ++wv) t += sT[(wv * MT + m) * 64 + lane];
         double v = 0.0;
         if (c < N) v = chol ? t * t : sA[m * N + c] * t;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        v = fm::wave_sum_dpp(v);
         if (lane == 0) part[(size_t)tile_c * Mtot + mg0 + m] = v;
       }
     }
@@ -411,10 +405,7 @@ __global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
         if (m < M && n < N) Ks[(size_t)m * N + n] = kv * sSc[col];
         f = fma(kv, sAl[col], f);  // alpha is 0 beyond N
       }
-      f += __shfl_xor(f, 1, 64);
-      f += __shfl_xor(f, 2, 64);
-      f += __shfl_xor(f, 4, 64);
-      f += __shfl_xor(f, 8, 64);
+      f = fm::row16_sum_dpp(f);
       if (li == 0) sF[row][wn] = f;
     }
   __syncthreads();
