@@ -159,9 +159,16 @@ void launch_small(hipStream_t st, const EntArgs& a, const double* d_table) {
   size_t lds = sizeof(double) * ((size_t)SW * nacc * 64 + (size_t)a.row_count * a.ml.D + 8);
   if (extra_row && sizeof(double) * (size_t)a.extra_lds > lds) lds = sizeof(double) * (size_t)a.extra_lds;
   if (a.want_grad) {
-    if (lds > 32 * 1024)
-      (void)hipFuncSetAttribute((const void*)entmc_small_kernel<DP, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
+    if (lds > 32 * 1024) {  // raised once per device and size (function attributes are per device)
+      static size_t lds_limit[64] = {};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (lds > lds_limit[dev & 63]) {
+        (void)hipFuncSetAttribute((const void*)entmc_small_kernel<DP, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_limit[dev & 63] = lds;
+      }
+    }
     hipLaunchKernelGGL((entmc_small_kernel<DP, true>), grid, block, lds, st, a, d_table);
   } else {
     hipLaunchKernelGGL((entmc_small_kernel<DP, false>), grid, block, lds, st, a, d_table);
