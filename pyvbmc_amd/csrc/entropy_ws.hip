@@ -94,6 +94,22 @@ constexpr int ws_min_waves(int dp, int ktmax, bool grad) {
 #endif
 }
 
+// End-of-workgroup reduction through an LDS transpose: every wave writes its per-lane accumulators
+// as rows [item][lane] (stride 65), then one THREAD sums one row.  A wave reduction costs ~30
+// dependent VALU instructions per accumulator even on DPP, and a workgroup has 4 x (1 + 2 DP + KT)
+// of them -- 3 us of the ~40 us a workgroup lives at BASELINE config 3; this way it is 64 pipelined
+// LDS reads per row.  Two half-size passes bound the buffer (35 KB at D_p = 10, KT = 13); it lives
+// in the dynamic LDS region (which the Adam loop's pre workgroup uses instead, adam_dev.h).
+// Returns the buffer size in doubles, 0 = keep the DPP reductions (buffer too large for the
+// kernel's occupancy).
+constexpr int ws_epi_half(int dp, int ktmax) { return (1 + 2 * dp + ktmax + 1) / 2; }
+constexpr int ws_epi_doubles(int dp, int ktmax, bool grad) {
+  if (!grad) return 0;
+  const int n = WAVES * ws_epi_half(dp, ktmax) * 65;
+  const int cap = (ws_min_waves(dp, ktmax, grad) >= 2 ? 44 : 100) * 1024 / 8;
+  return n <= cap ? n : 0;
+}
+
 template <int DP, int KTMAX, bool GRAD, bool EXACT, bool PHILOX>
 __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_kernel(
     EntArgs a, const double* __restrict__ T) {
@@ -102,7 +118,9 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   constexpr int GB = 4;                           // Philox mode: batches generated per round
   __shared__ double sE[PHILOX ? GB : 1][DP][64];  // their normals
   __shared__ double sRed[WAVES][2 * DP + 1];
-  extern __shared__ double sW[];                  // [K4]
+  extern __shared__ double dyn[];                 // [epilogue transpose buffer | sW[K4]]
+  constexpr int EPI = ws_epi_doubles(DP, KTMAX, GRAD);
+  double* sW = dyn + EPI;
 
   // Adam loop (adam.hip): grid row 0 is not an entropy row -- its first workgroup computes the
   // entropy-free part of the iteration's gradient beside the entropy workgroups (adam_dev.h)
@@ -111,7 +129,7 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
     if (a.extra != nullptr && blockIdx.y == 0) {
       if (blockIdx.x == 0) {
         const adam_dev::AdamDev& pa = *(const adam_dev::AdamDev*)a.extra;
-        if (a.extra_lds > 0) adam_dev::adam_pre_body<true>(pa, sW, &sRed[0][0]);
+        if (a.extra_lds > 0) adam_dev::adam_pre_body<true>(pa, dyn, &sRed[0][0]);
         else adam_dev::adam_pre_body<false>(pa, nullptr, &sRed[0][0]);
       }
       return;
@@ -309,28 +327,69 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   }
 
   // ---- workgroup reduction ----
-  {
-    const double v = wave_sum(slog_acc);
-    if (lane == 0) sRed[wave][0] = v;
-  }
-  if (GRAD) {
+  if constexpr (EPI > 0) {
+    constexpr int NI = 1 + 2 * DP + KTMAX, HALF = ws_epi_half(DP, KTMAX);
 #pragma unroll
-    for (int d = 0; d < DP; ++d) {
-      const double vmu = wave_sum(mu_acc[d]);
-      const double vlam = wave_sum(lam_acc[d]);
-      if (lane == 0) {
-        sRed[wave][1 + d] = vmu;
-        sRed[wave][1 + DP + d] = vlam;
+    for (int ph = 0; ph < 2; ++ph) {
+      const int i0 = ph * HALF;
+      double* mine = dyn + ((long)wave * HALF - i0) * 65 + lane;  // mine[it * 65], it in [i0, i0 + HALF)
+      if (ph == 0) mine[0] = slog_acc;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        if (1 + d >= i0 && 1 + d < i0 + HALF) mine[(1 + d) * 65] = mu_acc[d];
+        if (1 + DP + d >= i0 && 1 + DP + d < i0 + HALF) mine[(1 + DP + d) * 65] = lam_acc[d];
       }
+#pragma unroll
+      for (int kk = 0; kk < KTMAX; ++kk)
+        if (1 + 2 * DP + kk >= i0 && 1 + 2 * DP + kk < i0 + HALF) mine[(1 + 2 * DP + kk) * 65] = Wacc[kk];
+      __syncthreads();
+      for (int r = tid; r < WAVES * HALF; r += WG) {
+        const int wv = r / HALF, it = i0 + (r - wv * HALF);
+        if (it < NI) {
+          const double* row = dyn + (size_t)r * 65;
+          double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+          for (int l = 0; l < 64; l += 4) {
+            s0 += row[l];
+            s1 += row[l + 1];
+            s2 += row[l + 2];
+            s3 += row[l + 3];
+          }
+          const double sum = (s0 + s1) + (s2 + s3);
+          if (it <= 2 * DP) {
+            sRed[wv][it] = sum;
+          } else {
+            const int kk = it - 1 - 2 * DP;
+            if (4 * kk + wv < K4) sW[4 * kk + wv] = sum;
+          }
+        }
+      }
+      __syncthreads();
     }
+  } else {
+    {
+      const double v = wave_sum(slog_acc);
+      if (lane == 0) sRed[wave][0] = v;
+    }
+    if (GRAD) {
 #pragma unroll
-    for (int kk = 0; kk < KTMAX; ++kk)
-      if (EXACT || kk < KT) {
-        const double v = wave_sum(Wacc[kk]);
-        if (lane == 0) sW[4 * kk + wave] = v;
+      for (int d = 0; d < DP; ++d) {
+        const double vmu = wave_sum(mu_acc[d]);
+        const double vlam = wave_sum(lam_acc[d]);
+        if (lane == 0) {
+          sRed[wave][1 + d] = vmu;
+          sRed[wave][1 + DP + d] = vlam;
+        }
       }
+#pragma unroll
+      for (int kk = 0; kk < KTMAX; ++kk)
+        if (EXACT || kk < KT) {
+          const double v = wave_sum(Wacc[kk]);
+          if (lane == 0) sW[4 * kk + wave] = v;
+        }
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   double* out = a.partial + ((int64_t)j * a.chunks + chunk) * a.stride;
   for (int t = tid; t < a.stride; t += WG) {
@@ -358,7 +417,7 @@ template <int DP, int KTMAX>
 void launch_one(hipStream_t st, const EntArgs& a, const double* d_table, hipEvent_t e0, hipEvent_t e1) {
   const int K = a.ml.K;
   const int K4 = ((K + 3) / 4) * 4;
-  size_t lds = sizeof(double) * (size_t)K4;
+  size_t lds = sizeof(double) * ((size_t)K4 + ws_epi_doubles(DP, KTMAX, a.want_grad != 0));
   // the table carries zero-density padding rows up to 4*ceil(K/4), so the guard-free
   // variant applies whenever ceil(K/4) == KTMAX
   const bool exact = ((K + 3) / 4 == KTMAX);
