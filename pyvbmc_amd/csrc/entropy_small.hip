@@ -8,8 +8,9 @@
 //     workgroup = component j,  lane = component k (K <= 64),  the four waves split the rows.
 //
 // Everything indexed by k -- the (j,k) table row written by prep.hip -- is loaded ONCE into the
-// lane's registers; everything indexed by the row (its D normals) is wave-uniform and feeds the
-// FMAs as scalar operands.  The only cross-lane traffic per row is the two density sums q+ and q-.
+// lane's registers; everything indexed by the row (its D normals) is wave-uniform: the component's
+// block of normals is staged in LDS with one coalesced batch of loads and read back by broadcast.
+// The only cross-lane traffic per row is the two density sums q+ and q- (DPP, fastmath.h).
 // All gradient sums are kept per lane (i.e. per k) and reduced over lanes once at the end:
 //     A_d(k) = sum_rows e_d   gd_k,   B_d(k) = sum_rows e_d^2 gs_k,   W(k) = sum_rows (t+ + t-)
 //     t+- = r+-_k / q+-,   gs_k = wis2_k (t+ + t-),   gd_k = wis2_k (t+ - t-),
