@@ -230,8 +230,9 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
         //   sum_k w_k/sigma_k^2 (mu'_jd - mu'_kd) W_jk   (entropy_ws.hip, pass 2)
         const double* mup = mix + ml.o_mup;
         const double* is2 = mix + ml.o_is2;
+        // lanes run over k within one partial row (coalesced), then over the chunks
         for (int i = lane; i < K * chunks; i += 64) {
-          const int k = i / chunks, c = i - k * chunks;
+          const int c = i / K, k = i - c * K;
           const double Wjk = partial[((int64_t)j * chunks + c) * stride + 2 + 2 * D + k];
           v = fma(w[k] * is2[k] * (mup[j * D + d] - mup[k * D + d]), Wjk, v);
         }
