@@ -38,9 +38,10 @@ def optimize(wl, n_candidates=256, n_iters=200, seed=0, verbose=True):
     gp.update(X_new=wl.X, y_new=wl.y, s2_new=wl.s2, hyp=wl.hyp)
     bnd = synthetic.default_theta_bnd(wl)
     theta0 = vp.get_parameters()
-    t0 = time.perf_counter()
     cands = theta0[None, :] + 0.3 * rng.standard_normal((n_candidates, theta0.size))
     cands[0] = theta0
+    _neg_elcbo_batch(cands[:1], gp, vp, bnd)  # first device use: context, GP upload (L^-1), scratch buffers
+    t0 = time.perf_counter()
     F_sieve = _neg_elcbo_batch(cands, gp, vp, bnd)
     best = int(np.argmin(F_sieve))
     t1 = time.perf_counter()
