@@ -136,6 +136,9 @@ static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red) 
   // ---- phase 1 (all 256 lanes, two independent jobs):
   //  * GP expected log joint, per (k, d) term (host twin: api_gp.hip glj_finalize)
   //  * soft bounds (_vp_bound_loss :537-606): gradient dL and this thread's share of the loss
+  // (1/tau by v_rsq + Newton and 1/S as a factor: a float64 division is a ~20-instruction dependent
+  // chain, and this workgroup is nothing but dependent chains)
+  const double inv_S = 1.0 / S;
   for (int idx = tid; idx < K * D; idx += 256) {
     const int k = idx / D, d = idx - k * D;
     const double sgk = sg[k], wk = w[k], lam = lm[d], m = mu[idx];
@@ -144,16 +147,16 @@ static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red) 
       const double* h = hyp + (size_t)s * a.P;
       const double* r = res + ((size_t)s * K + k) * st;
       const double tau2 = sgk * sgk * lam * lam + ell2[s * D + d];
-      const double tau = sqrt(tau2);
+      const double rtau = fm::rsqrt_fast(tau2);
       const double U = r[1 + d], T = r[1 + D + d] - r[0];
-      double gm = wk * (-U / tau);
-      gs_acc += (lam * lam / tau2) * T / S;
+      double gm = wk * (-U * rtau);
+      gs_acc += (lam * lam * (rtau * rtau)) * T * inv_S;
       if (quad) {
         const double xm = h[D + 3 + d], io = iom2[s * D + d];
         gm -= wk * io * (m - xm);
-        nu_acc += io * (m * m + sgk * sgk * lam * lam - 2.0 * m * xm + xm * xm) / S;
+        nu_acc += io * (m * m + sgk * sgk * lam * lam - 2.0 * m * xm + xm * xm) * inv_S;
       }
-      gm_acc += gm / S;
+      gm_acc += gm * inv_S;
     }
     gmu[idx] = gm_acc;
     tgs[idx] = gs_acc;
@@ -203,9 +206,9 @@ static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red) 
     }
     for (int s = 0; s < S; ++s) {
       const double* h = hyp + (size_t)s * a.P;
-      b0 += (res[((size_t)s * K + k) * st] + (a.mean_kind == VBMC_MEAN_ZERO ? 0.0 : h[D + 2])) / S;
+      b0 += (res[((size_t)s * K + k) * st] + (a.mean_kind == VBMC_MEAN_ZERO ? 0.0 : h[D + 2])) * inv_S;
       if (quad)
-        for (int d = 0; d < D; ++d) qbar += iom2[s * D + d] * lm[d] * lm[d] / S;
+        for (int d = 0; d < D; ++d) qbar += iom2[s * D + d] * lm[d] * lm[d] * inv_S;
     }
     const double wI = b0 - 0.5 * nu;  // mean over s of I_sk
     gpart += wk * wI;
@@ -239,9 +242,9 @@ static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red) 
         const double sgk = sg[k], wk = w[k];
         const double tau2 = sgk * sgk * lam * lam + ell2[s * D + d];
         const double T = r[1 + D + d] - r[0];
-        double gl = wk * (sgk * sgk / tau2) * lam * T;
+        double gl = wk * (sgk * sgk * fm::rcp_fast(tau2)) * lam * T;
         if (quad) gl -= wk * sgk * sgk * iom2[s * D + d] * lam;
-        acc += gl / S;
+        acc += gl * inv_S;
       }
       if (a.has_bnd && o_lm)
         for (int k = ns; k < K; k += 16) accb += dL[sc0 + d * K + k];

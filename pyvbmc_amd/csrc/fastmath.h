@@ -41,6 +41,15 @@ __device__ __forceinline__ double rcp_fast(double x) {
   return r;
 }
 
+// 1/sqrt(x) for normal x > 0 to ~1 ulp: v_rsq_f64 + two Newton steps.
+__device__ __forceinline__ double rsqrt_fast(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  r = fma(r, fma(-h * r, r, 0.5), r);
+  r = fma(r, fma(-h * r, r, 0.5), r);
+  return r;
+}
+
 // ln(x) for finite x > 0 (normal or subnormal); x == 0 -> -inf.
 // x = 2^e m, m in [sqrt(1/2), sqrt(2)); ln m = 2 atanh(s), s = (m-1)/(m+1).
 __device__ __forceinline__ double log_fast(double x) {
