@@ -73,6 +73,7 @@ __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, do
   s2 = (red[0] + red[1]) + (red[2] + red[3]);
   mx = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
   const double nl = sqrt(s2 / D);  // lambda -> unit RMS, sigma absorbs it
+  const double inl = 1.0 / nl;
   // ---- round 2: unnormalised weights and their sum; product of the normalised lambdas ----
   double wsum = 0.0, pr = 1.0;
   if (o_w)
@@ -84,7 +85,7 @@ __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, do
       w[k] = we;
       wsum += we;
     }
-  for (int d = tid; d < D; d += 256) pr *= lm[d] / nl;  // this thread's own entries of round 1
+  for (int d = tid; d < D; d += 256) pr *= lm[d] * inl;  // this thread's own entries of round 1
   wsum = wave_sum(wsum);
   pr = fm::wave_prod_dpp(pr);
   if (lane == 0) {
@@ -104,7 +105,7 @@ __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, do
     const double m = o_mu ? theta[i] : mu[i];
     mu[i] = m;
     p[ml.o_mu + i] = m;
-    p[ml.o_mup + i] = m / (lm[d] / nl);
+    p[ml.o_mup + i] = m * fm::rcp_fast(lm[d] * inl);
   }
   for (int k = tid; k < K; k += 256) {
     const double s = (o_sg ? exp(theta[p_sg + k]) : sg[k]) * nl;
@@ -116,19 +117,20 @@ __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, do
     }
     sg[k] = s;
     w[k] = wk;
-    p[ml.o_is2 + k] = 1.0 / (s * s);
-    p[ml.o_rc + k] = nconst / sD;
+    const double rsD = nconst * fm::rcp_fast(sD);
+    p[ml.o_is2 + k] = fm::rcp_fast(s * s);
+    p[ml.o_rc + k] = rsD;
     p[ml.o_lrc + k] = l2n - D * log2(s);
-    p[ml.o_wc + k] = wk * nconst / sD;
+    p[ml.o_wc + k] = wk * rsD;
     p[ml.o_sig + k] = s;
     p[ml.o_w + k] = wk;
   }
   __syncthreads();
   for (int d = tid; d < D; d += 256) {
-    const double l = lm[d] / nl;
+    const double l = lm[d] * inl;
     lm[d] = l;
     p[ml.o_lam + d] = l;
-    p[ml.o_ilam + d] = 1.0 / l;
+    p[ml.o_ilam + d] = fm::rcp_fast(l);
   }
 }
 
@@ -201,9 +203,12 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamDev a, int do_step, 
   };
   if (do_step) load_chunk(0);
   // minimize_adam.py:92-98 (evaluated while the loads above are in flight)
-  const double c1 = 1.0 / (1.0 - pow(a.beta1, (double)(iter + 1)));
-  const double c2 = 1.0 / (1.0 - pow(a.beta2, (double)(iter + 1)));
-  const double step = a.master_min + (a.master_max - a.master_min) * exp(-(double)(iter + 1) / a.master_decay);
+  // beta^(i+1) and exp(-(i+1)/decay) as exp2 of host-prepared logarithms (pow() is ~200 dependent
+  // instructions; the powers are accurate to ~1e-15 relative for any iteration count in use)
+  const double it1 = (double)(iter + 1);
+  const double c1 = 1.0 / (1.0 - fm::exp2_fast(it1 * a.l2_beta1));
+  const double c2 = 1.0 / (1.0 - fm::exp2_fast(it1 * a.l2_beta2));
+  const double step = a.master_min + (a.master_max - a.master_min) * fm::exp2_fast(-it1 * a.l2e_over_decay);
   double* x_row = a.x_tab + (size_t)iter * n;
   double* y_out = a.y_tab + 3 * (size_t)iter;
   __syncthreads();
@@ -367,6 +372,9 @@ static void fill_dev(const vbmc_ctx* ctx, const AdamState& st, AdamDev& a) {
   a.beta1 = 0.9;
   a.beta2 = 0.999;
   a.c_norm = 1.0 / std::pow(2.0 * M_PI, 0.5 * ctx->D);
+  a.l2_beta1 = std::log2(a.beta1);
+  a.l2_beta2 = std::log2(a.beta2);
+  a.l2e_over_decay = 1.4426950408889634 / st.master_decay;
   a.master_min = st.master_min;
   a.master_max = st.master_max;
   a.master_decay = st.master_decay;

@@ -37,6 +37,7 @@ struct AdamDev {
   double tol_con, w_thresh, w_pen;
   double fudge, beta1, beta2;
   double c_norm;  // 1 / (2 pi)^(D/2)
+  double l2_beta1, l2_beta2, l2e_over_decay;  // log2 beta1, log2 beta2, log2(e) / master_decay
   double master_min, master_max, master_decay;  // step-size schedule (minimize_adam.py:92-98)
   // The iteration index is iter_base[0] + it_off: the base lives in device memory (set once per
   // vbmc_adam_run call) and the offset is a launch constant, so the launch arguments of a batch
