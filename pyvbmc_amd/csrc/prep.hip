@@ -85,12 +85,12 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
     // wave 0: 1/tau_d, mu_dk and lnnf = 2 hyp[D] + sum_d (hyp[d] - log tau_d)
     double term = 0.0;
     for (int d = tid; d < D; d += 64) {
-      const double ell = exp(h[d]);
+      const double ell = fm::exp2_fast(0x1.71547652b82fep+0 * h[d]);  // exp(h_d)
       const double lam = a.mix[a.ml.o_lam + d];
       const double tau2 = sigk * sigk * lam * lam + ell * ell;
-      sItau[d] = rsqrt(tau2);
+      sItau[d] = fm::rsqrt_fast(tau2);
       sMu[d] = a.mix[a.ml.o_mu + k * D + d];
-      term += h[d] - 0.5 * log(tau2);
+      term += h[d] - 0.5 * fm::log_fast(tau2);
     }
     term = wave_sum(term);
     if (tid == 0) sMisc[0] = 2.0 * h[D] + term;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
       const double dl = (sMu[d] - a.X[(size_t)n * D + d]) * sItau[d];
       d2 = fma(dl, dl, d2);
     }
-    const double z = exp(lnnf - 0.5 * d2);
+    const double z = fm::exp2_fast(0x1.71547652b82fep+0 * (lnnf - 0.5 * d2));  // exp(.)
     sZa[n] = z * a.alpha[(size_t)s * N + n];
     if (a.Z) a.Z[((size_t)s * K + k) * N + n] = z;
   }
