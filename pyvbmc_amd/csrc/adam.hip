@@ -56,7 +56,7 @@ __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, do
   // ---- round 1: raw lambda and its sum of squares; max of the eta tail ----
   double s2 = 0.0, mx = -INFINITY;
   for (int d = tid; d < D; d += 256) {
-    const double l = o_lm ? exp(theta[p_lm + d]) : lm[d];
+    const double l = o_lm ? fm::exp2_fast(0x1.71547652b82fep+0 * theta[p_lm + d]) : lm[d];  // exp(.)
     lm[d] = l;
     s2 = fma(l, l, s2);
   }
@@ -81,7 +81,7 @@ __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, do
       const double e = theta[p_w + k] - mx;
       theta[p_w + k] = e;
       eta[k] = e;
-      const double we = exp(e);
+      const double we = fm::exp2_fast(0x1.71547652b82fep+0 * e);
       w[k] = we;
       wsum += we;
     }
@@ -96,7 +96,7 @@ __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, do
   wsum = (red[8] + red[9]) + (red[10] + red[11]);
   pr = (red[12] * red[13]) * (red[14] * red[15]);
   const double nconst = a.c_norm / pr;  // 1 / (2 pi)^(D/2) / prod(lambda)   (entmc_vbmc.py:54-56)
-  const double l2n = log2(nconst);
+  const double l2n = 0x1.71547652b82fep+0 * fm::log_fast(nconst);
   // ---- the pack and the final attributes (lm stays raw until every reader is through) ----
   const MixLayout& ml = a.ml;
   double* p = a.mix;
@@ -108,7 +108,7 @@ __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, do
     p[ml.o_mup + i] = m * fm::rcp_fast(lm[d] * inl);
   }
   for (int k = tid; k < K; k += 256) {
-    const double s = (o_sg ? exp(theta[p_sg + k]) : sg[k]) * nl;
+    const double s = (o_sg ? fm::exp2_fast(0x1.71547652b82fep+0 * theta[p_sg + k]) : sg[k]) * nl;
     const double wk = o_w ? w[k] / wsum : w[k];
     double sD = 1.0, b = s;  // sigma^D by repeated squaring, as the host pack (ctx.hip)
     for (int e = D; e > 0; e >>= 1) {
@@ -120,7 +120,7 @@ __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, do
     const double rsD = nconst * fm::rcp_fast(sD);
     p[ml.o_is2 + k] = fm::rcp_fast(s * s);
     p[ml.o_rc + k] = rsD;
-    p[ml.o_lrc + k] = l2n - D * log2(s);
+    p[ml.o_lrc + k] = l2n - D * (0x1.71547652b82fep+0 * fm::log_fast(s));
     p[ml.o_wc + k] = wk * rsD;
     p[ml.o_sig + k] = s;
     p[ml.o_w + k] = wk;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamDev a, int do_step, 
     if (o_w) {
       double ps = 0.0, pd = 0.0;
       for (int k = tid; k < K; k += 256) {
-        const double e = exp(eta[k]);
+        const double e = fm::exp2_fast(0x1.71547652b82fep+0 * eta[k]);
         ee[k] = e;
         ps += e;
         pd += e * (k == tid ? rw : raw[f_w + k]);

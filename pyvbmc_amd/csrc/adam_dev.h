@@ -129,8 +129,8 @@ static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red) 
   for (int i = tid; i < S * D; i += 256) {
     const int s = i / D, d = i - s * D;
     const double* h = hyp + (size_t)s * a.P;
-    ell2[i] = exp(2.0 * h[d]);
-    iom2[i] = quad ? exp(-2.0 * h[2 * D + 3 + d]) : 0.0;
+    ell2[i] = fm::exp2_fast(2.0 * 0x1.71547652b82fep+0 * h[d]);  // exp(2 h_d)
+    iom2[i] = quad ? fm::exp2_fast(-2.0 * 0x1.71547652b82fep+0 * h[2 * D + 3 + d]) : 0.0;
   }
   __syncthreads();
 
@@ -222,7 +222,7 @@ static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red) 
     }
     gw[k] = g;
     if (o_w) {  // softmax Jacobian of the entropy-free weight gradient (entmc_vbmc.py:122-130)
-      const double e = exp(eta[k]);
+      const double e = fm::exp2_fast(0x1.71547652b82fep+0 * eta[k]);
       ee[k] = e;
       ps += e;
       pd += e * g;
