@@ -107,6 +107,25 @@ int vbmc_last_kernel_ms(vbmc_ctx* ctx, int which, double* ms_out);
  * Profiling aid for bench.py / DESIGN.md; no reference counterpart. */
 int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
 
+/* Per-context switches for tests and measurements (no reference counterpart).  Each starts
+ * from the environment variable in brackets, read when the context is created.
+ *   "entmc_kernel" [VBMC_ENTMC_KERNEL=valu -> 1]: 0 = pick the kernel by shape (default),
+ *                  1 = always the generic thread-per-row kernel (on-device cross-check)
+ *   "elbo_pregen"  [VBMC_ELBO_PREGEN]: 1 = Philox draws generated ahead of the entropy
+ *                  kernel (default), 0 = generated in-line by it; same values either way
+ *   "elbo_ahead"   [VBMC_ELBO_AHEAD]: 1 = after a Philox evaluation with seed s the draws of
+ *                  seed s+1 are generated speculatively while the host finalises (default),
+ *                  0 = never
+ * Unknown key -> VBMC_E_ARG. */
+int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value);
+
+/* Launch geometry of the most recent Monte-Carlo entropy of this ctx (vbmc_entmc,
+ * vbmc_neg_elcbo, the optimiser loop): out[0] = kernel (0 generic, 1 wave-split, 2 small-
+ * sample), out[1] = 64-row batches per workgroup (the wave-split kernel's batch loop count),
+ * out[2] = workgroups per component, out[3] = 1 if the draws were read from HBM, 0 if
+ * generated in-line.  Lets the parity tests assert which code path they exercised. */
+int vbmc_last_entmc_plan(const vbmc_ctx* ctx, int out[4]);
+
 /* ---- mixture state: VariationalPosterior attributes --------------------- */
 
 /* Upload the mixture (variational_posterior.py:106-138: mu (D,K), sigma (1,K),

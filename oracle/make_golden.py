@@ -164,6 +164,49 @@ def case(name, cfg, S_multi, seed, all_flag_combos=False, **shrink):
     print(f"wrote {name}: D={wl.D} K={wl.K} N={wl.N} NsK={NsK} keys={len(out)}")
 
 
+def mid(name, cfg, seed, **shrink):
+    """Mid-size cases whose only job is to drive the wave-split entropy kernel through its
+    MULTI-BATCH workgroup loop (K * NsK/2 > 32768 rows => rg >= 2, csrc/entropy.hip entmc_plan)
+    with reference-generated values: ``entmc_vbmc`` value and all four gradient blocks, and the
+    call Adam makes (``_neg_elcbo(compute_grad=True, theta_bnd=...)``, inside and outside the
+    soft bounds).  Inputs are the seeded synthetic ones; only small arrays are stored (the
+    draws are re-created from ``seed`` by the tests: legacy ``np.random.seed``)."""
+    import time
+
+    wl = synthetic.make_workload(cfg, S=1, **shrink)
+    NsK = wl.NsK
+    out = dict(
+        cfg=cfg, D=wl.D, K=wl.K, N=wl.N, Ns_total=wl.Ns_total, NsK=NsK, seed=seed,
+        mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta,
+        X=wl.X, y=wl.y, hyp=wl.hyp, theta=wl.theta,
+        s2=np.zeros(0) if wl.s2 is None else wl.s2,
+    )
+    t0 = time.time()
+    for gf in ((False,) * 4, (True,) * 4):
+        vp = ref_vp(wl)
+        np.random.seed(seed)
+        H, dH = entmc_vbmc(vp, NsK, gf, True)
+        out[f"entmc_H_{flagname(gf)}_1"], out[f"entmc_dH_{flagname(gf)}_1"] = H, dH
+    gp = ref_gp(wl, wl.hyp[:1])
+    bnd = synthetic.default_theta_bnd(wl)
+    theta_out = wl.theta.copy()
+    theta_out[0] = bnd["ub"][0] + 0.3
+    theta_out[wl.D * wl.K] = bnd["ub"][wl.D * wl.K] + 0.2 - np.log(wl.lambd[0])
+    theta_out[-1] += 0.7
+    out["theta_out"] = theta_out
+    for tag, th in (("bnd", wl.theta), ("bndout", theta_out)):
+        vp = ref_vp(wl)
+        np.random.seed(seed)
+        th_in = th.copy()
+        F, dF, G, H, _ = _neg_elcbo(th_in, gp, vp, 0.0, NsK, True, False, bnd, 0.0, False)
+        out[f"elbo_{tag}_mc_F"], out[f"elbo_{tag}_mc_dF"] = F, dF
+        out[f"elbo_{tag}_mc_G"], out[f"elbo_{tag}_mc_H"] = G, H
+        out[f"elbo_{tag}_mc_theta_after"] = th_in
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print(f"wrote {name}: D={wl.D} K={wl.K} N={wl.N} NsK={NsK} K*rows={wl.K * NsK // 2} "
+          f"({time.time() - t0:.0f} s of reference time)")
+
+
 def matlab_known():
     """Known-answer DATA held by the reference's own tests, re-packed as npz."""
     out = {}
@@ -353,6 +396,10 @@ if __name__ == "__main__":
         "c2s": lambda: case("c2s", 2, S_multi=3, seed=2, Ns_total=20 * 200),
         "c3s": lambda: case("c3s", 3, S_multi=8, seed=3, Ns_total=50 * 200),
         "c5s": lambda: case("c5s", 5, S_multi=2, seed=5, Ns_total=100 * 100),
+        # multi-batch workgroups of the entropy kernel (K * NsK / 2 rows: 50 000, 50 000, 100 000)
+        "c2f": lambda: mid("c2f", 2, seed=12),
+        "c3m": lambda: mid("c3m", 3, seed=13, Ns_total=50 * 2000),
+        "c5m": lambda: mid("c5m", 5, seed=15, Ns_total=100 * 2000),
         "matlab_known": matlab_known,
         "misc": misc,
         "adam": adam,

@@ -63,6 +63,8 @@ SIGNATURES = {
         [_vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)],
     ),
     "vbmc_synchronize": (C.c_int, [_vp]),
+    "vbmc_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "vbmc_last_entmc_plan": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "vbmc_set_timing": (C.c_int, [_vp, C.c_int]),
     "vbmc_last_kernel_ms": (C.c_int, [_vp, C.c_int, _dp]),
     "vbmc_last_host_us": (C.c_int, [_vp, _dp]),
@@ -217,6 +219,18 @@ class Context:
     def set_timing(self, on):
         """HIP event pair around the dominant kernels (off by default: each record costs ~6 us)."""
         self.check(self._lib.vbmc_set_timing(self._h, 1 if on else 0))
+
+    def set_option(self, key, value):
+        """Per-context test / measurement switch (vbmc_set_option in include/vbmc_hip.h)."""
+        self.check(self._lib.vbmc_set_option(self._h, key.encode(), int(value)))
+
+    def last_entmc_plan(self):
+        """Launch geometry of the most recent Monte-Carlo entropy: which kernel ran, how many
+        64-row batches each workgroup looped over, workgroups per component, draw source."""
+        out = (C.c_int * 4)()
+        self.check(self._lib.vbmc_last_entmc_plan(self._h, out))
+        return {"kernel": ("valu", "ws", "small")[out[0]] if out[0] >= 0 else None, "rg": out[1],
+                "chunks": out[2], "resident_draws": bool(out[3])}
 
     def last_kernel_ms(self, which=0):
         v = C.c_double()

@@ -17,6 +17,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from ._duck import ctx_of, upload_vp
 from .gp import upload_gp
 
 ACQ_STD, ACQ_LOG, ACQ_VANILLA, ACQ_NOISY = 0, 1, 2, 3
@@ -79,7 +80,7 @@ class AbstractAcqFcn:
     def _estimate_observation_noise(self, Xs, gp, optim_state):
         """Noise at the nearest training input (abstract_acq_fcn.py:224-256)."""
         pos = nearest_neighbour(Xs / optim_state.get("gp_length_scale"),
-                                gp.temporary_data.get("X_rescaled"), ctx=getattr(gp, "ctx", None))
+                                gp.temporary_data.get("X_rescaled"), ctx=getattr(gp, "_ctx", None))
         return gp.temporary_data.get("sn2_new")[pos]
 
     def __call__(self, Xs, gp, vp, function_logger, optim_state):
@@ -89,8 +90,8 @@ class AbstractAcqFcn:
         if Xs.ndim == 1:
             Xs = Xs[None, :]
         Xs = self._real2int(Xs, vp.parameter_transformer, optim_state.get("integer_vars"))
-        ctx = vp.ctx
-        vp._upload(ctx)
+        ctx = ctx_of(vp)
+        upload_vp(vp, ctx)
         upload_gp(gp, ctx)
         xs = _lib.f64(Xs)
         M = xs.shape[0]

@@ -1,6 +1,7 @@
 // Context, device memory and mixture/eps/GP state upload for libvbmc_hip.so.
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -49,9 +50,18 @@ int ensure_pinned(vbmc_ctx* ctx, size_t n) {
   return 0;
 }
 
+static void options_from_env(vbmc_ctx* c) {
+  const char* e = getenv("VBMC_ENTMC_KERNEL");
+  c->opt_entmc_valu = (e && e[0] == 'v') ? 1 : 0;  // VBMC_ENTMC_KERNEL=valu
+  e = getenv("VBMC_ELBO_PREGEN");
+  c->opt_elbo_pregen = !(e && e[0] == '0');
+  e = getenv("VBMC_ELBO_AHEAD");
+  c->opt_elbo_ahead = !(e && e[0] == '0');
+}
+
 extern "C" {
 
-int vbmc_abi_version(void) { return 1; }
+int vbmc_abi_version(void) { return 2; }
 
 int vbmc_device_count(int* n_out) {
   int n = 0;
@@ -72,6 +82,7 @@ int vbmc_ctx_create(int device_id, vbmc_ctx** out) {
     // CPU tests of the sharded path); every kernel-launching entry point refuses it.
     vbmc_ctx* h = new vbmc_ctx();
     h->device = -1;
+    options_from_env(h);
     *out = h;
     return VBMC_OK;
   }
@@ -87,6 +98,7 @@ int vbmc_ctx_create(int device_id, vbmc_ctx** out) {
     return vbmc_fail(nullptr, VBMC_E_ARG, "device_id %d out of range [0,%d)", device_id, n);
   vbmc_ctx* ctx = new vbmc_ctx();
   ctx->device = device_id;
+  options_from_env(ctx);
   e = hipSetDevice(device_id);
   if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_id);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -152,6 +164,21 @@ int vbmc_synchronize(vbmc_ctx* ctx) {
   if (ctx->device < 0) return VBMC_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, stream_wait(ctx));
+  return VBMC_OK;
+}
+
+int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
+  if (!ctx || !key) return VBMC_E_ARG;
+  if (!strcmp(key, "entmc_kernel")) ctx->opt_entmc_valu = value == 1;
+  else if (!strcmp(key, "elbo_pregen")) ctx->opt_elbo_pregen = value != 0;
+  else if (!strcmp(key, "elbo_ahead")) ctx->opt_elbo_ahead = value != 0;
+  else return vbmc_fail(ctx, VBMC_E_ARG, "vbmc_set_option: unknown key '%s'", key);
+  return VBMC_OK;
+}
+
+int vbmc_last_entmc_plan(const vbmc_ctx* ctx, int out[4]) {
+  if (!ctx || !out) return VBMC_E_ARG;
+  for (int i = 0; i < 4; ++i) out[i] = ctx->last_plan[i];
   return VBMC_OK;
 }
 

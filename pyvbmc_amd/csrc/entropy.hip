@@ -412,12 +412,8 @@ int launch_entmc_dp(vbmc_ctx* ctx, const EntArgs& a) {
 
 }  // namespace
 
-static bool use_ws_kernel(int D, int K) {
-  static const int forced = [] {
-    const char* e = getenv("VBMC_ENTMC_KERNEL");
-    return (e && e[0] == 'v') ? 1 : 0;  // VBMC_ENTMC_KERNEL=valu forces the generic kernel
-  }();
-  if (forced == 1) return false;
+static bool use_ws_kernel(const vbmc_ctx* ctx, int D, int K) {
+  if (ctx->opt_entmc_valu) return false;  // vbmc_set_option("entmc_kernel", 1) / VBMC_ENTMC_KERNEL=valu
   return D <= 32 && K <= 128;
 }
 
@@ -445,7 +441,7 @@ int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
   a.seed = seed;
   a.eps_mode = eps_mode;
   a.want_grad = want_grad;
-  p.ws = use_ws_kernel(D, K);
+  p.ws = use_ws_kernel(ctx, D, K);
   p.inv_ns = 1.0 / (double)ns_per_comp;
   int rows_per_wg = WG;
   a.rg = 1;
@@ -490,10 +486,7 @@ void entmc_fill_prep(const vbmc_ctx* ctx, const EntPlan& p, PrepArgs& a) {
 // resident-draw form on the identical values.  Call after entmc_plan + entmc_fill_prep.
 // VBMC_ELBO_PREGEN=0 keeps the generation inside the entropy kernel.
 int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& pa) {
-  static const bool on = [] {
-    const char* e = getenv("VBMC_ELBO_PREGEN");
-    return !(e && e[0] == '0');
-  }();
+  const bool on = ctx->opt_elbo_pregen != 0;
   const int D = ctx->D, K = ctx->K;
   const size_t n_eps = (size_t)K * (size_t)p.a.row_count * D;
   if (!on || p.a.eps_mode != VBMC_EPS_PHILOX || n_eps == 0 || n_eps > ((size_t)1 << 28)) return 0;
@@ -512,6 +505,10 @@ int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p) {
   // kernel is bracketed by two records (each a barrier packet, ~6 us between dependent kernels)
   hipEvent_t e0 = ctx->timing ? ctx->ev[0] : nullptr, e1 = ctx->timing ? ctx->ev[1] : nullptr;
   const bool small = p.ws && entmc_small_applies(a, p.DP);
+  ctx->last_plan[0] = small ? 2 : (p.ws ? 1 : 0);
+  ctx->last_plan[1] = a.rg;
+  ctx->last_plan[2] = a.chunks;
+  ctx->last_plan[3] = a.eps_mode == VBMC_EPS_RESIDENT ? 1 : 0;
   const bool bracket = ctx->timing && (!p.ws || small);
   if (bracket) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   if (small) {

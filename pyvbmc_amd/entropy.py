@@ -11,9 +11,12 @@ stream: for every component j ascending, ``np.random.randn(Ns//2, D)``
 (entmc_vbmc.py:64-68).  ``rng="numpy"`` (default) does exactly that on the host and
 ships the draws to HBM, so a seeded call returns the reference's value to
 rounding.  ``rng="philox"`` generates the draws inside the kernel (Philox4x32-10 +
-Box-Muller) from a 64-bit seed taken from ``np.random`` (one ``randint`` call, so
-runs stay reproducible under ``np.random.seed``): statistically equivalent, not
+Box-Muller) from a 64-bit seed derived from ``np.random`` (see ``philox_seed``: runs
+stay reproducible under ``np.random.seed``): statistically equivalent, not
 stream-identical, and removes the host RNG + PCIe cost.
+
+``vp`` may be any object with the reference's public mixture attributes (a real
+``pyvbmc`` ``VariationalPosterior`` included): see pyvbmc_amd/_duck.py.
 """
 import ctypes as C
 import os
@@ -21,6 +24,7 @@ import os
 import numpy as np
 
 from . import _lib
+from ._duck import ctx_of, upload_vp
 
 DEFAULT_RNG = os.environ.get("VBMC_HIP_RNG", "numpy")
 
@@ -38,6 +42,45 @@ def draw_eps_half(K, D, Ns):
     return eps
 
 
+def _np_fingerprint_reader():
+    """A cheap fingerprint of NumPy's global MT19937 state (its position and first two key
+    words), read in place: ``np.random.get_state()`` copies 2.5 KB and costs ~35 us, more than
+    the host has per evaluation.  The layout (``uint32 key[624]; int pos``) is checked against
+    ``get_state`` once; on any mismatch there is no fingerprint and every call draws afresh."""
+    try:
+        addr = np.random.mtrand._rand._bit_generator.ctypes.state_address
+        words = (C.c_uint32 * 625).from_address(addr)
+        st = np.random.get_state()
+        if st[0] != "MT19937" or (words[0], words[1], words[624]) != (int(st[1][0]), int(st[1][1]), int(st[2])):
+            return None
+        return lambda: (words[0], words[1], words[624])
+    except Exception:
+        return None
+
+
+_np_fingerprint = _np_fingerprint_reader()
+
+
+def philox_seed(ctx):
+    """The device generator's seed for a call that was not given one.
+
+    Per context a sequence ``s0, s0+1, s0+2, ...``: ``s0`` is one ``np.random.randint`` draw,
+    taken on first use and again whenever NumPy's global generator was touched since the last
+    call (re-seeded or consumed by anyone) -- so scripts stay reproducible under
+    ``np.random.seed`` and replaying from a re-seed replays the draws.  Consecutive seeds are
+    what lets the library generate the next evaluation's draws while the host is busy with
+    this one's result (``vbmc_neg_elcbo``, option ``elbo_ahead``)."""
+    st = ctx.__dict__.get("_philox_seq")
+    fp = _np_fingerprint() if _np_fingerprint is not None else None
+    if st is not None and fp is not None and st[1] == fp:
+        seed = (st[0] + 1) & 0x3FFFFFFFFFFFFFFF
+    else:
+        seed = int(np.random.randint(0, 2**62, dtype=np.int64))
+        fp = _np_fingerprint() if _np_fingerprint is not None else None
+    ctx.__dict__["_philox_seq"] = (seed, fp)
+    return seed
+
+
 def _n_grad(vp, bits):
     D, K = vp.D, vp.K
     return D * K * bool(bits & 1) + K * bool(bits & 2) + D * bool(bits & 4) + K * bool(bits & 8)
@@ -46,8 +89,8 @@ def _n_grad(vp, bits):
 def entmc_vbmc(vp, Ns, grad_flags=tuple([True] * 4), jacobian_flag=True, *, rng=None, seed=None,
                eps_half=None, ctx=None, return_raw=False):
     """Monte-Carlo entropy of the variational posterior and its gradient."""
-    ctx = vp.ctx if ctx is None else ctx
-    vp._upload(ctx)
+    ctx = ctx_of(vp, ctx)
+    upload_vp(vp, ctx)
     D, K = vp.D, vp.K
     ns = _even_ns(Ns)
     h = ns // 2
@@ -65,7 +108,7 @@ def entmc_vbmc(vp, Ns, grad_flags=tuple([True] * 4), jacobian_flag=True, *, rng=
         mode, seed = _lib.EPS_RESIDENT, 0
     elif rng == "philox":
         if seed is None:
-            seed = int(np.random.randint(0, 2**63 - 1, dtype=np.int64))
+            seed = philox_seed(ctx)
         mode = _lib.EPS_PHILOX
     else:
         raise ValueError(f"unknown rng {rng!r}")
@@ -86,8 +129,8 @@ def entmc_vbmc(vp, Ns, grad_flags=tuple([True] * 4), jacobian_flag=True, *, rng=
 
 def entlb_vbmc(vp, grad_flags=tuple([True] * 4), jacobian_flag=True, *, ctx=None):
     """Entropy lower bound (Jensen) of the variational posterior and its gradient."""
-    ctx = vp.ctx if ctx is None else ctx
-    vp._upload(ctx)
+    ctx = ctx_of(vp, ctx)
+    upload_vp(vp, ctx)
     bits = _lib.flags_to_bits(grad_flags)
     H = C.c_double()
     dH = np.empty(_n_grad(vp, bits))

@@ -103,10 +103,37 @@ def mean_kind_of(gp):
     return _MEAN_KINDS[name]
 
 
+def _gp_fingerprint(gp):
+    """Cheap state key of a GP duck type: identities of X, of the posteriors array, of every
+    posterior record and of its alpha / L / hyp arrays, plus the end elements of each array.
+    It catches what the reference does to a GP between two calls -- ``gp.posteriors[s] = ...``
+    (active_importance_sampling.py:207-209), attribute re-binding, ``gp.X`` replaced or
+    extended by ``gp.update`` (active_sample.py:584) -- and in-place edits that reach an
+    array's first or last element; an edit strictly inside an array needs ``invalidate_gp``.
+    ~1 us per posterior: this runs in front of every ELBO evaluation."""
+    ps, X = gp.posteriors, gp.X
+    key = [id(ps), id(X), X.shape[0], X.item(0), X.item(-1)]
+    held = [ps, X]
+    for p in ps:
+        a, h, L = p.alpha, p.hyp, p.L
+        key += (id(p), id(a), id(L), id(h), a.item(0), a.item(-1), h.item(0), h.item(-1),
+                L.item(0), L.item(-1), bool(p.L_chol))
+        held += (p, a, L, h)
+    return tuple(key), held
+
+
+def invalidate_gp(ctx=None):
+    """Forget the GP the context holds: the next call uploads it again.  Only needed after
+    editing GP arrays in place in a way the fingerprint cannot see (see ``_gp_fingerprint``)."""
+    ctx = _lib.default_context() if ctx is None else ctx
+    ctx._gp_key = ctx._gp_ref = None
+
+
 def upload_gp(gp, ctx):
-    """Ship X and the posterior records of ``gp`` to the context (cached per GP state)."""
-    key = (id(gp.posteriors), id(gp.X), len(gp.posteriors))
-    if getattr(ctx, "_gp_key", None) == key and getattr(ctx, "_gp_ref", None) is gp.posteriors:
+    """Ship X and the posterior records of ``gp`` to the context (skipped while the GP's
+    fingerprint is the one already uploaded)."""
+    key, held = _gp_fingerprint(gp)
+    if getattr(ctx, "_gp_key", None) == key:
         return
     X = _lib.f64(gp.X)
     N, D = X.shape
@@ -118,6 +145,7 @@ def upload_gp(gp, ctx):
     sW = _lib.f64(np.stack([np.ravel(p.sW) * np.ones(N) for p in posts]))
     chol = np.ascontiguousarray([1 if p.L_chol else 0 for p in posts], dtype=np.int32)
     mult = _lib.f64([float(getattr(p, "sn2_mult", 1.0)) for p in posts])
+    ctx._gp_key = None
     ctx.check(
         ctx._lib.vbmc_set_gp(
             ctx._h, N, D, S, hyp.shape[1], mean_kind_of(gp), _lib.ptr(X), _lib.ptr(hyp),
@@ -125,7 +153,8 @@ def upload_gp(gp, ctx):
             _lib.ptr(mult),
         )
     )
-    ctx._gp_key, ctx._gp_ref = key, gp.posteriors
+    # the held references keep every fingerprinted object alive, so an id cannot be recycled
+    ctx._gp_key, ctx._gp_ref = key, held
 
 
 class GP:

@@ -18,7 +18,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .entropy import _even_ns, draw_eps_half
+from ._duck import ctx_of, optimize_mask, store_mixture, upload_vp
+from .entropy import _even_ns, draw_eps_half, philox_seed
 from .gp import upload_gp
 
 BATCH_SIZE = 20  # minimize_adam.py:66
@@ -95,17 +96,17 @@ def minimize_adam_elbo(theta0, gp, vp, Ns, theta_bnd=None, beta=0.0, lb=None, ub
     *evaluated* iterate; its caller overwrites them right away, :283-300)."""
     if beta != 0 and np.isfinite(beta):
         raise NotImplementedError("Computation of the gradient of ELBO with full variance not supported")
-    ctx = vp.ctx if ctx is None else ctx
+    ctx = ctx_of(vp, ctx)
     K, D = vp.K, vp.D
     theta0 = _lib.f64(np.ravel(theta0))
     n = theta0.size
     ns = _even_ns(Ns)
     if ns <= 0:
         raise ValueError("minimize_adam_elbo needs Ns > 0 (the stochastic entropy)")
-    vp._upload(ctx)
+    upload_vp(vp, ctx)
     upload_gp(gp, ctx)
     opts = _lib.ElboOpts()
-    opts.ns_per_comp, opts.compute_grad, opts.optimize_mask = ns, 1, vp.optimize_mask()
+    opts.ns_per_comp, opts.compute_grad, opts.optimize_mask = ns, 1, optimize_mask(vp)
     opts.row_begin, opts.row_count = 0, -1
     keep = []
     if theta_bnd is not None:
@@ -125,7 +126,9 @@ def minimize_adam_elbo(theta0, gp, vp, Ns, theta_bnd=None, beta=0.0, lb=None, ub
         opts.eps_mode, opts.seed = _lib.EPS_RESIDENT, 0
     elif mode == "philox":
         if seed is None:
-            seed = int(np.random.randint(0, 2**62, dtype=np.int64))
+            seed = philox_seed(ctx)
+            # the loop consumes seed, seed+1, ... seed+max_iter-1: keep the context's sequence clear of them
+            ctx.__dict__["_philox_seq"] = ((seed + int(max_iter)) & 0x3FFFFFFFFFFFFFFF, ctx.__dict__["_philox_seq"][1])
         opts.eps_mode, opts.seed = _lib.EPS_PHILOX, int(seed)
     else:
         raise ValueError(f"unknown rng {mode!r}")
@@ -162,13 +165,7 @@ def minimize_adam_elbo(theta0, gp, vp, Ns, theta_bnd=None, beta=0.0, lb=None, ub
         rc = lib.vbmc_adam_end(h_, _lib.ptr(th), _lib.ptr(mu), _lib.ptr(sg), _lib.ptr(lm), _lib.ptr(w),
                                _lib.ptr(eta), C.byref(it))
     ctx.check(rc)
-    vp.mu = mu.T.copy()
-    vp.sigma = sg.reshape(1, -1)
-    vp.lambd = lm.reshape(-1, 1)
-    vp.w = w.reshape(1, -1)
-    if vp.optimize_weights:
-        vp.eta = eta.reshape(1, -1)
-    vp._mode = None
+    store_mixture(vp, mu, sg, lm, w, eta if vp.optimize_weights else None)
     i = done - 1
     lo = max(i - b + 1, 0)
     x_tab = x_rows[:done].T.copy()

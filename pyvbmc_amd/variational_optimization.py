@@ -17,7 +17,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .entropy import DEFAULT_RNG, _even_ns, draw_eps_half, entlb_vbmc, entmc_vbmc
+from ._duck import ctx_of, optimize_mask, store_mixture, upload_vp
+from .entropy import DEFAULT_RNG, _even_ns, draw_eps_half, entlb_vbmc, entmc_vbmc, philox_seed
 from .gp import upload_gp
 
 
@@ -93,8 +94,8 @@ def _gp_log_joint(vp, gp, grad_flags, avg_flag=True, jacobian_flag=True, compute
     if np.isscalar(grad_flags):
         grad_flags = (bool(grad_flags),) * 4
     bits = _lib.flags_to_bits(grad_flags)
-    ctx = vp.ctx if ctx is None else ctx
-    vp._upload(ctx)
+    ctx = ctx_of(vp, ctx)
+    upload_vp(vp, ctx)
     upload_gp(gp, ctx)
     D, K, S = vp.D, vp.K, len(gp.posteriors)
     jac = bool(jacobian_flag)
@@ -148,7 +149,7 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
             "Computing the gradient of variational parameters and "
             "requesting per-component results at the same time."
         )
-    ctx = vp.ctx if ctx is None else ctx
+    ctx = ctx_of(vp, ctx)
     K, D = vp.K, vp.D
 
     if separate_K or compute_var or beta != 0:
@@ -158,9 +159,9 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
     # ---- fused path: one library call ---------------------------------------------------
     # theta overwrites every optimised block; the current attributes only need to be on
     # the device when some block is NOT optimised or the context holds another (D, K)
-    mask = vp.optimize_mask()
+    mask = optimize_mask(vp)
     if mask != 15 or getattr(ctx, "D", None) != D or getattr(ctx, "K", None) != K:
-        vp._upload(ctx)
+        upload_vp(vp, ctx)
     upload_gp(gp, ctx)
     n_theta = np.size(theta)
     fc = _fused_call(ctx, D, K, n_theta, theta_bnd)
@@ -182,7 +183,7 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
             opts.eps_mode, opts.seed = _lib.EPS_RESIDENT, 0
         elif mode == "philox":
             if seed is None:
-                seed = int(np.random.randint(0, 2**63 - 1, dtype=np.int64))
+                seed = philox_seed(ctx)
             opts.eps_mode, opts.seed = _lib.EPS_PHILOX, seed
         else:
             raise ValueError(f"unknown rng {mode!r}")
@@ -190,15 +191,9 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
     if rc != 0:
         ctx.check(rc)
     # mirror the reference's side effects on vp and on the caller's theta
-    vp.mu = fc.mu.T.copy()
-    vp.sigma = fc.sg.reshape(1, -1).copy()
-    vp.lambd = fc.lm.reshape(-1, 1).copy()
-    vp.w = fc.w.reshape(1, -1).copy()
-    if vp.optimize_weights:
-        vp.eta = fc.eta.reshape(1, -1).copy()
-        if isinstance(theta, np.ndarray) and theta.dtype == np.float64:
-            theta[-K:] = fc.th[-K:]
-    vp._mode = None
+    store_mixture(vp, fc.mu, fc.sg, fc.lm, fc.w, fc.eta if vp.optimize_weights else None)
+    if vp.optimize_weights and isinstance(theta, np.ndarray) and theta.dtype == np.float64:
+        theta[-K:] = fc.th[-K:]
     return fc.F.value, (fc.dF.copy() if compute_grad else None), fc.G.value, fc.H.value, 0
 
 
@@ -208,13 +203,13 @@ def _neg_elcbo_batch(thetas, gp, vp, theta_bnd=None, *, ctx=None, return_parts=F
     compute_grad=False, theta_bnd=theta_bnd)[0]`` for every row of ``thetas`` -- lower-bound
     entropy, no gradient.  ``vp`` supplies D, K, the optimise flags and the values of
     non-optimised blocks; unlike the per-candidate call it is NOT mutated, nor are the rows."""
-    ctx = vp.ctx if ctx is None else ctx
+    ctx = ctx_of(vp, ctx)
     thetas = np.ascontiguousarray(np.atleast_2d(thetas), dtype=np.float64)
     B, n_theta = thetas.shape
-    vp._upload(ctx)
+    upload_vp(vp, ctx)
     upload_gp(gp, ctx)
     opts = _lib.ElboOpts()
-    opts.ns_per_comp, opts.compute_grad, opts.optimize_mask = 0, 0, vp.optimize_mask()
+    opts.ns_per_comp, opts.compute_grad, opts.optimize_mask = 0, 0, optimize_mask(vp)
     keep = []
     if theta_bnd is not None:
         lb, ub = _lib.f64(theta_bnd["lb"].ravel()), _lib.f64(theta_bnd["ub"].ravel())
@@ -233,10 +228,12 @@ def _neg_elcbo_batch(thetas, gp, vp, theta_bnd=None, *, ctx=None, return_parts=F
 
 
 class _FusedCall:
-    """Pre-built argument block of vbmc_neg_elcbo for one (ctx, D, K, theta_bnd): the
-    ctypes pointers of the persistent buffers are created once, not per evaluation."""
+    """Pre-built argument block of vbmc_neg_elcbo for one (ctx, D, K, n_theta): the ctypes
+    pointers of the persistent buffers are created once, not per evaluation.  The soft
+    bounds are re-bound on every call (``bind_bounds``), so a ``theta_bnd`` whose entries
+    were reassigned or edited in place is honoured."""
 
-    def __init__(self, ctx, D, K, n_theta, theta_bnd):
+    def __init__(self, ctx, D, K, n_theta):
         self.th = np.empty(n_theta)
         self.dF = np.empty(n_theta)
         self.mu = np.empty((K, D))
@@ -244,13 +241,7 @@ class _FusedCall:
         self.F, self.G, self.H = C.c_double(), C.c_double(), C.c_double()
         o = self.opts = _lib.ElboOpts()
         o.row_begin, o.row_count, o.seed = 0, -1, 0
-        self.bnd = theta_bnd
-        if theta_bnd is not None:
-            self.lb, self.ub = _lib.f64(theta_bnd["lb"].ravel()), _lib.f64(theta_bnd["ub"].ravel())
-            o.bnd_lb, o.bnd_ub, o.n_bnd = _lib.ptr(self.lb), _lib.ptr(self.ub), self.lb.size
-            o.tol_con = float(theta_bnd["tol_con"])
-            o.weight_threshold = float(theta_bnd.get("weight_threshold", 0.0))
-            o.weight_penalty = float(theta_bnd.get("weight_penalty", 0.0))
+        self.lb_src = self.ub_src = self.lb = self.ub = None
         self.fn = ctx._lib.vbmc_neg_elcbo
         self.args = (
             ctx._h, _lib.ptr(self.th), n_theta, C.byref(o), C.byref(self.F), _lib.ptr(self.dF),
@@ -258,15 +249,35 @@ class _FusedCall:
             _lib.ptr(self.w), _lib.ptr(self.eta),
         )
 
+    def bind_bounds(self, theta_bnd):
+        o = self.opts
+        if theta_bnd is None:
+            if self.lb is not None:
+                o.bnd_lb, o.bnd_ub, o.n_bnd = None, None, 0
+                self.lb_src = self.ub_src = self.lb = self.ub = None
+            return
+        lb, ub = theta_bnd["lb"], theta_bnd["ub"]
+        if lb is not self.lb_src or ub is not self.ub_src:
+            # f64() of a contiguous float64 array is a view: in-place edits stay visible
+            # through the pointer; anything else is copied afresh on every call
+            self.lb, self.ub = _lib.f64(np.ravel(lb)), _lib.f64(np.ravel(ub))
+            self.direct = np.shares_memory(self.lb, lb) and np.shares_memory(self.ub, ub)
+            self.lb_src, self.ub_src = (lb, ub) if self.direct else (None, None)
+            o.bnd_lb, o.bnd_ub, o.n_bnd = _lib.ptr(self.lb), _lib.ptr(self.ub), self.lb.size
+        o.tol_con = float(theta_bnd["tol_con"])
+        o.weight_threshold = float(theta_bnd.get("weight_threshold", 0.0))
+        o.weight_penalty = float(theta_bnd.get("weight_penalty", 0.0))
+
 
 def _fused_call(ctx, D, K, n_theta, theta_bnd):
     cache = ctx.__dict__.setdefault("_fused_cache", {})
-    key = (D, K, n_theta, id(theta_bnd))
+    key = (D, K, n_theta)
     fc = cache.get(key)
-    if fc is None or fc.bnd is not theta_bnd:
+    if fc is None:
         if len(cache) > 16:
             cache.clear()
-        fc = cache[key] = _FusedCall(ctx, D, K, n_theta, theta_bnd)
+        fc = cache[key] = _FusedCall(ctx, D, K, n_theta)
+    fc.bind_bounds(theta_bnd)
     return fc
 
 

@@ -25,6 +25,7 @@ import sys
 import numpy as np
 
 from . import _lib
+from ._duck import upload_vp
 
 
 class IdentityTransformer:
@@ -93,18 +94,10 @@ class VariationalPosterior:
         self._ctx = value
 
     def _upload(self, ctx=None):
-        """Push the current attributes to the device context."""
-        ctx = self.ctx if ctx is None else ctx
-        ctx.set_mixture(
-            np.asarray(self.mu, dtype=np.float64).reshape(self.D, self.K),
-            self.sigma, self.lambd, self.w, self.eta,
-        )
-        return ctx
-
-    def optimize_mask(self):
-        return _lib.flags_to_bits(
-            (self.optimize_mu, self.optimize_sigma, self.optimize_lambd, self.optimize_weights)
-        )
+        """Push the current attributes to the device context (pyvbmc_amd._duck.upload_vp;
+        the hot-path functions call that helper directly, so they accept any object with
+        the reference's public attributes, not just this class)."""
+        return upload_vp(self, self.ctx if ctx is None else ctx)
 
     # -- bounds (:140-239) ------------------------------------------------------------
     def get_bounds(self, X, options, K=None):

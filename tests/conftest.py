@@ -33,3 +33,6 @@ def golden():
 
 
 CASES = ["c1", "c2s", "c3s", "c5s"]
+# mid-size cases (oracle/make_golden.py `mid`): K * NsK/2 rows exceed one batch per workgroup of the
+# wave-split entropy kernel, so its batch loop runs rg >= 2 times
+MID_CASES = ["c2f", "c3m", "c5m"]

@@ -1,5 +1,10 @@
-"""Importance-sampling helpers that sit directly on top of the accelerated primitives --
-mirror of the small functions of ``pyvbmc/vbmc/active_importance_sampling.py`` (reference
+"""TEST INFRASTRUCTURE (not part of the product: SURVEY.md section 2 marks active importance
+sampling out of scope).  Its only job is to drive the device ``gp.predict`` / ``vp.pdf`` through the
+MATLAB known-answer fixtures the reference holds for them (``fess.mat``,
+``activesample_proposalpdf.mat``; reference tests test_active_importance_sampling.py:113-250).
+
+Importance-sampling helpers that sit directly on top of the accelerated primitives --
+restatement of the small functions of ``pyvbmc/vbmc/active_importance_sampling.py`` (reference
 ``active_sample_proposal_pdf`` :317-390, ``fess`` :426-478, ``renormalize_weights`` :481-483,
 ``get_mcmc_opts`` :393-423) and of the importance-sampling log densities of the
 information-theoretic acquisition functions (``acq_fcn_viqr.py:159-247``,

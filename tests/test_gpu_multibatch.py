@@ -1,0 +1,229 @@
+"""GPU parity at the sizes and kernel instantiations the entropy kernel really runs.
+
+The wave-split kernel gives a workgroup ``rg = ceil(K * rows / (128 * CUs))`` batches of 64
+antithetic-pair rows (csrc/entropy.hip entmc_plan).  The small goldens all stay at rg == 1, so the
+batch loop, the q double buffer, the Philox rounds of four batches and the accumulators carried
+across batches are exercised here: reference-generated goldens at rg >= 2 (``c2f``, ``c3m`` and
+``c5m`` -- the 1-wave/SIMD 512-register build at D=20, K=100), oracle comparisons at rg in {3, 5, 6}
+for exact and padded K, and BASELINE config 3 at full size with every gradient entry compared.
+Each test asserts the launch geometry it meant to exercise (``vbmc_last_entmc_plan``).
+"""
+import numpy as np
+import pytest
+from conftest import MID_CASES
+from helpers import oracle_gp, oracle_mix, rel_err
+
+from oracle import entropy_ref, mixture_ref, philox_ref
+from pyvbmc_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pyvbmc_amd import _lib
+
+    c = _lib.Context(0)
+    _lib.set_default_context(c)
+    yield c
+    _lib.set_default_context(None)
+    c.close()
+
+
+def make_vp(g, ctx):
+    from pyvbmc_amd import VariationalPosterior
+
+    vp = VariationalPosterior(int(g["D"]), int(g["K"]))
+    vp.mu = g["mu"].copy()
+    vp.sigma = g["sigma"].reshape(1, -1).copy()
+    vp.lambd = g["lambd"].reshape(-1, 1).copy()
+    vp.w = g["w"].reshape(1, -1).copy()
+    vp.eta = g["eta"].reshape(1, -1).copy()
+    vp.ctx = ctx
+    return vp
+
+
+def make_gp(g, ctx, hyp):
+    from pyvbmc_amd import gp as gpm
+
+    s2 = g["s2"] if g["s2"].size else None
+    gp = gpm.GP(int(g["D"]), gpm.SquaredExponential(), gpm.NegativeQuadratic(),
+                gpm.GaussianNoise(constant_add=True, user_provided_add=s2 is not None))
+    gp.ctx = ctx
+    gp.update(X_new=g["X"], y_new=g["y"], s2_new=s2, hyp=hyp)
+    return gp
+
+
+def expected_rg(ctx, K, rows):
+    cus = ctx.device_info()["cu_count"]
+    return min(16, max(1, -(-K * rows // (128 * cus))))
+
+
+@pytest.mark.parametrize("kernel", ["ws", "valu"])
+@pytest.mark.parametrize("name", MID_CASES)
+def test_mid_cases_vs_reference(ctx, golden, name, kernel):
+    """Reference values (goldens made by running the reference) at rg >= 2, through the
+    wave-split kernel and through the generic kernel (``entmc_kernel`` = 1)."""
+    from pyvbmc_amd import entmc_vbmc
+    from pyvbmc_amd.variational_optimization import _neg_elcbo
+
+    g = golden(name)
+    K, D, NsK, seed = int(g["K"]), int(g["D"]), int(g["NsK"]), int(g["seed"])
+    ctx.set_option("entmc_kernel", 1 if kernel == "valu" else 0)
+    try:
+        for gf in ((False,) * 4, (True,) * 4):
+            vp = make_vp(g, ctx)
+            np.random.seed(seed)
+            H, dH = entmc_vbmc(vp, NsK, gf, True)
+            plan = ctx.last_entmc_plan()
+            assert plan["kernel"] == kernel, plan
+            if kernel == "ws":
+                assert plan["rg"] == expected_rg(ctx, K, NsK // 2) and plan["rg"] >= 2, plan
+            tag = "1111" if gf[0] else "0000"
+            Href, dref = g[f"entmc_H_{tag}_1"], g[f"entmc_dH_{tag}_1"]
+            assert abs(H - Href) <= 1e-10 * abs(Href), (name, kernel, H, Href)
+            assert dH.shape == dref.shape
+            if dref.size:
+                err = rel_err(dH, dref)
+                print(f"{name}/{kernel}: rg={plan['rg']} |dH-ref|/max|ref| = {err:.2e}")
+                assert err < 1e-9, (name, kernel, err)
+        wl = synthetic.make_workload(int(g["cfg"]), S=1, D=D, K=K, N=int(g["N"]), Ns_total=int(g["Ns_total"]))
+        bnd = synthetic.default_theta_bnd(wl)
+        gp = make_gp(g, ctx, g["hyp"][:1])
+        for tag, th in (("bnd", g["theta"]), ("bndout", g["theta_out"])):
+            th_in = th.copy()
+            vp = make_vp(g, ctx)
+            np.random.seed(seed)
+            F, dF, G, H, _ = _neg_elcbo(th_in, gp, vp, 0.0, NsK, True, False, bnd)
+            key = f"elbo_{tag}_mc"
+            assert abs(F - g[key + "_F"]) <= 1e-9 * abs(g[key + "_F"]), (key, F, g[key + "_F"])
+            assert rel_err(dF, g[key + "_dF"]) < 1e-8, (key, rel_err(dF, g[key + "_dF"]))
+            assert abs(G - g[key + "_G"]) <= 1e-9 * abs(G) and abs(H - g[key + "_H"]) <= 1e-9 * abs(H)
+            assert np.allclose(th_in, g[key + "_theta_after"], rtol=0, atol=1e-15)
+            if kernel == "ws":
+                assert ctx.last_entmc_plan()["rg"] >= 2
+    finally:
+        ctx.set_option("entmc_kernel", 0)
+
+
+def synthetic_mix(D, K, seed):
+    rng = np.random.default_rng(seed)
+    mu = 1.5 * rng.standard_normal((D, K))
+    sigma = 0.4 * np.exp(0.4 * rng.standard_normal(K))
+    lambd = np.exp(0.3 * rng.standard_normal(D))
+    w = rng.dirichlet(np.ones(K))
+    return mixture_ref.Mixture.make(mu, sigma, lambd, w)
+
+
+# (D, K, target rg): K=8 -> ceil(K/4) = 2 < KTMAX = 8 (padded, !EXACT); K=32 -> 8 == KTMAX (EXACT);
+# K=50, D=10 -> the bench instantiation <10,13,...> (EXACT); rg not a multiple of the Philox round (4)
+SHAPES = [(3, 8, 3), (3, 32, 5), (10, 50, 6), (5, 13, 2)]
+
+
+@pytest.mark.parametrize("draws", ["resident", "pregen", "inline"])
+@pytest.mark.parametrize("D,K,rg", SHAPES)
+def test_multibatch_vs_oracle(ctx, D, K, rg, draws):
+    """H and all four gradient blocks against the oracle on identical draws, for every source of
+    the draws: uploaded (NumPy stream), Philox generated ahead into HBM, Philox generated in-line
+    by the entropy kernel (its four-batch rounds through LDS)."""
+    from pyvbmc_amd import VariationalPosterior, entmc_vbmc
+
+    cus = ctx.device_info()["cu_count"]
+    # rows so that K * rows lands inside (rg-1, rg] * 128 * CUs, deliberately not a multiple of 64
+    rows = (rg * 128 * cus - 128 * cus // 3) // K
+    rows -= rows % 2
+    rows += 1 if rows % 64 == 0 else 0
+    NsK = 2 * rows
+    assert expected_rg(ctx, K, rows) == rg
+    mix = synthetic_mix(D, K, 100 * D + K)
+    vp = VariationalPosterior(D, K)
+    vp.ctx = ctx
+    vp.mu, vp.sigma, vp.lambd = mix.mu.copy(), mix.sigma.reshape(1, -1), mix.lambd.reshape(-1, 1)
+    vp.w, vp.eta = mix.w.reshape(1, -1), mix.eta.reshape(1, -1)
+    seed = 0xABCDEF0 + 17 * K + rg
+    ctx.set_option("elbo_pregen", 0 if draws == "inline" else 1)
+    try:
+        if draws == "resident":
+            eps = synthetic.draw_eps_half(K, D, NsK, seed % 1000)
+            H, dH = entmc_vbmc(vp, NsK, (True,) * 4, True, eps_half=eps)
+        else:
+            eps = philox_ref.eps_half(K, rows, D, seed)
+            H, dH = entmc_vbmc(vp, NsK, (True,) * 4, True, rng="philox", seed=seed)
+        plan = ctx.last_entmc_plan()
+    finally:
+        ctx.set_option("elbo_pregen", 1)
+    assert plan["kernel"] == "ws" and plan["rg"] == rg, plan
+    assert plan["resident_draws"] == (draws != "inline"), plan
+    Ho, dHo = entropy_ref.entmc(mix, NsK, (True,) * 4, True, eps_half=eps)
+    errs = [rel_err(dH[a:b], dHo[a:b]) for a, b in ((0, D * K), (D * K, D * K + K), (D * K + K, D * K + K + D),
+                                                    (D * K + K + D, D * K + 2 * K + D))]
+    print(f"D={D} K={K} rg={rg} {draws}: H rel {abs(H - Ho) / abs(Ho):.2e}; blocks mu/sigma/lambda/w {errs}")
+    assert abs(H - Ho) <= 1e-10 * abs(Ho)
+    assert max(errs) < 1e-9, errs
+
+
+def test_full_size_config3_every_gradient_entry(ctx):
+    """BASELINE config 3 at full size (D=10, K=50, Ns=1e6 -> rg=16 on <10,13,...>): H and all
+    610 gradient entries against the oracle on the same draws, for the wave-split and the generic
+    kernel; plus determinism and antithetic symmetry."""
+    from pyvbmc_amd import VariationalPosterior, entmc_vbmc
+
+    wl = synthetic.make_workload(3)
+    K, D, NsK = wl.K, wl.D, wl.NsK
+    assert NsK == 20000
+    vp = VariationalPosterior(D, K)
+    vp.ctx = ctx
+    vp.mu, vp.sigma, vp.lambd = wl.mu.copy(), wl.sigma.reshape(1, -1), wl.lambd.reshape(-1, 1)
+    vp.w, vp.eta = wl.w.reshape(1, -1), wl.eta.reshape(1, -1)
+    eps = synthetic.draw_eps_half(K, D, NsK, 3)
+    mix = mixture_ref.Mixture.make(wl.mu, wl.sigma, wl.lambd, wl.w, wl.eta)
+    Ho, dHo = entropy_ref.entmc(mix, NsK, (True,) * 4, True, eps_half=eps)
+    assert dHo.size == 610
+    for kernel in ("ws", "valu"):
+        ctx.set_option("entmc_kernel", 1 if kernel == "valu" else 0)
+        try:
+            H, dH = entmc_vbmc(vp, NsK, (True,) * 4, True, eps_half=eps)
+            plan = ctx.last_entmc_plan()
+            H2, dH2 = entmc_vbmc(vp, NsK, (True,) * 4, True, eps_half=eps)
+            H3, dH3 = entmc_vbmc(vp, NsK, (True,) * 4, True, eps_half=-eps)
+        finally:
+            ctx.set_option("entmc_kernel", 0)
+        assert plan["kernel"] == kernel
+        if kernel == "ws":
+            assert plan["rg"] == expected_rg(ctx, K, NsK // 2) >= 8, plan
+        err = rel_err(dH, dHo)
+        print(f"config 3 full size / {kernel}: H rel {abs(H - Ho) / abs(Ho):.2e}, dH rel {err:.2e}, plan {plan}")
+        assert abs(H - Ho) <= 1e-10 * abs(Ho)
+        assert err < 1e-9
+        assert H2 == H and np.array_equal(dH, dH2)  # bit-reproducible
+        assert abs(H3 - H) <= 1e-13 * abs(H) and rel_err(dH3, dH) < 1e-11  # same sample set
+    # Philox draws at full size: value + gradient on the restated generator's draws
+    seed = 20250929
+    eps_p = philox_ref.eps_half(K, NsK // 2, D, seed)
+    Hp, dHp = entmc_vbmc(vp, NsK, (True,) * 4, True, rng="philox", seed=seed)
+    Hpo, dHpo = entropy_ref.entmc(mix, NsK, (True,) * 4, True, eps_half=eps_p)
+    assert abs(Hp - Hpo) <= 1e-10 * abs(Hpo) and rel_err(dHp, dHpo) < 1e-9
+
+
+def test_config5_share_on_one_gpu(ctx):
+    """BASELINE config 5's per-GPU share (D=20, K=100, Ns=4e6/8 -> 2 500 rows per component,
+    rg=8 on the 1-wave/SIMD build): H and every gradient entry vs the oracle on Philox draws."""
+    from pyvbmc_amd import VariationalPosterior, entmc_vbmc
+
+    wl = synthetic.make_workload(5, Ns_total=4_000_000 // 8)
+    K, D, NsK = wl.K, wl.D, wl.NsK
+    assert (K, D, NsK) == (100, 20, 5000)
+    vp = VariationalPosterior(D, K)
+    vp.ctx = ctx
+    vp.mu, vp.sigma, vp.lambd = wl.mu.copy(), wl.sigma.reshape(1, -1), wl.lambd.reshape(-1, 1)
+    vp.w, vp.eta = wl.w.reshape(1, -1), wl.eta.reshape(1, -1)
+    seed = 555
+    H, dH = entmc_vbmc(vp, NsK, (True,) * 4, True, rng="philox", seed=seed)
+    plan = ctx.last_entmc_plan()
+    assert plan["kernel"] == "ws" and plan["rg"] == expected_rg(ctx, K, NsK // 2) >= 4, plan
+    eps = philox_ref.eps_half(K, NsK // 2, D, seed)
+    mix = mixture_ref.Mixture.make(wl.mu, wl.sigma, wl.lambd, wl.w, wl.eta)
+    Ho, dHo = entropy_ref.entmc(mix, NsK, (True,) * 4, True, eps_half=eps)
+    err = rel_err(dH, dHo)
+    print(f"config 5 share: H rel {abs(H - Ho) / abs(Ho):.2e}, dH rel {err:.2e}, plan {plan}")
+    assert abs(H - Ho) <= 1e-10 * abs(Ho) and err < 1e-9

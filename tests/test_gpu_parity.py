@@ -184,10 +184,21 @@ def test_gp_log_joint_vs_reference(ctx, golden, name):
         assert dG is None
         assert abs(G - g[f"glj_{tag}_var_G"]) <= TIGHT * abs(G)
         assert rel_err(I_sk, g[f"glj_{tag}_I_sk"]) < 1e-10
-        # variance: difference of O(sf^2) terms -> relative to the J scale
-        assert rel_err(J_sjk, g[f"glj_{tag}_J_sjk"]) < 1e-7
+        # The variance terms are differences of O(sf^2) quantities: J_jk = sf^2 [exp(..) - z_j' K^-1 z_k]
+        # cancels to << sf^2, so the error floor is eps * sf^2 (times the weights for varG), not
+        # eps * |J|.  Asserted on that scale at 1e-10 -- like the predictive variance -- and the
+        # error relative to the value itself is printed (and bounded loosely).
+        sf2 = float(np.max(np.exp(2 * hyp[:, int(g["D"])])))
+        Jref = g[f"glj_{tag}_J_sjk"]
+        e_J = float(np.max(np.abs(J_sjk - Jref)))
+        e_v = float(np.max(np.abs(np.ravel(varG) - np.ravel(g[f"glj_{tag}_varG"]))))
+        e_ss = abs(var_ss - g[f"glj_{tag}_var_ss"])
+        print(f"{name}/{tag}: |dJ|={e_J:.2e} (sf2={sf2:.3g}, max|J|={np.max(np.abs(Jref)):.2e}) "
+              f"|dvarG|={e_v:.2e} (varG~{float(np.max(np.abs(g[f'glj_{tag}_varG']))):.2e}) |dvar_ss|={e_ss:.2e}")
+        assert e_J <= 1e-10 * sf2
+        assert e_v <= 1e-10 * sf2 and e_ss <= 1e-10 * sf2
+        assert rel_err(J_sjk, Jref) < 1e-7
         assert rel_err(np.ravel(varG), np.ravel(g[f"glj_{tag}_varG"])) < 1e-5
-        assert abs(var_ss - g[f"glj_{tag}_var_ss"]) <= 1e-5 * max(abs(var_ss), 1e-300)
 
 
 def test_gp_log_joint_unsupported_combinations(ctx, golden):
@@ -233,9 +244,10 @@ def test_neg_elcbo_vs_reference(ctx, golden, name):
     r = _neg_elcbo(g["theta"].copy(), gp, vp, 0.0, NsK, False, True, None, 0.0, True)
     assert len(r) == 11 and r[1] is None and r[5] is None
     assert abs(r[0] - g["elbo_full_F"]) <= 1e-9 * abs(r[0])
-    assert rel_err(np.ravel(r[4]), np.ravel(g["elbo_full_varF"])) < 1e-5
+    sf2 = float(np.exp(2 * g["hyp"][0, D]))
+    assert np.max(np.abs(np.ravel(r[4]) - np.ravel(g["elbo_full_varF"]))) <= 1e-10 * sf2
     assert rel_err(r[9], g["elbo_full_I_sk"]) < 1e-10
-    assert rel_err(r[10], g["elbo_full_J_sjk"]) < 1e-7
+    assert np.max(np.abs(r[10] - g["elbo_full_J_sjk"])) <= 1e-10 * sf2
 
 
 def test_neg_elcbo_argument_errors(ctx, golden):
@@ -386,52 +398,7 @@ def test_entmc_analytic_single_gaussian(ctx):
     assert dH1.shape == (K,)
 
 
-def test_full_size_config3_against_oracle(ctx):
-    """BASELINE config 3 at full size (D=10, K=50, N=400, Ns=1e6): entropy value
-    vs the oracle (value-only keeps the oracle at a few seconds), gradient via
-    size-independent properties."""
-    from pyvbmc_amd import VariationalPosterior, entmc_vbmc
-
-    wl = synthetic.make_workload(3)
-    K, D, NsK = wl.K, wl.D, wl.NsK
-    assert NsK == 20000
-    vp = VariationalPosterior(D, K)
-    vp.ctx = ctx
-    vp.mu, vp.sigma, vp.lambd = wl.mu.copy(), wl.sigma.reshape(1, -1), wl.lambd.reshape(-1, 1)
-    vp.w, vp.eta = wl.w.reshape(1, -1), wl.eta.reshape(1, -1)
-    eps = synthetic.draw_eps_half(K, D, NsK, 3)
-    H, dH = entmc_vbmc(vp, NsK, (True,) * 4, True, eps_half=eps)
-    mix = mixture_ref.Mixture.make(wl.mu, wl.sigma, wl.lambd, wl.w, wl.eta)
-    Ho, _ = entropy_ref.entmc(mix, NsK, (False,) * 4, True, eps_half=eps)
-    assert abs(H - Ho) <= TOL_ELBO * abs(Ho)
-    assert abs(H - Ho) <= 1e-10 * abs(Ho)
-    # determinism: same inputs -> bit-identical outputs
-    H2, dH2 = entmc_vbmc(vp, NsK, (True,) * 4, True, eps_half=eps)
-    assert H2 == H and np.array_equal(dH, dH2)
-    # antithetic symmetry: negating every draw leaves the estimate unchanged (sample set identical)
-    H3, dH3 = entmc_vbmc(vp, NsK, (True,) * 4, True, eps_half=-eps)
-    assert abs(H3 - H) <= 1e-13 * abs(H) and rel_err(dH3, dH) < 1e-11
-    # softmax-Jacobian'd weight gradient sums to ~0 (rows of J_w sum to zero)
-    assert abs(np.sum(dH[-K:])) < 1e-10 * np.max(np.abs(dH[-K:]))
-    # gradient wrt mu vs central finite differences on the same draws.  The reference's
-    # estimator drops a zero-mean term of the pathwise derivative (entmc_vbmc.py:98), so
-    # the two agree only to Monte-Carlo accuracy (the reference's own check uses rtol 1e-2)
-    theta0 = wl.theta
-    idx = [0, 7, D * K - 1]
-    for i in idx:
-        hstep = 1e-5
-        vals = []
-        for sgn in (+1, -1):
-            vq = VariationalPosterior(D, K)
-            vq.ctx = ctx
-            th = theta0.copy()
-            th[i] += sgn * hstep
-            vq.mu = th[: D * K].reshape((D, K), order="F")
-            vq.sigma, vq.lambd = wl.sigma.reshape(1, -1), wl.lambd.reshape(-1, 1)
-            vq.w, vq.eta = wl.w.reshape(1, -1), wl.eta.reshape(1, -1)
-            vals.append(entmc_vbmc(vq, NsK, (False,) * 4, True, eps_half=eps)[0])
-        fd = (vals[0] - vals[1]) / (2 * hstep)
-        assert abs(fd - dH[i]) <= 2e-2 * np.max(np.abs(dH[: D * K])), (i, fd, dH[i])
+# (BASELINE config 3 at full size, every gradient entry vs the oracle: tests/test_gpu_multibatch.py)
 
 
 def test_rccl_call_path_single_rank(golden):

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(str(_lib.LIB_PATH))
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.load().vbmc_abi_version() == 1
+    assert _lib.load().vbmc_abi_version() == 2
 
 
 def test_no_gpu_means_loud_failure():

@@ -8,7 +8,7 @@ import itertools
 
 import numpy as np
 import pytest
-from conftest import CASES
+from conftest import CASES, MID_CASES
 from helpers import oracle_gp, oracle_mix, rel_err
 
 from oracle import elbo_ref, entropy_ref, gp_ref, mixture_ref
@@ -35,6 +35,30 @@ def test_entmc_matches_reference(golden, name):
             assert dH.shape == ref.shape
             if ref.size:
                 assert rel_err(dH, ref) < 1e-11
+
+
+@pytest.mark.parametrize("name", MID_CASES)
+def test_mid_cases_match_reference(golden, name):
+    """The mid-size goldens (reference-generated) pin the oracle at the sizes where the
+    device kernel runs several batches per workgroup."""
+    g = golden(name)
+    K, D, NsK, seed = int(g["K"]), int(g["D"]), int(g["NsK"]), int(g["seed"])
+    eps = synthetic.draw_eps_half(K, D, NsK, seed)
+    H, dH = entropy_ref.entmc(oracle_mix(g), NsK, (True,) * 4, True, eps_half=eps)
+    assert abs(H - g["entmc_H_1111_1"]) <= TOL * abs(H)
+    assert rel_err(dH, g["entmc_dH_1111_1"]) < 1e-11
+    if name == "c5m":
+        return  # the ELBO part below costs another ~20 s of oracle time at D=20, K=100
+    wl = synthetic.make_workload(int(g["cfg"]), S=1, D=D, K=K, N=int(g["N"]), Ns_total=int(g["Ns_total"]))
+    bnd = synthetic.default_theta_bnd(wl)
+    gp = oracle_gp(g, g["hyp"][:1])
+    for tag, th in (("bnd", g["theta"]), ("bndout", g["theta_out"])):
+        th_in = th.copy()
+        F, dF, G, H, _ = elbo_ref.neg_elcbo(th_in, gp, oracle_mix(g), 0.0, NsK, True, False, bnd, False, eps_half=eps)
+        key = f"elbo_{tag}_mc"
+        assert abs(F - g[key + "_F"]) <= 1e-11 * abs(F), key
+        assert rel_err(dF, g[key + "_dF"]) < 1e-10, key
+        assert np.array_equal(th_in, g[key + "_theta_after"]), key
 
 
 @pytest.mark.parametrize("name", CASES)

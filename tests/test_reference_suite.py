@@ -331,7 +331,7 @@ def matlab_gp_and_points(ctx):
 @pytest.mark.gpu
 def test_fess(ctx, golden):
     """vbmc/test_active_importance_sampling.py:113: MATLAB's fractional effective sample sizes."""
-    from pyvbmc_amd.active_importance_sampling import fess
+    from is_helpers import fess
 
     m = golden("matlab_known")
     D, X, gp, Xa = matlab_gp_and_points(ctx)
@@ -351,7 +351,7 @@ def test_fess(ctx, golden):
 @pytest.mark.gpu
 def test_active_sample_proposal_pdf(ctx, golden):
     """vbmc/test_active_importance_sampling.py:178: MATLAB's log importance weights, VIQR and IMIQR."""
-    from pyvbmc_amd.active_importance_sampling import AcqFcnIMIQR, AcqFcnVIQR, active_sample_proposal_pdf
+    from is_helpers import AcqFcnIMIQR, AcqFcnVIQR, active_sample_proposal_pdf
 
     m = golden("matlab_known")
     D, X, gp, Xa = matlab_gp_and_points(ctx)
@@ -377,7 +377,7 @@ def test_is_log_densities_and_weights():
     """acq_fcn_viqr.py:159-247 / acq_fcn_imiqr.py:173-260 log densities; renormalize_weights :481."""
     from scipy.stats import norm
 
-    from pyvbmc_amd.active_importance_sampling import AcqFcnIMIQR, AcqFcnVIQR, get_mcmc_opts, renormalize_weights
+    from is_helpers import AcqFcnIMIQR, AcqFcnVIQR, get_mcmc_opts, renormalize_weights
 
     v, i = AcqFcnVIQR(), AcqFcnIMIQR(quantile=0.9)
     assert np.isclose(v.u, norm.ppf(0.75)) and np.isclose(i.u, norm.ppf(0.9))
