@@ -207,6 +207,100 @@ def mid(name, cfg, seed, **shrink):
           f"({time.time() - t0:.0f} s of reference time)")
 
 
+def gpcov():
+    """Pin the GP posterior records' consumption conventions with the reference's IN-TREE code.
+
+    gpyreg is absent, so (L, sW, L_chol, alpha) of a posterior are built by oracle/gp_ref.py.  What
+    PyVBMC itself does with those records is in the reference tree: step 3 of
+    ``active_importance_sampling`` (vbmc/active_importance_sampling.py:262-306) forms
+    ``C_tmp = (L'L)^-1 K(X,Xa) / sn2_eff`` (``L_chol``) or ``L K(X,Xa)`` (otherwise) with
+    ``solve_triangular`` on ``posteriors[s].L``, and ``AcqFcnVIQR/IMIQR._compute_acquisition_function``
+    (acq_fcn_viqr.py:93-141, acq_fcn_imiqr.py:100-141) turn that into posterior cross-covariances.
+    Here the reference runs on stub GPs with MODERATE length scales (K* far from 0) -- homoskedastic,
+    heteroskedastic (user s2) and one sample with sn2 < 1e-6 (``L_chol=False``) -- and the implied
+    predictive variances / covariances are stored: sf^2 -/+ sum_n K(xa,X)_n C_tmp_n.  The tests hold
+    gp_ref.predict, a dense first-principles solve and the device kernels to them at 1e-10.
+    The two acquisition classes' values on the same GPs are stored too."""
+    from types import SimpleNamespace
+
+    from pyvbmc.acquisition_functions import AcqFcnIMIQR, AcqFcnVIQR
+    from pyvbmc.vbmc.active_importance_sampling import active_importance_sampling
+
+    class Opts(dict):
+        def eval(self, key, env):
+            return self[key]
+
+    out = {}
+    D, N, K = 3, 60, 2
+    rng = np.random.default_rng(4242)
+    X = rng.standard_normal((N, D))
+    y = (-0.5 * np.sum(X**2, axis=1) + 0.3 * np.sin(2 * X[:, 0]) + 0.05 * rng.standard_normal(N)).reshape(-1, 1)
+    s2 = rng.uniform(0.01, 1.0, size=(N, 1))
+
+    def hyp_rows(log_sn):
+        rows = []
+        for i, ls in enumerate(log_sn):
+            ell = np.log(np.array([0.8, 1.3, 1.0]) * (1.0 + 0.4 * i))
+            rows.append(np.concatenate([ell, [np.log(2.0 + i)], [ls], [0.3], 0.1 * np.ones(D), np.log(2.0) * np.ones(D)]))
+        return np.array(rows)
+
+    cases = {
+        "homo": (hyp_rows([np.log(0.05), np.log(0.08)]), None),
+        "hetero": (hyp_rows([np.log(0.05), np.log(0.02)]), s2),
+        "tiny": (hyp_rows([np.log(3e-4), np.log(0.05)]), None),  # sample 0: sn2 = 9e-8 < 1e-6 -> L_chol False
+    }
+    out.update(X=X, y=y, s2=s2, D=D, N=N)
+    vp = VariationalPosterior(D, K)
+    vp.mu = np.array([[0.3, -0.6], [-0.2, 0.5], [0.1, 0.4]])
+    vp.sigma = np.array([[0.6, 0.9]])
+    vp.lambd = np.array([[1.1], [0.8], [1.0]])
+    vp.lambd = vp.lambd / np.sqrt(np.mean(vp.lambd**2))
+    vp.w = np.array([[0.35, 0.65]])
+    vp.eta = np.log(vp.w)
+    out.update(vp_mu=vp.mu, vp_sigma=vp.sigma.ravel(), vp_lambd=vp.lambd.ravel(), vp_w=vp.w.ravel())
+    Xs = rng.standard_normal((32, D)) * 1.2
+    Xs[:4] = X[:4] + 0.02 * rng.standard_normal((4, D))
+    out["Xs"] = Xs
+    for name, (hyp, s2c) in cases.items():
+        wl = SimpleNamespace(D=D, X=X, y=y, s2=s2c)
+        gp = ref_gp(wl, hyp)
+        S = hyp.shape[0]
+        out[f"{name}_hyp"] = hyp
+        out[f"{name}_L_chol"] = np.array([int(p.L_chol) for p in gp.posteriors])
+        sf2 = np.exp(2 * hyp[:, D])
+        length = np.exp(hyp[0, :D])
+        gp.temporary_data["X_rescaled"] = X / length
+        gp.temporary_data["sn2_new"] = 0.01 + rng.random(N)
+        out[f"{name}_sn2_new"] = gp.temporary_data["sn2_new"]
+        for acq_cls, opts in (
+            (AcqFcnVIQR, Opts(active_importance_sampling_mcmc_samples=48)),
+            (AcqFcnIMIQR, Opts(active_importance_sampling_vp_samples=30, active_importance_sampling_box_samples=18,
+                               active_importance_sampling_mcmc_samples=0)),
+        ):
+            tag = f"{name}_{acq_cls.__name__}"
+            acq = acq_cls()
+            np.random.seed(11)
+            ais = active_importance_sampling(vp, gp, acq, opts)
+            Xa, KaX, Ct = ais["X"], ais["K_Xa_X"], ais["C_tmp"]
+            assert Xa.ndim == 2 and KaX.shape == (S, Xa.shape[0], N) and Ct.shape == (S, N, Xa.shape[0])
+            vr = np.einsum("san,sna->as", KaX, Ct)  # sum_n K(xa, X_n) C_tmp[n, a]
+            sign = np.where(out[f"{name}_L_chol"] == 1, -1.0, 1.0)
+            out[f"{tag}_Xa"] = Xa
+            out[f"{tag}_fs2_implied"] = sf2[None, :] + sign[None, :] * vr  # (Na, S), unclamped
+            # cross terms between the first 8 points: K(xa,X) C_tmp, to be subtracted from / added to K(xa,xa')
+            out[f"{tag}_cross_implied"] = np.einsum("san,snb->sab", KaX[:, :8, :], Ct[:, :, :8])
+            out[f"{tag}_ais_f_s2"], out[f"{tag}_ais_ln_weights"] = ais["f_s2"], ais["ln_weights"]
+            st = dict(integer_vars=None, lb_eps_orig=X.min(0) - 3.0, ub_eps_orig=X.max(0) + 3.0,
+                      gp_length_scale=length, variance_regularized_acq_fcn=False, active_importance_sampling=ais)
+            flog = SimpleNamespace(y_max=float(np.max(y)))
+            with np.errstate(all="ignore"):
+                out[f"{tag}_acq"] = acq(Xs.copy(), gp, vp, flog, st)
+        print(f"gpcov {name}: L_chol={out[f'{name}_L_chol']}, "
+              f"min implied fs2/sf2 = {np.min(out[f'{name}_AcqFcnVIQR_fs2_implied'] / sf2):.3e}")
+    np.savez_compressed(OUT / "gpcov.npz", **out)
+    print("wrote gpcov:", len(out), "keys")
+
+
 def matlab_known():
     """Known-answer DATA held by the reference's own tests, re-packed as npz."""
     out = {}
@@ -400,6 +494,7 @@ if __name__ == "__main__":
         "c2f": lambda: mid("c2f", 2, seed=12),
         "c3m": lambda: mid("c3m", 3, seed=13, Ns_total=50 * 2000),
         "c5m": lambda: mid("c5m", 5, seed=15, Ns_total=100 * 2000),
+        "gpcov": gpcov,
         "matlab_known": matlab_known,
         "misc": misc,
         "adam": adam,

@@ -94,8 +94,19 @@ struct vbmc_ctx {
   double* d_mix = nullptr;
   size_t d_mix_cap = 0;
 
-  double* d_epsgen = nullptr;  // draws generated by the prep launch (fused objective, Philox mode)
-  size_t d_epsgen_cap = 0;
+  // Philox draws generated ahead of the entropy kernel (fused objective): two buffers, so the
+  // draws of evaluation i+1 can be generated behind evaluation i's finish kernel while the host
+  // is busy with result i (api_elbo.hip); `ahead` says what the speculative buffer holds
+  double* d_epsgen[2] = {nullptr, nullptr};
+  size_t d_epsgen_cap[2] = {0, 0};
+  int gen_cur = 0;  // buffer the current evaluation reads
+  struct AheadDraws {
+    bool valid = false;
+    uint64_t seed = 0;
+    int K = 0, D = 0, buf = 0;
+    int64_t rows = 0, n_half = 0, row_begin = 0;
+  } ahead;
+  hipEvent_t ev_done = nullptr;  // end of an evaluation's own launches (the host waits for this, not for the ahead generation)
 
   // resident antithetic half draws: [K][eps_rows][D]
   double* d_eps = nullptr;
@@ -221,6 +232,9 @@ int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
                int64_t row_count, int want_grad, EntPlan& p);
 void entmc_fill_prep(const vbmc_ctx* ctx, const EntPlan& p, PrepArgs& a);
 int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& a);
+// after the finish launch: queue the generation of seed+1's draws into the other buffer (no-op
+// unless this evaluation read pre-generated Philox draws and the "elbo_ahead" option is on)
+int entmc_launch_ahead(vbmc_ctx* ctx, const EntPlan& p);
 int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p);
 // `gen`: optional slice of draws for spare workgroups of the finish launch to generate
 int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out, const GenSlice* gen = nullptr);

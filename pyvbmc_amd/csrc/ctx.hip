@@ -103,6 +103,7 @@ int vbmc_ctx_create(int device_id, vbmc_ctx** out) {
   if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_id);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   for (int i = 0; i < 10 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming);
   if (e != hipSuccess) {
     int rc = vbmc_fail(nullptr, VBMC_E_HIP, "context setup failed: %s", hipGetErrorString(e));
     delete ctx;
@@ -133,7 +134,9 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
                     ctx->gp.d_xc, ctx->gp.d_smeta};
   for (double* b : bufs)
     if (b) (void)hipFree(b);
-  if (ctx->d_epsgen) (void)hipFree(ctx->d_epsgen);
+  for (double* b : ctx->d_epsgen)
+    if (b) (void)hipFree(b);
+  if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
   for (int i = 0; i < 10; ++i)

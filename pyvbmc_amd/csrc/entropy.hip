@@ -490,12 +490,50 @@ int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& pa) {
   const int D = ctx->D, K = ctx->K;
   const size_t n_eps = (size_t)K * (size_t)p.a.row_count * D;
   if (!on || p.a.eps_mode != VBMC_EPS_PHILOX || n_eps == 0 || n_eps > ((size_t)1 << 28)) return 0;
-  int rc = ensure_dev(ctx, &ctx->d_epsgen, &ctx->d_epsgen_cap, n_eps);
-  if (rc) return rc;
-  pa.gen = make_gen_slice(ctx->d_epsgen, K, D, p.a.row_count, p.a.n_half, p.a.row_begin, p.a.seed, nullptr, 0.0, 1.0);
+  vbmc_ctx::AheadDraws& ah = ctx->ahead;
+  int cur;
+  if (ah.valid && ah.seed == p.a.seed && ah.K == K && ah.D == D && ah.rows == p.a.row_count &&
+      ah.n_half == p.a.n_half && ah.row_begin == p.a.row_begin) {
+    // the previous evaluation already queued exactly these draws (entmc_launch_ahead)
+    cur = ah.buf;
+  } else {
+    cur = ah.valid ? 1 - ah.buf : 0;  // keep clear of a speculative buffer that is not the one wanted
+    int rc = ensure_dev(ctx, &ctx->d_epsgen[cur], &ctx->d_epsgen_cap[cur], n_eps);
+    if (rc) return rc;
+    pa.gen = make_gen_slice(ctx->d_epsgen[cur], K, D, p.a.row_count, p.a.n_half, p.a.row_begin, p.a.seed, nullptr, 0.0, 1.0);
+  }
+  ah.valid = false;
+  ctx->gen_cur = cur;
   p.a.eps_mode = VBMC_EPS_RESIDENT;
-  p.a.eps = ctx->d_epsgen;
+  p.a.eps = ctx->d_epsgen[cur];
   p.a.eps_rows = p.a.row_count;
+  return 0;
+}
+
+int entmc_launch_ahead(vbmc_ctx* ctx, const EntPlan& p) {
+  const EntArgs& a = p.a;
+  if (!ctx->opt_elbo_ahead || a.eps == nullptr || a.eps != ctx->d_epsgen[ctx->gen_cur]) return 0;
+  const int D = ctx->D, K = ctx->K, other = 1 - ctx->gen_cur;
+  const size_t n_eps = (size_t)K * (size_t)a.row_count * D;
+  if (ctx->d_epsgen_cap[other] < n_eps || !ctx->d_epsgen[other]) {
+    // first use only.  ensure_dev would wait for the stream when growing an existing buffer, and
+    // that wait must not sit between this evaluation's launches and its result: allocate fresh
+    if (ctx->d_epsgen[other]) return 0;  // too small: leave it; the next evaluation re-plans
+    int rc = ensure_dev(ctx, &ctx->d_epsgen[other], &ctx->d_epsgen_cap[other], n_eps);
+    if (rc) return rc;
+  }
+  vbmc_ctx::AheadDraws& ah = ctx->ahead;
+  ah.seed = a.seed + 1;
+  ah.K = K;
+  ah.D = D;
+  ah.rows = a.row_count;
+  ah.n_half = a.n_half;
+  ah.row_begin = a.row_begin;
+  ah.buf = other;
+  const GenSlice g = make_gen_slice(ctx->d_epsgen[other], K, D, a.row_count, a.n_half, a.row_begin, ah.seed, nullptr, 0.0, 1.0);
+  int rc = launch_eps_gen(ctx, ctx->stream, g);
+  if (rc) return rc;
+  ah.valid = true;
   return 0;
 }
 

@@ -99,12 +99,13 @@ def test_device_adam_loop_and_acquisition_accept_reference_style_objects(ctx, go
     bnd = synthetic.default_theta_bnd(wl)
     outs = []
     for cls in ("plain", "mirror"):
+        gp = PlainGP(oracle_gp(g, g["hyp"][:1]))  # the same posterior records for both
         if cls == "plain":
-            vp, gp = PlainVP(g), PlainGP(oracle_gp(g, g["hyp"][:1]))
+            vp = PlainVP(g)
         else:
-            from test_gpu_multibatch import make_gp, make_vp
+            from test_gpu_multibatch import make_vp
 
-            vp, gp = make_vp(g, ctx), make_gp(g, ctx, g["hyp"][:1])
+            vp = make_vp(g, ctx)
         x, y, xt, yt, it = minimize_adam_elbo(g["theta"].copy(), gp, vp, NsK, bnd, max_iter=40, seed=11, rng="philox")
         outs.append((x, y, xt, yt, vp.mu.copy()))
         assert vp.mu.shape == (D, K) and vp.sigma.shape == (1, K)

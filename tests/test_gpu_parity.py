@@ -324,6 +324,50 @@ def test_gp_predict_vs_oracle(ctx, golden, name):
     assert np.max(np.abs(ys2 - oys2)) <= 1e-10 * max(1.0, sf2)
 
 
+@pytest.mark.parametrize("name", ["homo", "hetero", "tiny"])
+def test_gp_predict_vs_reference_in_tree_solves(ctx, golden, name):
+    """tests/golden/gpcov.npz (made by running the reference's solve_triangular code on the
+    posterior records, oracle/make_golden.py gpcov): moderate length scales, heteroskedastic
+    noise, and a GP whose first sample takes the L_chol=False branch.  Device predictive
+    variances at 1e-10 of sf^2 -- through the mirror GP class (its own records) and through an
+    attribute-only GP carrying the oracle's records."""
+    from helpers import PlainGP
+    from pyvbmc_amd import gp as gpm
+    from pyvbmc_amd.gp import upload_gp
+
+    c = golden("gpcov")
+    D = int(c["D"])
+    hyp = c[f"{name}_hyp"]
+    s2 = c["s2"] if name == "hetero" else None
+    gp = gpm.GP(D, gpm.SquaredExponential(), gpm.NegativeQuadratic(),
+                gpm.GaussianNoise(constant_add=True, user_provided_add=s2 is not None))
+    gp.ctx = ctx
+    gp.update(X_new=c["X"], y_new=c["y"], s2_new=s2, hyp=hyp)
+    assert [int(p.L_chol) for p in gp.posteriors] == list(c[f"{name}_L_chol"])
+    ogp = gp_ref.make_gp(c["X"], c["y"], hyp, gp_ref.MEAN_NEGQUAD, s2=s2, noise_user=s2 is not None)
+    sf2 = float(np.exp(2 * np.max(hyp[:, D])))
+    for cls in ("AcqFcnVIQR", "AcqFcnIMIQR"):
+        Xa, imp = c[f"{name}_{cls}_Xa"], c[f"{name}_{cls}_fs2_implied"]
+        fmu, fs2 = gp.predict(Xa, separate_samples=True)
+        omu, _ = gp_ref.predict(ogp, Xa, separate_samples=True)
+        err = float(np.max(np.abs(fs2 - imp)))
+        print(f"gpcov {name}/{cls}: max|fs2 - implied| = {err:.2e} (sf2 = {sf2:.3g}, min fs2 = {imp.min():.2e})")
+        assert err <= 1e-10 * sf2
+        assert np.max(np.abs(fmu - omu)) <= 1e-10 * max(1.0, float(np.max(np.abs(omu))))
+        # the same through the C ABI with an attribute-only GP (records from the oracle)
+        pgp = PlainGP(ogp)
+        upload_gp(pgp, ctx)
+        import ctypes as C
+        from pyvbmc_amd import _lib
+        xs = _lib.f64(Xa)
+        f1, f2 = np.empty((xs.shape[0], hyp.shape[0])), np.empty((xs.shape[0], hyp.shape[0]))
+        ctx.check(ctx._lib.vbmc_gp_predict(ctx._h, xs.shape[0], _lib.ptr(xs), 0, 1, _lib.ptr(f1), _lib.ptr(f2)))
+        assert np.max(np.abs(f2 - imp)) <= 1e-10 * sf2
+    # the small-batch variance kernel (<= 32 points) takes its own path: same answers
+    fmu, fs2 = gp.predict(c[f"{name}_AcqFcnVIQR_Xa"][:5], separate_samples=True)
+    assert np.max(np.abs(fs2 - c[f"{name}_AcqFcnVIQR_fs2_implied"][:5])) <= 1e-10 * sf2
+
+
 def test_gp_predict_matlab_known(ctx, golden):
     """The reference's MATLAB fixture for gp.predict (test_active_importance_sampling.py:178-250)."""
     from pyvbmc_amd import gp as gpm

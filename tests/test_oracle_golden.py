@@ -240,3 +240,46 @@ def test_soft_bound_loss_known(golden):
     L, dL = elbo_ref.soft_bound_loss(g["sbl_x"], np.full(3, -10.0), np.full(3, 10.0), compute_grad=True)
     assert np.isclose(L, 156250.0) and np.isclose(L, g["sbl_L"])
     assert np.allclose(dL, [12500.0, -25000.0, 0.0]) and np.allclose(dL, g["sbl_dL"])
+
+
+GPCOV_CASES = ["homo", "hetero", "tiny"]
+
+
+def gpcov_gp(c, name):
+    s2 = c["s2"] if name == "hetero" else None
+    return gp_ref.make_gp(c["X"], c["y"], c[f"{name}_hyp"], gp_ref.MEAN_NEGQUAD, s2=s2, noise_user=s2 is not None)
+
+
+@pytest.mark.parametrize("name", GPCOV_CASES)
+def test_posterior_records_vs_reference_in_tree_solves(golden, name):
+    """tests/golden/gpcov.npz: the reference's own solve_triangular code
+    (active_importance_sampling.py:279-306) run on the posterior records -- homoskedastic,
+    heteroskedastic, and L_chol=False -- gives these predictive variances / cross terms.
+    gp_ref.predict and a dense first-principles solve must agree at 1e-10 (of sf^2)."""
+    c = golden("gpcov")
+    D, N = int(c["D"]), int(c["N"])
+    gp = gpcov_gp(c, name)
+    hyp = c[f"{name}_hyp"]
+    assert [int(p.L_chol) for p in gp.posteriors] == list(c[f"{name}_L_chol"])
+    if name == "tiny":
+        assert list(c[f"{name}_L_chol"]) == [0, 1]  # both branches in one GP
+    for cls in ("AcqFcnVIQR", "AcqFcnIMIQR"):
+        Xa = c[f"{name}_{cls}_Xa"]
+        imp = c[f"{name}_{cls}_fs2_implied"]
+        fmu, fs2 = gp_ref.predict(gp, Xa, separate_samples=True)
+        for s in range(hyp.shape[0]):
+            sf2 = np.exp(2 * hyp[s, D])
+            assert np.max(np.abs(fs2[:, s] - imp[:, s])) <= 1e-10 * sf2, (name, cls, s)
+            # dense first principles: (K + diag(sn2))^-1 with no Cholesky / no record at all
+            Kxx = gp_ref.se_ard(hyp[s, : D + 1], c["X"], c["X"])
+            sn2 = np.exp(2 * hyp[s, D + 1]) + (c["s2"].ravel() if name == "hetero" else 0.0)
+            Ks = gp_ref.se_ard(hyp[s, : D + 1], c["X"], Xa)
+            sol = np.linalg.solve(Kxx + np.diag(np.full(N, 1.0) * sn2), Ks)
+            dense = sf2 - np.sum(Ks * sol, axis=0)
+            # (the dense solve itself loses ~cond(K) * eps: compare at 1e-8 of sf^2)
+            assert np.max(np.abs(dense - imp[:, s])) <= 1e-8 * sf2, (name, cls, s)
+            cross = Ks[:, :8].T @ sol[:, :8]
+            sign = 1.0 if c[f"{name}_L_chol"][s] else -1.0  # C_tmp = L K with L = -(K+S)^-1 when !L_chol
+            assert np.max(np.abs(sign * cross - c[f"{name}_{cls}_cross_implied"][s])) <= 1e-8 * sf2
+        # the f_s2 the reference's importance-sampling bookkeeping stored came from predict: same numbers
+        assert np.max(np.abs(fs2 - c[f"{name}_{cls}_ais_f_s2"])) <= 1e-10 * np.exp(2 * np.max(hyp[:, D]))
