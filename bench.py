@@ -33,18 +33,27 @@ FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet: FP64 vector == FP64 matrix (MFMA) p
 HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md
 
 
+# per-GPU Monte-Carlo sample count of each BASELINE config that has a bench line (config 4 is
+# config 3's shape on 8 GPUs, config 5 is quoted on 8 GPUs: its per-GPU share is Ns/8)
+PER_GPU_NS = {2: 100_000, 3: 1_000_000, 5: 4_000_000 // 8}
+MIN_TIMED_S = 0.5  # the timed region repeats its K steps until it is at least this long
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--config", type=int, default=3, help="BASELINE config for the per-GPU shape")
+    p.add_argument("--config", type=int, default=3, choices=sorted(PER_GPU_NS),
+                   help="BASELINE config whose per-GPU shape is run (3 = the headline metric's)")
     p.add_argument("--rng", choices=["philox", "resident"], default="philox",
                    help="philox: fresh in-kernel draws every eval; resident: HBM-resident eps reused")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-secondary", action="store_true",
+                   help="skip the secondary figures (predict roofline, device-resident loop, reference stream)")
     p.add_argument("--cpu-sample-nsk", type=int, default=0,
-                   help="per-component samples of the CPU-baseline run (0 = the workload's own: two full "
-                        "evaluations, ~10 s of host work at config 3)")
+                   help="per-component samples of the CPU-baseline run (0 = a sample sized for ~10-30 s of "
+                        "host work: the whole workload at configs 2 and 3, a fifth of it at config 5)")
     p.add_argument("--cpu-reps", type=int, default=2)
     return p.parse_args()
 
@@ -111,8 +120,9 @@ def main():
     ctx = _lib.Context(local_rank)
     _lib.set_default_context(ctx)
     comm.init_from_env(ctx)
+    comm_rank, comm_world = ctx.comm_info()  # what RCCL itself reports
 
-    wl = synthetic.make_workload(a.config)
+    wl = synthetic.make_workload(a.config, Ns_total=PER_GPU_NS[a.config])
     D, K = wl.D, wl.K
     nsk_job = wl.NsK * world                   # per-component samples of the whole job
     ns_job = nsk_job * K
@@ -167,50 +177,82 @@ def main():
                                               None, None, None, None, None))
             return Fc.value, dF, Gc.value, Hc.value, 0
 
-    # Secondary roofline (third way): gp.predict at the acquisition batch size,
-    # its GEMM flops against the FP64 matrix-core peak.  Timed with HIP events around the three
-    # predict launches (K* on MFMA, variance GEMM on MFMA, finish), so `frac` is a lower bound
-    # for the GEMM alone.
-    M_pred = 8192
-    xs_pred = np.random.default_rng(7).standard_normal((M_pred, D))
-    gp.predict(xs_pred, separate_samples=True)
-    pm = []
-    ctx.set_timing(True)
-    for _ in range(5):
+    predict_roofline = adam_loop = reference_stream = None
+    if not a.no_secondary:
+        # Secondary roofline (third way): gp.predict at the acquisition batch size,
+        # its GEMM flops against the FP64 matrix-core peak.  Timed with HIP events around the three
+        # predict launches (K* on MFMA, variance GEMM on MFMA, finish), so `frac` is a lower bound
+        # for the GEMM alone.
+        M_pred = 8192
+        xs_pred = np.random.default_rng(7).standard_normal((M_pred, D))
         gp.predict(xs_pred, separate_samples=True)
-        pm.append(ctx.last_kernel_ms(3))
-    ctx.set_timing(False)
-    nt = (wl.N + 63) // 64
-    gemm_flops = 2.0 * M_pred * 64 * sum(min((c + 1) * 64, wl.N) for c in range(nt))  # triangular skip
-    pred_ms = float(np.median(pm))
-    predict_roofline = {
-        "kernel": "predict_kstar_mfma + predict_var_mfma + predict_finish (S=1, M=8192)",
-        "bound": "mfma", "achieved": gemm_flops / (pred_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
-        "unit": "TFLOP/s", "frac": gemm_flops / (pred_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-        "kernels_ms": pred_ms, "gemm_flops": gemm_flops,
-    }
-    # Secondary figure (not `value`): the same evaluation inside the device-resident optimiser
-    # loop -- no host round trip per evaluation; every rank runs it (the
-    # all-reduce is in-stream).  Measured first: it also brings the GPU clocks up before the
-    # W warm-up steps and the timed region.
-    from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+        pm = []
+        ctx.set_timing(True)
+        for _ in range(5):
+            gp.predict(xs_pred, separate_samples=True)
+            pm.append(ctx.last_kernel_ms(3))
+        ctx.set_timing(False)
+        nt = (wl.N + 63) // 64
+        gemm_flops = 2.0 * M_pred * 64 * sum(min((c + 1) * 64, wl.N) for c in range(nt))  # triangular skip
+        pred_ms = float(np.median(pm))
+        predict_roofline = {
+            "kernel": "predict_kstar_mfma + predict_var_mfma + predict_finish (S=1, M=8192)",
+            "bound": "mfma", "achieved": gemm_flops / (pred_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": gemm_flops / (pred_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            "kernels_ms": pred_ms, "gemm_flops": gemm_flops,
+        }
+        # Secondary figure (not `value`): the same evaluation inside the device-resident optimiser
+        # loop -- no host round trip per evaluation; every rank runs it (the
+        # all-reduce is in-stream).  Measured first: it also brings the GPU clocks up before the
+        # W warm-up steps and the timed region.
+        from pyvbmc_amd.minimize_adam import minimize_adam_elbo
 
-    n_loop = max(200, min(a.steps, 400))
-    kw = dict(max_iter=n_loop, use_early_stopping=False, seed=12345, rng="philox")
-    minimize_adam_elbo(theta.copy(), gp, vp, nsk_job, bnd, **kw)  # warm-up
-    ctx.comm_barrier()
-    t1 = time.perf_counter()
-    loop = minimize_adam_elbo(theta.copy(), gp, vp, nsk_job, bnd, **kw)
-    ctx.comm_barrier()
-    dt_loop = ctx.comm_max(time.perf_counter() - t1)
-    adam_loop = {
-        "iterations": n_loop,
-        "us_per_iteration": 1e6 * dt_loop / n_loop,
-        "evals_per_s": (n_loop / dt_loop) * (ns_job / 1e6),
-        "F_first_last": [float(loop[3][0]), float(loop[3][-1])],
-    }
+        n_loop = max(200, min(a.steps, 400))
+        kw = dict(max_iter=n_loop, use_early_stopping=False, seed=12345, rng="philox")
+        minimize_adam_elbo(theta.copy(), gp, vp, nsk_job, bnd, **kw)  # warm-up
+        ctx.comm_barrier()
+        t1 = time.perf_counter()
+        loop = minimize_adam_elbo(theta.copy(), gp, vp, nsk_job, bnd, **kw)
+        ctx.comm_barrier()
+        dt_loop = ctx.comm_max(time.perf_counter() - t1)
+        adam_loop = {
+            "iterations": n_loop,
+            "us_per_iteration": 1e6 * dt_loop / n_loop,
+            "evals_per_s": (n_loop / dt_loop) * (ns_job / PER_GPU_NS[a.config]),
+            "F_first_last": [float(loop[3][0]), float(loop[3][-1])],
+        }
+        if world == 1:
+            # Secondary figure (never `value`): the drop-in's DEFAULT draw source, rng="numpy" -- the
+            # reference's MT19937 stream drawn on the host and shipped over PCIe every evaluation
+            # (bit-identical inputs to the reference's).  The headline needs rng="philox".
+            _neg_elcbo(theta.copy(), gp, vp, 0.0, nsk_job, True, False, bnd, rng="numpy")
+            n_ref = 3
+            t1 = time.perf_counter()
+            for _ in range(n_ref):
+                _neg_elcbo(theta.copy(), gp, vp, 0.0, nsk_job, True, False, bnd, rng="numpy")
+            dt_ref = (time.perf_counter() - t1) / n_ref
+            reference_stream = {
+                "evals_per_s": 1.0 / dt_ref, "ms_per_eval": 1e3 * dt_ref, "evals": n_ref,
+                "what": "rng='numpy' (the default): host np.random.randn of K*NsK/2*D normals + H2D copy per "
+                        "evaluation, PCIe-inclusive; dominated by the host generator",
+            }
     for _ in range(a.warmup):
         out = step()
+    ctx.synchronize()
+    # a short calibration run (after the warm-up, so first-call allocations are out of it) sizes
+    # the timed region
+    n_cal = max(3, min(20, a.steps))
+    t_w = time.perf_counter()
+    for _ in range(n_cal):
+        out = step()
+    ctx.synchronize()
+    est = (time.perf_counter() - t_w) / n_cal
+    # The timed region is R back-to-back repetitions of the K requested steps, R chosen so that it
+    # lasts >= MIN_TIMED_S whatever K is (a 20-step region is 3 ms: too short to mean anything).
+    # All ranks must agree on R: take the maximum estimate.
+    est = ctx.comm_max(est)
+    repeats = max(1, int(np.ceil(1.1 * MIN_TIMED_S / max(a.steps * est, 1e-9))))
+    n_timed = repeats * a.steps
     ctx.comm_barrier()
     ctx.synchronize()
     # HIP events on the ctx stream bracket the main kernel on every TIMED_EVERY-th step of the
@@ -220,7 +262,7 @@ def main():
     kern_ms = []
     host_us = np.zeros(5)
     t0 = time.perf_counter()
-    for i in range(a.steps):
+    for i in range(n_timed):
         timed = i % TIMED_EVERY == 0
         ctx.set_timing(timed)
         out = step()
@@ -235,32 +277,44 @@ def main():
     F = out[0]
     if not np.isfinite(F):
         sys.exit("non-finite objective")
+    plan = ctx.last_entmc_plan()
 
-    ms_per_step = 1e3 * dt / a.steps
-    evals_per_s = a.steps / dt
-    value = evals_per_s * (ns_job / 1e6)
+    ms_per_step = 1e3 * dt / n_timed
+    evals_per_s = n_timed / dt
+    value = evals_per_s * (ns_job / PER_GPU_NS[a.config])
     k_ms = float(np.mean(kern_ms))
     flops = algorithmic_flops(D, K, ns_job / world, grad=True)  # per launch (this rank's rows)
     achieved = flops / (k_ms * 1e-3) / 1e12
-    # the draws the entropy kernel reads: resident, or (Philox mode) generated into HBM by the prep
-    # launch -- unless VBMC_ELBO_PREGEN=0 keeps the generation inside the entropy kernel
-    inline_gen = a.rng == "philox" and os.environ.get("VBMC_ELBO_PREGEN", "1")[:1] == "0"
-    eps_bytes = 0.0 if inline_gen else (ns_job / world / 2) * D * 8
-    traffic = None
+    achieved_e2e = flops / (ms_per_step * 1e-3) / 1e12
+    # the draws the entropy kernel reads: resident, or (Philox mode) generated into HBM ahead of it
+    # -- unless VBMC_ELBO_PREGEN=0 keeps the generation inside the entropy kernel
+    eps_bytes = (ns_job / world / 2) * D * 8 if plan["resident_draws"] else 0.0
+    traffic, traffic_from = None, None
     try:  # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc passes, see profiles/README.md)
         tj = json.load(open(ROOT / "profiles" / "traffic.json"))
-        if a.config == 3 and a.rng in tj:
-            traffic = tj[a.rng]["hbm_bytes_per_launch"]
+        ent = tj.get(f"config{a.config}", {}).get(a.rng)
+        if ent:
+            traffic = ent["hbm_bytes_per_launch"]
+            traffic_from = {"file": "profiles/traffic.json", "source": ent.get("source"),
+                            "collected": ent.get("collected"), "how": tj.get("_comment")}
     except (OSError, ValueError, KeyError):
         pass
+    if a.config == 3:
+        metric = "ELBO+entropy evals/sec at D=10, K=50, N=400, Ns=1e6 (1e6-sample-equivalent evals/s)"
+    else:
+        metric = (f"ELBO+entropy evals/sec at D={D}, K={K}, N={wl.N}, Ns={PER_GPU_NS[a.config]:.0e} per GPU "
+                  f"(BASELINE config {a.config}'s per-GPU share; secondary line)")
     res = {
-        "metric": "ELBO+entropy evals/sec at D=10, K=50, N=400, Ns=1e6 (1e6-sample-equivalent evals/s)",
+        "metric": metric,
         "value": value,
         "unit": "evals/s",
         "n_gpus": world,
+        "comm_world": comm_world,
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": ms_per_step,
+        "timed_steps": n_timed,
+        "timed_region_s": dt,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -272,33 +326,47 @@ def main():
                         f"with soft bounds, eps={a.rng}",
             "evals_per_s_job": evals_per_s,
             "parallelism": f"sample-sharded x{world}, 1 RCCL all-reduce/eval" if world > 1 else "single GPU",
+            "timed_region": f"{repeats} x {a.steps} steps back to back (>= {MIN_TIMED_S} s), one barrier + "
+                            f"synchronize on either side",
+            "entropy_launch": plan,
         },
         "roofline": {
-            "kernel": "entmc main kernel",
+            "kernel": "entmc main kernel (%s)" % plan["kernel"],
             "bound": "mfma",
-            "bound_detail": "float64 FMA throughput: on MI355X the FP64 vector and FP64 matrix (MFMA) "
-                            "peaks are the same 78.6 TFLOP/s; exp/log not counted as flops",
+            "bound_detail": "FP64 arithmetic issue.  The kernel executes NO MFMA instruction: it is bound by the "
+                            "float64 vector FMA pipe, whose peak on MI355X equals the dense FP64 matrix peak "
+                            "(78.6 TFLOP/s) -- the label the contract offers for a compute bound; exp/log not "
+                            "counted as flops",
             "achieved": achieved,
             "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP64_PEAK_TFLOPS,
             "traffic": traffic,
+            "traffic_from": traffic_from,
             "kernel_ms": k_ms,
-            "kernel_ms_from": f"HIP events around the kernel on every {TIMED_EVERY}th of the {a.steps} timed steps "
+            "kernel_ms_from": f"HIP events around the kernel on every {TIMED_EVERY}th of the {n_timed} timed steps "
                               f"({len(kern_ms)} launches)",
             "algorithmic_flops_per_launch": flops,
             "hbm_bytes_per_launch_algorithmic": eps_bytes,
             "hbm_achieved_GBs": (eps_bytes / (k_ms * 1e-3) / 1e9) if eps_bytes else 0.0,
             "hbm_peak_GBs": HBM_PEAK_GBS,
         },
+        "roofline_e2e": {
+            "what": "the same algorithmic flops over the whole host-driven step (ms_per_step): upload, prep, "
+                    "entropy, finish, host finalisation and Python included",
+            "achieved": achieved_e2e, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved_e2e / FP64_PEAK_TFLOPS,
+        },
         "predict_roofline": predict_roofline,
         "device_resident_adam_loop": adam_loop,
+        "reference_stream": reference_stream,
         "F": F,
         "host_us_per_step": dict(zip(["pack_upload", "launch", "wait_device", "finalize", "c_total"],
-                                     (host_us / a.steps).round(2).tolist())),
+                                     (host_us / n_timed).round(2).tolist())),
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(wl, a.cpu_sample_nsk, a.cpu_reps)
+        nsk_cpu = a.cpu_sample_nsk or (wl.NsK // 5 if a.config == 5 else wl.NsK)
+        res["cpu_baseline"] = cpu_baseline(wl, nsk_cpu, a.cpu_reps)
         res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(res))

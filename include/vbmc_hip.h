@@ -361,6 +361,10 @@ int vbmc_comm_unique_id(uint8_t id_out[128]);
  * raw entropy accumulator over `world` ranks. */
 int vbmc_comm_init(vbmc_ctx* ctx, const uint8_t id[128], int rank, int world);
 int vbmc_comm_destroy(vbmc_ctx* ctx);
+/* Rank and size of the communicator as RCCL reports them (ncclCommUserRank / ncclCommCount);
+ * 0 and 1 without a communicator.  bench.py prints the size as `comm_world` so a multi-GPU
+ * line can be checked against the ranks that really took part. */
+int vbmc_comm_info(vbmc_ctx* ctx, int* rank_out, int* world_out);
 /* Device-side barrier + max over ranks of a host double (bench timing). */
 int vbmc_comm_allreduce_max(vbmc_ctx* ctx, double* value_inout);
 int vbmc_comm_barrier(vbmc_ctx* ctx);

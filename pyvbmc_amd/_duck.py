@@ -31,19 +31,20 @@ def upload_vp(vp, ctx):
 
 
 def optimize_mask(vp):
-    return _lib.flags_to_bits(
-        (vp.optimize_mu, vp.optimize_sigma, vp.optimize_lambd, vp.optimize_weights)
-    )
+    return ((1 if vp.optimize_mu else 0) | (2 if vp.optimize_sigma else 0) | (4 if vp.optimize_lambd else 0)
+            | (8 if vp.optimize_weights else 0))
 
 
 def store_mixture(vp, mu_KD, sigma, lambd, w, eta=None):
     """Write a mixture back into ``vp`` with the reference's attribute shapes -- the side
     effect of ``vp.set_parameters(theta)`` (variational_posterior.py:680-759)."""
-    vp.mu = np.array(mu_KD, dtype=np.float64).T.copy()
-    vp.sigma = np.array(sigma, dtype=np.float64).reshape(1, -1)
-    vp.lambd = np.array(lambd, dtype=np.float64).reshape(-1, 1)
-    vp.w = np.array(w, dtype=np.float64).reshape(1, -1)
+    # (float64 ndarrays in: .copy() is the cheapest way to detach them from the call's buffers --
+    # this runs once per ELBO evaluation)
+    vp.mu = mu_KD.T.copy()
+    vp.sigma = sigma.reshape(1, -1).copy()
+    vp.lambd = lambd.reshape(-1, 1).copy()
+    vp.w = w.reshape(1, -1).copy()
     if eta is not None:
-        vp.eta = np.array(eta, dtype=np.float64).reshape(1, -1)
+        vp.eta = eta.reshape(1, -1).copy()
     if hasattr(vp, "_mode"):
         vp._mode = None  # set_parameters drops the cached mode (:759)

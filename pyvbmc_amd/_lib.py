@@ -112,6 +112,7 @@ SIGNATURES = {
     "vbmc_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "vbmc_comm_init": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
     "vbmc_comm_destroy": (C.c_int, [_vp]),
+    "vbmc_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vbmc_comm_allreduce_max": (C.c_int, [_vp, _dp]),
     "vbmc_comm_barrier": (C.c_int, [_vp]),
 }
@@ -264,6 +265,12 @@ class Context:
         buf = (C.c_uint8 * 128).from_buffer_copy(uid_bytes)
         self.check(self._lib.vbmc_comm_init(self._h, buf, rank, world))
         self.rank, self.world = rank, world
+
+    def comm_info(self):
+        """(rank, world) of the communicator as RCCL itself reports them; (0, 1) without one."""
+        r, w = C.c_int(), C.c_int()
+        self.check(self._lib.vbmc_comm_info(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
 
     def comm_barrier(self):
         self.check(self._lib.vbmc_comm_barrier(self._h))

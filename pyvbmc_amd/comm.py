@@ -34,6 +34,21 @@ def env_rank_world():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+def _rendezvous_dir():
+    """A directory only this user can enter (mode 0700, owned by us, not a symlink): nobody
+    else can pre-create or swap the rendezvous file."""
+    import stat
+    import tempfile
+
+    base = Path(os.environ.get("VBMC_RDZV_DIR", tempfile.gettempdir()))
+    d = base / f"vbmc_rdzv_{os.getuid()}"
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError(f"{d} must be a directory owned by uid {os.getuid()} with mode 0700")
+    return d
+
+
 def _rendezvous_path():
     key = "_".join(
         [
@@ -43,24 +58,45 @@ def _rendezvous_path():
             str(os.getppid()),
         ]
     )
-    return Path(os.environ.get("VBMC_RDZV_DIR", "/tmp")) / f"vbmc_rdzv_{key}.uid"
+    return _rendezvous_dir() / f"{key}.uid"
+
+
+def _launcher_start_time():
+    """Start time (epoch seconds) of the parent process -- the launcher all local ranks share.
+    A rendezvous file older than the launcher is a leftover of an earlier launch that happened
+    to reuse the same key (port, run id, recycled pid) and must not be joined."""
+    try:
+        fields = Path(f"/proc/{os.getppid()}/stat").read_text().rsplit(")", 1)[1].split()
+        ticks = int(fields[19])  # starttime, field 22 of /proc/<pid>/stat
+        btime = next(int(l.split()[1]) for l in Path("/proc/stat").read_text().splitlines() if l.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, IndexError, StopIteration):
+        return time.time() - 5.0
 
 
 def exchange_unique_id(rank, world, make_id, timeout=300.0):
-    """Rank 0 creates the id and publishes it atomically; the others poll for it."""
+    """Rank 0 creates the id and publishes it atomically (exclusive create in a private
+    directory, then rename); the others poll for a file newer than the launcher."""
     path = _rendezvous_path()
     t0 = time.time()
+    not_before = _launcher_start_time() - 1.0
     if rank == 0:
         uid = make_id()
         tmp = path.with_suffix(".tmp%d" % os.getpid())
-        tmp.write_bytes(uid)
+        for stale in (tmp, path):
+            try:
+                stale.unlink()
+            except FileNotFoundError:
+                pass
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(uid)
         os.replace(tmp, path)
         return uid
     while True:
         try:
-            st = path.stat()
-            # ignore leftovers of an earlier launch that reused the same key
-            if st.st_size == 128 and st.st_mtime >= t0 - 120.0:
+            st = os.lstat(path)
+            if st.st_size == 128 and st.st_uid == os.getuid() and st.st_mtime >= not_before:
                 return path.read_bytes()
         except FileNotFoundError:
             pass

@@ -669,6 +669,7 @@ extern "C" int vbmc_adam_end(vbmc_ctx* ctx, double* theta_out, double* mu_KxD, d
   ctx->lambd.assign(aux.begin() + K * D + K, aux.begin() + K * D + K + D);
   ctx->w.assign(aux.begin() + K * D + K + D, aux.begin() + K * D + 2 * K + D);
   ctx->eta.assign(aux.begin() + K * D + 2 * K + D, aux.end());
+  ctx->exp_eta_valid = false;
   ctx->pack_valid = true;
   if (theta_out) memcpy(theta_out, th.data(), sizeof(double) * st->n_theta);
   if (mu_KxD) memcpy(mu_KxD, ctx->mu.data(), sizeof(double) * K * D);

@@ -6,21 +6,28 @@
 #include "common.h"
 
 // w_grad <- J_w @ w_grad, J_w = -ee ee^T / s^2 + diag(ee)/s, ee = exp(eta)
-// (entmc_vbmc.py:122-130).
-void softmax_jacobian_apply(const std::vector<double>& eta, const double* g, double* out) {
-  const int K = (int)eta.size();
-  std::vector<double> ee(K);
-  double s = 0.0;
-  for (int k = 0; k < K; ++k) {
-    ee[k] = std::exp(eta[k]);
-    s += ee[k];
+// (entmc_vbmc.py:122-130).  exp(eta) is cached in the context until eta changes: one ELBO
+// evaluation applies this Jacobian three times (GP term, entropy, weight penalty).
+void softmax_jacobian_apply(vbmc_ctx* ctx, const double* g, double* out) {
+  const int K = (int)ctx->eta.size();
+  if (!ctx->exp_eta_valid || (int)ctx->exp_eta.size() != K) {
+    ctx->exp_eta.resize(K);
+    double s = 0.0;
+    for (int k = 0; k < K; ++k) {
+      ctx->exp_eta[k] = std::exp(ctx->eta[k]);
+      s += ctx->exp_eta[k];
+    }
+    ctx->exp_eta_sum = s;
+    ctx->exp_eta_valid = true;
   }
+  const double* ee = ctx->exp_eta.data();
+  const double s = ctx->exp_eta_sum;
   double dot = 0.0;
   for (int k = 0; k < K; ++k) dot += ee[k] * g[k];
   for (int k = 0; k < K; ++k) out[k] = -ee[k] * dot / (s * s) + ee[k] * g[k] / s;
 }
 
-int entropy_pack(const vbmc_ctx* ctx, double H, const double* mu, const double* sg,
+int entropy_pack(vbmc_ctx* ctx, double H, const double* mu, const double* sg,
                  const double* lm, const double* wg, int grad_flags, int jacobian_flag,
                  double* H_out, double* dH_out) {
   const int D = ctx->D, K = ctx->K;
@@ -41,7 +48,7 @@ int entropy_pack(const vbmc_ctx* ctx, double H, const double* mu, const double* 
   }
   if (grad_flags & 8) {
     if (jacobian_flag)
-      softmax_jacobian_apply(ctx->eta, wg, dH_out + pos);
+      softmax_jacobian_apply(ctx, wg, dH_out + pos);
     else
       memcpy(dH_out + pos, wg, sizeof(double) * K);
     pos += K;

@@ -141,7 +141,7 @@ void glj_finalize(const vbmc_ctx* ctx, const double* res, int want_grad, GljHost
 }
 
 // dG blocks: mu always; sigma/lambda/w only under jacobian_flag (:1528-1546).
-int glj_pack(const vbmc_ctx* ctx, const double* mu, const double* sg, const double* lm,
+int glj_pack(vbmc_ctx* ctx, const double* mu, const double* sg, const double* lm,
              const double* wg, int grad_flags, int jacobian_flag, double* out) {
   const int D = ctx->D, K = ctx->K;
   int pos = 0;
@@ -160,7 +160,7 @@ int glj_pack(const vbmc_ctx* ctx, const double* mu, const double* sg, const doub
     pos += D;
   }
   if (jacobian_flag && (grad_flags & 8)) {
-    if (out) softmax_jacobian_apply(ctx->eta, wg, out + pos);
+    if (out) softmax_jacobian_apply(ctx, wg, out + pos);
     pos += K;
   }
   return pos;

@@ -24,6 +24,8 @@ struct RcclApi {
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
 };
 RcclApi g_rccl;
 
@@ -43,6 +45,8 @@ int rccl_load(vbmc_ctx* ctx) {
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
   a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+  a.CommCount = (decltype(a.CommCount))dlsym(h, "ncclCommCount");
+  a.CommUserRank = (decltype(a.CommUserRank))dlsym(h, "ncclCommUserRank");
   if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString)
     return vbmc_fail(ctx, VBMC_E_RCCL, "librccl.so.1 lacks an expected symbol");
   g_rccl = a;
@@ -109,6 +113,21 @@ int vbmc_comm_destroy(vbmc_ctx* ctx) {
     ctx->world = 1;
     ctx->rank = 0;
   }
+  return VBMC_OK;
+}
+
+int vbmc_comm_info(vbmc_ctx* ctx, int* rank_out, int* world_out) {
+  if (!ctx) return VBMC_E_ARG;
+  int r = 0, w = 1;
+  if (ctx->comm) {
+    // what RCCL itself reports for this communicator, not what the caller passed to vbmc_comm_init
+    if (!g_rccl.CommCount || !g_rccl.CommUserRank)
+      return vbmc_fail(ctx, VBMC_E_RCCL, "librccl.so.1 lacks ncclCommCount / ncclCommUserRank");
+    NCCL_TRY(ctx, g_rccl.CommCount((ncclComm_t)ctx->comm, &w));
+    NCCL_TRY(ctx, g_rccl.CommUserRank((ncclComm_t)ctx->comm, &r));
+  }
+  if (rank_out) *rank_out = r;
+  if (world_out) *world_out = w;
   return VBMC_OK;
 }
 

@@ -75,7 +75,7 @@ struct GljHost {
 // host scratch of one fused evaluation, kept in the context so that the hot call allocates nothing
 struct ElboScratch {
   GljHost glj;
-  std::vector<double> dG, dH, dF, mu, sg, lm, wg, ext, ln_sigma, ln_lambd, dL, wpen, jw;
+  std::vector<double> dG, dH, dF, dFb, mu, sg, lm, wg, ext, ln_sigma, ln_lambd, dL, wpen, jw;
 };
 
 struct vbmc_ctx {
@@ -131,6 +131,10 @@ struct vbmc_ctx {
   int opt_entmc_valu = 0;   // 1: always the generic entropy kernel
   int opt_elbo_pregen = 1;  // Philox draws generated ahead of the entropy kernel
   int opt_elbo_ahead = 1;   // ... and those of seed+1 speculatively behind the finish kernel
+  // exp(eta) and its sum, shared by the three softmax Jacobians of an evaluation
+  std::vector<double> exp_eta;
+  double exp_eta_sum = 0.0;
+  bool exp_eta_valid = false;
   int last_plan[4] = {-1, 0, 0, 0};  // see vbmc_last_entmc_plan
 
   GpState gp;
@@ -268,13 +272,13 @@ int launch_sq_dist(vbmc_ctx* ctx, const double* d_a, int64_t n, const double* d_
 // host finalisation of the GP expected log joint (api_gp.hip)
 void glj_finalize(const vbmc_ctx* ctx, const double* res, int want_grad, GljHost& o);
 // packs dG for one sample (or the average) into out; returns its length
-int glj_pack(const vbmc_ctx* ctx, const double* mu, const double* sg, const double* lm,
+int glj_pack(vbmc_ctx* ctx, const double* mu, const double* sg, const double* lm,
              const double* wg, int grad_flags, int jacobian_flag, double* out);
 // comm
 int comm_allreduce_sum(vbmc_ctx* ctx, double* d_buf, int n);
 
 // host finalisation (api_entropy.hip) -------------------------------------
-void softmax_jacobian_apply(const std::vector<double>& eta, const double* g, double* out);
-int entropy_pack(const vbmc_ctx* ctx, double H, const double* mu, const double* sg,
+void softmax_jacobian_apply(vbmc_ctx* ctx, const double* g, double* out);  // J_w(ctx->eta) @ g
+int entropy_pack(vbmc_ctx* ctx, double H, const double* mu, const double* sg,
                  const double* lm, const double* wg, int grad_flags, int jacobian_flag,
                  double* H_out, double* dH_out);

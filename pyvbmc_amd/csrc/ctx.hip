@@ -57,6 +57,7 @@ static void options_from_env(vbmc_ctx* c) {
   c->opt_elbo_pregen = !(e && e[0] == '0');
   e = getenv("VBMC_ELBO_AHEAD");
   c->opt_elbo_ahead = !(e && e[0] == '0');
+
 }
 
 extern "C" {
@@ -139,6 +140,7 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
+
   for (int i = 0; i < 10; ++i)
     if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -175,6 +177,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   if (!strcmp(key, "entmc_kernel")) ctx->opt_entmc_valu = value == 1;
   else if (!strcmp(key, "elbo_pregen")) ctx->opt_elbo_pregen = value != 0;
   else if (!strcmp(key, "elbo_ahead")) ctx->opt_elbo_ahead = value != 0;
+
   else return vbmc_fail(ctx, VBMC_E_ARG, "vbmc_set_option: unknown key '%s'", key);
   return VBMC_OK;
 }
@@ -332,6 +335,7 @@ int set_mixture_host(vbmc_ctx* ctx, int D, int K, const double* mu_KxD, const do
       memcmp(ctx->lambd.data(), lambd_D, sizeof(double) * D) == 0 &&
       memcmp(ctx->w.data(), w_K, sizeof(double) * K) == 0) {
     if (eta_K) ctx->eta.assign(eta_K, eta_K + K);
+    ctx->exp_eta_valid = false;
     return 0;
   }
   ctx->pack_valid = false;
@@ -345,6 +349,7 @@ int set_mixture_host(vbmc_ctx* ctx, int D, int K, const double* mu_KxD, const do
     ctx->eta.assign(eta_K, eta_K + K);
   else
     ctx->eta.assign((size_t)K, 0.0);
+  ctx->exp_eta_valid = false;
   for (int k = 0; k < K; ++k)
     if (!(ctx->sigma[k] > 0.0) || !std::isfinite(ctx->sigma[k]))
       return vbmc_fail(ctx, VBMC_E_NONFINITE, "set_mixture: sigma[%d]=%g must be finite and > 0", k,

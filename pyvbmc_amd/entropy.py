@@ -19,6 +19,7 @@ stream-identical, and removes the host RNG + PCIe cost.
 ``pyvbmc`` ``VariationalPosterior`` included): see pyvbmc_amd/_duck.py.
 """
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -31,7 +32,7 @@ DEFAULT_RNG = os.environ.get("VBMC_HIP_RNG", "numpy")
 
 def _even_ns(Ns):
     """The reference rounds Ns up to even (entmc_vbmc.py:61)."""
-    return int(np.ceil(Ns / 2)) * 2
+    return math.ceil(Ns / 2) * 2
 
 
 def draw_eps_half(K, D, Ns):

@@ -116,10 +116,10 @@ def _gp_fingerprint(gp):
     held = [ps, X]
     for p in ps:
         a, h, L = p.alpha, p.hyp, p.L
-        key += (id(p), id(a), id(L), id(h), a.item(0), a.item(-1), h.item(0), h.item(-1),
-                L.item(0), L.item(-1), bool(p.L_chol))
+        key += (id(p), id(a), id(L), id(h), a.item(0), a.item(-1), h.item(0), h.item(-1), L.item(-1),
+                p.L_chol)
         held += (p, a, L, h)
-    return tuple(key), held
+    return key, held
 
 
 def invalidate_gp(ctx=None):

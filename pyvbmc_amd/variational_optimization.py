@@ -13,6 +13,7 @@ kernel, entropy kernels, optional all-reduce, bound losses) with a single
 device round trip.
 """
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -136,7 +137,7 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
     or the 11-tuple when ``separate_K``.  Keyword-only extras select the source of
     the Monte-Carlo draws (see pyvbmc_amd.entropy).
     """
-    if not np.isfinite(beta):
+    if not math.isfinite(beta):
         beta = 0
     if compute_var is None:
         compute_var = beta != 0
@@ -192,7 +193,7 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
         ctx.check(rc)
     # mirror the reference's side effects on vp and on the caller's theta
     store_mixture(vp, fc.mu, fc.sg, fc.lm, fc.w, fc.eta if vp.optimize_weights else None)
-    if vp.optimize_weights and isinstance(theta, np.ndarray) and theta.dtype == np.float64:
+    if vp.optimize_weights and type(theta) is np.ndarray and theta.dtype == fc.th.dtype:
         theta[-K:] = fc.th[-K:]
     return fc.F.value, (fc.dF.copy() if compute_grad else None), fc.G.value, fc.H.value, 0
 

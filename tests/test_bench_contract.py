@@ -25,6 +25,8 @@ def test_bench_prints_one_contract_line():
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert "D=10" in d["metric"] and "K=50" in d["metric"] and "workload" in d["config"]
     assert d["value"] > 0 and abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]  # Ns_job = 1e6
+    assert d["timed_steps"] % 8 == 0 and d["timed_region_s"] >= 0.4 and d["comm_world"] == 1
+    assert 0 < d["roofline_e2e"]["frac"] < d["roofline"]["frac"] and d["roofline"]["traffic_from"]["file"]
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
