@@ -106,7 +106,13 @@ struct vbmc_ctx {
     int K = 0, D = 0, buf = 0;
     int64_t rows = 0, n_half = 0, row_begin = 0;
   } ahead;
-  hipEvent_t ev_done = nullptr;  // end of an evaluation's own launches (the host waits for this, not for the ahead generation)
+  // completion word of the fused objective: the finish kernel's last result wave stores the
+  // evaluation's sequence number into pinned host memory and the host polls it -- the spare
+  // workgroups of the same launch go on generating the next evaluation's draws meanwhile
+  uint64_t* h_done = nullptr;   // pinned, device-visible
+  uint64_t* hd_done = nullptr;  // its device-side address
+  int* d_done_cnt = nullptr;    // result waves finished so far (reset by the last one)
+  uint64_t done_seq = 0;
 
   // resident antithetic half draws: [K][eps_rows][D]
   double* d_eps = nullptr;
@@ -187,6 +193,13 @@ static inline int raw_len(int D, int K) { return 1 + D * K + 2 * K + D; }
 // A slice of the draw buffer eps[K][rows][D] for other kernels' spare workgroups to fill: the
 // (row, pair) items [item_begin, item_begin + item_count) of the K * rows * ceil(D/2) items, 256 per
 // workgroup.  The values depend on (seed, row, pair) only, so any kernel may generate any slice.
+// completion signalling of entmc_finish_kernel (all null/0: none)
+struct DoneSignal {
+  int* cnt = nullptr;        // device counter of finished result waves
+  uint64_t* flag = nullptr;  // device-visible pinned word that receives `seq` when all are done
+  uint64_t seq = 0;
+};
+
 struct GenSlice {
   double* eps = nullptr;
   int K = 0, D = 0;
@@ -236,12 +249,13 @@ int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
                int64_t row_count, int want_grad, EntPlan& p);
 void entmc_fill_prep(const vbmc_ctx* ctx, const EntPlan& p, PrepArgs& a);
 int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& a);
-// after the finish launch: queue the generation of seed+1's draws into the other buffer (no-op
-// unless this evaluation read pre-generated Philox draws and the "elbo_ahead" option is on)
-int entmc_launch_ahead(vbmc_ctx* ctx, const EntPlan& p);
+
 int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p);
 // `gen`: optional slice of draws for spare workgroups of the finish launch to generate
-int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out, const GenSlice* gen = nullptr);
+int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out, const GenSlice* gen = nullptr,
+                        const DoneSignal* done = nullptr);
+// the slice of seed+1's draws the finish launch's spare workgroups should generate (n_blocks == 0: none)
+GenSlice entmc_ahead_slice(vbmc_ctx* ctx, const EntPlan& p);
 void glj_fill_prep(const vbmc_ctx* ctx, int want_grad, double* res, double* Z, PrepArgs& a);
 
 // kernels' host launchers (one per .hip file) -------------------------------

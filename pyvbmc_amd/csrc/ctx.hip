@@ -104,7 +104,13 @@ int vbmc_ctx_create(int device_id, vbmc_ctx** out) {
   if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_id);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   for (int i = 0; i < 10 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_done, 64, hipHostMallocDefault);
+  if (e == hipSuccess) {
+    ctx->h_done[0] = 0;
+    e = hipHostGetDevicePointer((void**)&ctx->hd_done, ctx->h_done, 0);
+  }
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_done_cnt, 64);
+  if (e == hipSuccess) e = hipMemset(ctx->d_done_cnt, 0, 64);
   if (e != hipSuccess) {
     int rc = vbmc_fail(nullptr, VBMC_E_HIP, "context setup failed: %s", hipGetErrorString(e));
     delete ctx;
@@ -137,7 +143,8 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
     if (b) (void)hipFree(b);
   for (double* b : ctx->d_epsgen)
     if (b) (void)hipFree(b);
-  if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
+  if (ctx->h_done) (void)hipHostFree(ctx->h_done);
+  if (ctx->d_done_cnt) (void)hipFree(ctx->d_done_cnt);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
 

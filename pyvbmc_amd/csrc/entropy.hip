@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
                                                            const double* __restrict__ mix,
                                                            MixLayout ml, double inv_ns,
                                                            int want_grad, int mu_from_w,
-                                                           double* __restrict__ raw, GenSlice gen) {
+                                                           double* __restrict__ raw, GenSlice gen,
+                                                           DoneSignal done) {
   const int D = ml.D, K = ml.K;
   {
     // spare workgroups after the reduction's own: a slice of the next draws (Adam loop)
@@ -257,7 +258,24 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
       v = -inv_ns * (sl + s);
     }
   }
-  if (lane == 0) raw[t] = v;
+  if (lane == 0) {
+    if (!done.flag) {
+      raw[t] = v;
+    } else {
+      // `raw` is pinned host memory and the host polls `done.flag` instead of waiting for the
+      // stream.  No fence: a system-scope release would write back every dirty L2 line (tens of MB
+      // when the draw generation runs next to this kernel).  Instead the result goes out as a
+      // write-through (sc0 sc1) store, the wave waits until it has been acknowledged, and only
+      // then counts itself; the last wave to count publishes the sequence number the same way
+      // (MI355X_MICROARCH.md, hand-off with a drained sc1 payload and flag).
+      __hip_atomic_store(raw + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      if (__hip_atomic_fetch_add(done.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n - 1) {
+        __hip_atomic_store(done.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -510,17 +528,17 @@ int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& pa) {
   return 0;
 }
 
-int entmc_launch_ahead(vbmc_ctx* ctx, const EntPlan& p) {
+GenSlice entmc_ahead_slice(vbmc_ctx* ctx, const EntPlan& p) {
   const EntArgs& a = p.a;
-  if (!ctx->opt_elbo_ahead || a.eps == nullptr || a.eps != ctx->d_epsgen[ctx->gen_cur]) return 0;
+  GenSlice none;
+  if (!ctx->opt_elbo_ahead || a.eps == nullptr || a.eps != ctx->d_epsgen[ctx->gen_cur]) return none;
   const int D = ctx->D, K = ctx->K, other = 1 - ctx->gen_cur;
   const size_t n_eps = (size_t)K * (size_t)a.row_count * D;
   if (ctx->d_epsgen_cap[other] < n_eps || !ctx->d_epsgen[other]) {
     // first use only.  ensure_dev would wait for the stream when growing an existing buffer, and
     // that wait must not sit between this evaluation's launches and its result: allocate fresh
-    if (ctx->d_epsgen[other]) return 0;  // too small: leave it; the next evaluation re-plans
-    int rc = ensure_dev(ctx, &ctx->d_epsgen[other], &ctx->d_epsgen_cap[other], n_eps);
-    if (rc) return rc;
+    if (ctx->d_epsgen[other]) return none;  // too small: leave it; the next evaluation re-plans
+    if (ensure_dev(ctx, &ctx->d_epsgen[other], &ctx->d_epsgen_cap[other], n_eps)) return none;
   }
   vbmc_ctx::AheadDraws& ah = ctx->ahead;
   ah.seed = a.seed + 1;
@@ -530,11 +548,8 @@ int entmc_launch_ahead(vbmc_ctx* ctx, const EntPlan& p) {
   ah.n_half = a.n_half;
   ah.row_begin = a.row_begin;
   ah.buf = other;
-  const GenSlice g = make_gen_slice(ctx->d_epsgen[other], K, D, a.row_count, a.n_half, a.row_begin, ah.seed, nullptr, 0.0, 1.0);
-  int rc = launch_eps_gen(ctx, ctx->stream, g);
-  if (rc) return rc;
-  ah.valid = true;
-  return 0;
+  ah.valid = true;  // the caller launches the slice right away
+  return make_gen_slice(ctx->d_epsgen[other], K, D, a.row_count, a.n_half, a.row_begin, ah.seed, nullptr, 0.0, 1.0);
 }
 
 int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p) {
@@ -609,12 +624,14 @@ int launch_eps_gen(vbmc_ctx* ctx, hipStream_t st, const GenSlice& g) {
   return 0;
 }
 
-int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out, const GenSlice* gen) {
+int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out, const GenSlice* gen,
+                        const DoneSignal* done) {
   const int n_out = raw_len(ctx->D, ctx->K);
   const GenSlice g = gen ? *gen : GenSlice();
+  const DoneSignal ds = done ? *done : DoneSignal();
   hipLaunchKernelGGL(entmc_finish_kernel, dim3((n_out + 3) / 4 + g.n_blocks), dim3(256), 0, ctx->stream,
                      p.a.partial, p.a.chunks, p.a.stride, ctx->d_mix, ctx->ml, p.inv_ns,
-                     p.a.want_grad, p.ws ? 1 : 0, raw_out, g);
+                     p.a.want_grad, p.ws ? 1 : 0, raw_out, g, ds);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
