@@ -263,15 +263,10 @@ def main():
     kern_ms = []
     host_us = np.zeros(5)
     n_host = 0
-    # (only the wave-split kernel carries its events on the dispatch; the other entropy kernels are
-    # bracketed by event records, ~6 us each in the queue: there the timing is switched on for the
-    # sampled steps only)
-    on_dispatch = ctx.last_entmc_plan()["kernel"] == "ws"
-    ctx.set_timing(on_dispatch)
     t0 = time.perf_counter()
     for i in range(n_timed):
-        if not on_dispatch and i % SAMPLE_EVERY <= 1:
-            ctx.set_timing(i % SAMPLE_EVERY == 0)
+        if i % SAMPLE_EVERY <= 1:
+            ctx.set_timing(i % SAMPLE_EVERY == 0)  # on for the sampled step, off again after it
         out = step()
         if i % SAMPLE_EVERY == 0:
             kern_ms.append(ctx.last_kernel_ms(0))

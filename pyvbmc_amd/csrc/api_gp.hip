@@ -22,13 +22,25 @@ extern "C" int vbmc_set_gp(vbmc_ctx* ctx, int N, int D, int S, int P, int mean_k
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, stream_wait(ctx));
   GpState& g = ctx->gp;
-  double** bufs[] = {&g.d_X, &g.d_alpha, &g.d_L, &g.d_Linv, &g.d_sW, &g.d_hyp, &g.d_xc, &g.d_smeta};
-  for (double** b : bufs)
-    if (*b) {
-      HIP_TRY(ctx, hipFree(*b));
-      *b = nullptr;
-    }
   g.set = false;
+  // device buffers are kept across GP updates and only grown (active sampling updates the GP after
+  // every new point: N creeps up by one)
+  const size_t nn = (size_t)N * N;
+  auto grow = [&](double** p, size_t* cap, size_t n) -> int {
+    if (*p && *cap >= n) return 0;
+    if (*p) HIP_TRY(ctx, hipFree(*p));
+    *p = nullptr;
+    const size_t want = n + n / 8 + 64;
+    HIP_TRY(ctx, hipMalloc((void**)p, sizeof(double) * want));
+    *cap = want;
+    return 0;
+  };
+  int rc;
+  if ((rc = grow(&g.d_X, &g.cap_X, (size_t)N * D)) || (rc = grow(&g.d_alpha, &g.cap_alpha, (size_t)S * N)) ||
+      (rc = grow(&g.d_L, &g.cap_L, (size_t)S * nn)) || (rc = grow(&g.d_Linv, &g.cap_Linv, (size_t)S * nn)) ||
+      (rc = grow(&g.d_sW, &g.cap_sW, (size_t)S * N)) || (rc = grow(&g.d_hyp, &g.cap_hyp, (size_t)S * P)) ||
+      (rc = grow(&g.d_xc, &g.cap_xc, (size_t)D)) || (rc = grow(&g.d_smeta, &g.cap_smeta, (size_t)3 * S)))
+    return rc;
   g.N = N; g.D = D; g.S = S; g.P = P; g.mean_kind = mean_kind;
   g.hyp.assign(hyp_SxP, hyp_SxP + (size_t)S * P);
   g.L_chol.assign(L_chol_S, L_chol_S + S);
@@ -39,36 +51,30 @@ extern "C" int vbmc_set_gp(vbmc_ctx* ctx, int N, int D, int S, int P, int mean_k
     g.sn2_eff[s] = 1.0 / (sw0 * sw0);  // variational_optimization.py:1398
     g.sn2_mult[s] = sn2_mult_S ? sn2_mult_S[s] : 1.0;
   }
-  const size_t nn = (size_t)N * N;
-  HIP_TRY(ctx, hipMalloc((void**)&g.d_X, sizeof(double) * N * D));
-  HIP_TRY(ctx, hipMalloc((void**)&g.d_alpha, sizeof(double) * S * N));
-  HIP_TRY(ctx, hipMalloc((void**)&g.d_L, sizeof(double) * S * nn));
-  HIP_TRY(ctx, hipMalloc((void**)&g.d_Linv, sizeof(double) * S * nn));
-  HIP_TRY(ctx, hipMalloc((void**)&g.d_sW, sizeof(double) * S * N));
-  HIP_TRY(ctx, hipMalloc((void**)&g.d_hyp, sizeof(double) * S * P));
-  HIP_TRY(ctx, hipMemcpyAsync(g.d_X, X_NxD, sizeof(double) * N * D, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(g.d_alpha, alpha_SxN, sizeof(double) * S * N, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(g.d_L, L_SxNxN, sizeof(double) * S * nn, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(g.d_sW, sW_SxN, sizeof(double) * S * N, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(g.d_hyp, hyp_SxP, sizeof(double) * S * P, hipMemcpyHostToDevice, ctx->stream));
   // centre of the |a|^2 + |b|^2 - 2 a.b expansion in predict (cf. _sq_dist's mean shift,
   // acquisition_functions/abstract_acq_fcn.py:212-217)
-  std::vector<double> xc(D, 0.0);
+  g.h_small.assign((size_t)D + 3 * (size_t)S, 0.0);
+  double* xc = g.h_small.data();
   for (int n = 0; n < N; ++n)
     for (int d = 0; d < D; ++d) xc[d] += X_NxD[(size_t)n * D + d];
   for (int d = 0; d < D; ++d) xc[d] /= N;
-  HIP_TRY(ctx, hipMalloc((void**)&g.d_xc, sizeof(double) * D));
-  HIP_TRY(ctx, hipMemcpy(g.d_xc, xc.data(), sizeof(double) * D, hipMemcpyHostToDevice));
-  std::vector<double> smeta(3 * (size_t)S);
+  double* smeta = xc + D;
   for (int s = 0; s < S; ++s) {
     smeta[3 * s] = g.L_chol[s] ? 1.0 : 0.0;
     smeta[3 * s + 1] = g.sn2_mult[s];
     smeta[3 * s + 2] = 1.0 / g.sn2_eff[s];
   }
-  HIP_TRY(ctx, hipMalloc((void**)&g.d_smeta, sizeof(double) * 3 * S));
-  HIP_TRY(ctx, hipMemcpy(g.d_smeta, smeta.data(), sizeof(double) * 3 * S, hipMemcpyHostToDevice));
+  // (the caller's arrays are pageable: these copies return once the source has been staged, and
+  // everything queued here is waited for below before the caller's memory can change)
+  HIP_TRY(ctx, hipMemcpyAsync(g.d_smeta, smeta, sizeof(double) * 3 * S, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(g.d_L, L_SxNxN, sizeof(double) * S * nn, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(g.d_X, X_NxD, sizeof(double) * N * D, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(g.d_alpha, alpha_SxN, sizeof(double) * S * N, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(g.d_sW, sW_SxN, sizeof(double) * S * N, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(g.d_hyp, hyp_SxP, sizeof(double) * S * P, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(g.d_xc, xc, sizeof(double) * D, hipMemcpyHostToDevice, ctx->stream));
   // L^-1 of the Cholesky samples, once per GP update
-  int rc = launch_trinv(ctx);
+  rc = launch_trinv(ctx);
   if (rc) return rc;
   HIP_TRY(ctx, stream_wait(ctx));
   g.set = true;

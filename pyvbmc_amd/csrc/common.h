@@ -60,6 +60,8 @@ struct GpState {
   double* d_hyp = nullptr;    // S x P
   double* d_xc = nullptr;     // D : column means of X (centre of the pairwise-distance expansion)
   double* d_smeta = nullptr;  // S x 3 : (L_chol as 0/1, sn2_mult, 1/sn2_eff) per sample, for kernels batched over s
+  size_t cap_X = 0, cap_alpha = 0, cap_L = 0, cap_Linv = 0, cap_sW = 0, cap_hyp = 0, cap_xc = 0, cap_smeta = 0;
+  std::vector<double> h_small;  // host source of the xc / smeta uploads
 };
 
 // per-sample results of the GP expected log joint on the host (api_gp.hip glj_finalize)

@@ -216,9 +216,10 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
   const int n = 1 + D * K + 2 * K + D;
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (t >= n) return;
+  if (t >= n && !done.flag) return;  // (with a completion word every wave of the block meets at the barrier below)
   double v = 0.0;
-  if (t == 0) {
+  if (t >= n) {
+  } else if (t == 0) {
     for (int i = lane; i < K * chunks; i += 64) v -= w[i / chunks] * partial[(int64_t)i * stride];
     v = wave_sum(v) * inv_ns;
   } else if (want_grad) {
@@ -258,22 +259,27 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
       v = -inv_ns * (sl + s);
     }
   }
-  if (lane == 0) {
-    if (!done.flag) {
-      raw[t] = v;
-    } else {
-      // `raw` is pinned host memory and the host polls `done.flag` instead of waiting for the
-      // stream.  No fence: a system-scope release would write back every dirty L2 line (tens of MB
-      // when the draw generation runs next to this kernel).  Instead the result goes out as a
-      // write-through (sc0 sc1) store, the wave waits until it has been acknowledged, and only
-      // then counts itself; the last wave to count publishes the sequence number the same way
-      // (MI355X_MICROARCH.md, hand-off with a drained sc1 payload and flag).
-      __hip_atomic_store(raw + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-      if (__hip_atomic_fetch_add(done.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n - 1) {
-        __hip_atomic_store(done.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
+  if (!done.flag) {
+    if (lane == 0) raw[t] = v;
+    return;
+  }
+  // `raw` is pinned host memory and the host polls `done.flag` instead of waiting for the stream.
+  // No fence: a system-scope release would write back every dirty L2 line.  Instead each result
+  // goes out as a write-through (sc0 sc1) store and its wave waits until the store has been
+  // acknowledged; then the workgroup meets at a barrier and counts itself with ONE atomic (611
+  // increments of a single word would take ~7 us: a word saturates at ~88 atomics per us), and the
+  // last workgroup to count publishes the sequence number the same way (MI355X_MICROARCH.md,
+  // hand-off with a drained sc1 payload and flag).
+  if (lane == 0 && t < n) {
+    __hip_atomic_store(raw + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int n_main = (n + 3) / 4;
+    if (__hip_atomic_fetch_add(done.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_main - 1) {
+      __hip_atomic_store(done.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }

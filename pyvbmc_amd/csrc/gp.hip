@@ -22,8 +22,144 @@ __device__ inline double wave_sum(double v) {
   return fm::wave_sum_dpp(v);
 }
 
-// Inverse of an upper-triangular matrix, one thread per column (back substitution);
-// run once per vbmc_set_gp.
+// ---------------------------------------------------------------------------
+// Inverse of the upper-triangular Cholesky factor, once per vbmc_set_gp (it stands in for the
+// reference's pairs of triangular solves, variational_optimization.py:1489-1501).  Blocked, 64 x 64
+// blocks, U padded with the identity up to a multiple of 64:
+//   1. trinv_diag_kernel: every diagonal block is inverted in LDS by back substitution, one
+//      thread per column (64^2/2 multiply-adds each);
+//   2. trinv_strip_kernel: X = U^-1 solves U X = I one strip of 16 columns at a time; a workgroup
+//      owns a strip of block column j and walks the block rows i = j .. 0,
+//          X_i = Dinv_i (E_i - sum_{m = i+1..j} U_im X_m),
+//      the sum and the product with the inverted diagonal block on the FP64 matrix cores
+//      (v_mfma_f64_16x16x4_f64: wave w owns rows 16 w .. 16 w + 15 of the block row), the strip
+//      of X in LDS.  ceil(N/16) workgroups per GP sample: 25 at N = 400.
+// N <= 1088 (the strip must fit the 160 KB of LDS); larger N keep the one-thread-per-column kernel.
+constexpr int TRB = 64, TRS = 16;
+
+__global__ __launch_bounds__(64) void trinv_diag_kernel(const double* __restrict__ L, int N,
+                                                        const double* __restrict__ smeta,
+                                                        double* __restrict__ Dinv, int nb) {
+  const int s = blockIdx.y, b = blockIdx.x, c = threadIdx.x;
+  if (smeta[3 * s] == 0.0) return;  // not a Cholesky sample: nothing to invert
+  __shared__ double sUT[TRB][TRB];  // sUT[r][m] = u_mr: the column above the diagonal element r, contiguous
+  __shared__ double sRinv[TRB];     // 1 / u_rr
+  const double* A = L + (size_t)s * N * N;
+  const int r0 = b * TRB;
+  {
+    // all 64 row loads in flight at once (clamped addresses, the padding is patched in afterwards)
+    double u[TRB];
+    const int gc = r0 + c, gcc = min(gc, N - 1);
+#pragma unroll
+    for (int r = 0; r < TRB; ++r) u[r] = A[(size_t)min(r0 + r, N - 1) * N + gcc];
+#pragma unroll
+    for (int r = 0; r < TRB; ++r) {
+      const int gr = r0 + r;
+      const double v = (gr < N && gc < N) ? (gc >= gr ? u[r] : 0.0) : (gr == gc ? 1.0 : 0.0);
+      sUT[c][r] = v;  // element (r, c) of the block
+      if (r == c) sRinv[c] = 1.0 / v;
+    }
+  }
+  __syncthreads();
+  // Column c of the inverse by back substitution, column-oriented so that the multiply-adds of a
+  // step are independent of each other: with s_m = delta_mc to start,
+  //   for r = 63 .. 0:   x_r = s_r / u_rr;   s_m -= u_mr x_r  for all m < r.
+  // Everything is unrolled and lives in registers (x_r = 0 for r > c comes out by itself); the
+  // u_mr of a step are contiguous broadcast LDS reads that do not depend on the arithmetic.
+  double x[TRB];
+#pragma unroll
+  for (int m = 0; m < TRB; ++m) x[m] = (m == c) ? 1.0 : 0.0;
+#pragma unroll
+  for (int r = TRB - 1; r >= 0; --r) {
+    const double xr = x[r] * sRinv[r];
+    x[r] = xr;
+#pragma unroll
+    for (int m = 0; m < r; ++m) x[m] = fma(-sUT[r][m], xr, x[m]);
+  }
+  double* out = Dinv + ((size_t)s * nb + b) * TRB * TRB;
+#pragma unroll
+  for (int r = 0; r < TRB; ++r) out[r * TRB + c] = x[r];
+}
+
+__global__ __launch_bounds__(256) void trinv_strip_kernel(const double* __restrict__ L, int N,
+                                                          const double* __restrict__ smeta,
+                                                          const double* __restrict__ Dinv, int nb,
+                                                          double* __restrict__ Li) {
+  const int s = blockIdx.y;
+  if (smeta[3 * s] == 0.0) return;
+  extern __shared__ double lds[];
+  const int c0 = blockIdx.x * TRS, j = c0 / TRB;
+  double* sX = lds;                          // [(j+1)*64][16]: the strip of X, rows of block rows 0..j
+  double* sR = lds + (size_t)(j + 1) * TRB * TRS;  // [64][16]: right-hand side of the current block row
+  const double* A = L + (size_t)s * N * N;
+  double* B = Li + (size_t)s * N * N;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  // rows below block row j of this strip are zero
+  for (int idx = tid; idx < (N - min(N, (j + 1) * TRB)) * TRS; idx += 256) {
+    const int r = (j + 1) * TRB + idx / TRS, c = c0 + idx % TRS;
+    if (c < N) B[(size_t)r * N + c] = 0.0;
+  }
+  for (int i = j; i >= 0; --i) {
+    const int rw = i * TRB + wave * 16;  // first global row of this wave's 16 rows
+    // ---- R = E_i - sum_{m>i} U_im X_m on this wave's 16 rows ----
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    const int k_begin = (i + 1) * TRB, k_end = (j + 1) * TRB;  // contraction over rows of X already known
+    const int ar = rw + li;                                    // row of U this lane feeds
+    const bool ar_ok = ar < N;
+    const double* Arow = A + (size_t)ar * N;
+    // 16 columns of U per round.  The contraction order inside a round is free, so lane group lk
+    // takes the four CONSECUTIVE columns k0 + 4 lk + q (q = step): one 32-byte load per lane and
+    // 128 contiguous bytes per matrix row, instead of four 8-byte loads 32 bytes apart.  The next
+    // round's columns are requested before the matrix instructions of the current one.
+    auto loadA = [&](int k0, double (&a)[4]) {
+      const int kc = k0 + 4 * lk;
+      if (ar_ok && kc + 3 < N) {
+        const double2 lo = *(const double2*)(Arow + kc), hi = *(const double2*)(Arow + kc + 2);
+        a[0] = lo.x; a[1] = lo.y; a[2] = hi.x; a[3] = hi.y;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = (ar_ok && kc + q < N) ? Arow[kc + q] : 0.0;  // (padding of U: off-diagonal 0)
+      }
+    };
+    double a_cur[4], a_nxt[4];
+    if (k_begin < k_end) loadA(k_begin, a_cur);
+    for (int k0 = k_begin; k0 < k_end; k0 += 16) {
+      if (k0 + 16 < k_end) loadA(k0 + 16, a_nxt);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double bq = sX[(size_t)(k0 + 4 * lk + q) * TRS + li];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[q], bq, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 16 + lk + 4 * r;                   // row within block row i
+      const double e = (i * TRB + row == c0 + li) ? 1.0 : 0.0;  // E: identity columns of this strip
+      sR[row * TRS + li] = e - acc[r];
+    }
+    __syncthreads();
+    // ---- X_i = Dinv_i R (Dinv_i upper triangular: k >= 16 wave) ----
+    double4_t x = {0.0, 0.0, 0.0, 0.0};
+    const double* Di = Dinv + ((size_t)s * nb + i) * TRB * TRB + (size_t)(wave * 16 + li) * TRB;
+    for (int k0 = wave * 16; k0 < TRB; k0 += 4) {
+      const double av = Di[k0 + lk];
+      const double bv = sR[(k0 + lk) * TRS + li];
+      x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i * TRB + wave * 16 + lk + 4 * r, c = c0 + li;
+      sX[(size_t)row * TRS + li] = x[r];
+      if (row < N && c < N) B[(size_t)row * N + c] = x[r];
+    }
+    __syncthreads();
+  }
+}
+
+// Fallback for N beyond the strip kernel's LDS: one thread per column (back substitution).
 __global__ void trinv_upper_kernel(const double* __restrict__ L, int N, double* __restrict__ Li) {
   const int s = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -618,8 +754,28 @@ int launch_gp_var(vbmc_ctx* ctx, const double* d_Z, double* d_V, double* d_Q) {
 
 int launch_trinv(vbmc_ctx* ctx) {
   GpState& g = ctx->gp;
-  hipLaunchKernelGGL(trinv_upper_kernel, dim3((g.N + 63) / 64, g.S), dim3(64), 0, ctx->stream,
-                     g.d_L, g.N, g.d_Linv);
+  const int N = g.N, S = g.S;
+  const int nb = (N + TRB - 1) / TRB;
+  const size_t lds = sizeof(double) * ((size_t)nb * TRB * TRS + TRB * TRS);
+  if (lds > 156 * 1024) {  // N > 1088
+    hipLaunchKernelGGL(trinv_upper_kernel, dim3((N + 63) / 64, S), dim3(64), 0, ctx->stream, g.d_L, N, g.d_Linv);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+  }
+  int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, (size_t)S * nb * TRB * TRB);
+  if (rc) return rc;
+  double* Dinv = ctx->d_scratch;
+  hipLaunchKernelGGL(trinv_diag_kernel, dim3(nb, S), dim3(64), 0, ctx->stream, (const double*)g.d_L, N,
+                     (const double*)g.d_smeta, Dinv, nb);
+  static size_t lds_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (lds > 48 * 1024 && lds > lds_set[dev & 63]) {
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)trinv_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set[dev & 63] = lds;
+  }
+  hipLaunchKernelGGL(trinv_strip_kernel, dim3((N + TRS - 1) / TRS, S), dim3(256), lds, ctx->stream,
+                     (const double*)g.d_L, N, (const double*)g.d_smeta, (const double*)Dinv, nb, g.d_Linv);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }

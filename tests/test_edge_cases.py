@@ -92,6 +92,26 @@ def test_entropy_far_apart_components(ctx):
     assert np.all(np.isfinite(dH)) and rel_err(dH, dHo) < 1e-7
 
 
+@pytest.mark.parametrize("N", [17, 130, 200, 448, 800, 1100])
+def test_blocked_triangular_inverse(ctx, N):
+    """vbmc_set_gp forms L^-1 with the blocked kernels (64 x 64 diagonal blocks inverted in LDS,
+    16-column strips by back substitution on the FP64 matrix cores; N = 1100 takes the
+    one-thread-per-column fallback): the predictive variance -- which is sf^2 - |L^-T k*|^2 -- against
+    the oracle's triangular solves, for N on and off the block boundaries, S = 2."""
+    wl, wd = case(3, 5, N, 40, S=2)
+    _, gp = objects(wd, ctx)
+    ogp = oracle_gp(wd)
+    rng = np.random.default_rng(N)
+    xs = np.vstack([rng.standard_normal((60, 3)), wl.X[: min(N, 10)] + 1e-3 * rng.standard_normal((min(N, 10), 3))])
+    fmu, fs2 = gp.predict(xs, separate_samples=True)
+    omu, os2 = gp_ref.predict(ogp, xs, separate_samples=True)
+    sf2 = float(np.exp(2 * wl.hyp[0, 3]))
+    err = float(np.max(np.abs(fs2 - os2)))
+    print(f"N={N}: max |fs2 - oracle| = {err:.2e} (sf2 = {sf2:.3g})")
+    assert np.max(np.abs(fmu - omu)) <= 1e-10 * max(1.0, np.max(np.abs(omu)))
+    assert err <= 1e-10 * max(1.0, sf2)
+
+
 @pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 129])
 def test_gp_sizes_around_the_tiles(ctx, N):
     """_gp_log_joint (+variance), predict and the fused objective for N around the 64-wide
