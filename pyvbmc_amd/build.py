@@ -44,6 +44,7 @@ FLAGS = [
 
 WS_DPS = [2, 4, 6, 8, 10, 12, 16, 20, 24, 32]  # must match VBMC_WS_DPS in entropy_args.h
 WS_EXTRA = os.environ.get("VBMC_WS_EXTRA_FLAGS", "").split()  # experiments on the entropy kernel only
+ALL_EXTRA = os.environ.get("VBMC_EXTRA_FLAGS", "").split()    # experiments: flags for every translation unit
 
 
 def _sources():
@@ -53,7 +54,7 @@ def _sources():
 def _jobs(bdir):
     """(source, object, extra flags) for every translation unit; the wave-split entropy
     kernel is compiled once per padded D so the instantiations build in parallel."""
-    jobs = [(src, bdir / (src.stem + ".o"), []) for src in _sources()]
+    jobs = [(src, bdir / (src.stem + ".o"), list(ALL_EXTRA)) for src in _sources()]
     for dp in WS_DPS:
         jobs.append((CSRC / "entropy_ws.hip", bdir / f"entropy_ws_dp{dp}.o", [f"-DVBMC_DP={dp}"] + WS_EXTRA))
     return jobs
