@@ -48,7 +48,12 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   const int D = ctx->D, K = ctx->K;
   const int mask = opts->optimize_mask;
   const bool o_mu = mask & 1, o_sg = mask & 2, o_lm = mask & 4, o_w = mask & 8;
+  // theta -> mixture -> pinned pack now; its upload is issued further down, back to back with the
+  // launches that wait for it (a copy issued here would sit finished in the queue while the
+  // planning below runs: 4 us of idle GPU per evaluation)
+  ctx->defer_mix_upload = true;
   int rc = vbmc_theta_to_mixture(ctx, theta, n_theta, mask, mu_KxD, sigma_K, lambd_D, w_K, eta_K);
+  ctx->defer_mix_upload = false;
   if (rc) return rc;
   if (o_w) {
     // the reference shifts its caller's theta tail in place (:1082-1085)
@@ -89,8 +94,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   // all-reduce and is copied back afterwards.
   rc = ensure_pinned(ctx, n_res + (size_t)n_raw);
   if (rc) return rc;
-  double* hp_dev = nullptr;  // device-side address of the pinned block
-  HIP_TRY(ctx, hipHostGetDevicePointer((void**)&hp_dev, ctx->h_pinned, 0));
+  double* hp_dev = ctx->hp_dev;  // device-side address of the pinned block
   double* res_out = hp_dev;
   double* raw_host = hp_dev + n_res;
   static const bool force_coll = [] {
@@ -118,6 +122,8 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     rc = entmc_pregen(ctx, plan, pa);  // Philox draws generated by extra blocks of the prep launch
     if (rc) return rc;
   }
+  rc = upload_packed_mixture(ctx);
+  if (rc) return rc;
   rc = launch_prep(ctx, pa);  // GP sums + (j,k) table rows, one launch
   if (rc) return rc;
   bool polled = false;

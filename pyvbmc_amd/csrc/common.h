@@ -133,12 +133,17 @@ struct vbmc_ctx {
   size_t h_pack_cap = 0;
   bool pack_in_flight = false;   // a mixture-pack upload was queued and the stream not waited for since
   bool pack_valid = false;     // d_mix holds the pack of the host copies (mu, sigma, lambd, w)
+  bool defer_mix_upload = false;  // set_mixture_host packs but leaves the copy to upload_packed_mixture
+  double* hp_dev = nullptr;    // device-side address of h_pinned (cached: the query is an API call)
   bool timing = false;         // record the HIP event pair around the dominant kernel (vbmc_set_timing)
   double host_us[5] = {0, 0, 0, 0, 0};  // see vbmc_last_host_us
   // vbmc_set_option switches (defaults from the environment at context creation)
   int opt_entmc_valu = 0;   // 1: always the generic entropy kernel
   int opt_elbo_pregen = 1;  // Philox draws generated ahead of the entropy kernel
   int opt_elbo_ahead = 1;   // ... and those of seed+1 speculatively behind the finish kernel
+  int opt_mix_kernel = 1;   // the mixture pack goes up through a copy kernel of our own instead of hipMemcpyAsync
+  double* h_pack_dev = nullptr;     // device-side address of h_pack ...
+  double* h_pack_dev_of = nullptr;  // ... valid for this h_pack
   // exp(eta) and its sum, shared by the three softmax Jacobians of an evaluation
   std::vector<double> exp_eta;
   double exp_eta_sum = 0.0;
@@ -180,6 +185,7 @@ void write_mixture_pack(const MixLayout& ml, const double* mu_KxD, const double*
                         const double* lambd, const double* w, double* p);
 int theta_to_arrays(int D, int K, const double* theta, int n_theta, int optimize_mask, double* mu,
                     double* sg, double* lm, double* w, double* eta);
+int upload_packed_mixture(vbmc_ctx* ctx);
 int set_mixture_host(vbmc_ctx* ctx, int D, int K, const double* mu_KxD, const double* sigma_K,
                      const double* lambd_D, const double* w_K, const double* eta_K, bool skip_if_same);
 

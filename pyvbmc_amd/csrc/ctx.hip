@@ -47,6 +47,7 @@ int ensure_pinned(vbmc_ctx* ctx, size_t n) {
   size_t want = n + n / 4 + 64;
   HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_pinned, want * sizeof(double), hipHostMallocDefault));
   ctx->h_pinned_cap = want;
+  HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ctx->hp_dev, ctx->h_pinned, 0));
   return 0;
 }
 
@@ -57,6 +58,8 @@ static void options_from_env(vbmc_ctx* c) {
   c->opt_elbo_pregen = !(e && e[0] == '0');
   e = getenv("VBMC_ELBO_AHEAD");
   c->opt_elbo_ahead = !(e && e[0] == '0');
+  e = getenv("VBMC_MIX_KERNEL");
+  c->opt_mix_kernel = !(e && e[0] == '0');
 
 }
 
@@ -184,6 +187,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   if (!strcmp(key, "entmc_kernel")) ctx->opt_entmc_valu = value == 1;
   else if (!strcmp(key, "elbo_pregen")) ctx->opt_elbo_pregen = value != 0;
   else if (!strcmp(key, "elbo_ahead")) ctx->opt_elbo_ahead = value != 0;
+  else if (!strcmp(key, "mix_kernel")) ctx->opt_mix_kernel = value != 0;
 
   else return vbmc_fail(ctx, VBMC_E_ARG, "vbmc_set_option: unknown key '%s'", key);
   return VBMC_OK;
@@ -294,8 +298,8 @@ int theta_to_arrays(int D, int K, const double* theta, int n_theta, int optimize
   return 0;
 }
 
-// Host-side derivation of the kernel-friendly mixture pack + upload.
-static int upload_mixture(vbmc_ctx* ctx) {
+// Host-side derivation of the kernel-friendly mixture pack (into the pinned staging buffer) ...
+static int pack_mixture(vbmc_ctx* ctx) {
   const int D = ctx->D, K = ctx->K;
   ctx->ml.plan(D, K);
   const MixLayout& ml = ctx->ml;
@@ -317,12 +321,37 @@ static int upload_mixture(vbmc_ctx* ctx) {
     HIP_TRY(ctx, stream_wait(ctx));
     ctx->pack_in_flight = false;
   }
-  double* p = ctx->h_pack;
-  write_mixture_pack(ml, ctx->mu.data(), ctx->sigma.data(), ctx->lambd.data(), ctx->w.data(), p);
-  int rc = ensure_dev(ctx, &ctx->d_mix, &ctx->d_mix_cap, (size_t)ml.total);
-  if (rc) return rc;
-  // pinned source: a true asynchronous copy (pack_in_flight guards the buffer's reuse)
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mix, p, sizeof(double) * ml.total, hipMemcpyHostToDevice,
+  write_mixture_pack(ml, ctx->mu.data(), ctx->sigma.data(), ctx->lambd.data(), ctx->w.data(), ctx->h_pack);
+  return ensure_dev(ctx, &ctx->d_mix, &ctx->d_mix_cap, (size_t)ml.total);
+}
+
+// ... and its upload: one asynchronous copy from pinned memory (pack_in_flight guards the buffer's
+// reuse).  Split from the packing so that the fused objective can issue the copy and the launches
+// that wait for it back to back, after all its planning (vbmc_neg_elcbo).
+namespace {
+// the pack upload as a kernel of our own: a kernel -> kernel dependency in one queue starts with no
+// gap, a runtime copy -> kernel dependency costs ~4 us on this stack
+__global__ void mix_upload_kernel(const double* __restrict__ src, double* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+}  // namespace
+
+int upload_packed_mixture(vbmc_ctx* ctx) {
+  if (ctx->device < 0) return 0;
+  if (ctx->opt_mix_kernel) {
+    double* src = nullptr;
+    if (ctx->h_pack_dev_of != ctx->h_pack) {
+      HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ctx->h_pack_dev, ctx->h_pack, 0));
+      ctx->h_pack_dev_of = ctx->h_pack;
+    }
+    src = ctx->h_pack_dev;
+    const int n = ctx->ml.total;
+    hipLaunchKernelGGL(mix_upload_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const double*)src,
+                       ctx->d_mix, n);
+    HIP_TRY(ctx, hipGetLastError());
+  } else
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mix, ctx->h_pack, sizeof(double) * ctx->ml.total, hipMemcpyHostToDevice,
                               ctx->stream));
   ctx->pack_in_flight = true;
   ctx->pack_valid = true;
@@ -366,7 +395,9 @@ int set_mixture_host(vbmc_ctx* ctx, int D, int K, const double* mu_KxD, const do
       return vbmc_fail(ctx, VBMC_E_NONFINITE, "set_mixture: lambd[%d]=%g must be finite and > 0", d,
                        ctx->lambd[d]);
   ctx->mix_set = true;
-  return upload_mixture(ctx);
+  int rc = pack_mixture(ctx);
+  if (rc || ctx->defer_mix_upload) return rc;
+  return upload_packed_mixture(ctx);
 }
 
 extern "C" {
