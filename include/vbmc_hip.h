@@ -322,6 +322,26 @@ int vbmc_acq_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int kind, doub
                   double tol_gp_var, const double* sn2_M, double* acq_M, double* f_bar_M,
                   double* var_tot_M);
 
+/* The importance-sampled acquisition functions for noisy targets, AcqFcnVIQR
+ * (acquisition_functions/acq_fcn_viqr.py:30-160) and AcqFcnIMIQR (acq_fcn_imiqr.py:29-177).
+ *
+ * vbmc_acq_is_set uploads, once per active-sampling round, what the reference keeps in
+ * optim_state["active_importance_sampling"] (vbmc/active_importance_sampling.py:262-306) for the
+ * GP of vbmc_set_gp (S samples, N points): the importance points Xa (Na x D, or S x Na x D with
+ * per_sample_xa -- IMIQR after MCMC), C_tmp[s] = (K+Sigma)^-1 K(X, Xa) resp. L K(X, Xa) (S x N x Na;
+ * for IMIQR, which stores K_Xa_X instead, the caller forms it the same way), the predictive
+ * variances f_s2 at Xa (Na x S as the reference stores them) and ln_weights (S x Na; NULL = VIQR's
+ * constant weights).
+ * vbmc_acq_is_eval evaluates the acquisition at M points of the transformed space: predictive
+ * variance at the points, posterior cross-covariance with Xa, tau2 = C^2 / (f_s2 + sn2), s_pred,
+ * log-sum-exp over Xa and over the GP samples; sn2_M = observation noise at the points
+ * (_estimate_observation_noise), u = norm.ppf(quantile).  Integer rounding and the hard-bound mask
+ * stay on the host, as for vbmc_acq_eval. */
+int vbmc_acq_is_set(vbmc_ctx* ctx, int64_t Na, const double* Xa, int per_sample_xa,
+                    const double* Ctmp_SxNxNa, const double* fs2a_NaxS, const double* lnw_SxNa);
+int vbmc_acq_is_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, const double* sn2_M, double u,
+                     double* acq_M, double* var_tot_M /* nullable: for the variance regularisation */);
+
 /* AbstractAcqFcn._sq_dist (acquisition_functions/abstract_acq_fcn.py:195-222):
  * c[i][j] = max(|a_i - mu|^2 + |b_j - mu|^2 - 2 (a_i - mu).(b_j - mu), 0), mu the common
  * mean the reference subtracts first.  argmin_n (nullable) = np.argmin(c, axis=1), the
@@ -341,6 +361,12 @@ int vbmc_sq_dist(vbmc_ctx* ctx, int64_t n, int64_t m, int D, const double* a_nxD
  * (grouped by component).  x_NxD / comp_N nullable. */
 int vbmc_mixture_sample(vbmc_ctx* ctx, int64_t N, uint64_t seed, int balance_flag, double* x_NxD,
                         int32_t* comp_N);
+/* The same with multivariate Student-t tails of `df` degrees of freedom (:329-340, :345-353):
+ * x_n = mu_i + lambda o z_n * t_n * sigma_i with t_n = (df/2) / sqrt(G_n), G_n ~ Gamma(df/2, scale
+ * df/2) (Marsaglia-Tsang on Philox stream 4, one variate per sample).  df = +inf or 0: Gaussian
+ * (vbmc_mixture_sample); df < 0 -> VBMC_E_ARG (numpy's gamma raises on a negative shape too). */
+int vbmc_mixture_sample_t(vbmc_ctx* ctx, int64_t N, uint64_t seed, int balance_flag, double df,
+                          double* x_NxD, int32_t* comp_N);
 
 /* VariationalPosterior.kl_div, Monte-Carlo branch (gauss_flag=False, :1107-1126), between
  * the ctx mixture (vp1) and a second mixture over the same D: N balanced samples of each

@@ -71,3 +71,50 @@ def acq_call(kind, Xs, gp, mix, y_max, optim_state, X_rescaled=None, sn2_new=Non
                         np.any(Xs > optim_state["ub_eps_orig"], axis=1))  # :134-138
     acq[out] = np.inf
     return acq
+
+
+def quantile_acq(gp, Xs, sn2, ais, u, use_weights):
+    """AcqFcnVIQR / AcqFcnIMIQR._compute_acquisition_function restated (acq_fcn_viqr.py:80-158,
+    acq_fcn_imiqr.py:77-171) on an oracle GP (gp_ref.GPData): posterior cross-covariance between
+    the points and the importance points from dense solves, then the log-sum-exp of
+    ln_w + u s_pred + log1p(-exp(-2 u s_pred)) over the importance points and over the GP samples.
+    ``ais``: dict with X (Na, D), f_s2 (Na, S), ln_weights (S, Na)."""
+    import numpy as np
+
+    from . import gp_ref
+
+    D, X = gp.D, gp.X
+    Xa = ais["X"]
+    _, f_s2 = gp_ref.predict(gp, Xs, separate_samples=True)
+    y_s2 = f_s2 + np.reshape(sn2, (-1, 1))
+    S = len(gp.posteriors)
+    acq = np.zeros((Xs.shape[0], S))
+    for s, post in enumerate(gp.posteriors):
+        hyp = post.hyp[: D + 1]
+        K_Xs_X = gp_ref.se_ard(hyp, Xs, X)
+        K_Xs_Xa = gp_ref.se_ard(hyp, Xs, Xa)
+        K_X_Xa = gp_ref.se_ard(hyp, X, Xa)
+        if post.L_chol:
+            import scipy.linalg as sla
+
+            sn2_eff = 1 / post.sW[0] ** 2
+            c_tmp = sla.solve_triangular(post.L, sla.solve_triangular(post.L, K_X_Xa, trans=1, check_finite=False),
+                                         check_finite=False) / sn2_eff
+            C = K_Xs_Xa - K_Xs_X @ c_tmp
+        else:
+            C = K_Xs_Xa + K_Xs_X @ (post.L @ K_X_Xa)
+        tau2 = C**2 / y_s2[:, s].reshape(-1, 1)
+        s_pred = np.sqrt(np.maximum(ais["f_s2"][:, s].T - tau2, 0.0))
+        with np.errstate(all="ignore"):
+            zz = u * s_pred + np.log1p(-np.exp(-2 * u * s_pred))
+            if use_weights:
+                zz = zz + ais["ln_weights"][s, :]
+            ln_max = np.amax(zz, axis=1)
+            ln_max[ln_max == -np.inf] = 0.0
+            acq[:, s] = ln_max + np.log(np.sum(np.exp(zz - ln_max.reshape(-1, 1)), axis=1))
+    if S > 1:
+        with np.errstate(all="ignore"):
+            M = np.amax(acq, axis=1)
+            M[M == -np.inf] = 0.0
+            return M + np.log(np.sum(np.exp(acq - M.reshape(-1, 1)), axis=1) / S)
+    return acq.ravel()

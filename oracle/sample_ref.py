@@ -43,11 +43,63 @@ def component_labels(w, N, seed, balance_flag):
     return lab
 
 
-def sample(mix, N, seed, balance_flag=False):
+def gamma_variates(idx, shape, seed):
+    """Gamma(shape, 1) variates of the device generator (csrc/sample.hip philox_gamma): Marsaglia &
+    Tsang with round r taking its normal from Philox(n, 2r, 4) and its uniforms from Philox(n, 2r+1, 4)."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    small = shape < 1.0
+    sh = shape + 1.0 if small else shape
+    d = sh - 1.0 / 3.0
+    c = 1.0 / np.sqrt(9.0 * d)
+    g = np.full(idx.size, d)
+    up = np.ones(idx.size)
+    todo = np.ones(idx.size, dtype=bool)
+    lo, hi = philox_ref._split(idx)
+    k0, k1 = int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF
+
+    def two_uniforms(r):
+        x0, x1, x2, x3 = philox_ref.philox4x32_10(lo[todo], hi[todo], np.full(todo.sum(), r, dtype=np.uint32),
+                                                  np.full(todo.sum(), 4, dtype=np.uint32), k0, k1)
+        a = ((x0.astype(np.uint64) << np.uint64(32)) | x1.astype(np.uint64)) >> np.uint64(11)
+        b = ((x2.astype(np.uint64) << np.uint64(32)) | x3.astype(np.uint64)) >> np.uint64(11)
+        return a, b
+
+    for r in range(64):
+        if not todo.any():
+            break
+        a, b = two_uniforms(2 * r)
+        u1 = (a + np.uint64(1)).astype(np.float64) * 2.0**-53
+        u2 = b.astype(np.float64) * 2.0**-53
+        z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+        t = 1.0 + c * z
+        a, b = two_uniforms(2 * r + 1)
+        U = (a + np.uint64(1)).astype(np.float64) * 2.0**-53
+        Up = (b + np.uint64(1)).astype(np.float64) * 2.0**-53
+        with np.errstate(all="ignore"):
+            v = t**3
+            ok = (t > 0) & (np.log(U) < 0.5 * z * z + d - d * v + d * np.log(np.where(t > 0, v, 1.0)))
+        where = np.flatnonzero(todo)[ok]
+        g[where] = d * v[ok]
+        up[where] = Up[ok]
+        todo[where] = False
+    if small:
+        g = g * np.exp(np.log(up) / shape)
+    return g
+
+
+def sample(mix, N, seed, balance_flag=False, df=np.inf):
     lab = component_labels(mix.w, N, seed, balance_flag)
-    z = philox_ref.normals(np.arange(N, dtype=np.uint64), mix.D, seed, 2)
+    idx = np.arange(N, dtype=np.uint64)
+    z = philox_ref.normals(idx, mix.D, seed, 2)
     lam = mix.lambd.reshape(1, -1)
-    x = mix.mu.T[lab] + lam * z * mix.sigma.ravel()[lab][:, None]     # :321-327
+    if not (np.isfinite(df) and df != 0):
+        return mix.mu.T[lab] + lam * z * mix.sigma.ravel()[lab][:, None], lab  # :321-327
+    G = gamma_variates(idx, df / 2, seed) * (df / 2)                   # np.random.gamma(df/2, df/2) (:330, :346)
+    t = (df / 2 / np.sqrt(G))[:, None]
+    if mix.K > 1:
+        x = mix.mu.T[lab] + lam * z * t * mix.sigma.ravel()[lab][:, None]  # :332-336
+    else:
+        x = mix.mu.T[lab] + lam * t * z * mix.sigma.ravel()[lab][:, None]  # :349-353
     return x, lab
 
 

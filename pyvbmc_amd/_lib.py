@@ -106,8 +106,11 @@ SIGNATURES = {
         C.c_int,
         [_vp, C.c_int64, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp, _dp],
     ),
+    "vbmc_acq_is_set": (C.c_int, [_vp, C.c_int64, _dp, C.c_int, _dp, _dp, _dp]),
+    "vbmc_acq_is_eval": (C.c_int, [_vp, C.c_int64, _dp, _dp, C.c_double, _dp, _dp]),
     "vbmc_sq_dist": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, _dp, _dp, _dp, C.POINTER(C.c_int64)]),
     "vbmc_mixture_sample": (C.c_int, [_vp, C.c_int64, C.c_uint64, C.c_int, _dp, C.POINTER(C.c_int32)]),
+    "vbmc_mixture_sample_t": (C.c_int, [_vp, C.c_int64, C.c_uint64, C.c_int, C.c_double, _dp, C.POINTER(C.c_int32)]),
     "vbmc_kl_div_mc": (C.c_int, [_vp, C.c_int64, C.c_uint64, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "vbmc_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "vbmc_comm_init": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]),

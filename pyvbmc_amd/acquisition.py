@@ -9,8 +9,12 @@ variational density and the acquisition formula run in one library call
 acquisition values come back.  What needs the caller's ``parameter_transformer`` -- rounding
 of integer variables and the hard-bound mask -- stays here on the host, as NumPy.
 
-The information-theoretic members (``AcqFcnVIQR``, ``AcqFcnIMIQR``) are not part of this
-path; asking ``string_to_acq`` for them raises ``NotImplementedError``.
+The two importance-sampled members for noisy targets, ``AcqFcnVIQR`` and ``AcqFcnIMIQR``
+(reference acq_fcn_viqr.py, acq_fcn_imiqr.py), evaluate through ``vbmc_acq_is_set`` /
+``vbmc_acq_is_eval`` (csrc/api_acq_is.hip): the importance state the reference prepares once per
+active-sampling round (``optim_state["active_importance_sampling"]``) is uploaded once and stays
+in HBM while the acquisition is evaluated thousands of times.  Preparing that state
+(``active_importance_sampling``) is the reference's own code and out of scope here.
 """
 import ctypes as C
 
@@ -141,14 +145,142 @@ class AcqFcnNoisy(AbstractAcqFcn):
     _kind = ACQ_NOISY
 
 
+class _QuantileAcq(AbstractAcqFcn):
+    """Shared parts of AcqFcnVIQR / AcqFcnIMIQR (reference acq_fcn_viqr.py, acq_fcn_imiqr.py)."""
+
+    _kind = "is"
+
+    def __init__(self, quantile=0.75):
+        from scipy.stats import norm
+
+        self.acq_info = {"log_flag": True, "importance_sampling": True, "importance_sampling_vp": False,
+                         "quantile": quantile, "compute_var_log_joint": False}
+        self.u = norm.ppf(quantile)
+
+    # importance-sampling log densities (acq_fcn_viqr.py:159-247, acq_fcn_imiqr.py:173-260): NumPy
+    # on top of the device gp.predict
+    def is_log_added(self, **kwargs):
+        f_s = np.sqrt(kwargs["f_s2"])
+        return self.u * f_s + np.log1p(-np.exp(-2 * self.u * f_s))
+
+    @staticmethod
+    def _c_tmp(gp, ais):
+        """C_tmp[s] = (L'L)^-1 K(X, Xa) / sn2_eff, or L K(X, Xa) for a non-Cholesky sample -- what
+        active_importance_sampling.py:279-306 stores for VIQR; IMIQR stores K_Xa_X and repeats the
+        solves on every call (acq_fcn_imiqr.py:127-141): formed once here instead."""
+        if ais.get("C_tmp") is not None:
+            return np.ascontiguousarray(ais["C_tmp"], dtype=np.float64)
+        from scipy.linalg import solve_triangular
+
+        K_Xa_X = ais["K_Xa_X"]
+        out = np.empty((K_Xa_X.shape[0], K_Xa_X.shape[2], K_Xa_X.shape[1]))
+        for s, p in enumerate(gp.posteriors):
+            if p.L_chol:
+                sn2_eff = 1 / np.ravel(p.sW)[0] ** 2
+                out[s] = solve_triangular(p.L, solve_triangular(p.L, K_Xa_X[s].T, trans=True, check_finite=False),
+                                          check_finite=False) / sn2_eff
+            else:
+                out[s] = p.L @ K_Xa_X[s].T
+        return out
+
+    def _upload_state(self, gp, ais, ctx):
+        key = (id(ais), id(ais.get("X")), id(ais.get("f_s2")), id(ais.get("ln_weights")), id(gp.posteriors))
+        if ctx.__dict__.get("_acq_is_key") == key:
+            return
+        Xa = _lib.f64(ais["X"])
+        per_sample = Xa.ndim == 3
+        Na = Xa.shape[-2]
+        ctmp = _lib.f64(self._c_tmp(gp, ais))
+        fs2a = _lib.f64(ais["f_s2"])
+        lnw = None if self.acq_info.get("variational_importance_sampling") else _lib.f64(ais["ln_weights"])
+        ctx.check(ctx._lib.vbmc_acq_is_set(ctx._h, Na, _lib.ptr(Xa), int(per_sample), _lib.ptr(ctmp),
+                                           _lib.ptr(fs2a), _lib.ptr(lnw)))
+        ctx.__dict__["_acq_is_key"], ctx.__dict__["_acq_is_ref"] = key, (ais, gp.posteriors)
+
+    def __call__(self, Xs, gp, vp, function_logger, optim_state):
+        Xs = np.asarray(Xs, dtype=np.float64)
+        if Xs.ndim == 1:
+            Xs = Xs[None, :]
+        Xs = self._real2int(Xs, vp.parameter_transformer, optim_state.get("integer_vars"))
+        ctx = ctx_of(vp)
+        upload_gp(gp, ctx)
+        self._upload_state(gp, optim_state["active_importance_sampling"], ctx)
+        xs = _lib.f64(Xs)
+        M = xs.shape[0]
+        sn2 = _lib.f64(np.ravel(self._estimate_observation_noise(Xs, gp, optim_state)))
+        acq = np.empty(M)
+        reg = bool(optim_state.get("variance_regularized_acq_fcn"))
+        var_tot = np.empty(M) if reg else None
+        ctx.check(ctx._lib.vbmc_acq_is_eval(ctx._h, M, _lib.ptr(xs), _lib.ptr(sn2), float(self.u), _lib.ptr(acq),
+                                            _lib.ptr(var_tot)))
+        # regularisation, clamp and hard bounds of AbstractAcqFcn.__call__ (abstract_acq_fcn.py:110-139)
+        if reg:
+            tol_var = optim_state.get("tol_gp_var")
+            low = var_tot < tol_var
+            acq[low] += tol_var / var_tot[low] - 1  # log_flag is set for both classes
+        acq = np.maximum(acq, -np.finfo(np.float64).max)
+        X_orig = vp.parameter_transformer.inverse(Xs)
+        out = np.logical_or(np.any(X_orig < optim_state.get("lb_eps_orig"), axis=1),
+                            np.any(X_orig > optim_state.get("ub_eps_orig"), axis=1))
+        acq[out] = np.inf
+        return acq
+
+
+class AcqFcnVIQR(_QuantileAcq):
+    """Variational interquantile range (reference acq_fcn_viqr.py): simple Monte Carlo over the VP."""
+
+    def __init__(self, quantile=0.75):
+        super().__init__(quantile)
+        self.acq_info["variational_importance_sampling"] = True
+
+    def is_log_base(self, x, **kwargs):
+        return np.zeros(kwargs["f_s2"].shape)
+
+    def is_log_full(self, x, **kwargs):
+        f_s2 = kwargs.pop("f_s2", None)
+        if f_s2 is None:
+            gp = kwargs.get("gp")
+            if gp is None:
+                raise ValueError("Must provide gp as keyword argument if f_s2 is not provided.")
+            __, f_s2 = gp.predict(np.atleast_2d(x), add_noise=True)
+        return self.is_log_added(f_s2=f_s2, **kwargs)
+
+
+class AcqFcnIMIQR(_QuantileAcq):
+    """Integrated median interquantile range (reference acq_fcn_imiqr.py)."""
+
+    def __init__(self, quantile=0.75):
+        super().__init__(quantile)
+        self.acq_info["variational_importance_sampling"] = False
+
+    def is_log_base(self, x, **kwargs):
+        return kwargs["f_mu"]
+
+    def is_log_full(self, x, **kwargs):
+        f_mu, f_s2 = kwargs.pop("f_mu", None), kwargs.pop("f_s2", None)
+        if f_mu is None or f_s2 is None:
+            gp = kwargs.get("gp")
+            if gp is None:
+                raise ValueError("Must provide gp as keyword argument if f_mu / f_s2 are not provided.")
+            f_mu, f_s2 = gp.predict(np.atleast_2d(x), add_noise=True)
+        return self.is_log_base(x, f_mu=f_mu) + self.is_log_added(f_s2=f_s2, **kwargs)
+
+
 def string_to_acq(string):
     """Reference utilities.py:6: evaluate a constructor string such as ``"AcqFcnLog()"``."""
-    names = {c.__name__: c for c in (AcqFcn, AcqFcnLog, AcqFcnVanilla, AcqFcnNoisy)}
-    head = string.strip().split("(")[0]
-    if head in ("AcqFcnVIQR", "AcqFcnIMIQR"):
-        raise NotImplementedError(f"{head} is not on the accelerated path")
-    if head not in names:
+    names = {c.__name__: c for c in (AcqFcn, AcqFcnLog, AcqFcnVanilla, AcqFcnNoisy, AcqFcnVIQR, AcqFcnIMIQR)}
+    import ast
+
+    # the reference evals the string; here only `Name(...)` with literal arguments is accepted
+    try:
+        call = ast.parse(string.strip(), mode="eval").body
+        ok = isinstance(call, ast.Call) and isinstance(call.func, ast.Name) and call.func.id in names
+        args = [ast.literal_eval(a) for a in call.args] if ok else []
+        kwargs = {k.arg: ast.literal_eval(k.value) for k in call.keywords} if ok else {}
+    except (SyntaxError, ValueError):
+        ok = False
+    if not ok:
         raise ValueError(f"unknown acquisition function {string!r}")
-    return names[head]()
+    return names[call.func.id](*args, **kwargs)
 
 

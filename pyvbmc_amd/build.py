@@ -27,6 +27,7 @@ SOURCES = [
     "api_batch.hip",
     "adam.hip",
     "api_acq.hip",
+    "api_acq_is.hip",
     "sample.hip",
     "comm.hip",
 ]

@@ -157,8 +157,10 @@ struct vbmc_ctx {
 
   ElboScratch elbo;      // api_elbo.hip
   void* adam = nullptr;  // device-resident optimiser state (adam.hip)
+  void* acq_is = nullptr;  // resident importance-sampling state of AcqFcnVIQR / IMIQR (api_acq_is.hip)
 };
 void adam_free(vbmc_ctx* ctx);
+void acq_is_free(vbmc_ctx* ctx);
 
 // error helpers -----------------------------------------------------------
 int vbmc_fail(vbmc_ctx* ctx, int code, const char* fmt, ...);

@@ -139,6 +139,7 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   vbmc_comm_destroy(ctx);
   adam_free(ctx);
+  acq_is_free(ctx);
   double* bufs[] = {ctx->d_mix, ctx->d_eps, ctx->d_scratch, ctx->d_out, ctx->gp.d_X,
                     ctx->gp.d_alpha, ctx->gp.d_L, ctx->gp.d_Linv, ctx->gp.d_sW, ctx->gp.d_hyp,
                     ctx->gp.d_xc, ctx->gp.d_smeta};

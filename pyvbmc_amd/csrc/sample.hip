@@ -10,6 +10,7 @@
 // index), with counter word 3 separating the streams:
 //     c = (n_lo, n_hi, pair, 2)        normals of dimensions 2 pair, 2 pair + 1 of sample n
 //     c = (n_lo, n_hi, 0,    3)        the uniform that picks the component of sample n
+//     c = (n_lo, n_hi, r,    4)        round r of the gamma variate of sample n (Student-t tails)
 // oracle/sample_ref.py restates both.  Component choice: inverse CDF of the weights
 // (np.random.choice(p=w), :316-319); with balance_flag the first sum_k floor(w_k N) samples
 // are split exactly according to the weights and the remaining ones are drawn from the
@@ -36,12 +37,47 @@ struct SampleArgs {
   uint64_t seed;
   double* x;              // N x D or null
   int32_t* comp;          // N or null
+  double df;              // degrees of freedom of the multivariate-t tails; <= 0 or inf: Gaussian
 };
 
 __device__ __forceinline__ double philox_uniform(uint64_t n, uint32_t c3, uint64_t seed) {
   Philox4 r = philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 0u, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
   const uint64_t a = (((uint64_t)r.x[0] << 32) | r.x[1]) >> 11;
   return (double)a * 0x1.0p-53;  // [0, 1)
+}
+
+// Gamma(shape, 1) variate of sample n by Marsaglia & Tsang's method (ACM TOMS 26, 2000): with
+// d = shape' - 1/3, c = 1/sqrt(9 d): z ~ N(0,1), v = (1 + c z)^3, accept when v > 0 and
+// ln U < z^2/2 + d - d v + d ln v; shape < 1 goes through shape' = shape + 1 and a factor U'^(1/shape).
+// Round r takes its normal from Philox(n, 2r, 4) and its uniforms U, U' from Philox(n, 2r+1, 4):
+// a pure function of (seed, n), restated by oracle/sample_ref.py.  64 rounds at >= 95 %
+// acceptance each: the fall-through (value d) has probability < 1e-80.
+__device__ inline double philox_gamma(uint64_t n, double shape, uint64_t seed) {
+  const bool small = shape < 1.0;
+  const double sh = small ? shape + 1.0 : shape;
+  const double d = sh - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+  double g = d, up = 1.0;
+  for (uint32_t r = 0; r < 64; ++r) {
+    Philox4 q = philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 2 * r, 4u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint64_t ua = (((uint64_t)q.x[0] << 32) | q.x[1]) >> 11, ub = (((uint64_t)q.x[2] << 32) | q.x[3]) >> 11;
+    const double u1 = (double)(ua + 1) * 0x1.0p-53, u2 = (double)ub * 0x1.0p-53;
+    double sn, cs;
+    fm::sincospi_fast(2.0 * u2, sn, cs);
+    const double z = sqrt(-2.0 * fm::log_fast(u1)) * cs;
+    const double t = 1.0 + c * z;
+    if (t <= 0.0) continue;
+    const double v = t * t * t;
+    q = philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 2 * r + 1, 4u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint64_t uc = (((uint64_t)q.x[0] << 32) | q.x[1]) >> 11, ud = (((uint64_t)q.x[2] << 32) | q.x[3]) >> 11;
+    const double U = (double)(uc + 1) * 0x1.0p-53;
+    if (fm::log_fast(U) < 0.5 * z * z + d - d * v + d * fm::log_fast(v)) {
+      g = d * v;
+      up = (double)(ud + 1) * 0x1.0p-53;
+      break;
+    }
+  }
+  if (small) g *= exp(fm::log_fast(up) / shape);
+  return g;
 }
 
 __global__ __launch_bounds__(256) void mixture_sample_kernel(SampleArgs a) {
@@ -62,6 +98,13 @@ __global__ __launch_bounds__(256) void mixture_sample_kernel(SampleArgs a) {
   const double* mu = a.mix + a.ml.o_mu + (size_t)k * D;
   const double* lam = a.mix + a.ml.o_lam;
   const double sg = a.mix[a.ml.o_sig + k];
+  // multivariate-t tails (:329-340): t = df/2 / sqrt(G), G ~ Gamma(df/2, scale df/2)
+  const bool heavy = a.df > 0.0 && a.df < INFINITY;
+  double tf = 1.0;
+  if (heavy) {
+    const double G = philox_gamma((uint64_t)n, 0.5 * a.df, a.seed) * (0.5 * a.df);
+    tf = 0.5 * a.df / sqrt(G);
+  }
   for (int p = 0; 2 * p < D; ++p) {
     double z0, z1;
     Philox4 r = philox4x32_10((uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)p, 2u,
@@ -75,8 +118,16 @@ __global__ __launch_bounds__(256) void mixture_sample_kernel(SampleArgs a) {
     z0 = rad * c;
     z1 = rad * s;
     const int d0 = 2 * p, d1 = 2 * p + 1;
-    a.x[n * D + d0] = mu[d0] + (lam[d0] * z0) * sg;  // the reference's association (:323-326)
-    if (d1 < D) a.x[n * D + d1] = mu[d1] + (lam[d1] * z1) * sg;
+    if (!heavy) {
+      a.x[n * D + d0] = mu[d0] + (lam[d0] * z0) * sg;  // the reference's association (:323-326)
+      if (d1 < D) a.x[n * D + d1] = mu[d1] + (lam[d1] * z1) * sg;
+    } else if (K > 1) {  // mu + lam * z * t * sigma (:332-336)
+      a.x[n * D + d0] = mu[d0] + ((lam[d0] * z0) * tf) * sg;
+      if (d1 < D) a.x[n * D + d1] = mu[d1] + ((lam[d1] * z1) * tf) * sg;
+    } else {  // mu + lam * t * z * sigma (:349-353)
+      a.x[n * D + d0] = mu[d0] + ((lam[d0] * tf) * z0) * sg;
+      if (d1 < D) a.x[n * D + d1] = mu[d1] + ((lam[d1] * tf) * z1) * sg;
+    }
   }
 }
 
@@ -145,7 +196,8 @@ void make_selector(const double* w, int K, int64_t N, int balance, Selector& s) 
 // Draw N samples of `d_pack` into d_x (device), optionally labels into d_comp.
 // d_sel: device scratch of (K+1) int64 + K doubles.
 int launch_sample(vbmc_ctx* ctx, const double* d_pack, const MixLayout& ml, const double* w_host,
-                  int64_t N, uint64_t seed, int balance, void* d_sel, double* d_x, int32_t* d_comp) {
+                  int64_t N, uint64_t seed, int balance, void* d_sel, double* d_x, int32_t* d_comp,
+                  double df = INFINITY) {
   const int K = ml.K;
   Selector s;
   make_selector(w_host, K, N, balance, s);
@@ -164,6 +216,7 @@ int launch_sample(vbmc_ctx* ctx, const double* d_pack, const MixLayout& ml, cons
   a.seed = seed;
   a.x = d_x;
   a.comp = d_comp;
+  a.df = df;
   hipLaunchKernelGGL(mixture_sample_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, a);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
@@ -173,7 +226,14 @@ int launch_sample(vbmc_ctx* ctx, const double* d_pack, const MixLayout& ml, cons
 
 extern "C" int vbmc_mixture_sample(vbmc_ctx* ctx, int64_t N, uint64_t seed, int balance_flag,
                                    double* x_NxD, int32_t* comp_N) {
+  return vbmc_mixture_sample_t(ctx, N, seed, balance_flag, INFINITY, x_NxD, comp_N);
+}
+
+extern "C" int vbmc_mixture_sample_t(vbmc_ctx* ctx, int64_t N, uint64_t seed, int balance_flag, double df,
+                                     double* x_NxD, int32_t* comp_N) {
   if (!ctx || N < 0) return VBMC_E_ARG;
+  if (df < 0.0 || df != df)
+    return vbmc_fail(ctx, VBMC_E_ARG, "mixture_sample: df=%g (the reference's gamma draw needs df > 0)", df);
   if (!ctx->mix_set) return vbmc_fail(ctx, VBMC_E_ARG, "mixture_sample: mixture not set");
   if (N == 0) return VBMC_OK;
   NEED_DEVICE(ctx);
@@ -191,7 +251,7 @@ extern "C" int vbmc_mixture_sample(vbmc_ctx* ctx, int64_t N, uint64_t seed, int 
   double* d_x = x_NxD ? ctx->d_scratch : nullptr;
   int32_t* d_c = comp_N ? (int32_t*)(ctx->d_scratch + n_x) : nullptr;
   void* d_sel = (void*)(ctx->d_scratch + n_x + n_c);
-  rc = launch_sample(ctx, ctx->d_mix, ctx->ml, ctx->w.data(), N, seed, balance_flag, d_sel, d_x, d_c);
+  rc = launch_sample(ctx, ctx->d_mix, ctx->ml, ctx->w.data(), N, seed, balance_flag, d_sel, d_x, d_c, df);
   if (rc) return rc;
   if (x_NxD)
     HIP_TRY(ctx, hipMemcpyAsync(x_NxD, d_x, sizeof(double) * n_x, hipMemcpyDeviceToHost, ctx->stream));

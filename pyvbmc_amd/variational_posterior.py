@@ -148,15 +148,16 @@ class VariationalPosterior:
         if N < 1:
             return np.zeros((0, self.D)), np.zeros((0, 1))
         mode = os.environ.get("VBMC_HIP_RNG", "numpy") if rng is None else rng
-        if mode == "philox" and not (np.isfinite(df) and df != 0):
+        if mode == "philox" and not (np.isfinite(df) and df < 0):  # (df < 0: numpy's gamma raises, below)
             N = int(N)
             ctx = self._upload()
             if seed is None:
                 seed = int(np.random.randint(0, 2**62, dtype=np.int64))
             x = np.empty((N, self.D))
             i = np.empty(N, dtype=np.int32)
-            ctx.check(ctx._lib.vbmc_mixture_sample(ctx._h, N, int(seed), int(bool(balance_flag)), _lib.ptr(x),
-                                                   i.ctypes.data_as(C.POINTER(C.c_int32))))
+            tdf = float(df) if (np.isfinite(df) and df != 0) else float("inf")
+            ctx.check(ctx._lib.vbmc_mixture_sample_t(ctx._h, N, int(seed), int(bool(balance_flag)), tdf, _lib.ptr(x),
+                                                     i.ctypes.data_as(C.POINTER(C.c_int32))))
             if balance_flag and shuffle and self.K > 1:
                 perm = np.random.permutation(N)
                 x, i = x[perm], i[perm]

@@ -19,74 +19,9 @@ import sys
 from math import ceil
 
 import numpy as np
-from scipy.stats import norm
 
 
-class _QuantileAcq:
-    """Shared importance-sampling pieces of AcqFcnVIQR / AcqFcnIMIQR."""
-
-    def __init__(self, quantile=0.75):
-        self.acq_info = {
-            "log_flag": True,
-            "importance_sampling": True,
-            "quantile": quantile,
-            "compute_var_log_joint": False,
-        }
-        self.u = norm.ppf(quantile)
-
-    def get_info(self):
-        return self.acq_info
-
-    def is_log_added(self, **kwargs):
-        """log sinh(u f_s) up to a constant, f_s the predictive standard deviation."""
-        f_s = np.sqrt(kwargs["f_s2"])
-        return self.u * f_s + np.log1p(-np.exp(-2 * self.u * f_s))
-
-    def __call__(self, *args, **kwargs):
-        raise NotImplementedError(f"{type(self).__name__}: only the importance-sampling densities are provided")
-
-
-class AcqFcnVIQR(_QuantileAcq):
-    """Variational interquantile range: simple Monte Carlo over the VP (reference acq_fcn_viqr.py)."""
-
-    def __init__(self, quantile=0.75):
-        super().__init__(quantile)
-        self.acq_info["importance_sampling_vp"] = False
-        self.acq_info["variational_importance_sampling"] = True
-
-    def is_log_base(self, x, **kwargs):
-        return np.zeros(kwargs["f_s2"].shape)
-
-    def is_log_full(self, x, **kwargs):
-        f_s2 = kwargs.pop("f_s2", None)
-        if f_s2 is None:
-            gp = kwargs.get("gp")
-            if gp is None:
-                raise ValueError("Must provide gp as keyword argument if f_s2 is not provided.")
-            __, f_s2 = gp.predict(np.atleast_2d(x), add_noise=True)
-        return self.is_log_added(f_s2=f_s2, **kwargs)
-
-
-class AcqFcnIMIQR(_QuantileAcq):
-    """Integrated median interquantile range: the base density is the GP mean (reference
-    acq_fcn_imiqr.py)."""
-
-    def __init__(self, quantile=0.75):
-        super().__init__(quantile)
-        self.acq_info["importance_sampling_vp"] = False
-        self.acq_info["variational_importance_sampling"] = False
-
-    def is_log_base(self, x, **kwargs):
-        return kwargs["f_mu"]
-
-    def is_log_full(self, x, **kwargs):
-        f_mu, f_s2 = kwargs.pop("f_mu", None), kwargs.pop("f_s2", None)
-        if f_mu is None or f_s2 is None:
-            gp = kwargs.get("gp")
-            if gp is None:
-                raise ValueError("Must provide gp as keyword argument if f_mu / f_s2 are not provided.")
-            f_mu, f_s2 = gp.predict(np.atleast_2d(x), add_noise=True)
-        return self.is_log_base(x, f_mu=f_mu) + self.is_log_added(f_s2=f_s2, **kwargs)
+# (AcqFcnVIQR / AcqFcnIMIQR themselves are product classes now: pyvbmc_amd.acquisition)
 
 
 def active_sample_proposal_pdf(Xa, gp, vp_is, w_vp, rect_delta, acq_fcn):

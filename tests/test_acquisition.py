@@ -71,10 +71,11 @@ def test_string_to_acq_names():
     assert isinstance(string_to_acq("AcqFcnLog()"), AcqFcnLog)
     assert isinstance(string_to_acq("AcqFcnNoisy()"), AcqFcnNoisy)
     assert string_to_acq("AcqFcnLog()").get_info()["log_flag"] is True
-    with pytest.raises(NotImplementedError):
-        string_to_acq("AcqFcnVIQR()")
-    with pytest.raises(ValueError):
-        string_to_acq("os.system('true')")
+    assert string_to_acq("AcqFcnVIQR()").get_info()["importance_sampling"] is True
+    assert string_to_acq("AcqFcnIMIQR(quantile=0.9)").get_info()["quantile"] == 0.9
+    for bad in ("os.system('true')", "AcqFcnLog().__class__", "AcqFcnLog(__import__('os'))", "Nope()"):
+        with pytest.raises(ValueError):
+            string_to_acq(bad)
 
 
 # ---------------------------------------------------------------- GPU
@@ -197,3 +198,148 @@ def test_predict_far_from_origin(ctx):
     sf2 = float(np.exp(2 * hyp[0, wl.D]))
     assert np.max(np.abs(fmu - omu)) <= 1e-10 * max(1.0, np.max(np.abs(omu)))
     assert np.max(np.abs(fs2 - os2)) <= 1e-10 * max(1.0, sf2)
+
+
+# ---------------------------------------------------------------- importance-sampled acquisitions (noisy targets)
+GPCOV = ["homo", "hetero", "tiny"]
+
+
+def gpcov_objects(c, name):
+    from scipy.stats import norm
+
+    from oracle import gp_ref
+
+    s2 = c["s2"] if name == "hetero" else None
+    hyp = c[f"{name}_hyp"]
+    ogp = gp_ref.make_gp(c["X"], c["y"], hyp, gp_ref.MEAN_NEGQUAD, s2=s2, noise_user=s2 is not None)
+    length = np.exp(hyp[0, : int(c["D"])])
+    d = ((c["Xs"][:, None, :] / length - (c["X"] / length)[None, :, :]) ** 2).sum(-1)
+    sn2 = c[f"{name}_sn2_new"][np.argmin(d, axis=1)]
+    return ogp, length, sn2, norm.ppf(0.75)
+
+
+@pytest.mark.parametrize("name", GPCOV)
+def test_oracle_quantile_acq_vs_reference(golden, name):
+    """tests/golden/gpcov.npz holds AcqFcnVIQR / AcqFcnIMIQR values produced by the reference's own
+    classes (oracle/make_golden.py gpcov): the oracle restatement reproduces them."""
+    c = golden("gpcov")
+    ogp, length, sn2, u = gpcov_objects(c, name)
+    for cls, usew in (("AcqFcnVIQR", False), ("AcqFcnIMIQR", True)):
+        ais = dict(X=c[f"{name}_{cls}_Xa"], f_s2=c[f"{name}_{cls}_ais_f_s2"], ln_weights=c[f"{name}_{cls}_ais_ln_weights"])
+        a = acq_ref.quantile_acq(ogp, c["Xs"], sn2, ais, u, usew)
+        assert np.max(np.abs(a - c[f"{name}_{cls}_acq"])) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GPCOV)
+def test_device_quantile_acq_vs_reference(name, golden):
+    """The mirror classes' full __call__ (device predict, cross-covariance product on the matrix
+    cores, log-sum-exp) against the reference's values -- homoskedastic, heteroskedastic and a GP
+    with a non-Cholesky sample -- with attribute-only GP / VP objects."""
+    from helpers import PlainGP, PlainVP
+
+    from oracle import gp_ref, mixture_ref
+    from pyvbmc_amd import _lib
+    from pyvbmc_amd.acquisition import AcqFcnIMIQR, AcqFcnVIQR, string_to_acq
+
+    c = golden("gpcov")
+    ctx = _lib.Context(0)
+    _lib.set_default_context(ctx)
+    try:
+        ogp, length, sn2, u = gpcov_objects(c, name)
+        gp = PlainGP(ogp)
+        gp.temporary_data["X_rescaled"] = c["X"] / length
+        gp.temporary_data["sn2_new"] = c[f"{name}_sn2_new"]
+        vp = PlainVP(mixture_ref.Mixture.make(c["vp_mu"], c["vp_sigma"], c["vp_lambd"], c["vp_w"]))
+        flog = SimpleNamespace(y_max=float(np.max(c["y"])))
+        for cls in (AcqFcnVIQR, AcqFcnIMIQR):
+            tag = f"{name}_{cls.__name__}"
+            Xa = c[f"{tag}_Xa"]
+            ais = dict(X=Xa, f_s2=c[f"{tag}_ais_f_s2"], ln_weights=c[f"{tag}_ais_ln_weights"])
+            # what the reference's active_importance_sampling step 3 stores: K_Xa_X (and C_tmp for VIQR)
+            ais["K_Xa_X"] = np.stack([gp_ref.se_ard(p.hyp[:4], Xa, c["X"]) for p in ogp.posteriors])
+            st = dict(integer_vars=None, lb_eps_orig=c["X"].min(0) - 3.0, ub_eps_orig=c["X"].max(0) + 3.0,
+                      gp_length_scale=length, variance_regularized_acq_fcn=False, active_importance_sampling=ais)
+            acq = cls()
+            v = acq(c["Xs"].copy(), gp, vp, flog, st)
+            err = float(np.max(np.abs(v - c[f"{tag}_acq"])))
+            print(f"{tag}: max |acq - reference| = {err:.2e}")
+            assert err < 1e-9
+            assert np.array_equal(acq(c["Xs"][5].copy(), gp, vp, flog, st), v[5:6])  # 1-D input, cached state
+        assert isinstance(string_to_acq("AcqFcnVIQR()"), AcqFcnVIQR)
+        assert string_to_acq("AcqFcnIMIQR(quantile=0.9)").acq_info["quantile"] == 0.9
+    finally:
+        _lib.set_default_context(None)
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_quantile_acq_vs_oracle_larger():
+    """A larger case against the oracle: M = 1500 points, 420 importance points, S = 3 (one
+    non-Cholesky sample), per-sample importance points (IMIQR after MCMC) and the variance
+    regularisation."""
+    from helpers import PlainGP, PlainVP
+
+    from oracle import gp_ref, mixture_ref
+    from pyvbmc_amd import _lib
+    from pyvbmc_amd.acquisition import AcqFcnIMIQR, AcqFcnVIQR
+    from scipy.stats import norm
+
+    rng = np.random.default_rng(31)
+    D, N, S, M, Na = 4, 150, 3, 1500, 420
+    X = rng.standard_normal((N, D))
+    y = (-0.5 * np.sum(X**2, axis=1) + 0.05 * rng.standard_normal(N)).reshape(-1, 1)
+    hyp = np.array([np.concatenate([np.log(0.8 + 0.3 * rng.random(D)), [np.log(2.0)], [ls], [0.1], np.zeros(D), np.zeros(D)])
+                    for ls in (np.log(0.05), np.log(3e-4), np.log(0.1))])
+    ogp = gp_ref.make_gp(X, y, hyp, gp_ref.MEAN_NEGQUAD)
+    assert [p.L_chol for p in ogp.posteriors] == [True, False, True]
+    ctx = _lib.Context(0)
+    _lib.set_default_context(ctx)
+    try:
+        gp = PlainGP(ogp)
+        length = np.exp(hyp[0, :D])
+        gp.temporary_data["X_rescaled"] = X / length
+        gp.temporary_data["sn2_new"] = 0.01 + rng.random(N)
+        vp = PlainVP(mixture_ref.Mixture.make(rng.standard_normal((D, 3)), [0.5, 0.7, 0.9], np.ones(D), [0.2, 0.3, 0.5]))
+        Xs = 1.3 * rng.standard_normal((M, D))
+        d = ((Xs[:, None, :] / length - (X / length)[None, :, :]) ** 2).sum(-1)
+        sn2 = gp.temporary_data["sn2_new"][np.argmin(d, axis=1)]
+        Xa = rng.standard_normal((Na, D))
+        _, fs2a = gp_ref.predict(ogp, Xa, separate_samples=True)
+        lnw = rng.standard_normal((S, Na))
+        base = dict(integer_vars=None, lb_eps_orig=np.full(D, -50.0), ub_eps_orig=np.full(D, 50.0), gp_length_scale=length)
+        flog = SimpleNamespace(y_max=0.0)
+        for cls, usew in ((AcqFcnVIQR, False), (AcqFcnIMIQR, True)):
+            ais = dict(X=Xa, f_s2=fs2a, ln_weights=lnw,
+                       K_Xa_X=np.stack([gp_ref.se_ard(p.hyp[: D + 1], Xa, X) for p in ogp.posteriors]))
+            ref = acq_ref.quantile_acq(ogp, Xs, sn2, ais, norm.ppf(0.75), usew)
+            v = cls()(Xs.copy(), gp, vp, flog, dict(base, variance_regularized_acq_fcn=False, active_importance_sampling=ais))
+            assert np.max(np.abs(v - ref)) < 1e-9 * max(1.0, np.max(np.abs(ref)))
+            # variance regularisation on top
+            _, f_s2 = gp_ref.predict(ogp, Xs, separate_samples=True)
+            fmu, _ = gp_ref.predict(ogp, Xs, separate_samples=True)
+            var_tot = f_s2.mean(axis=1) + fmu.var(axis=1, ddof=1)
+            tol = float(np.sort(var_tot)[100])
+            ref_reg = ref.copy()
+            low = var_tot < tol
+            ref_reg[low] += tol / var_tot[low] - 1
+            v = cls()(Xs.copy(), gp, vp, flog, dict(base, variance_regularized_acq_fcn=True, tol_gp_var=tol,
+                                                   active_importance_sampling=dict(ais)))
+            assert np.max(np.abs(v - ref_reg) / np.maximum(1.0, np.abs(ref_reg))) < 1e-8
+        # IMIQR with per-sample importance points (X of shape (S, Na, D))
+        Xa3 = rng.standard_normal((S, Na, D))
+        fs2a3 = np.stack([gp_ref.predict(ogp, Xa3[s], separate_samples=True)[1][:, s] for s in range(S)], axis=1)
+        ais3 = dict(X=Xa3, f_s2=fs2a3, ln_weights=lnw,
+                    K_Xa_X=np.stack([gp_ref.se_ard(p.hyp[: D + 1], Xa3[s], X) for s, p in enumerate(ogp.posteriors)]))
+        v = AcqFcnIMIQR()(Xs[:200].copy(), gp, vp, flog, dict(base, variance_regularized_acq_fcn=False,
+                                                             active_importance_sampling=ais3))
+        # oracle per sample, then the reference's log-mean-exp over the samples
+        per = np.stack([acq_ref.quantile_acq(gp_ref.GPData(D, X, y, None, gp_ref.MEAN_NEGQUAD, [ogp.posteriors[s]]),
+                                             Xs[:200], sn2[:200], dict(X=Xa3[s], f_s2=fs2a3[:, s:s + 1], ln_weights=lnw[s:s + 1]),
+                                             norm.ppf(0.75), True) for s in range(S)], axis=1)
+        mx = per.max(axis=1)
+        ref3 = mx + np.log(np.sum(np.exp(per - mx[:, None]), axis=1) / S)
+        assert np.max(np.abs(v - ref3)) < 1e-9 * max(1.0, np.max(np.abs(ref3)))
+    finally:
+        _lib.set_default_context(None)
+        ctx.close()

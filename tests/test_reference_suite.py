@@ -351,7 +351,8 @@ def test_fess(ctx, golden):
 @pytest.mark.gpu
 def test_active_sample_proposal_pdf(ctx, golden):
     """vbmc/test_active_importance_sampling.py:178: MATLAB's log importance weights, VIQR and IMIQR."""
-    from is_helpers import AcqFcnIMIQR, AcqFcnVIQR, active_sample_proposal_pdf
+    from is_helpers import active_sample_proposal_pdf
+    from pyvbmc_amd.acquisition import AcqFcnIMIQR, AcqFcnVIQR
 
     m = golden("matlab_known")
     D, X, gp, Xa = matlab_gp_and_points(ctx)
@@ -377,7 +378,8 @@ def test_is_log_densities_and_weights():
     """acq_fcn_viqr.py:159-247 / acq_fcn_imiqr.py:173-260 log densities; renormalize_weights :481."""
     from scipy.stats import norm
 
-    from is_helpers import AcqFcnIMIQR, AcqFcnVIQR, get_mcmc_opts, renormalize_weights
+    from is_helpers import get_mcmc_opts, renormalize_weights
+    from pyvbmc_amd.acquisition import AcqFcnIMIQR, AcqFcnVIQR
 
     v, i = AcqFcnVIQR(), AcqFcnIMIQR(quantile=0.9)
     assert np.isclose(v.u, norm.ppf(0.75)) and np.isclose(i.u, norm.ppf(0.9))

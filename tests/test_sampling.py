@@ -146,6 +146,49 @@ def test_device_sampler_vs_oracle(ctx, name, balance):
         assert np.array_equal(np.sort(xp[:, 0]), np.sort(x[:, 0])) and np.array_equal(np.bincount(ip), np.bincount(i))
 
 
+def test_oracle_gamma_variates_are_gamma():
+    """The restated device gamma stream (Marsaglia-Tsang on Philox): moments and a KS test against
+    scipy's gamma, for a shape above and one below 1."""
+    from scipy import stats
+
+    for shape in (2.5, 0.4):
+        g = sample_ref.gamma_variates(np.arange(200000, dtype=np.uint64), shape, 99)
+        assert abs(g.mean() - shape) < 6 * np.sqrt(shape / g.size)
+        assert abs(g.var() - shape) < 0.05 * shape
+        assert stats.kstest(g[:20000], "gamma", args=(shape,)).pvalue > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,df", [("c1", 3.0), ("c2s", 7.5), ("c2s", 0.8)])
+def test_device_student_t_sampler_vs_oracle(ctx, name, df):
+    """Heavy-tailed sampling (reference variational_posterior.py:329-353) on the device generator:
+    identical component labels, samples to rounding against the oracle on the restated streams,
+    and the radial law of a multivariate t."""
+    wl, wd = workload(name)
+    vp, mix = host_vp(wd, ctx), oracle_mix(wd)
+    N = 20001
+    for balance in (False, True):
+        x, i = vp.sample(N, orig_flag=False, balance_flag=balance, df=df, rng="philox", seed=41, shuffle=False)
+        xo, io = sample_ref.sample(mix, N, 41, balance_flag=balance, df=df)
+        assert np.array_equal(i, io)
+        scale = np.maximum(1.0, np.abs(xo))
+        assert np.max(np.abs(x - xo) / scale) <= 1e-12
+    # K = 1 takes the reference's other association (lam * t * z)
+    one = dict(wd, K=1, mu=wd["mu"][:, :1], sigma=wd["sigma"][:1], w=np.ones(1), eta=np.zeros(1))
+    v1, m1 = host_vp(one, ctx), oracle_mix(one)
+    x, _ = v1.sample(5000, orig_flag=False, df=df, rng="philox", seed=5)
+    xo, _ = sample_ref.sample(m1, 5000, 5, df=df)
+    assert np.max(np.abs(x - xo) / np.maximum(1.0, np.abs(xo))) <= 1e-12
+    # statistical: |(x - mu)/(lam sigma)|^2 / D ~ F(D, df)
+    if df > 2:
+        from scipy import stats
+
+        r2 = np.sum(((x - m1.mu.T) / (m1.lambd.reshape(1, -1) * m1.sigma[0])) ** 2, axis=1) / wl.D
+        assert stats.kstest(r2, "f", args=(wl.D, df)).pvalue > 1e-3
+    with pytest.raises(ValueError):
+        vp.sample(10, orig_flag=False, df=-3.0, rng="philox", seed=1)
+
+
 @pytest.mark.gpu
 def test_device_sampler_single_component_and_moments(ctx):
     wl, wd = workload("c2s")
