@@ -1,8 +1,9 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence profiles/README.md describes, on a GPU box:
-#     gpurun -- 'bash tools/collect_profile.sh r01c'
-# then locally:  python tools/summarize_profile.py gpurun_out/r01c r01c
-#                python tools/summarize_rows_pmc.py gpurun_out/r01c r01c
+#     gpurun -- 'bash tools/collect_profile.sh r02'
+# then locally:  python tools/summarize_profile.py gpurun_out/r02 r02
+#                python tools/summarize_rows_pmc.py gpurun_out/r02 r02
+# Every pass runs from /tmp with TMPDIR=/tmp; the PMC passes carry --kernel-trace only.
 set -u
 TAG=${1:-prof}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
@@ -11,23 +12,40 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 B="python $REPO/bench.py --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats     -o s -- $B --steps 50 --warmup 5 > $OUT/bench_under_rocprof_philox.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_res -o s -- $B --steps 50 --warmup 5 --rng resident > $OUT/bench_under_rocprof_resident.json 2>/dev/null
-for mode in philox resident; do
-  extra=""; [ $mode = resident ] && extra="--rng resident"
-  for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${c}_$mode -o p -- $B --steps 10 --warmup 2 $extra > /dev/null 2>&1
+# kernel-trace summaries of the bench command: the headline config (both draw sources) and configs 2, 5
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats     -o s -- $B --steps 50 --warmup 5 > $OUT/bench_under_rocprof_c3_philox.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_res -o s -- $B --steps 50 --warmup 5 --rng resident --no-secondary > $OUT/bench_under_rocprof_c3_resident.json 2>/dev/null
+for c in 2 5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c$c -o s -- $B --config $c --steps 50 --warmup 5 > $OUT/bench_under_rocprof_c$c.json 2>/dev/null
+done
+# HBM traffic of the kernels, one counter per pass, configs 3 and 5 (and 2)
+for c in 3 5 2; do
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_${ctr}_c$c -o p -- $B --config $c --steps 10 --warmup 2 --no-secondary > /dev/null 2>&1
   done
 done
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_SQ1 -o p -- $B --steps 10 --warmup 2 > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/pmc_SQ2 -o p -- $B --steps 10 --warmup 2 > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT/pmc_SQ3 -o p -- $B --steps 10 --warmup 2 > /dev/null 2>&1
+# issue / occupancy counters, configs 3 and 5
+for c in 3 5; do
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_SQ1_c$c -o p -- $B --config $c --steps 10 --warmup 2 --no-secondary > /dev/null 2>&1
+  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/pmc_SQ2_c$c -o p -- $B --config $c --steps 10 --warmup 2 --no-secondary > /dev/null 2>&1
+  rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT/pmc_SQ3_c$c -o p -- $B --config $c --steps 10 --warmup 2 --no-secondary > /dev/null 2>&1
+done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_adam -o s -- python $REPO/tools/adam_loop_profile.py > $OUT/adam_loop.txt 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_rows -o s -- python $REPO/tools/bench_rows.py > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_rows_mfma -o p -- python $REPO/tools/bench_rows.py > /dev/null 2>&1
+# the host-driven step's timeline
+bash $REPO/tools/step_timeline.sh $OUT/timeline --no-secondary > $OUT/timeline_stdout.txt 2>&1
+# keep only the small per-pass summaries (the raw traces exceed what gpurun copies back)
+find $OUT -name "*_kernel_trace.csv" -delete
+find $OUT -name "*_agent_info.csv" -delete
+find $OUT -name "*.db" -delete
+find $OUT -type f -size +8M -delete
 # un-profiled bench lines of the same build
 cd $REPO
-python bench.py --steps 200 --warmup 20 > $OUT/bench_philox.json 2>/dev/null
-python bench.py --steps 200 --warmup 20 --rng resident > $OUT/bench_resident.json 2>/dev/null
+python bench.py --steps 200 --warmup 20 > $OUT/bench_c3_philox.json 2>/dev/null
+python bench.py --steps 200 --warmup 20 --rng resident --no-secondary > $OUT/bench_c3_resident.json 2>/dev/null
+python bench.py --config 5 --steps 100 --warmup 10 > $OUT/bench_c5.json 2>/dev/null
+python bench.py --config 2 --steps 200 --warmup 20 > $OUT/bench_c2.json 2>/dev/null
 python tools/bench_rows.py > $OUT/rows.json 2>/dev/null
-ls $OUT
+python tools/gp_probe.py > $OUT/gp_probe.txt 2>/dev/null
+du -sh $OUT; ls $OUT

@@ -21,14 +21,23 @@ from pathlib import Path
 src, tag = Path(sys.argv[1]), sys.argv[2]
 out = Path(__file__).resolve().parent.parent / "profiles"
 out.mkdir(exist_ok=True)
-for mode, d in (("philox", "stats"), ("resident", "stats_res"), ("adam_loop", "stats_adam")):
+for mode, d in (("philox", "stats"), ("resident", "stats_res"), ("adam_loop", "stats_adam"), ("config2", "stats_c2"),
+                ("config5", "stats_c5")):
     f = src / d / "s_kernel_stats.csv"
     if f.exists():
         shutil.copy(f, out / f"{tag}_kernel_stats_{mode}.csv")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for p in sorted(src.glob("pmc_*/p_counter_collection.csv")):
+    if "rows_mfma" in p.parent.name:
+        continue  # tools/summarize_rows_pmc.py
     for r in csv.DictReader(open(p)):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for extra in ("timeline/timeline.txt", "gp_probe.txt", "adam_loop.txt", "rows.json"):
+    f = src / extra
+    if f.exists():
+        shutil.copy(f, out / f"{tag}_{Path(extra).name}")
+for f in sorted(src.glob("bench_*.json")):
+    shutil.copy(f, out / f"{tag}_{f.name}")
 rows = []
 summary = {}
 for k, v in acc.items():
