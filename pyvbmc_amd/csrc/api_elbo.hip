@@ -122,6 +122,16 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     rc = entmc_pregen(ctx, plan, pa);  // Philox draws generated by extra blocks of the prep launch
     if (rc) return rc;
   }
+  // single GPU, Philox draws read from the ahead buffers: the host polls completion words instead of
+  // waiting for the stream (see below); the GP part gets one of its own so that G / dG are
+  // finalised while the entropy kernel runs
+  const bool can_poll = mc && !multi && opts->eps_mode == VBMC_EPS_PHILOX && ctx->opt_elbo_ahead &&
+                        plan.a.eps != nullptr && plan.a.eps == ctx->d_epsgen[ctx->gen_cur];
+  if (can_poll) {
+    pa.done.cnt = ctx->d_done_cnt + 8;
+    pa.done.flag = ctx->hd_done + 4;
+    pa.done.seq = ++ctx->done_seq;  // the finish kernel publishes the same number to its own word
+  }
   rc = upload_packed_mixture(ctx);
   if (rc) return rc;
   rc = launch_prep(ctx, pa);  // GP sums + (j,k) table rows, one launch
@@ -139,12 +149,12 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     // next to the 611 latency-bound result waves stretch them to 39 us.)
     GenSlice ahead_gen;
     DoneSignal done;
-    if (!multi && opts->eps_mode == VBMC_EPS_PHILOX) {
+    if (can_poll) {
       ahead_gen = entmc_ahead_slice(ctx, plan);
       if (ahead_gen.n_blocks > 0) {
         done.cnt = ctx->d_done_cnt;
         done.flag = ctx->hd_done;
-        done.seq = ++ctx->done_seq;
+        done.seq = ctx->done_seq;
         polled = true;
       }
     }
@@ -254,19 +264,54 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   }
   ctx->host_us[1] = us_since(t_launch);
   const auto t_wait = clk::now();
-  if (polled) {
-    // spin on the completion word (the GPU is <= ~100 us away); a stuck device falls back to the
+  auto spin_on = [&](const volatile uint64_t* f, uint64_t want) {
+    // spin on a completion word (the GPU is <= ~100 us away); a stuck device falls back to the
     // stream wait, which reports the error
-    const volatile uint64_t* f = ctx->h_done;
-    const uint64_t want = ctx->done_seq;
     unsigned spins = 0;
-    bool ok = false;
     for (;;) {
-      if (*f == want) { ok = true; break; }
+      if (*f == want) break;
       __builtin_ia32_pause();
-      if ((++spins & 0xFFFF) == 0 && us_since(t_wait) > 5e6) break;
+      if ((++spins & 0xFFFF) == 0 && us_since(t_wait) > 5e6) return false;
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return true;
+  };
+  // ---- host finalisation, GP part (as soon as the prep launch's sums have landed) ----
+  GljHost& o = sc.glj;
+  double Gv = 0.0;
+  std::vector<double>&dGv = sc.dG, &dHv = sc.dH;
+  auto finalize_gp = [&]() -> int {
+    glj_finalize(ctx, ctx->h_pinned, grad_flags != 0, o);
+    for (int s = 0; s < S; ++s) Gv += o.G[s];
+    Gv /= S;
+    dGv.assign((size_t)n_theta, 0.0);
+    if (grad_flags) {
+      // average the per-sample blocks (linear), then Jacobians
+      std::vector<double>&mu = sc.mu, &sg = sc.sg, &lm = sc.lm, &wg = sc.wg;
+      mu.assign((size_t)K * D, 0.0);
+      sg.assign(K, 0.0);
+      lm.assign(D, 0.0);
+      wg.assign(K, 0.0);
+      for (int s = 0; s < S; ++s) {
+        for (int i = 0; i < K * D; ++i) mu[i] += o.mu[(size_t)s * K * D + i] / S;
+        for (int k = 0; k < K; ++k) sg[k] += o.sigma[(size_t)s * K + k] / S;
+        for (int d = 0; d < D; ++d) lm[d] += o.lambd[(size_t)s * D + d] / S;
+        for (int k = 0; k < K; ++k) wg[k] += o.w[(size_t)s * K + k] / S;
+      }
+      const int n = glj_pack(ctx, mu.data(), sg.data(), lm.data(), wg.data(), grad_flags, 1, dGv.data());
+      if (n != n_theta) return vbmc_fail(ctx, VBMC_E_ARG, "neg_elcbo: gradient length %d != n_theta %d", n, n_theta);
+    }
+    return 0;
+  };
+  bool gp_done = false;
+  if (polled) {
+    bool ok = spin_on(ctx->h_done + 4, ctx->done_seq);
+    if (ok) {
+      rc = finalize_gp();  // overlaps the entropy kernel
+      if (rc) return rc;
+      gp_done = true;
+      ok = spin_on(ctx->h_done, ctx->done_seq);
+    }
     if (!ok) HIP_TRY(ctx, stream_wait(ctx));
   } else {
     HIP_TRY(ctx, stream_wait(ctx));
@@ -274,32 +319,11 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   ctx->pack_in_flight = false;  // the pack upload precedes everything waited for
   ctx->host_us[2] = us_since(t_wait);
   const auto t_fin = clk::now();
-
-  // ---- host finalisation ---------------------------------------------------
-  GljHost& o = sc.glj;
-  glj_finalize(ctx, ctx->h_pinned, grad_flags != 0, o);
-  double Gv = 0.0;
-  for (int s = 0; s < S; ++s) Gv += o.G[s];
-  Gv /= S;
-  std::vector<double>&dGv = sc.dG, &dHv = sc.dH;
-  dGv.assign((size_t)n_theta, 0.0);
-  dHv.assign((size_t)n_theta, 0.0);
-  if (grad_flags) {
-    // average the per-sample blocks (linear), then Jacobians
-    std::vector<double>&mu = sc.mu, &sg = sc.sg, &lm = sc.lm, &wg = sc.wg;
-    mu.assign((size_t)K * D, 0.0);
-    sg.assign(K, 0.0);
-    lm.assign(D, 0.0);
-    wg.assign(K, 0.0);
-    for (int s = 0; s < S; ++s) {
-      for (int i = 0; i < K * D; ++i) mu[i] += o.mu[(size_t)s * K * D + i] / S;
-      for (int k = 0; k < K; ++k) sg[k] += o.sigma[(size_t)s * K + k] / S;
-      for (int d = 0; d < D; ++d) lm[d] += o.lambd[(size_t)s * D + d] / S;
-      for (int k = 0; k < K; ++k) wg[k] += o.w[(size_t)s * K + k] / S;
-    }
-    const int n = glj_pack(ctx, mu.data(), sg.data(), lm.data(), wg.data(), grad_flags, 1, dGv.data());
-    if (n != n_theta) return vbmc_fail(ctx, VBMC_E_ARG, "neg_elcbo: gradient length %d != n_theta %d", n, n_theta);
+  if (!gp_done) {
+    rc = finalize_gp();
+    if (rc) return rc;
   }
+  dHv.assign((size_t)n_theta, 0.0);
   double Hv = 0.0;
   if (mc || lb_dev) {
     const double* r = ctx->h_pinned + n_res;

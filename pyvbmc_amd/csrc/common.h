@@ -240,6 +240,10 @@ struct PrepArgs {
   // kernel -- throughput work that fills the GPU while the few table / GP blocks above sit in
   // their latency chains
   GenSlice gen;
+  // optional completion word of the GP part (res must then be pinned host memory): the GP blocks
+  // store their sums write-through, drain, and the last one to count publishes done.seq, so the
+  // host can finalise G / dG while the entropy kernel runs
+  DoneSignal done;
 };
 // the slice [frac_begin, frac_end) of the K * rows * ceil(D/2) draw items of eps[K][rows][D]
 GenSlice make_gen_slice(double* eps, int K, int D, int64_t rows, int64_t n_half, int64_t row_begin,

@@ -109,7 +109,7 @@ int vbmc_ctx_create(int device_id, vbmc_ctx** out) {
   for (int i = 0; i < 10 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
   if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_done, 64, hipHostMallocDefault);
   if (e == hipSuccess) {
-    ctx->h_done[0] = 0;
+    for (int i = 0; i < 8; ++i) ctx->h_done[i] = 0;
     e = hipHostGetDevicePointer((void**)&ctx->hd_done, ctx->h_done, 0);
   }
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_done_cnt, 64);

@@ -109,6 +109,11 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
   }
   __syncthreads();
   double* out = a.res + ((size_t)s * K + k) * (1 + 2 * D);
+  const bool sig = a.done.flag != nullptr;
+  auto put = [&](double* p, double v) {
+    if (sig) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // write-through to pinned memory
+    else *p = v;
+  };
   {
     double acc = 0.0;
     for (int n = tid; n < N; n += 256) acc += sZa[n];
@@ -132,13 +137,23 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
       au = fm::row16_sum_dpp(au);
       at = fm::row16_sum_dpp(at);
       if (ns == 0) {
-        out[1 + d] = au;
-        out[1 + D + d] = at;
+        put(out + 1 + d, au);
+        put(out + 1 + D + d, at);
       }
     }
   }
+  if (sig) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this thread's results have been acknowledged
   __syncthreads();
-  if (tid == 0) out[0] = (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]);
+  if (tid == 0) {
+    put(out, (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]));
+    if (sig) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      if (__hip_atomic_fetch_add(a.done.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.n_glj * a.batch - 1) {
+        __hip_atomic_store(a.done.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.done.flag, a.done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 }  // namespace
