@@ -105,15 +105,15 @@ extern "C" int vbmc_acq_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int
   mb = mb > 65536 ? 65536 : (mb < 64 ? 64 : (mb / 64) * 64);
   if (M < mb) mb = M;
   // scratch: xs | Ks [S] | part,fpart [S] | fmu[S] | fs2[S] | dens | sn2 | acq | f_bar | var_tot
-  const size_t need = (size_t)mb * D + (size_t)S * mb * N + 2 * (size_t)S * ntiles * mb +
-                      2 * (size_t)S * mb + 5 * (size_t)mb;
+  const size_t ks_n = predict_ks_elems(S, mb, N);
+  const size_t need = align32((size_t)mb * D) + ks_n + 2 * (size_t)S * ntiles * mb + 2 * (size_t)S * mb + 5 * (size_t)mb;
   int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, need);
   if (rc) return rc;
   rc = ensure_pinned(ctx, 3 * (size_t)mb);
   if (rc) return rc;
   double* d_xs = ctx->d_scratch;
-  double* d_Ks = d_xs + (size_t)mb * D;
-  double* d_part = d_Ks + (size_t)S * mb * N;
+  double* d_Ks = d_xs + align32((size_t)mb * D);  // 256-byte aligned: read by 16-byte LDS-direct loads
+  double* d_part = d_Ks + ks_n;
   double* d_fmu = d_part + 2 * (size_t)S * ntiles * mb;
   double* d_fs2 = d_fmu + (size_t)S * mb;
   double* d_dens = d_fs2 + (size_t)S * mb;

@@ -250,15 +250,16 @@ extern "C" int vbmc_acq_is_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, 
   mb = mb > 16384 ? 16384 : (mb < 64 ? 64 : (mb / 64) * 64);
   if (M < mb) mb = M;
   // scratch: xs | Ks [S] | part [S] | fmu [S] | fs2 [S] | sn2 | Kx (mb x N) | T (mb x Na) | acq_s [S] | acq
-  const size_t need = (size_t)mb * D + (size_t)S * mb * N + 2 * (size_t)S * ntiles * mb + 2 * (size_t)S * mb +
+  const size_t ks_n = predict_ks_elems(S, mb, N);
+  const size_t need = align32((size_t)mb * D) + ks_n + 2 * (size_t)S * ntiles * mb + 2 * (size_t)S * mb +
                       (size_t)mb + (size_t)mb * N + (size_t)mb * Na + (size_t)S * mb + 2 * (size_t)mb;
   int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, need);
   if (rc) return rc;
   rc = ensure_pinned(ctx, 2 * (size_t)mb);
   if (rc) return rc;
   double* d_xs = ctx->d_scratch;
-  double* d_Ks = d_xs + (size_t)mb * D;
-  double* d_part = d_Ks + (size_t)S * mb * N;
+  double* d_Ks = d_xs + align32((size_t)mb * D);  // 256-byte aligned: read by 16-byte LDS-direct loads
+  double* d_part = d_Ks + ks_n;
   double* d_fmu = d_part + 2 * (size_t)S * ntiles * mb;
   double* d_fs2 = d_fmu + (size_t)S * mb;
   double* d_sn2 = d_fs2 + (size_t)S * mb;

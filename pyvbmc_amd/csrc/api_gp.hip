@@ -38,6 +38,7 @@ extern "C" int vbmc_set_gp(vbmc_ctx* ctx, int N, int D, int S, int P, int mean_k
   int rc;
   if ((rc = grow(&g.d_X, &g.cap_X, (size_t)N * D)) || (rc = grow(&g.d_alpha, &g.cap_alpha, (size_t)S * N)) ||
       (rc = grow(&g.d_L, &g.cap_L, (size_t)S * nn)) || (rc = grow(&g.d_Linv, &g.cap_Linv, (size_t)S * nn)) ||
+      (rc = grow(&g.d_LinvP, &g.cap_LinvP, (size_t)S * predict_ld(N) * predict_ld(N))) ||
       (rc = grow(&g.d_sW, &g.cap_sW, (size_t)S * N)) || (rc = grow(&g.d_hyp, &g.cap_hyp, (size_t)S * P)) ||
       (rc = grow(&g.d_xc, &g.cap_xc, (size_t)D)) || (rc = grow(&g.d_smeta, &g.cap_smeta, (size_t)3 * S)))
     return rc;
@@ -299,14 +300,15 @@ extern "C" int vbmc_gp_predict(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, i
   mb = mb > 65536 ? 65536 : (mb < 64 ? 64 : (mb / 64) * 64);
   if (M < mb) mb = M;
   // scratch: xs (mb*D) | Ks [S](mb*N) | part, fpart [S](2*ntiles*mb) | fmu [S][mb] | fs2 [S][mb]
-  const size_t need = (size_t)mb * D + (size_t)S * mb * N + 2 * (size_t)S * ntiles * mb + 2 * (size_t)S * mb;
+  const size_t ks_n = predict_ks_elems(S, mb, N);
+  const size_t need = align32((size_t)mb * D) + ks_n + 2 * (size_t)S * ntiles * mb + 2 * (size_t)S * mb;
   int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, need);
   if (rc) return rc;
   rc = ensure_pinned(ctx, 2 * (size_t)S * mb);
   if (rc) return rc;
   double* d_xs = ctx->d_scratch;
-  double* d_Ks = d_xs + (size_t)mb * D;
-  double* d_part = d_Ks + (size_t)S * mb * N;
+  double* d_Ks = d_xs + align32((size_t)mb * D);  // 256-byte aligned: read by 16-byte LDS-direct loads
+  double* d_part = d_Ks + ks_n;
   double* d_fmu = d_part + 2 * (size_t)S * ntiles * mb;
   double* d_fs2 = d_fmu + (size_t)S * mb;
   std::vector<double> mu_s, s2_s;

@@ -56,11 +56,12 @@ struct GpState {
   double* d_alpha = nullptr;  // S x N
   double* d_L = nullptr;      // S x N x N
   double* d_Linv = nullptr;   // S x N x N : inverse of the upper Cholesky factor (L_chol samples)
+  double* d_LinvP = nullptr;  // S x ld x ld, ld = predict_ld(N): the same, zero padded (predict_var_dma_kernel)
   double* d_sW = nullptr;     // S x N
   double* d_hyp = nullptr;    // S x P
   double* d_xc = nullptr;     // D : column means of X (centre of the pairwise-distance expansion)
   double* d_smeta = nullptr;  // S x 3 : (L_chol as 0/1, sn2_mult, 1/sn2_eff) per sample, for kernels batched over s
-  size_t cap_X = 0, cap_alpha = 0, cap_L = 0, cap_Linv = 0, cap_sW = 0, cap_hyp = 0, cap_xc = 0, cap_smeta = 0;
+  size_t cap_X = 0, cap_alpha = 0, cap_L = 0, cap_Linv = 0, cap_LinvP = 0, cap_sW = 0, cap_hyp = 0, cap_xc = 0, cap_smeta = 0;
   std::vector<double> h_small;  // host source of the xc / smeta uploads
 };
 
@@ -141,6 +142,7 @@ struct vbmc_ctx {
   int opt_entmc_valu = 0;   // 1: always the generic entropy kernel
   int opt_elbo_pregen = 1;  // Philox draws generated ahead of the entropy kernel
   int opt_elbo_ahead = 1;   // ... and those of seed+1 speculatively behind the finish kernel
+  int opt_predict_dma = 1;  // predict's variance product through the LDS-direct kernel (batches on Cholesky samples)
   int opt_mix_kernel = 1;   // the mixture pack goes up through a copy kernel of our own instead of hipMemcpyAsync
   double* h_pack_dev = nullptr;     // device-side address of h_pack ...
   double* h_pack_dev_of = nullptr;  // ... valid for this h_pack
@@ -290,6 +292,13 @@ int launch_mixture_pdf_on(vbmc_ctx* ctx, const double* d_pack, const MixLayout& 
 int launch_gp_log_joint(vbmc_ctx* ctx, int want_grad, double* d_res, double* d_Z);
 int launch_gp_var(vbmc_ctx* ctx, const double* d_Z, double* d_V, double* d_Q);
 int launch_trinv(vbmc_ctx* ctx);
+// leading dimension of the padded operands of predict's variance product, and the size of the
+// K* scratch of a batch of mb points (rows rounded up to whole 64-row tiles)
+inline size_t align32(size_t n) { return (n + 31) & ~(size_t)31; }
+inline int predict_ld(int N) { return (N + 63) / 64 * 64; }
+inline size_t predict_ks_elems(int S, int64_t mb, int N) {
+  return (size_t)S * (size_t)((mb + 63) / 64 * 64) * (size_t)predict_ld(N);
+}
 int launch_gp_predict_all(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* d_Ks, double* d_part,
                           int add_noise, double* d_fmu, double* d_fs2, int64_t ld);
 // c[n][m] = |a_n - b_m|^2 (centred expansion, cross term on the FP64 matrix cores), optional

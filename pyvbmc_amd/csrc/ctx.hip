@@ -60,7 +60,8 @@ static void options_from_env(vbmc_ctx* c) {
   c->opt_elbo_ahead = !(e && e[0] == '0');
   e = getenv("VBMC_MIX_KERNEL");
   c->opt_mix_kernel = !(e && e[0] == '0');
-
+  e = getenv("VBMC_PREDICT_DMA");
+  c->opt_predict_dma = !(e && e[0] == '0');
 }
 
 extern "C" {
@@ -141,7 +142,7 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   adam_free(ctx);
   acq_is_free(ctx);
   double* bufs[] = {ctx->d_mix, ctx->d_eps, ctx->d_scratch, ctx->d_out, ctx->gp.d_X,
-                    ctx->gp.d_alpha, ctx->gp.d_L, ctx->gp.d_Linv, ctx->gp.d_sW, ctx->gp.d_hyp,
+                    ctx->gp.d_alpha, ctx->gp.d_L, ctx->gp.d_Linv, ctx->gp.d_LinvP, ctx->gp.d_sW, ctx->gp.d_hyp,
                     ctx->gp.d_xc, ctx->gp.d_smeta};
   for (double* b : bufs)
     if (b) (void)hipFree(b);
@@ -189,7 +190,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "elbo_pregen")) ctx->opt_elbo_pregen = value != 0;
   else if (!strcmp(key, "elbo_ahead")) ctx->opt_elbo_ahead = value != 0;
   else if (!strcmp(key, "mix_kernel")) ctx->opt_mix_kernel = value != 0;
-
+  else if (!strcmp(key, "predict_dma")) ctx->opt_predict_dma = value != 0;
   else return vbmc_fail(ctx, VBMC_E_ARG, "vbmc_set_option: unknown key '%s'", key);
   return VBMC_OK;
 }

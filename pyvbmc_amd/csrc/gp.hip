@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "common.h"
+#include <type_traits>
 #include "fastmath.h"
 
 namespace {
@@ -378,6 +379,273 @@ __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __r
   if (tid < TS && m0 + tid < M) part[(size_t)tile_c * M + m0 + tid] = sRow[tid][0] + sRow[tid][1];
 }
 
+// ---------------------------------------------------------------------------
+// predict, stage 2 for batches of points on L_chol samples: the same partial sums
+//   part[ct][m] = sum_{c in tile ct} T[m][c]^2,  T = A (M x N) * B (N x N upper triangular),
+// with a main loop that holds no vector-ALU work.  On gfx950 v_mfma_f64_16x16x4_f64 runs on the
+// double-precision vector units and nothing else the SIMD issues overlaps it
+// (tools/ubench_mfma_valu.hip, profiles/r02_predict_gemm_ablation.md): the address arithmetic,
+// staging registers and ds_writes of predict_var_mfma_kernel above are paid on top of the matrix
+// time.  Here
+//   * panels (32 deep: A 64 x 32, B 32 x 64 = 32 KB per stage, two stages) come in by
+//     global_load_lds_dwordx4 -- scalar base + per-lane offsets fixed before the loop, no staging
+//     registers, no LDS stores;
+//   * operands are padded (leading dimension ld = N rounded up to 64, zero filled, see
+//     pad_square_kernel and predict_kstar_mfma_kernel's lda), so the loop has no bounds tests;
+//   * the LDS image is lane-linear per DMA instruction; the A rows are XOR-swizzled on the SOURCE
+//     address (16-byte chunk q of row r sits in slot q ^ (r & 15)), which makes the ds_read_b128
+//     of an A fragment conflict-free in each of the instruction's 16-lane groups
+//     (MI355X_MICROARCH.md, LDS); B needs none;
+//   * one ds_read_b128 feeds two matrix instructions: the contraction index is permuted inside a
+//     panel (MFMA step 2t+h, lane group lk  <->  k = 8t + 2 lk + h: an A chunk holds h = 0, 1)
+//     and a wave's two column tiles are the even / odd columns of its 32 (a B chunk holds both);
+//   * column tiles are folded so that every workgroup has (nearly) the same number of panels
+//     (see the kernel); a workgroup's items are one panel sequence through the pipeline.
+// One barrier per panel; the DMA of panel i+1 is in flight during the matrix work of panel i.
+constexpr int DK = 32;                        // panel depth
+constexpr int DMA_STAGE = 2 * TS * DK * 8;    // bytes of one stage: A panel, then B panel
+constexpr int DMA_LDS = 2 * DMA_STAGE + TS * 2 * 8;
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const void* glds_src_t;
+typedef __attribute__((address_space(3))) void* glds_dst_t;
+
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {
+  const uint64_t v = (uint64_t)p;
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  return (const char*)(((uint64_t)hi << 32) | (uint64_t)lo);
+}
+
+#ifdef DMA_ABL_TIMES
+__device__ unsigned long long g_dma_times[8192 * 4];
+#endif
+__global__ __launch_bounds__(256, 2) void predict_var_dma_kernel(const double* __restrict__ A,
+                                                                 const double* __restrict__ B,
+                                                                 int64_t M, int N, int ld,
+                                                                 int64_t a_stride,
+                                                                 double* __restrict__ part,
+                                                                 int64_t part_stride, int nrt, int G) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  const int nct = (N + TS - 1) / TS;
+  // Work assignment.  The triangular skip makes column tile c cost min(N, 64 c + 64) / 32 panels,
+  // two workgroups are resident per CU and a CU's matrix pipes are shared by whatever runs there,
+  // so the kernel ends when the CU with the largest panel total does.  Every workgroup therefore
+  // gets (close to) the same total, 2 nct panels: per row tile the top column tile alone, the
+  // others folded (nct-1-j, j-1), j = 1 .. (nct-1)/2; with nct even the middle tile nct/2 - 1 is
+  // left over and shares a workgroup with the middle tile of the next row tile.  Row tiles are
+  // taken in groups of two for that: nct + 1 workgroups per group; groups are dealt round robin
+  // to the XCDs (block b runs on XCD b % 8), so that every workgroup of a group finds the
+  // group's A rows in the same L2.  The grid is padded to 8 * ceil(ngroups / 8) * (nct + 1).
+  // (M = 8192, N = 400: 512 workgroups of 13 or 14 panels, two per CU.)
+  int it_c[2], it_g[2], nitem = 0;  // up to two (row tile, column tile) items
+  {
+    const int x = blockIdx.x & 7, o = blockIdx.x >> 3;
+    const int ngr = (G + 1) / 2;
+    const int cnt = x < ngr ? (ngr - x + 7) / 8 : 0;  // groups of this XCD
+    if (o >= cnt * (nct + 1)) return;
+    const int grp = x + 8 * (o / (nct + 1)), w = o % (nct + 1);
+    const int h = (nct - 1) / 2, per_row = 1 + h;
+    if (w < 2 * per_row) {
+      const int g = 2 * grp + w / per_row, j = w % per_row;
+      if (g < G) {
+        it_g[0] = it_g[1] = g;
+        it_c[0] = j == 0 ? nct - 1 : nct - 1 - j;
+        it_c[1] = j - 1;
+        nitem = j == 0 ? 1 : 2;
+      }
+    } else {  // nct even: the two middle tiles of the group
+      it_c[0] = it_c[1] = nct / 2 - 1;
+      it_g[0] = 2 * grp;
+      it_g[1] = 2 * grp + 1;
+      nitem = it_g[1] < G ? 2 : 1;
+    }
+    if (nitem == 0) return;
+  }
+#ifdef DMA_ABL_TIMES
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    g_dma_times[blockIdx.x * 4] = wall_clock64();
+    g_dma_times[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+  }
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wc = wave & 1;
+  const int li = lane & 15, lk = lane >> 4;
+  // panels of an item: n < min(N, 64 c + 64) (upper-triangular B: n <= c)
+  const int P1 = (min(N, it_c[0] * TS + TS) + DK - 1) / DK;
+  const int P = P1 + (nitem > 1 ? (min(N, it_c[1] * TS + TS) + DK - 1) / DK : 0);
+  const char* Arow[2];
+  const char* Bcol[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int g = it_g[nitem > 1 ? q : 0], c = it_c[nitem > 1 ? q : 0];
+    const int z = g / nrt;
+    const int64_t m0 = (int64_t)(g - z * nrt) * TS;
+    Arow[q] = uniform_ptr(A + (size_t)z * a_stride + (size_t)m0 * ld);
+    Bcol[q] = uniform_ptr(B + (size_t)z * ld * ld + c * TS);
+  }
+  // DMA source offsets (bytes).  A: instruction j of wave w fills rows 16 w + 4 j + (lane >> 4),
+  // slot lane & 15;  B: rows 2 (4 w + j) + (lane >> 5), chunk lane & 31.
+  unsigned voffA[4], voffB[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = 16 * wave + 4 * j + (lane >> 4);
+    voffA[j] = (unsigned)r * (unsigned)ld * 8u + (unsigned)(((lane & 15) ^ (r & 15)) * 16);
+    const int kb = 2 * (4 * wave + j) + (lane >> 5);
+    voffB[j] = (unsigned)kb * (unsigned)ld * 8u + (unsigned)((lane & 31) * 16);
+  }
+  // fragment addresses (bytes inside a stage)
+  unsigned offA[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) offA[t] = (unsigned)((wm * 32 + li) * 256 + 64 * (t ^ (li >> 2)) + 16 * (lk ^ (li & 3)));
+  const unsigned offB = (unsigned)(TS * DK * 8 + 2 * lk * 512 + (16 * wc + li) * 16);
+  // DMA instruction j (0..3: A, 4..7: B) of a panel (scalar bases ag / bg) into `stage`.  The eight
+  // instructions of the next panel are spread over the matrix instructions of the current one
+  // (one behind every group of four), where their issue costs nothing.
+  // (inline assembly: the scalar-base form `global_load_lds_dwordx4 voff, s[base]` -- hipcc's builtin
+  // re-materialises a 64-bit vector address per instruction, and every vector-ALU instruction in
+  // this loop is time the matrix pipe stands still.  The compiler does not count these loads:
+  // DMA_BARRIER waits for them explicitly.)
+  const unsigned lds0 = (unsigned)(uintptr_t)dsm + (unsigned)wave * 4096u;
+  auto dma = [&](int j, int stage, const char* ag, const char* bg) {
+    const unsigned dst = lds0 + (unsigned)(stage * DMA_STAGE + (j < 4 ? j * 1024 : TS * DK * 8 + (j - 4) * 1024));
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(j < 4 ? voffA[j] : voffB[j - 4]), "s"(j < 4 ? ag : bg), "s"(dst)
+                 : "memory");
+  };
+  auto base_a = [&](int i) {
+#ifdef DMA_ABL_SAMEPANEL
+    i = 0;
+#endif
+    const bool second = i >= P1;
+    return uniform_ptr((second ? Arow[1] : Arow[0]) + (size_t)((second ? i - P1 : i) * DK) * 8);
+  };
+  auto base_b = [&](int i) {
+#ifdef DMA_ABL_SAMEPANEL
+    i = 0;
+#endif
+    const bool second = i >= P1;
+    return uniform_ptr((second ? Bcol[1] : Bcol[0]) + (size_t)((second ? i - P1 : i) * DK) * ld * 8);
+  };
+  double4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  // fragments of k-step pair t+1 are read before the matrix instructions of pair t are issued
+  auto compute = [&](int stage, auto prefetch, const char* ag, const char* bg) {
+    const unsigned char* sa = dsm + stage * DMA_STAGE;
+    double2_t fa[2][2], fb[2][2];  // [buffer][mt] / [buffer][h]
+    auto load = [&](int t, int buf) {
+#ifdef DMA_ABL_NOLDS
+      if (t > 0) return;
+#endif
+      fa[buf][0] = *(const double2_t*)(sa + offA[t]);
+      fa[buf][1] = *(const double2_t*)(sa + offA[t] + 16 * 256);
+      fb[buf][0] = *(const double2_t*)(sa + offB + (8 * t) * 512);
+      fb[buf][1] = *(const double2_t*)(sa + offB + (8 * t + 1) * 512);
+    };
+    load(0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int cur = t & 1;
+      if (t < 3) load(t + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][0][h], fb[cur][h][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][0][h], fb[cur][h][1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][1][h], fb[cur][h][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][1][h], fb[cur][h][1], acc[1][1], 0, 0, 0);
+#ifndef DMA_ABL_NODMA
+        if constexpr (decltype(prefetch)::value) dma(2 * t + h, stage ^ 1, ag, bg);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+#ifdef DMA_ABL_NOBAR
+#define DMA_BARRIER() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define DMA_BARRIER()                                  \
+  do {                                                 \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   \
+    __syncthreads();                                   \
+  } while (0)
+#endif
+  // row sums of T^2 over an item's 64 columns (the padding columns of B are zero)
+  double* sRow = (double*)(dsm + 2 * DMA_STAGE);  // [64][2]
+  auto finish_item = [&](int q) {
+    const int g = it_g[q], c = it_c[q];
+    const int z = g / nrt;
+    const int64_t m0 = (int64_t)(g - z * nrt) * TS;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * 32 + mt * 16 + lk + 4 * r;
+        double v = acc[mt][0][r] * acc[mt][0][r];
+        v = fma(acc[mt][1][r], acc[mt][1][r], v);
+        v = fm::row16_sum_dpp(v);
+        if (li == 0) sRow[row * 2 + wc] = v;
+        acc[mt][0][r] = 0.0;
+        acc[mt][1][r] = 0.0;
+      }
+    __syncthreads();
+    if (tid < TS && m0 + tid < M)
+      part[(size_t)z * part_stride + (size_t)c * M + m0 + tid] = sRow[tid * 2] + sRow[tid * 2 + 1];
+  };
+  {
+    const char* ag = base_a(0);
+    const char* bg = base_b(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dma(j, 0, ag, bg);
+  }
+  // one panel: wait for it, run it (with the next panel's DMA inside when there is one)
+  auto panel = [&](int i, int stage, auto prefetch) {
+    DMA_BARRIER();  // this wave's part of panel i has landed; behind the barrier, everyone's
+    const char* ag = nullptr;
+    const char* bg = nullptr;
+    if constexpr (decltype(prefetch)::value) {
+      ag = base_a(i + 1);
+      bg = base_b(i + 1);
+    }
+    compute(stage, prefetch, ag, bg);
+    if (i == P1 - 1 && P > P1) finish_item(0);
+  };
+  const std::true_type more;
+  const std::false_type last;
+  int i = 0;
+  for (; i + 2 < P; i += 2) {
+    panel(i, 0, more);
+    panel(i + 1, 1, more);
+  }
+  if (P - i == 2) {
+    panel(i, 0, more);
+    panel(i + 1, 1, last);
+  } else {
+    panel(i, 0, last);
+  }
+  finish_item(nitem - 1);
+#ifdef DMA_ABL_TIMES
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    g_dma_times[blockIdx.x * 4 + 1] = wall_clock64();
+    g_dma_times[blockIdx.x * 4 + 3] = P;
+  }
+#endif
+}
+
+// B[s] (N x N, row stride N) -> P[s] (ld x ld), zero filled beyond N: the operand layout of the
+// kernel above.
+__global__ __launch_bounds__(256) void pad_square_kernel(const double* __restrict__ B, int N, int ld,
+                                                         double* __restrict__ P) {
+  const int s = blockIdx.z, r = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ld) return;
+  P[((size_t)s * ld + r) * ld + c] = (r < N && c < N) ? B[((size_t)s * N + r) * N + c] : 0.0;
+}
+
 // The same partial sums for a handful of points (a CMA-ES population, a single candidate): with
 // M <= 32 the 64-row MFMA tile above is mostly padding and its ~25 sequential LDS panels are pure
 // latency (30 us for one point).  Here a workgroup owns 64 columns of one sample and a group of
@@ -463,14 +731,15 @@ __global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
     const double* __restrict__ X, const double* __restrict__ xs, const double* __restrict__ alpha,
     const double* __restrict__ sW, const double* __restrict__ hyp, const double* __restrict__ cen,
     const double* __restrict__ smeta, int P, int N, int D, int64_t M, double* __restrict__ Ks,
-    double* __restrict__ fpart, int64_t part_stride) {
-  // blockIdx.z = GP hyper-parameter sample: all S samples in one launch
+    int lda, int64_t ks_stride, double* __restrict__ fpart, int64_t part_stride) {
+  // blockIdx.z = GP hyper-parameter sample: all S samples in one launch.  Ks: row stride lda,
+  // sample stride ks_stride; lda > N (predict_var_dma_kernel's layout): columns N..lda-1 are zeroed.
   {
     const int s = blockIdx.z;
     alpha += (size_t)s * N;
     sW += (size_t)s * N;
     hyp += (size_t)s * P;
-    Ks += (size_t)s * M * N;
+    Ks += (size_t)s * ks_stride;
     fpart += (size_t)s * part_stride;
   }
   const int scale_sw = smeta[3 * blockIdx.z] != 0.0;  // L_chol sample: stage 2 wants sW o K*
@@ -538,7 +807,7 @@ __global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
         const int n = n0 + col;
         const double d2 = fmax(fma(-2.0, acc[mt][nt][r], sA2[row] + sB2[col]), 0.0);
         const double kv = fm::exp2_fast(fma(c, d2, l2sf2));
-        if (m < M && n < N) Ks[(size_t)m * N + n] = kv * sSc[col];
+        if (m < M && n < lda) Ks[(size_t)m * lda + n] = kv * sSc[col];  // sSc is 0 beyond N
         f = fma(kv, sAl[col], f);  // alpha is 0 beyond N
       }
       f = fm::row16_sum_dpp(f);
@@ -548,6 +817,13 @@ __global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
   if (tid < TS && m0 + tid < M) fpart[(size_t)blockIdx.x * M + m0 + tid] = sF[tid][0] + sF[tid][1];
 }
 
+#ifdef DMA_ABL_TIMES
+}  // namespace
+extern "C" int vbmc_debug_dma_times(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dma_times), sizeof(unsigned long long) * n);
+}
+namespace {
+#endif
 // a13: AbstractAcqFcn._sq_dist (acquisition_functions/abstract_acq_fcn.py:195-222):
 //   c[i][j] = max(|a_i - mu|^2 + |b_j - mu|^2 - 2 (a_i - mu).(b_j - mu), 0),
 // mu = the size-weighted mean of both sets (computed by the caller, `cen`).  Same tiling as
@@ -752,6 +1028,17 @@ int launch_gp_var(vbmc_ctx* ctx, const double* d_Z, double* d_V, double* d_Q) {
   return 0;
 }
 
+// the zero-padded copy of L^-1 predict_var_dma_kernel reads (leading dimension N rounded up to 64)
+static int launch_pad_linv(vbmc_ctx* ctx) {
+  GpState& g = ctx->gp;
+  if (!g.d_LinvP) return 0;
+  const int ld = predict_ld(g.N);
+  hipLaunchKernelGGL(pad_square_kernel, dim3((ld + 255) / 256, ld, g.S), dim3(256), 0, ctx->stream,
+                     (const double*)g.d_Linv, g.N, ld, g.d_LinvP);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
 int launch_trinv(vbmc_ctx* ctx) {
   GpState& g = ctx->gp;
   const int N = g.N, S = g.S;
@@ -760,7 +1047,7 @@ int launch_trinv(vbmc_ctx* ctx) {
   if (lds > 156 * 1024) {  // N > 1088
     hipLaunchKernelGGL(trinv_upper_kernel, dim3((N + 63) / 64, S), dim3(64), 0, ctx->stream, g.d_L, N, g.d_Linv);
     HIP_TRY(ctx, hipGetLastError());
-    return 0;
+    return launch_pad_linv(ctx);
   }
   int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, (size_t)S * nb * TRB * TRB);
   if (rc) return rc;
@@ -777,7 +1064,7 @@ int launch_trinv(vbmc_ctx* ctx) {
   hipLaunchKernelGGL(trinv_strip_kernel, dim3((N + TRS - 1) / TRS, S), dim3(256), lds, ctx->stream,
                      (const double*)g.d_L, N, (const double*)g.d_smeta, (const double*)Dinv, nb, g.d_Linv);
   HIP_TRY(ctx, hipGetLastError());
-  return 0;
+  return launch_pad_linv(ctx);
 }
 
 // All S GP samples, one batch of M points already on the device: three launches in total
@@ -790,11 +1077,30 @@ int launch_gp_predict_all(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* 
   const int ntiles = (N + TS - 1) / TS;
   const int64_t pstride = 2 * (int64_t)ntiles * M;
   const dim3 grid(ntiles, (unsigned)((M + TS - 1) / TS), S);
+  // M > 32 on Cholesky samples: the LDS-direct kernel on padded operands; otherwise the plain layout
+  bool dma = ctx->opt_predict_dma && !(M <= 32 && N <= 3000) && g.d_LinvP;
+  for (int s = 0; s < S && dma; ++s) dma = g.L_chol[s] != 0;
+  const int lda = dma ? ntiles * TS : N;
+  const int64_t ks_stride = dma ? (int64_t)((M + TS - 1) / TS) * TS * lda : M * N;
   hipLaunchKernelGGL(predict_kstar_mfma_kernel, grid, dim3(256), 0, ctx->stream, g.d_X, d_xs,
                      (const double*)g.d_alpha, (const double*)g.d_sW, (const double*)g.d_hyp,
-                     (const double*)g.d_xc, (const double*)g.d_smeta, g.P, N, D, M, d_Ks,
+                     (const double*)g.d_xc, (const double*)g.d_smeta, g.P, N, D, M, d_Ks, lda, ks_stride,
                      d_part + (size_t)ntiles * M, pstride);
-  if (M <= 32 && N <= 3000) {  // a handful of points: see predict_var_small_kernel (LDS <= 128 KB)
+  if (dma) {
+    static bool lds_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!lds_set[dev & 63]) {
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)predict_var_dma_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
+      lds_set[dev & 63] = true;
+    }
+    const int nrt = (int)((M + TS - 1) / TS), G = nrt * S;
+    const int ngr = (G + 1) / 2;
+    const dim3 pgrid((unsigned)(8 * ((ngr + 7) / 8) * (ntiles + 1)));
+    hipLaunchKernelGGL(predict_var_dma_kernel, pgrid, dim3(256), DMA_LDS, ctx->stream, (const double*)d_Ks,
+                       (const double*)g.d_LinvP, M, N, lda, ks_stride, d_part, pstride, nrt, G);
+  } else if (M <= 32 && N <= 3000) {  // a handful of points: see predict_var_small_kernel (LDS <= 128 KB)
     const dim3 sgrid(ntiles, (unsigned)((M + 3) / 4), S);
     const size_t lds = sizeof(double) * ((size_t)4 * N + 16 * 4 * 64);
     if (lds > 64 * 1024)

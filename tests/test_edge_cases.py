@@ -112,6 +112,32 @@ def test_blocked_triangular_inverse(ctx, N):
     assert err <= 1e-10 * max(1.0, sf2)
 
 
+@pytest.mark.parametrize("N,M,S", [(17, 33, 1), (64, 64, 2), (130, 333, 3), (449, 1000, 2), (512, 129, 1), (700, 2100, 1)])
+def test_predict_lds_direct_product(ctx, N, M, S):
+    """Batches of more than 32 points on Cholesky samples take predict_var_dma_kernel (padded
+    operands, LDS-direct loads, folded column tiles); `predict_dma = 0` forces the plain 64 x 64
+    kernel.  Same partial sums in a different order: the two must agree to rounding, and both with
+    the oracle, for N / M on and off the 64-wide tiles and the 32-deep panels."""
+    wl, wd = case(3, 5, N, 40, S=S)
+    _, gp = objects(wd, ctx)
+    ogp = oracle_gp(wd)
+    rng = np.random.default_rng(N + M)
+    xs = rng.standard_normal((M, 3))
+    xs[: min(N, 8)] = wl.X[: min(N, 8)] + 1e-3 * rng.standard_normal((min(N, 8), 3))
+    sf2 = float(np.exp(2 * wl.hyp[:, 3]).max())
+    try:
+        fmu, fs2 = gp.predict(xs, separate_samples=True)
+        ctx.set_option("predict_dma", 0)
+        pmu, ps2 = gp.predict(xs, separate_samples=True)
+    finally:
+        ctx.set_option("predict_dma", 1)
+    omu, os2 = gp_ref.predict(ogp, xs, separate_samples=True)
+    assert np.array_equal(fmu, pmu)  # the mean does not depend on the variance kernel
+    assert np.max(np.abs(fs2 - ps2)) <= 1e-12 * max(1.0, sf2)
+    assert np.max(np.abs(fs2 - os2)) <= 1e-10 * max(1.0, sf2)
+    assert np.max(np.abs(fmu - omu)) <= 1e-10 * max(1.0, np.max(np.abs(omu)))
+
+
 @pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 129])
 def test_gp_sizes_around_the_tiles(ctx, N):
     """_gp_log_joint (+variance), predict and the fused objective for N around the 64-wide
