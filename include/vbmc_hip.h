@@ -98,7 +98,8 @@ int vbmc_set_timing(vbmc_ctx* ctx, int on);
 /* Duration in milliseconds of the most recent TIMED launch (vbmc_set_timing) of the
  * dominant kernel of the given entry point, from HIP events on the ctx's own stream.
  * which: 0 = entmc main kernel, 1 = gp_log_joint, 2 = mixture pdf,
- *        3 = gp_predict, 4 = whole last vbmc_neg_elcbo device section. */
+ *        3 = gp_predict (its three launches), 4 = whole last vbmc_neg_elcbo device section,
+ *        5 = gp_predict's variance product kernel alone. */
 int vbmc_last_kernel_ms(vbmc_ctx* ctx, int which, double* ms_out);
 
 /* Host-side wall-clock breakdown (microseconds) of the most recent vbmc_neg_elcbo:

@@ -84,8 +84,8 @@ struct ElboScratch {
 struct vbmc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[10] = {};  // pairs: (0,1) entmc, (2,3) glj, (4,5) pdf, (6,7) predict, (8,9) elbo
-  bool ev_valid[5] = {false, false, false, false, false};
+  hipEvent_t ev[12] = {};  // pairs: (0,1) entmc, (2,3) glj, (4,5) pdf, (6,7) predict, (8,9) elbo, (10,11) predict's variance product
+  bool ev_valid[6] = {false, false, false, false, false, false};
   std::string err;
   hipDeviceProp_t prop;
 

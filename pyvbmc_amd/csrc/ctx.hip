@@ -107,7 +107,7 @@ int vbmc_ctx_create(int device_id, vbmc_ctx** out) {
   e = hipSetDevice(device_id);
   if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_id);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-  for (int i = 0; i < 10 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
+  for (int i = 0; i < 12 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
   if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_done, 64, hipHostMallocDefault);
   if (e == hipSuccess) {
     for (int i = 0; i < 8; ++i) ctx->h_done[i] = 0;
@@ -153,8 +153,8 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
 
-  for (int i = 0; i < 10; ++i)
-    if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  for (hipEvent_t e : ctx->ev)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -208,7 +208,7 @@ int vbmc_set_timing(vbmc_ctx* ctx, int on) {
 }
 
 int vbmc_last_kernel_ms(vbmc_ctx* ctx, int which, double* ms_out) {
-  if (!ctx || which < 0 || which > 4 || !ms_out) return VBMC_E_ARG;
+  if (!ctx || which < 0 || which > 5 || !ms_out) return VBMC_E_ARG;
   NEED_DEVICE(ctx);
   if (!ctx->ev_valid[which]) return vbmc_fail(ctx, VBMC_E_ARG, "no timed launch recorded for %d", which);
   HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2 * which + 1]));

@@ -15,6 +15,9 @@
 #include "fastmath.h"
 
 namespace {
+#if defined(DMA_ABL_TIMES) || defined(KSTAR_ABL_TIMES)
+__device__ unsigned long long g_dma_times[8192 * 4];
+#endif
 
 constexpr int WAVES = 4;
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -416,9 +419,6 @@ __device__ __forceinline__ const char* uniform_ptr(const void* p) {
   return (const char*)(((uint64_t)hi << 32) | (uint64_t)lo);
 }
 
-#ifdef DMA_ABL_TIMES
-__device__ unsigned long long g_dma_times[8192 * 4];
-#endif
 __global__ __launch_bounds__(256, 2) void predict_var_dma_kernel(const double* __restrict__ A,
                                                                  const double* __restrict__ B,
                                                                  int64_t M, int N, int ld,
@@ -743,6 +743,10 @@ __global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
     fpart += (size_t)s * part_stride;
   }
   const int scale_sw = smeta[3 * blockIdx.z] != 0.0;  // L_chol sample: stage 2 wants sW o K*
+#ifdef KSTAR_ABL_TIMES
+  const int kb_ = blockIdx.y * gridDim.x + blockIdx.x;
+  if (threadIdx.x == 0 && kb_ < 2048) g_dma_times[kb_ * 4] = wall_clock64();
+#endif
   __shared__ double sAm[TS * KDP];  // [64 m][d]
   __shared__ double sBn[TS * KDP];  // [64 n][d]
   __shared__ double sA2[TS], sB2[TS], sAl[TS], sSc[TS];
@@ -753,29 +757,58 @@ __global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
   const int64_t m0 = (int64_t)blockIdx.y * TS;
   const int n0 = blockIdx.x * TS;
   const int DQ = (D + 3) / 4;  // k-steps of 4
-  for (int idx = tid; idx < TS * DQ * 4; idx += 256) {
-    const int r = idx / (DQ * 4), d = idx - r * (DQ * 4);
-    const double iell = (d < D) ? exp(-hyp[d]) : 0.0;
-    const double c0 = (d < D) ? cen[d] : 0.0;
+  // Staging: thread = (row r = tid / 4, quarter q = tid % 4) takes the coordinates d = q, q + 4, ...
+  // of row r of both sets -- every global load of the workgroup is issued before the first is
+  // used (one memory latency, not one per pass), and the squared norms fall out of the same
+  // registers (quad sum by DPP), so a single barrier separates staging from the product.
+  {
+    const int r = tid >> 2, q = tid & 3;
     const int64_t m = m0 + r;
     const int n = n0 + r;
-    sAm[r * KDP + d] = (d < D && m < M) ? (xs[m * D + d] - c0) * iell : 0.0;
-    sBn[r * KDP + d] = (d < D && n < N) ? (X[(size_t)n * D + d] - c0) * iell : 0.0;
-  }
-  __syncthreads();
-  if (tid < TS) {
-    double a2 = 0.0, b2 = 0.0;
-    for (int d = 0; d < D; ++d) {
-      a2 = fma(sAm[tid * KDP + d], sAm[tid * KDP + d], a2);
-      b2 = fma(sBn[tid * KDP + d], sBn[tid * KDP + d], b2);
+    double va[8], vb[8], ie[8], ce[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int d = q + 4 * i;
+      const bool on = d < D;  // (D <= 32)
+      va[i] = (on && m < M) ? xs[m * D + d] : 0.0;
+      vb[i] = (on && n < N) ? X[(size_t)n * D + d] : 0.0;
+      ie[i] = on ? hyp[d] : 0.0;
+      ce[i] = on ? cen[d] : 0.0;
     }
-    sA2[tid] = a2;
-    sB2[tid] = b2;
-    const int n = n0 + tid;
-    sAl[tid] = (n < N) ? alpha[n] : 0.0;
-    sSc[tid] = (n < N) ? (scale_sw ? sW[n] : 1.0) : 0.0;
+    double a2 = 0.0, b2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int d = q + 4 * i;
+      if (d < DQ * 4) {
+        const bool on = d < D;
+#ifdef KSTAR_ABL_NOEXP
+        const double iell = on ? 1.0 - ie[i] : 0.0;
+#else
+        const double iell = on ? exp(-ie[i]) : 0.0;
+#endif
+        const double a = (on && m < M) ? (va[i] - ce[i]) * iell : 0.0;
+        const double b = (on && n < N) ? (vb[i] - ce[i]) * iell : 0.0;
+        sAm[r * KDP + d] = a;
+        sBn[r * KDP + d] = b;
+        a2 = fma(a, a, a2);
+        b2 = fma(b, b, b2);
+      }
+    }
+    a2 += fm::dpp_get<0xB1, 0xf>(a2);  // quad_perm [1,0,3,2]
+    a2 += fm::dpp_get<0x4E, 0xf>(a2);  // quad_perm [2,3,0,1]
+    b2 += fm::dpp_get<0xB1, 0xf>(b2);
+    b2 += fm::dpp_get<0x4E, 0xf>(b2);
+    if (q == 0) {
+      sA2[r] = a2;
+      sB2[r] = b2;
+      sAl[r] = (n < N) ? alpha[n] : 0.0;
+      sSc[r] = (n < N) ? (scale_sw ? sW[n] : 1.0) : 0.0;
+    }
   }
   __syncthreads();
+#ifdef KSTAR_ABL_TIMES
+  const unsigned long long ks_t1 = wall_clock64();
+#endif
   double4_t acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -791,6 +824,9 @@ __global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
     acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
     acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
   }
+#ifdef KSTAR_ABL_TIMES
+  const unsigned long long ks_t2 = wall_clock64();
+#endif
   // epilogue: kernel values, store, partial means
   const double l2sf2 = 2.0 * hyp[D] * 0x1.71547652b82fep+0;  // log2(sf^2)
   const double c = -0.5 * 0x1.71547652b82fep+0;              // -log2(e)/2
@@ -807,7 +843,12 @@ __global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
         const int n = n0 + col;
         const double d2 = fmax(fma(-2.0, acc[mt][nt][r], sA2[row] + sB2[col]), 0.0);
         const double kv = fm::exp2_fast(fma(c, d2, l2sf2));
-        if (m < M && n < lda) Ks[(size_t)m * lda + n] = kv * sSc[col];  // sSc is 0 beyond N
+#ifndef KSTAR_ABL_NOSTORE
+        // (sSc is 0 beyond N.)  Streaming store: the 8 N M bytes of K* are read next by another
+        // kernel on other XCDs; written through now they overlap with this kernel's arithmetic
+        // instead of being flushed from the L2s at its end.
+        if (m < M && n < lda) __builtin_nontemporal_store(kv * sSc[col], Ks + (size_t)m * lda + n);
+#endif
         f = fma(kv, sAl[col], f);  // alpha is 0 beyond N
       }
       f = fm::row16_sum_dpp(f);
@@ -815,9 +856,16 @@ __global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
     }
   __syncthreads();
   if (tid < TS && m0 + tid < M) fpart[(size_t)blockIdx.x * M + m0 + tid] = sF[tid][0] + sF[tid][1];
+#ifdef KSTAR_ABL_TIMES
+  if (threadIdx.x == 0 && kb_ < 2048) {
+    g_dma_times[kb_ * 4 + 1] = wall_clock64();
+    g_dma_times[kb_ * 4 + 2] = ks_t1;
+    g_dma_times[kb_ * 4 + 3] = ks_t2;
+  }
+#endif
 }
 
-#ifdef DMA_ABL_TIMES
+#if defined(DMA_ABL_TIMES) || defined(KSTAR_ABL_TIMES)
 }  // namespace
 extern "C" int vbmc_debug_dma_times(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dma_times), sizeof(unsigned long long) * n);
@@ -1086,6 +1134,7 @@ int launch_gp_predict_all(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* 
                      (const double*)g.d_alpha, (const double*)g.d_sW, (const double*)g.d_hyp,
                      (const double*)g.d_xc, (const double*)g.d_smeta, g.P, N, D, M, d_Ks, lda, ks_stride,
                      d_part + (size_t)ntiles * M, pstride);
+  if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[10], ctx->stream));
   if (dma) {
     static bool lds_set[64] = {};
     int dev = 0;
@@ -1113,6 +1162,10 @@ int launch_gp_predict_all(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* 
     hipLaunchKernelGGL(predict_var_mfma_kernel, grid, dim3(256), 0, ctx->stream, (const double*)d_Ks,
                        (const double*)g.d_Linv, M, N, 0, d_part, (double*)nullptr, (const double*)g.d_L,
                        (const double*)g.d_smeta, pstride);
+  }
+  if (ctx->timing) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[11], ctx->stream));
+    ctx->ev_valid[5] = true;
   }
   hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((M + 255) / 256), S), dim3(256), 0, ctx->stream,
                      (const double*)d_part, pstride, ntiles, M, D, g.P, g.mean_kind, (const double*)g.d_hyp,
