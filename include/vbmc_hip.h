@@ -117,7 +117,17 @@ int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
  *   "elbo_ahead"   [VBMC_ELBO_AHEAD]: 1 = after a Philox evaluation with seed s the draws of
  *                  seed s+1 are generated speculatively while the host finalises (default),
  *                  0 = never
- * Unknown key -> VBMC_E_ARG. */
+ *   "ahead_mode"   [VBMC_AHEAD_MODE]: where that speculative generation runs: 2 = spare
+ *                  workgroups of the finish launch (default), 0 = a launch of its own behind the
+ *                  finish kernel, 1 = a stream of its own (measured slower; kept as the record)
+ *   "mix_bar"      [VBMC_MIX_BAR]: 1 = in the polled host-driven step the CPU writes the mixture
+ *                  pack straight into (fine-grained) device memory and the GP sums run in the
+ *                  finish launch (default), 0 = upload kernel + GP sums in the prep launch
+ *   "mix_kernel"   [VBMC_MIX_KERNEL]: 1 = that upload is a copy kernel (default), 0 = hipMemcpyAsync
+ *   "predict_dma"  [VBMC_PREDICT_DMA]: 1 = gp_predict's variance product for batches of > 32
+ *                  points on Cholesky samples runs in the LDS-direct kernel (default), 0 = the
+ *                  plain 64 x 64-tile kernel (cross-check)
+ * The results of an evaluation do not depend on any of these.  Unknown key -> VBMC_E_ARG. */
 int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value);
 
 /* Launch geometry of the most recent Monte-Carlo entropy of this ctx (vbmc_entmc,

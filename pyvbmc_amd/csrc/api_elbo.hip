@@ -132,9 +132,27 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     pa.done.flag = ctx->hd_done + 4;
     pa.done.seq = ++ctx->done_seq;  // the finish kernel publishes the same number to its own word
   }
-  rc = upload_packed_mixture(ctx);
-  if (rc) return rc;
-  rc = launch_prep(ctx, pa);  // GP sums + (j,k) table rows, one launch
+  // Polled step: the CPU writes the pack into device memory itself (no upload launch; the prep
+  // launch copies it on for the later kernels) and the GP blocks move from the prep launch -- in
+  // front of the entropy kernel -- into the finish launch behind it.
+  PrepArgs gp_tail;
+  bool gp_in_tail = false;
+  double* fg = (can_poll && ctx->opt_mix_bar) ? write_pack_to_device(ctx) : nullptr;
+  if (fg) {
+    gp_tail = pa;
+    gp_tail.n_table = 0;
+    gp_tail.gen = GenSlice();
+    gp_tail.mix = ctx->d_mix;
+    gp_in_tail = pa.n_glj > 0;
+    pa.n_glj = 0;
+    pa.mix = fg;
+    pa.mix_copy = ctx->d_mix;
+    pa.mix_copy_n = ctx->ml.total;
+  } else {
+    rc = upload_packed_mixture(ctx);
+    if (rc) return rc;
+  }
+  rc = launch_prep(ctx, pa);  // (j,k) table rows (+ GP sums, + the draws when they are not ahead), one launch
   if (rc) return rc;
   bool polled = false;
   if (mc) {
@@ -158,9 +176,21 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
         polled = true;
       }
     }
-    rc = entmc_launch_finish(ctx, plan, raw_out, nullptr, polled ? &done : nullptr);
+    if (gp_in_tail && !polled) {  // (no ahead slice after all: the GP blocks still need a launch)
+      gp_tail.done = DoneSignal();
+    }
+    // where the speculative generation goes: (2) spare workgroups of the finish launch itself,
+    // (1) its own stream, queued before the finish launch, (0) a launch of its own behind the
+    // finish kernel on the main stream
+    const int gen_mode = ahead_gen.n_blocks > 0 ? ctx->opt_ahead_mode : -1;
+    if (gen_mode == 1) {
+      rc = entmc_launch_ahead(ctx, ahead_gen);
+      if (rc) return rc;
+    }
+    rc = entmc_launch_finish(ctx, plan, raw_out, gen_mode == 2 ? &ahead_gen : nullptr, polled ? &done : nullptr,
+                             gp_in_tail ? &gp_tail : nullptr);
     if (rc) return rc;
-    if (ahead_gen.n_blocks > 0) {  // a launch of its own behind the short finish kernel
+    if (gen_mode == 0) {
       rc = launch_eps_gen(ctx, ctx->stream, ahead_gen);
       if (rc) return rc;
     }

@@ -95,6 +95,9 @@ struct vbmc_ctx {
   std::vector<double> mu, sigma, lambd, w, eta;  // mu is K x D
   MixLayout ml;
   double* d_mix = nullptr;
+  double* d_mix_fg = nullptr;  // host-writable (fine-grained) device memory: the host-driven step writes the pack here itself
+  size_t d_mix_fg_cap = 0;
+  bool mix_fg_failed = false;
   size_t d_mix_cap = 0;
 
   // Philox draws generated ahead of the entropy kernel (fused objective): two buffers, so the
@@ -103,6 +106,13 @@ struct vbmc_ctx {
   double* d_epsgen[2] = {nullptr, nullptr};
   size_t d_epsgen_cap[2] = {0, 0};
   int gen_cur = 0;  // buffer the current evaluation reads
+  // the speculative generation runs on a stream of its own (it then fills the CUs the entropy
+  // kernel's workgroups leave and overlaps the finish launch and the host's turnaround instead of
+  // standing in front of the next evaluation's first launch); gen_ev is recorded behind it and
+  // queried before the entropy kernel that reads the draws is launched
+  hipStream_t gen_stream = nullptr;
+  hipEvent_t gen_ev = nullptr;
+  bool gen_pending = false;
   struct AheadDraws {
     bool valid = false;
     uint64_t seed = 0;
@@ -143,6 +153,8 @@ struct vbmc_ctx {
   int opt_elbo_pregen = 1;  // Philox draws generated ahead of the entropy kernel
   int opt_elbo_ahead = 1;   // ... and those of seed+1 speculatively behind the finish kernel
   int opt_predict_dma = 1;  // predict's variance product through the LDS-direct kernel (batches on Cholesky samples)
+  int opt_ahead_mode = 2;   // speculative draws: 2 = spare workgroups of the finish launch, 0 = a launch of their own behind it, 1 = on their own stream (measured: slower)
+  int opt_mix_bar = 1;      // host-driven step: pack written by the CPU into device memory (no upload launch), GP sums in the finish launch
   int opt_mix_kernel = 1;   // the mixture pack goes up through a copy kernel of our own instead of hipMemcpyAsync
   double* h_pack_dev = nullptr;     // device-side address of h_pack ...
   double* h_pack_dev_of = nullptr;  // ... valid for this h_pack
@@ -190,6 +202,7 @@ void write_mixture_pack(const MixLayout& ml, const double* mu_KxD, const double*
 int theta_to_arrays(int D, int K, const double* theta, int n_theta, int optimize_mask, double* mu,
                     double* sg, double* lm, double* w, double* eta);
 int upload_packed_mixture(vbmc_ctx* ctx);
+double* write_pack_to_device(vbmc_ctx* ctx);
 int set_mixture_host(vbmc_ctx* ctx, int D, int K, const double* mu_KxD, const double* sigma_K,
                      const double* lambd_D, const double* w_K, const double* eta_K, bool skip_if_same);
 
@@ -226,6 +239,10 @@ struct GenSlice {
 struct PrepArgs {
   const double* mix = nullptr;
   MixLayout ml;
+  // optional: one more workgroup copies mix[0 .. mix_copy_n) to mix_copy (the host-driven step
+  // hands the pack over in host-written device memory; the later launches read the ordinary copy)
+  double* mix_copy = nullptr;
+  int mix_copy_n = 0;
   // table part (n_table = K blocks, or 0)
   int n_table = 0, DP = 0, K4 = 0;
   double* table = nullptr;
@@ -252,6 +269,11 @@ GenSlice make_gen_slice(double* eps, int K, int D, int64_t rows, int64_t n_half,
                         uint64_t seed, const int* seed_add, double frac_begin, double frac_end);
 // wait for everything queued on the ctx stream (also: the pinned mixture pack is free again)
 inline hipError_t stream_wait(vbmc_ctx* ctx) {
+  if (ctx->gen_pending) {  // the speculative draws on their own stream
+    const hipError_t eg = hipStreamSynchronize(ctx->gen_stream);
+    if (eg != hipSuccess) return eg;
+    ctx->gen_pending = false;
+  }
   const hipError_t e = hipStreamSynchronize(ctx->stream);
   if (e == hipSuccess) ctx->pack_in_flight = false;
   return e;
@@ -268,10 +290,14 @@ int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& a);
 
 int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p);
 // `gen`: optional slice of draws for spare workgroups of the finish launch to generate
+// gp: optional GP blocks (glj_block.h) appended to the finish launch's grid
 int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out, const GenSlice* gen = nullptr,
-                        const DoneSignal* done = nullptr);
+                        const DoneSignal* done = nullptr, const PrepArgs* gp = nullptr);
 // the slice of seed+1's draws the finish launch's spare workgroups should generate (n_blocks == 0: none)
 GenSlice entmc_ahead_slice(vbmc_ctx* ctx, const EntPlan& p);
+// launch the speculative slice (on gen_stream when enabled) / wait until a pending one has completed
+int entmc_launch_ahead(vbmc_ctx* ctx, const GenSlice& g);
+int entmc_ahead_wait(vbmc_ctx* ctx);
 void glj_fill_prep(const vbmc_ctx* ctx, int want_grad, double* res, double* Z, PrepArgs& a);
 
 // kernels' host launchers (one per .hip file) -------------------------------

@@ -1,0 +1,103 @@
+// The GP expected-log-joint block (s, k) -- reference vbmc/variational_optimization.py:1400-1465:
+//     res[(s*K+k)*(1+2D) + it],  it = 0       : sum_n z_n alpha_n
+//                                it = 1..D    : sum_n delta_nd   z_n alpha_n
+//                                it = D+1..2D : sum_n delta_nd^2 z_n alpha_n
+//     z_n = exp(lnnf - 1/2 sum_d delta_nd^2),  delta_nd = (mu_dk - X_nd)/tau_dk,
+//     tau_dk = sqrt(sigma_k^2 lambda_d^2 + ell_d^2);  optionally Z[s][k][n] = z_n.
+// One 256-thread workgroup per (s, k); dynamic LDS of glj_block_lds(D, N) bytes.  Shared by the
+// prep launch (prep.hip) and, in the polled host-driven step, by the finish launch (entropy.hip),
+// where the 7 us latency chain of these blocks runs beside the reduction instead of in front of
+// the entropy kernel.
+#pragma once
+#include "common.h"
+#include "fastmath.h"
+
+inline size_t glj_block_lds(int D, int N) { return sizeof(double) * ((size_t)2 * D + N + 4 + 1); }
+
+// a.mix / a.res already advanced to this candidate; b = s * K + k
+__device__ __forceinline__ void glj_block(const PrepArgs& a, int b, double* lds) {
+  const int D = a.ml.D, K = a.ml.K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = b / K, k = b - s * K;
+  const int N = a.N;
+  double* sItau = lds;             // [D]
+  double* sMu = sItau + D;         // [D]
+  double* sZa = sMu + D;           // [N]
+  double* sPart = sZa + N;         // [4]
+  double* sMisc = sPart + 4;       // [1]
+  const double* h = a.hyp + (size_t)s * a.P;
+  const double sigk = a.mix[a.ml.o_sig + k];
+  if (tid < 64) {
+    // wave 0: 1/tau_d, mu_dk and lnnf = 2 hyp[D] + sum_d (hyp[d] - log tau_d)
+    double term = 0.0;
+    for (int d = tid; d < D; d += 64) {
+      const double ell = fm::exp2_fast(0x1.71547652b82fep+0 * h[d]);  // exp(h_d)
+      const double lam = a.mix[a.ml.o_lam + d];
+      const double tau2 = sigk * sigk * lam * lam + ell * ell;
+      sItau[d] = fm::rsqrt_fast(tau2);
+      sMu[d] = a.mix[a.ml.o_mu + k * D + d];
+      term += h[d] - 0.5 * fm::log_fast(tau2);
+    }
+    term = fm::wave_sum_dpp(term);
+    if (tid == 0) sMisc[0] = 2.0 * h[D] + term;
+  }
+  __syncthreads();
+  const double lnnf = sMisc[0];
+  for (int n = tid; n < N; n += 256) {
+    double d2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const double dl = (sMu[d] - a.X[(size_t)n * D + d]) * sItau[d];
+      d2 = fma(dl, dl, d2);
+    }
+    const double z = fm::exp2_fast(0x1.71547652b82fep+0 * (lnnf - 0.5 * d2));  // exp(.)
+    sZa[n] = z * a.alpha[(size_t)s * N + n];
+    if (a.Z) a.Z[((size_t)s * K + k) * N + n] = z;
+  }
+  __syncthreads();
+  double* out = a.res + ((size_t)s * K + k) * (1 + 2 * D);
+  const bool sig = a.done.flag != nullptr;
+  auto put = [&](double* p, double v) {
+    if (sig) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // write-through to pinned memory
+    else *p = v;
+  };
+  {
+    double acc = 0.0;
+    for (int n = tid; n < N; n += 256) acc += sZa[n];
+    acc = fm::wave_sum_dpp(acc);
+    if (lane == 0) sPart[wave] = acc;
+  }
+  if (a.want_grad) {
+    // thread = (slice ns of the points, dimension slot ds): every dimension's two sums advance
+    // side by side (independent loads, one short shuffle reduction over the 16 slices) instead
+    // of one block-wide reduction per dimension
+    const int ns = tid & 15, ds = tid >> 4;
+    for (int d = ds; d < D; d += 16) {
+      const double m = sMu[d], itau = sItau[d];
+      double au = 0.0, at = 0.0;
+      for (int n = ns; n < N; n += 16) {
+        const double dl = (m - a.X[(size_t)n * D + d]) * itau;
+        const double t = dl * sZa[n];
+        au += t;
+        at = fma(dl, t, at);
+      }
+      au = fm::row16_sum_dpp(au);
+      at = fm::row16_sum_dpp(at);
+      if (ns == 0) {
+        put(out + 1 + d, au);
+        put(out + 1 + D + d, at);
+      }
+    }
+  }
+  if (sig) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this thread's results have been acknowledged
+  __syncthreads();
+  if (tid == 0) {
+    put(out, (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]));
+    if (sig) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      if (__hip_atomic_fetch_add(a.done.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.n_glj * a.batch - 1) {
+        __hip_atomic_store(a.done.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.done.flag, a.done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}

@@ -9,10 +9,11 @@
 //                                   it = D+1..2D: sum_n delta_nd^2 z_n alpha_n
 //        z_n = exp(lnnf - 1/2 sum_d delta_nd^2),  delta_nd = (mu_dk - X_nd)/tau_dk,
 //        tau_dk = sqrt(sigma_k^2 lambda_d^2 + ell_d^2);  optionally Z[s][k][n] = z_n.
-//      The host turns these into G, dG (api_gp.hip: glj_finalize).
+//      The host turns these into G, dG (api_gp.hip: glj_finalize).  (Block body: glj_block.h.)
 #include "common.h"
 #include "fastmath.h"
 #include "philox.h"
+#include "glj_block.h"
 
 namespace {
 
@@ -23,7 +24,12 @@ __device__ __forceinline__ double wave_sum(double v) {
 __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
   extern __shared__ double lds[];
   const int D = a.ml.D, K = a.ml.K;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
+  if (a.mix_copy && blockIdx.x == gridDim.x - 1) {
+    // ---- copy block: the pack for the launches behind this one ----
+    for (int i = tid; i < a.mix_copy_n; i += 256) a.mix_copy[i] = a.mix[i];
+    return;
+  }
   a.mix += (size_t)blockIdx.y * a.mix_stride;  // batched sieve: one candidate mixture per grid.y
   a.res += (size_t)blockIdx.y * a.res_stride;
 
@@ -70,90 +76,8 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
     return;
   }
 
-  // ---- GP expected-log-joint block (s,k) ----
-  const int b = blockIdx.x - a.n_table;
-  const int s = b / K, k = b - s * K;
-  const int N = a.N;
-  double* sItau = lds;             // [D]
-  double* sMu = sItau + D;         // [D]
-  double* sZa = sMu + D;           // [N]
-  double* sPart = sZa + N;         // [4]
-  double* sMisc = sPart + 4;       // [1]
-  const double* h = a.hyp + (size_t)s * a.P;
-  const double sigk = a.mix[a.ml.o_sig + k];
-  if (tid < 64) {
-    // wave 0: 1/tau_d, mu_dk and lnnf = 2 hyp[D] + sum_d (hyp[d] - log tau_d)
-    double term = 0.0;
-    for (int d = tid; d < D; d += 64) {
-      const double ell = fm::exp2_fast(0x1.71547652b82fep+0 * h[d]);  // exp(h_d)
-      const double lam = a.mix[a.ml.o_lam + d];
-      const double tau2 = sigk * sigk * lam * lam + ell * ell;
-      sItau[d] = fm::rsqrt_fast(tau2);
-      sMu[d] = a.mix[a.ml.o_mu + k * D + d];
-      term += h[d] - 0.5 * fm::log_fast(tau2);
-    }
-    term = wave_sum(term);
-    if (tid == 0) sMisc[0] = 2.0 * h[D] + term;
-  }
-  __syncthreads();
-  const double lnnf = sMisc[0];
-  for (int n = tid; n < N; n += 256) {
-    double d2 = 0.0;
-    for (int d = 0; d < D; ++d) {
-      const double dl = (sMu[d] - a.X[(size_t)n * D + d]) * sItau[d];
-      d2 = fma(dl, dl, d2);
-    }
-    const double z = fm::exp2_fast(0x1.71547652b82fep+0 * (lnnf - 0.5 * d2));  // exp(.)
-    sZa[n] = z * a.alpha[(size_t)s * N + n];
-    if (a.Z) a.Z[((size_t)s * K + k) * N + n] = z;
-  }
-  __syncthreads();
-  double* out = a.res + ((size_t)s * K + k) * (1 + 2 * D);
-  const bool sig = a.done.flag != nullptr;
-  auto put = [&](double* p, double v) {
-    if (sig) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // write-through to pinned memory
-    else *p = v;
-  };
-  {
-    double acc = 0.0;
-    for (int n = tid; n < N; n += 256) acc += sZa[n];
-    acc = wave_sum(acc);
-    if (lane == 0) sPart[wave] = acc;
-  }
-  if (a.want_grad) {
-    // thread = (slice ns of the points, dimension slot ds): every dimension's two sums advance
-    // side by side (independent loads, one short shuffle reduction over the 16 slices) instead
-    // of one block-wide reduction per dimension
-    const int ns = tid & 15, ds = tid >> 4;
-    for (int d = ds; d < D; d += 16) {
-      const double m = sMu[d], itau = sItau[d];
-      double au = 0.0, at = 0.0;
-      for (int n = ns; n < N; n += 16) {
-        const double dl = (m - a.X[(size_t)n * D + d]) * itau;
-        const double t = dl * sZa[n];
-        au += t;
-        at = fma(dl, t, at);
-      }
-      au = fm::row16_sum_dpp(au);
-      at = fm::row16_sum_dpp(at);
-      if (ns == 0) {
-        put(out + 1 + d, au);
-        put(out + 1 + D + d, at);
-      }
-    }
-  }
-  if (sig) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this thread's results have been acknowledged
-  __syncthreads();
-  if (tid == 0) {
-    put(out, (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]));
-    if (sig) {
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      if (__hip_atomic_fetch_add(a.done.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.n_glj * a.batch - 1) {
-        __hip_atomic_store(a.done.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.done.flag, a.done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-  }
+  // ---- GP expected-log-joint block (s,k): glj_block.h ----
+  glj_block(a, blockIdx.x - a.n_table, lds);
 }
 
 }  // namespace
@@ -163,11 +87,11 @@ int launch_prep(vbmc_ctx* ctx, const PrepArgs& a) { return launch_prep_on(ctx, c
 int launch_prep_on(vbmc_ctx* ctx, hipStream_t stream, const PrepArgs& a) {
   const int D = a.ml.D;
   const int gblocks = a.n_glj;
-  const int grid = a.n_table + gblocks + a.gen.n_blocks;
+  const int grid = a.n_table + gblocks + a.gen.n_blocks + (a.mix_copy ? 1 : 0);
   if (grid <= 0) return 0;
   size_t lds = 0;
   if (gblocks > 0) {
-    lds = sizeof(double) * ((size_t)2 * D + a.N + 4 + 1);
+    lds = glj_block_lds(D, a.N);
     if (lds > 150 * 1024) return vbmc_fail(ctx, VBMC_E_UNSUP, "gp_log_joint: N=%d too large", a.N);
   }
   if (a.n_table > 0) {

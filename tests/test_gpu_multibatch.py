@@ -227,3 +227,55 @@ def test_config5_share_on_one_gpu(ctx):
     err = rel_err(dH, dHo)
     print(f"config 5 share: H rel {abs(H - Ho) / abs(Ho):.2e}, dH rel {err:.2e}, plan {plan}")
     assert abs(H - Ho) <= 1e-10 * abs(Ho) and err < 1e-9
+
+
+@pytest.mark.parametrize("S", [1, 3])
+def test_step_pipeline_variants_bit_identical(ctx, S):
+    """The host-driven step has several launch plans (include/vbmc_hip.h, vbmc_set_option): the pack
+    written by the CPU into device memory with the GP sums in the finish launch or an upload kernel
+    with the GP sums in the prep launch (`mix_bar`), and three places for the speculative
+    generation of the next seed's draws (`ahead_mode`).  They run the same kernels' code on the
+    same inputs: consecutive-seed evaluations (so that the speculation hits from the second one
+    on) must return bit-identical F, dF, G, H under every plan -- and the oracle's values."""
+    from pyvbmc_amd.variational_optimization import _neg_elcbo
+
+    wl = synthetic.make_workload(3, S=S, N=120)
+    D, K = wl.D, wl.K
+    g = dict(D=D, K=K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,
+             s2=wl.s2 if wl.s2 is not None else np.zeros(0))
+    gp = make_gp(g, ctx, wl.hyp)
+    rng = np.random.default_rng(5)
+    thetas = []
+    vp0 = make_vp(g, ctx)
+    th0 = vp0.get_parameters()
+    for i in range(4):
+        thetas.append(th0 + 0.05 * rng.standard_normal(th0.size))
+    NsK = 2 * 64 * 9  # per component; rows = 576
+
+    def run(mix_bar, ahead_mode):
+        ctx.set_option("mix_bar", mix_bar)
+        ctx.set_option("ahead_mode", ahead_mode)
+        out = []
+        try:
+            vp = make_vp(g, ctx)
+            for i, th in enumerate(thetas):
+                F, dF, G, H, _ = _neg_elcbo(th.copy(), gp, vp, 0.0, NsK, True, False, None, 0.0, False,
+                                            rng="philox", seed=900 + i)
+                out.append((F, dF.copy(), G, H))
+        finally:
+            ctx.set_option("mix_bar", 1)
+            ctx.set_option("ahead_mode", 2)
+        return out
+
+    base = run(1, 2)
+    for plan in [(1, 0), (1, 1), (0, 2), (0, 0), (0, 1)]:
+        got = run(*plan)
+        for (F, dF, G, H), (F0, dF0, G0, H0) in zip(got, base):
+            assert F == F0 and G == G0 and H == H0 and np.array_equal(dF, dF0), plan
+    # and the values themselves: the oracle on the restated generator's draws (last evaluation)
+    vp = make_vp(g, ctx)
+    vp.set_parameters(thetas[-1].copy())
+    mix = oracle_mix(dict(mu=vp.mu, sigma=vp.sigma.ravel(), lambd=vp.lambd.ravel(), w=vp.w.ravel(), eta=vp.eta.ravel()))
+    eps = philox_ref.eps_half(K, NsK // 2, D, 900 + len(thetas) - 1)
+    Ho, _ = entropy_ref.entmc(mix, NsK, (True,) * 4, False, eps_half=eps)
+    assert abs(base[-1][3] - Ho) <= 1e-10 * max(1.0, abs(Ho))
