@@ -195,6 +195,9 @@ __global__ __launch_bounds__(WG) void entmc_valu_kernel(EntArgs a) {
 // (entmc_vbmc.py:80,98,102-112 with the 1/Ns and w_j factors applied).
 // One wave per output element; lanes run over the (component j, chunk c) rows it sums.
 // `raw` may be device memory or device-visible pinned host memory.
+#ifdef FIN_TIMES
+__device__ unsigned long long g_fin_times[4];  // start of block 0, publish, latest end of any block, -
+#endif
 __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restrict__ partial,
                                                            int chunks, int stride,
                                                            const double* __restrict__ mix,
@@ -204,6 +207,10 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
                                                            DoneSignal done, PrepArgs gp) {
   extern __shared__ double fin_lds[];
   const int D = ml.D, K = ml.K;
+#ifdef FIN_TIMES
+  if (blockIdx.x == 0 && threadIdx.x == 0) { g_fin_times[0] = wall_clock64(); g_fin_times[2] = 0; }
+  struct EndStamp { __device__ ~EndStamp() { if (threadIdx.x == 0 && ((blockIdx.x & 127) == 0 || blockIdx.x + 8 >= gridDim.x)) atomicMax(&g_fin_times[2], wall_clock64()); } } end_stamp;
+#endif
   {
     // spare workgroups after the reduction's own: the GP expected-log-joint blocks of the
     // host-driven step (glj_block.h) -- independent of the entropy, their latency chain runs
@@ -288,9 +295,19 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
     if (__hip_atomic_fetch_add(done.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_main - 1) {
       __hip_atomic_store(done.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef FIN_TIMES
+      g_fin_times[1] = wall_clock64();
+#endif
     }
   }
 }
+#ifdef FIN_TIMES
+}  // namespace
+extern "C" int vbmc_debug_fin_times(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_times), sizeof(unsigned long long) * 4);
+}
+namespace {
+#endif
 
 // ---------------------------------------------------------------------------
 // entlb (entropy/entlb_vbmc.py:80-159): workgroup j owns row j of the K x K table

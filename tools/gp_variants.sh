@@ -1,16 +1,19 @@
 #!/bin/bash
-# Build variants/libvbmc_<name>.so: the shipped library with gp.hip recompiled under extra -D flags
-# (ablation of the predict kernels).  usage: tools/gp_variants.sh name "-DFLAG ..." [name flags ...]
+# Build variants/libvbmc_<name>.so: the shipped library with ONE translation unit (SRC, default
+# gp.hip) recompiled under extra -D flags (ablations, in-kernel timestamps).
+#   usage: [SRC=entropy.hip] tools/gp_variants.sh name "-DFLAG ..." [name flags ...]
 set -e
 cd "$(dirname "$0")/.."
 python -m pyvbmc_amd.build > /dev/null
 mkdir -p variants
 OBJ=pyvbmc_amd/csrc/_obj
+SRC=${SRC:-gp.hip}
+STEM=${SRC%.hip}
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $flags \
-    -c pyvbmc_amd/csrc/gp.hip -o variants/gp_$name.o
-  objs=$(ls $OBJ/*.o | grep -v "/gp.o")
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs variants/gp_$name.o -o variants/libvbmc_$name.so -ldl -Wl,-rpath,/opt/rocm/lib
+    -c pyvbmc_amd/csrc/$SRC -o variants/${STEM}_$name.o
+  objs=$(ls $OBJ/*.o | grep -v "/$STEM.o")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs variants/${STEM}_$name.o -o variants/libvbmc_$name.so -ldl -Wl,-rpath,/opt/rocm/lib
   echo "variants/libvbmc_$name.so"
 done
