@@ -33,6 +33,14 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_adam -o s -- python $REPO/tools/adam_loop_profile.py > $OUT/adam_loop.txt 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_rows -o s -- python $REPO/tools/bench_rows.py > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_rows_mfma -o p -- python $REPO/tools/bench_rows.py > /dev/null 2>&1
+# gp.predict at the acquisition batch size (M = 8192, config 3): durations, HBM traffic, matrix-pipe and LDS counters
+P="python $REPO/tools/predict_loop.py 3 8192 1 20"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_predict -o s -- $P > /dev/null 2>&1
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_${ctr}_predict -o p -- $P > /dev/null 2>&1
+done
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_MFMA_predict -o p -- $P > /dev/null 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_LDS_predict -o p -- $P > /dev/null 2>&1
 # the host-driven step's timeline
 bash $REPO/tools/step_timeline.sh $OUT/timeline --no-secondary > $OUT/timeline_stdout.txt 2>&1
 # keep only the small per-pass summaries (the raw traces exceed what gpurun copies back)
