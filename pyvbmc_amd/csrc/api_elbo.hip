@@ -31,6 +31,41 @@ static double soft_bound_loss(const std::vector<double>& x, const double* lb, co
   return y;
 }
 
+#ifdef FIN_TIMES
+// debug build: host steady_clock stamps (ns) of the last 64 evaluations -- entry, prep launch issued,
+// all launches issued, GP word seen, main word seen, exit -- and a clock pair for correlating them
+// with the kernels' wall_clock64 stamps (tools/step_times.py)
+static int64_t g_host_stamps[64][6];
+static uint64_t g_host_n = 0;
+static inline int64_t host_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+namespace {
+__global__ void clock_stamp_kernel(unsigned long long* out) {
+  if (threadIdx.x == 0) __hip_atomic_store(out, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+extern "C" int vbmc_debug_host_stamps(int64_t* out) {
+  memcpy(out, g_host_stamps, sizeof(g_host_stamps));
+  return (int)(g_host_n & 63);
+}
+// one (host ns, gpu ticks) pair: the GPU stamp is taken between the two host reads returned
+extern "C" int vbmc_debug_clock_pair(vbmc_ctx* ctx, int64_t* host_before, int64_t* host_after, unsigned long long* gpu) {
+  volatile unsigned long long* f = (volatile unsigned long long*)(ctx->h_done + 6);
+  *f = 0;
+  (void)hipStreamSynchronize(ctx->stream);
+  *host_before = host_ns();
+  hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(64), 0, ctx->stream, (unsigned long long*)(ctx->hd_done + 6));
+  while (*f == 0) __builtin_ia32_pause();
+  *host_after = host_ns();
+  *gpu = *f;
+  return 0;
+}
+#define HSTAMP(i) g_host_stamps[g_host_n & 63][i] = host_ns()
+#else
+#define HSTAMP(i) (void)0
+#endif
+
 extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
                               const vbmc_elbo_opts* opts, double* F, double* dF, double* G,
                               double* H, double* mu_KxD, double* sigma_K, double* lambd_D,
@@ -42,6 +77,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   if (ctx->gp.D != ctx->D) return vbmc_fail(ctx, VBMC_E_ARG, "neg_elcbo: GP/mixture D mismatch");
   using clk = std::chrono::steady_clock;
   const auto t_begin = clk::now();
+  HSTAMP(0);
   auto us_since = [](clk::time_point a) {
     return std::chrono::duration<double, std::micro>(clk::now() - a).count();
   };
@@ -127,10 +163,19 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   // finalised while the entropy kernel runs
   const bool can_poll = mc && !multi && opts->eps_mode == VBMC_EPS_PHILOX && ctx->opt_elbo_ahead &&
                         plan.a.eps != nullptr && plan.a.eps == ctx->d_epsgen[ctx->gen_cur];
+  double* stage = nullptr;  // device staging of both result blocks: [GP sums n_res | raw entropy n_raw]
   if (can_poll) {
+    rc = ensure_dev(ctx, &ctx->d_stage, &ctx->d_stage_cap, n_res + (size_t)n_raw);
+    if (rc) return rc;
+    stage = ctx->d_stage;
     pa.done.cnt = ctx->d_done_cnt + 8;
     pa.done.flag = ctx->hd_done + 4;
     pa.done.seq = ++ctx->done_seq;  // the finish kernel publishes the same number to its own word
+    // results leave through device memory: the last workgroup copies them to the pinned block in
+    // coalesced stores (DoneSignal; single 8-byte stores are one PCIe write each)
+    pa.done.host_out = res_out;
+    pa.done.host_n = (int)n_res;
+    pa.res = stage;
   }
   // Polled step: the CPU writes the pack into device memory itself (no upload launch; the prep
   // launch copies it on for the later kernels) and the GP blocks move from the prep launch -- in
@@ -152,6 +197,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     rc = upload_packed_mixture(ctx);
     if (rc) return rc;
   }
+  HSTAMP(1);
   rc = launch_prep(ctx, pa);  // (j,k) table rows (+ GP sums, + the draws when they are not ahead), one launch
   if (rc) return rc;
   bool polled = false;
@@ -173,21 +219,28 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
         done.cnt = ctx->d_done_cnt;
         done.flag = ctx->hd_done;
         done.seq = ctx->done_seq;
+        done.host_out = raw_out;
+        done.host_n = n_raw;
         polled = true;
       }
     }
     if (gp_in_tail && !polled) {  // (no ahead slice after all: the GP blocks still need a launch)
       gp_tail.done = DoneSignal();
+      gp_tail.res = res_out;
     }
     // where the speculative generation goes: (2) spare workgroups of the finish launch itself,
     // (1) its own stream, queued before the finish launch, (0) a launch of its own behind the
     // finish kernel on the main stream
     const int gen_mode = ahead_gen.n_blocks > 0 ? ctx->opt_ahead_mode : -1;
+    if (gen_mode == 2) {  // deferred-store form: 8 pairs per thread (philox.h)
+      ahead_gen.per_thread = 8;
+      ahead_gen.n_blocks = (int)((ahead_gen.item_count + 2047) / 2048);
+    }
     if (gen_mode == 1) {
       rc = entmc_launch_ahead(ctx, ahead_gen);
       if (rc) return rc;
     }
-    rc = entmc_launch_finish(ctx, plan, raw_out, gen_mode == 2 ? &ahead_gen : nullptr, polled ? &done : nullptr,
+    rc = entmc_launch_finish(ctx, plan, polled ? stage + n_res : raw_out, gen_mode == 2 ? &ahead_gen : nullptr, polled ? &done : nullptr,
                              gp_in_tail ? &gp_tail : nullptr);
     if (rc) return rc;
     if (gen_mode == 0) {
@@ -293,6 +346,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     }
   }
   ctx->host_us[1] = us_since(t_launch);
+  HSTAMP(2);
   const auto t_wait = clk::now();
   auto spin_on = [&](const volatile uint64_t* f, uint64_t want) {
     // spin on a completion word (the GPU is <= ~100 us away); a stuck device falls back to the
@@ -336,6 +390,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   bool gp_done = false;
   if (polled) {
     bool ok = spin_on(ctx->h_done + 4, ctx->done_seq);
+    HSTAMP(3);
     if (ok) {
       rc = finalize_gp();  // overlaps the entropy kernel
       if (rc) return rc;
@@ -348,6 +403,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   }
   ctx->pack_in_flight = false;  // the pack upload precedes everything waited for
   ctx->host_us[2] = us_since(t_wait);
+  HSTAMP(4);
   const auto t_fin = clk::now();
   if (!gp_done) {
     rc = finalize_gp();
@@ -375,6 +431,10 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     for (int i = 0; i < n_theta; ++i) dFv[i] += dFb[i];
   ctx->host_us[3] = us_since(t_fin);
   ctx->host_us[4] = us_since(t_begin);
+#ifdef FIN_TIMES
+  HSTAMP(5);
+  ++g_host_n;
+#endif
   if (F) *F = Fv;
   if (G) *G = Gv;
   if (H) *H = Hv;

@@ -95,6 +95,8 @@ struct vbmc_ctx {
   std::vector<double> mu, sigma, lambd, w, eta;  // mu is K x D
   MixLayout ml;
   double* d_mix = nullptr;
+  double* d_stage = nullptr;   // device staging of the results the polled step hands to the host (DoneSignal)
+  size_t d_stage_cap = 0;
   double* d_mix_fg = nullptr;  // host-writable (fine-grained) device memory: the host-driven step writes the pack here itself
   size_t d_mix_fg_cap = 0;
   bool mix_fg_failed = false;
@@ -223,7 +225,39 @@ struct DoneSignal {
   int* cnt = nullptr;        // device counter of finished result waves
   uint64_t* flag = nullptr;  // device-visible pinned word that receives `seq` when all are done
   uint64_t seq = 0;
+  // Staged hand-over (optional): the kernel's result pointer is then DEVICE memory, and the last
+  // workgroup to count copies host_n doubles from there to host_out (pinned) in coalesced stores
+  // before it publishes.  One 8-byte store per result straight to pinned memory is one PCIe write
+  // each -- ~1700 of them per evaluation queue up for 9-14 us in front of the completion word.
+  double* host_out = nullptr;
+  int host_n = 0;
 };
+
+#ifdef __HIPCC__
+// The staged hand-over's copy (DoneSignal): n doubles from device memory written by other workgroups
+// (write-through stores, already drained) to pinned host memory, by the 256 threads of one
+// workgroup.  Eight loads are in flight per thread before the first store (a load -> store chain
+// per element costs one memory latency each); sc1 loads read past this XCD's L2.
+__device__ __forceinline__ void staged_copy_to_host(const double* __restrict__ src, double* __restrict__ dst, int n) {
+  // (indices are clamped, not predicated: threads past the end repeat element n-1 -- the same value to
+  // the same address -- so the loop body has no branch and the compiler keeps all eight loads, then
+  // all eight write-through stores, in flight instead of draining the queue around every one)
+  for (int base = 0; base < n; base += 256 * 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(base + u * 256 + (int)threadIdx.x, n - 1);
+      v[u] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(base + u * 256 + (int)threadIdx.x, n - 1);
+      __hip_atomic_store(dst + i, v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): acknowledged
+}
+#endif
 
 struct GenSlice {
   double* eps = nullptr;
@@ -233,7 +267,8 @@ struct GenSlice {
   uint64_t seed = 0;
   const int* seed_add = nullptr;  // optional device-side addend (the Adam loop's iteration base)
   int64_t item_begin = 0, item_count = 0;
-  int n_blocks = 0;        // ceil(item_count / 256)
+  int n_blocks = 0;        // ceil(item_count / (256 * per_thread))
+  int per_thread = 1;      // items per thread; > 1: all of a thread's pairs are computed before the first is stored
 };
 
 struct PrepArgs {

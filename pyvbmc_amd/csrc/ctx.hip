@@ -150,7 +150,7 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   vbmc_comm_destroy(ctx);
   adam_free(ctx);
   acq_is_free(ctx);
-  double* bufs[] = {ctx->d_mix, ctx->d_mix_fg, ctx->d_eps, ctx->d_scratch, ctx->d_out, ctx->gp.d_X,
+  double* bufs[] = {ctx->d_mix, ctx->d_mix_fg, ctx->d_stage, ctx->d_eps, ctx->d_scratch, ctx->d_out, ctx->gp.d_X,
                     ctx->gp.d_alpha, ctx->gp.d_L, ctx->gp.d_Linv, ctx->gp.d_LinvP, ctx->gp.d_sW, ctx->gp.d_hyp,
                     ctx->gp.d_xc, ctx->gp.d_smeta};
   for (double* b : bufs)
@@ -368,6 +368,12 @@ double* write_pack_to_device(vbmc_ctx* ctx) {
       ctx->d_mix_fg = nullptr;
     }
     const size_t want = n * 2 + 64;
+    int large_bar = 0;  // CPU stores into device memory need the whole of it behind the PCIe BAR
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) != hipSuccess || !large_bar) {
+      (void)hipGetLastError();
+      ctx->mix_fg_failed = true;
+      return nullptr;
+    }
     if (hipExtMallocWithFlags((void**)&ctx->d_mix_fg, want * sizeof(double), hipDeviceMallocFinegrained) != hipSuccess) {
       (void)hipGetLastError();
       ctx->d_mix_fg = nullptr;

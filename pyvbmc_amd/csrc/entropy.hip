@@ -17,6 +17,10 @@
 #include "fastmath.h"
 #include "entropy_args.h"
 #include "philox.h"
+#ifdef FIN_TIMES
+__device__ unsigned long long g_glj_stamp;
+#define GLJ_STAMP() (g_glj_stamp = wall_clock64())
+#endif
 #include "glj_block.h"
 
 namespace {
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(WG) void entmc_valu_kernel(EntArgs a) {
 // One wave per output element; lanes run over the (component j, chunk c) rows it sums.
 // `raw` may be device memory or device-visible pinned host memory.
 #ifdef FIN_TIMES
-__device__ unsigned long long g_fin_times[4];  // start of block 0, publish, latest end of any block, -
+__device__ unsigned long long g_fin_times[4 + 3 * 64];  // [3] launch counter; per launch n % 64: start of block 0, publish, latest end
 #endif
 __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restrict__ partial,
                                                            int chunks, int stride,
@@ -210,6 +214,8 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
 #ifdef FIN_TIMES
   if (blockIdx.x == 0 && threadIdx.x == 0) { g_fin_times[0] = wall_clock64(); g_fin_times[2] = 0; }
   struct EndStamp { __device__ ~EndStamp() { if (threadIdx.x == 0 && ((blockIdx.x & 127) == 0 || blockIdx.x + 8 >= gridDim.x)) atomicMax(&g_fin_times[2], wall_clock64()); } } end_stamp;
+  // history: the slot of this launch is claimed by the publishing block (below); block 0's start and the
+  // running end maximum are copied there by the last-numbered block, which is dispatched last
 #endif
   {
     // spare workgroups after the reduction's own: the GP expected-log-joint blocks of the
@@ -285,26 +291,40 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
   // increments of a single word would take ~7 us: a word saturates at ~88 atomics per us), and the
   // last workgroup to count publishes the sequence number the same way (MI355X_MICROARCH.md,
   // hand-off with a drained sc1 payload and flag).
+  const bool staged = done.host_out != nullptr;  // raw is device memory; the last workgroup ships it
   if (lane == 0 && t < n) {
-    __hip_atomic_store(raw + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (staged) __hip_atomic_store(raw + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(raw + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   }
+  __shared__ int s_last;
   __syncthreads();
   if (threadIdx.x == 0) {
     const int n_main = (n + 3) / 4;
-    if (__hip_atomic_fetch_add(done.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_main - 1) {
-      __hip_atomic_store(done.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    s_last = __hip_atomic_fetch_add(done.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_main - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (staged) {  // one coalesced copy to the host instead of n single PCIe writes (DoneSignal)
+    staged_copy_to_host(raw, done.host_out, done.host_n);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(done.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef FIN_TIMES
-      g_fin_times[1] = wall_clock64();
+    g_fin_times[1] = wall_clock64();
+    const unsigned long long slot = g_fin_times[3]++ & 63;
+    g_fin_times[4 + 3 * slot] = g_fin_times[0];
+    g_fin_times[4 + 3 * slot + 1] = g_fin_times[1];
+    g_fin_times[4 + 3 * slot + 2] = g_glj_stamp;  // (the GP word of the PREVIOUS launch: it is published later than this)
 #endif
-    }
   }
 }
 #ifdef FIN_TIMES
 }  // namespace
 extern "C" int vbmc_debug_fin_times(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_times), sizeof(unsigned long long) * 4);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_times), sizeof(unsigned long long) * (4 + 3 * 64));
 }
 namespace {
 #endif

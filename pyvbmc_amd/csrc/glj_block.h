@@ -56,8 +56,10 @@ __device__ __forceinline__ void glj_block(const PrepArgs& a, int b, double* lds)
   __syncthreads();
   double* out = a.res + ((size_t)s * K + k) * (1 + 2 * D);
   const bool sig = a.done.flag != nullptr;
+  const bool staged = sig && a.done.host_out != nullptr;  // a.res is device memory; the last block ships it
   auto put = [&](double* p, double v) {
-    if (sig) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // write-through to pinned memory
+    if (staged) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through (sc1): read by another workgroup
+    else if (sig) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // write-through to pinned memory
     else *p = v;
   };
   {
@@ -94,10 +96,23 @@ __device__ __forceinline__ void glj_block(const PrepArgs& a, int b, double* lds)
     put(out, (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]));
     if (sig) {
       __builtin_amdgcn_s_waitcnt(0x0F70);
-      if (__hip_atomic_fetch_add(a.done.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.n_glj * a.batch - 1) {
-        __hip_atomic_store(a.done.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.done.flag, a.done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
+      const bool last = __hip_atomic_fetch_add(a.done.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.n_glj * a.batch - 1;
+      sMisc[0] = last ? 1.0 : 0.0;
     }
+  }
+  if (!sig) return;
+  __syncthreads();
+  if (sMisc[0] == 0.0) return;
+  // last block to count: every block's sums are in memory (drained write-through stores)
+  if (staged) {
+    staged_copy_to_host(a.res, a.done.host_out, a.done.host_n);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    __hip_atomic_store(a.done.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.done.flag, a.done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef GLJ_STAMP
+    GLJ_STAMP();
+#endif
   }
 }

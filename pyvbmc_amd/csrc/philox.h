@@ -44,9 +44,7 @@ __host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 __device__ inline void philox_normal_pair(uint64_t row, uint32_t pair, uint64_t seed, double& z0, double& z1);
 
 // workgroup `block` (0-based among the slice's n_blocks) of a 256-thread launch
-__device__ inline void gen_slice_block(const GenSlice& g, int block, int tid) {
-  const int64_t local = (int64_t)block * 256 + tid;
-  if (local >= g.item_count) return;
+__device__ inline void gen_item(const GenSlice& g, int64_t local, double& z0, double& z1, double*& dst, bool& two) {
   const int64_t t = g.item_begin + local;
   const int np = (g.D + 1) / 2;
   const int p = (int)(t % np);
@@ -54,11 +52,47 @@ __device__ inline void gen_slice_block(const GenSlice& g, int block, int tid) {
   const int64_t j = r / g.rows, i = r - j * g.rows;
   const uint64_t grow = (uint64_t)j * (uint64_t)g.n_half + (uint64_t)(g.row_begin + i);
   const uint64_t seed = g.seed + (g.seed_add ? (uint64_t)g.seed_add[0] : 0);
-  double z0, z1;
   philox_normal_pair(grow, (uint32_t)p, seed, z0, z1);
-  double* dst = g.eps + r * g.D + 2 * p;
-  dst[0] = z0;
-  if (2 * p + 1 < g.D) dst[1] = z1;
+  dst = g.eps + r * g.D + 2 * p;
+  two = 2 * p + 1 < g.D;
+}
+
+__device__ inline void gen_slice_block(const GenSlice& g, int block, int tid) {
+  if (g.per_thread <= 1) {
+    const int64_t local = (int64_t)block * 256 + tid;
+    if (local >= g.item_count) return;
+    double z0, z1;
+    double* dst;
+    bool two;
+    gen_item(g, local, z0, z1, dst, two);
+    dst[0] = z0;
+    if (two) dst[1] = z1;
+    return;
+  }
+  // Deferred-store form (the speculative generation inside the finish launch, api_elbo.hip): a
+  // thread computes its 8 pairs (items block * 2048 + i * 256 + tid: every store instruction of a
+  // wave still writes contiguous memory) and only then stores them.  The generation is arithmetic
+  // for its first two thirds, so the 40 MB of stores reach the memory system in the last third:
+  // the completion word the reduction workgroups of the same launch send to the host is not
+  // queued behind them (it arrived 14-17 us late otherwise).
+  constexpr int PT = 8;
+  double z[PT][2];
+  double* dst[PT];
+  bool two[PT];
+  const int64_t base = (int64_t)block * (256 * PT) + tid;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int64_t local = base + (int64_t)i * 256;
+    dst[i] = nullptr;
+    two[i] = false;
+    if (local < g.item_count) gen_item(g, local, z[i][0], z[i][1], dst[i], two[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < PT; ++i)
+    if (dst[i]) {
+      dst[i][0] = z[i][0];
+      if (two[i]) dst[i][1] = z[i][1];
+    }
 }
 
 __device__ inline void philox_normal_pair(uint64_t row, uint32_t pair, uint64_t seed,

@@ -21,8 +21,14 @@ __device__ __forceinline__ double wave_sum(double v) {
   return fm::wave_sum_dpp(v);
 }
 
+#ifdef FIN_TIMES
+__device__ unsigned long long g_prep_times[2 + 64];  // [0] launch counter, [2 + n % 64] start of block 0 of launch n
+#endif
 __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
   extern __shared__ double lds[];
+#ifdef FIN_TIMES
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_prep_times[2 + (g_prep_times[0]++ & 63)] = wall_clock64();
+#endif
   const int D = a.ml.D, K = a.ml.K;
   const int tid = threadIdx.x;
   if (a.mix_copy && blockIdx.x == gridDim.x - 1) {
@@ -82,6 +88,11 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
 
 }  // namespace
 
+#ifdef FIN_TIMES
+extern "C" int vbmc_debug_prep_times(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prep_times), sizeof(unsigned long long) * 66);
+}
+#endif
 int launch_prep(vbmc_ctx* ctx, const PrepArgs& a) { return launch_prep_on(ctx, ctx->stream, a); }
 
 int launch_prep_on(vbmc_ctx* ctx, hipStream_t stream, const PrepArgs& a) {
