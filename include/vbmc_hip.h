@@ -118,8 +118,10 @@ int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
  *                  seed s+1 are generated speculatively while the host finalises (default),
  *                  0 = never
  *   "ahead_mode"   [VBMC_AHEAD_MODE]: where that speculative generation runs: 2 = spare
- *                  workgroups of the finish launch (default), 0 = a launch of its own behind the
- *                  finish kernel, 1 = a stream of its own (measured slower; kept as the record)
+ *                  workgroups of the finish launch, eight pairs per thread stored after all are
+ *                  computed (default), 3 = the same with one pair per thread, 0 = a launch of its
+ *                  own behind the finish kernel, 1 = a stream of its own (measured slower; kept as
+ *                  the record)
  *   "mix_bar"      [VBMC_MIX_BAR]: 1 = in the polled host-driven step the CPU writes the mixture
  *                  pack straight into (fine-grained) device memory and the GP sums run in the
  *                  finish launch (default), 0 = upload kernel + GP sums in the prep launch

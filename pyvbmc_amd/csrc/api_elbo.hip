@@ -231,8 +231,10 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     // where the speculative generation goes: (2) spare workgroups of the finish launch itself,
     // (1) its own stream, queued before the finish launch, (0) a launch of its own behind the
     // finish kernel on the main stream
-    const int gen_mode = ahead_gen.n_blocks > 0 ? ctx->opt_ahead_mode : -1;
-    if (gen_mode == 2) {  // deferred-store form: 8 pairs per thread (philox.h)
+    int gen_mode = ahead_gen.n_blocks > 0 ? ctx->opt_ahead_mode : -1;
+    const bool defer = gen_mode == 2;  // (3 = the same placement with the generator's plain one-pair-per-thread form)
+    if (gen_mode == 3) gen_mode = 2;
+    if (defer) {  // 8 pairs per thread, stored after all are computed (philox.h)
       ahead_gen.per_thread = 8;
       ahead_gen.n_blocks = (int)((ahead_gen.item_count + 2047) / 2048);
     }

@@ -268,7 +268,7 @@ def test_step_pipeline_variants_bit_identical(ctx, S):
         return out
 
     base = run(1, 2)
-    for plan in [(1, 0), (1, 1), (0, 2), (0, 0), (0, 1)]:
+    for plan in [(1, 0), (1, 1), (1, 3), (0, 2), (0, 0), (0, 1)]:
         got = run(*plan)
         for (F, dF, G, H), (F0, dF0, G0, H0) in zip(got, base):
             assert F == F0 and G == G0 and H == H0 and np.array_equal(dF, dF0), plan
