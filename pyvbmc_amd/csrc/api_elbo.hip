@@ -183,13 +183,28 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   PrepArgs gp_tail;
   bool gp_in_tail = false;
   double* fg = (can_poll && ctx->opt_mix_bar) ? write_pack_to_device(ctx) : nullptr;
+  bool gp_in_ws = false;
   if (fg) {
-    gp_tail = pa;
-    gp_tail.n_table = 0;
-    gp_tail.gen = GenSlice();
-    gp_tail.mix = ctx->d_mix;
-    gp_in_tail = pa.n_glj > 0;
-    pa.n_glj = 0;
+    if (ctx->opt_gp_tail) {
+      gp_tail = pa;
+      gp_tail.n_table = 0;
+      gp_tail.gen = GenSlice();
+      gp_tail.mix = ctx->d_mix;
+      gp_in_tail = pa.n_glj > 0;
+      pa.n_glj = 0;
+      // placement 2: a last row of the entropy launch, if that grid leaves at least `chunks`
+      // workgroup slots free (one round: K * chunks <= CUs * resident workgroups per CU)
+      if (gp_in_tail && ctx->opt_gp_tail == 2 && plan.ws && !entmc_small_applies(plan.a, plan.DP)) {
+        const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        const int slots = cus * ws_min_waves(plan.DP, ws_ktmax_for(K), grad_flags != 0);
+        if (slots - K * plan.a.chunks >= plan.a.chunks) {
+          plan.a.gp = gp_tail;
+          plan.a.gp_items = gp_tail.n_glj;
+          gp_in_ws = true;
+          gp_in_tail = false;
+        }
+      }
+    }
     pa.mix = fg;
     pa.mix_copy = ctx->d_mix;
     pa.mix_copy_n = ctx->ml.total;
@@ -224,6 +239,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
         polled = true;
       }
     }
+    (void)gp_in_ws;
     if (gp_in_tail && !polled) {  // (no ahead slice after all: the GP blocks still need a launch)
       gp_tail.done = DoneSignal();
       gp_tail.res = res_out;

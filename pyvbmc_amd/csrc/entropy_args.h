@@ -21,7 +21,28 @@ struct EntArgs {
   // runs adam_dev::adam_pre_body on this argument block (device memory) -- see adam_dev.h
   const void* extra = nullptr;
   int extra_lds = 0;  // doubles of dynamic LDS that workgroup may use (0: it works from global memory)
+  // wave-split kernel only: gp_items > 0 appends ONE MORE grid row (the last) whose `chunks`
+  // workgroups work through the GP expected-log-joint items 0 .. gp_items-1 (glj_block.h) with the
+  // argument block `gp`.  Dispatched behind every entropy workgroup, they take the workgroup slots
+  // the entropy grid leaves free (the host checks that there are enough, api_elbo.hip), so the GP
+  // sums -- and the host's share of them -- are done long before the entropy kernel ends.
+  int gp_items = 0;
+  PrepArgs gp;
 };
+
+// register-array size (components per wave) the wave-split launcher picks, and the waves per SIMD
+// its build runs at (= resident workgroups per CU: a workgroup is one wave on each SIMD)
+constexpr int ws_ktmax_for(int K) {
+  const int KT = (K + 3) / 4;
+  return KT <= 8 ? 8 : KT <= 13 ? 13 : KT <= 16 ? 16 : KT <= 25 ? 25 : 32;
+}
+constexpr int ws_min_waves(int dp, int ktmax, bool grad) {
+#ifdef VBMC_WS_FORCE_WAVES
+  return VBMC_WS_FORCE_WAVES;
+#else
+  return (grad && 4 * dp + 3 * ktmax > 95) ? 1 : 2;
+#endif
+}
 
 struct EntPlan {
   EntArgs a;

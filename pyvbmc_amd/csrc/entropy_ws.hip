@@ -34,6 +34,7 @@
 #include "common.h"
 #include "entropy_args.h"
 #include "fastmath.h"
+#include "glj_block.h"
 
 // exp2 with its polynomial coefficients held in VGPRs (frees 20 SGPRs for table rows).  Degree
 // 10 here (fastmath.h uses 11): max relative error 4.1e-16 instead of 1.6e-16 in float64 Horner
@@ -86,13 +87,7 @@ __device__ __forceinline__ double wave_sum(double v) { return fm::wave_sum_dpp(v
 // Per-lane state is ~(4 DP + 3 KTMAX) doubles with gradients.  Up to ~95 it fits the 256
 // registers of 2 waves/SIMD; beyond that one wave per SIMD with the 512-register budget
 // (AGPRs as spill space) beats spilling to scratch memory.
-constexpr int ws_min_waves(int dp, int ktmax, bool grad) {
-#ifdef VBMC_WS_FORCE_WAVES
-  return VBMC_WS_FORCE_WAVES;
-#else
-  return (grad && 4 * dp + 3 * ktmax > 95) ? 1 : 2;
-#endif
-}
+// (ws_min_waves: entropy_args.h -- the host uses the same rule to count free workgroup slots)
 
 // End-of-workgroup reduction through an LDS transpose: every wave writes its per-lane accumulators
 // as rows [item][lane] (stride 65), then one THREAD sums one row.  A wave reduction costs ~30
@@ -134,6 +129,15 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
       }
       return;
     }
+  }
+  // Host-driven step (api_elbo.hip): the LAST grid row works through the GP expected-log-joint
+  // items in the workgroup slots this launch's entropy rows leave free (entropy_args.h)
+  if (a.gp_items > 0 && blockIdx.y == gridDim.y - 1) {
+    for (int it = blockIdx.x; it < a.gp_items; it += gridDim.x) {
+      glj_block(a.gp, it, dyn);
+      __syncthreads();
+    }
+    return;
   }
   const int D = a.ml.D, K = a.ml.K;
   const int KT = EXACT ? KTMAX : ((K + 3) >> 2), K4 = KT * 4;
@@ -423,8 +427,9 @@ void launch_one(hipStream_t st, const EntArgs& a, const double* d_table, hipEven
   const bool exact = ((K + 3) / 4 == KTMAX);
   const bool philox = a.eps_mode == VBMC_EPS_PHILOX;
   const bool extra_row = a.extra != nullptr && a.want_grad && !philox;  // see EXTRA_ROW in the kernel
-  const dim3 grid(a.chunks, K + (extra_row ? 1 : 0)), block(WG);
+  const dim3 grid(a.chunks, K + (extra_row ? 1 : 0) + (a.gp_items > 0 ? 1 : 0)), block(WG);
   if (extra_row && sizeof(double) * (size_t)a.extra_lds > lds) lds = sizeof(double) * (size_t)a.extra_lds;
+  if (a.gp_items > 0 && glj_block_lds(a.ml.D, a.gp.N) > lds) lds = glj_block_lds(a.ml.D, a.gp.N);
   int dev = 0;
   if (lds > 32 * 1024) (void)hipGetDevice(&dev);
   // (the raised dynamic-LDS limit is set once per instantiation and size)

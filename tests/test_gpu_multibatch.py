@@ -253,7 +253,11 @@ def test_step_pipeline_variants_bit_identical(ctx, S):
     NsK = 2 * 64 * 9  # per component; rows = 576
 
     def run(mix_bar, ahead_mode):
+        # (ahead_mode + 10 * k: GP sums in the finish launch (k = 1) / the prep launch (k = 0) instead of
+        # the entropy launch's last row)
+        gp_tail, ahead_mode = (ahead_mode // 10 - 1, ahead_mode % 10) if ahead_mode >= 10 else (2, ahead_mode)
         ctx.set_option("mix_bar", mix_bar)
+        ctx.set_option("gp_tail", gp_tail)
         ctx.set_option("ahead_mode", ahead_mode)
         out = []
         try:
@@ -264,11 +268,12 @@ def test_step_pipeline_variants_bit_identical(ctx, S):
                 out.append((F, dF.copy(), G, H))
         finally:
             ctx.set_option("mix_bar", 1)
+            ctx.set_option("gp_tail", 2)
             ctx.set_option("ahead_mode", 2)
         return out
 
     base = run(1, 2)
-    for plan in [(1, 0), (1, 1), (1, 3), (0, 2), (0, 0), (0, 1)]:
+    for plan in [(1, 0), (1, 1), (1, 3), (0, 2), (0, 0), (0, 1), (1, 22), (1, 12)]:
         got = run(*plan)
         for (F, dF, G, H), (F0, dF0, G0, H0) in zip(got, base):
             assert F == F0 and G == G0 and H == H0 and np.array_equal(dF, dF0), plan
