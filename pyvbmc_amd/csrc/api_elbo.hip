@@ -158,10 +158,11 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     rc = entmc_pregen(ctx, plan, pa);  // Philox draws generated by extra blocks of the prep launch
     if (rc) return rc;
   }
-  // single GPU, Philox draws read from the ahead buffers: the host polls completion words instead of
-  // waiting for the stream (see below); the GP part gets one of its own so that G / dG are
-  // finalised while the entropy kernel runs
-  const bool can_poll = mc && !multi && opts->eps_mode == VBMC_EPS_PHILOX && ctx->opt_elbo_ahead &&
+  // single GPU: the host polls completion words instead of waiting for the stream (see below); the
+  // GP part gets one of its own so that G / dG are finalised while the entropy kernel runs.  With
+  // Philox draws read from the ahead buffers the next evaluation's draws are generated speculatively.
+  const bool can_poll = mc && !multi;
+  const bool ahead_ok = can_poll && opts->eps_mode == VBMC_EPS_PHILOX && ctx->opt_elbo_ahead &&
                         plan.a.eps != nullptr && plan.a.eps == ctx->d_epsgen[ctx->gen_cur];
   double* stage = nullptr;  // device staging of both result blocks: [GP sums n_res | raw entropy n_raw]
   if (can_poll) {
@@ -229,15 +230,13 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     GenSlice ahead_gen;
     DoneSignal done;
     if (can_poll) {
-      ahead_gen = entmc_ahead_slice(ctx, plan);
-      if (ahead_gen.n_blocks > 0) {
-        done.cnt = ctx->d_done_cnt;
-        done.flag = ctx->hd_done;
-        done.seq = ctx->done_seq;
-        done.host_out = raw_out;
-        done.host_n = n_raw;
-        polled = true;
-      }
+      if (ahead_ok) ahead_gen = entmc_ahead_slice(ctx, plan);
+      done.cnt = ctx->d_done_cnt;
+      done.flag = ctx->hd_done;
+      done.seq = ctx->done_seq;
+      done.host_out = raw_out;
+      done.host_n = n_raw;
+      polled = true;
     }
     (void)gp_in_ws;
     if (gp_in_tail && !polled) {  // (no ahead slice after all: the GP blocks still need a launch)
