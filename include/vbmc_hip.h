@@ -123,8 +123,11 @@ int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
  *                  own behind the finish kernel, 1 = a stream of its own (measured slower; kept as
  *                  the record)
  *   "mix_bar"      [VBMC_MIX_BAR]: 1 = in the polled host-driven step the CPU writes the mixture
- *                  pack straight into (fine-grained) device memory and the GP sums run in the
- *                  finish launch (default), 0 = upload kernel + GP sums in the prep launch
+ *                  pack straight into (fine-grained) device memory (default), 0 = upload kernel,
+ *                  GP sums in the prep launch
+ *   "gp_tail"      [VBMC_GP_TAIL]: with mix_bar, where the GP expected-log-joint sums run: 2 = in
+ *                  the free workgroup slots of the entropy launch when its grid leaves enough
+ *                  (default; else 1), 1 = in the finish launch, 0 = in the prep launch
  *   "mix_kernel"   [VBMC_MIX_KERNEL]: 1 = that upload is a copy kernel (default), 0 = hipMemcpyAsync
  *   "predict_dma"  [VBMC_PREDICT_DMA]: 1 = gp_predict's variance product for batches of > 32
  *                  points on Cholesky samples runs in the LDS-direct kernel (default), 0 = the
