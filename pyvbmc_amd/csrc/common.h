@@ -156,6 +156,7 @@ struct vbmc_ctx {
   int opt_elbo_ahead = 1;   // ... and those of seed+1 speculatively behind the finish kernel
   int opt_predict_dma = 1;  // predict's variance product through the LDS-direct kernel (batches on Cholesky samples)
   int opt_ahead_mode = 2;   // speculative draws: 2 = spare workgroups of the finish launch, 0 = a launch of their own behind it, 1 = on their own stream (measured: slower)
+  int opt_ws_pair = 1;      // entropy kernel: co-resident workgroups take the same table row (scalar-cache locality)
   int opt_gp_tail = 2;      // with mix_bar: GP sums in a last row of the entropy launch (2; needs free workgroup slots, else 1), in the finish launch (1), in the prep launch (0)
   int opt_mix_bar = 1;      // host-driven step: pack written by the CPU into device memory (no upload launch), GP sums in the finish launch
   int opt_mix_kernel = 1;   // the mixture pack goes up through a copy kernel of our own instead of hipMemcpyAsync

@@ -62,6 +62,8 @@ static void options_from_env(vbmc_ctx* c) {
   c->opt_mix_kernel = !(e && e[0] == '0');
   e = getenv("VBMC_AHEAD_MODE");
   c->opt_ahead_mode = e ? atoi(e) : 2;
+  e = getenv("VBMC_WS_PAIR");
+  c->opt_ws_pair = !(e && e[0] == '0');
   e = getenv("VBMC_GP_TAIL");
   c->opt_gp_tail = e ? atoi(e) : 2;
   e = getenv("VBMC_MIX_BAR");
@@ -204,6 +206,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "predict_dma")) ctx->opt_predict_dma = value != 0;
   else if (!strcmp(key, "mix_bar")) ctx->opt_mix_bar = value != 0;
   else if (!strcmp(key, "gp_tail")) ctx->opt_gp_tail = value;
+  else if (!strcmp(key, "ws_pair")) ctx->opt_ws_pair = value != 0;
   else if (!strcmp(key, "ahead_mode")) {
     (void)entmc_ahead_wait(ctx);
     ctx->opt_ahead_mode = value;

@@ -530,6 +530,14 @@ int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
   }
   a.chunks = (int)((row_count + rows_per_wg - 1) / rows_per_wg);
   if (a.chunks < 1) a.chunks = 1;
+  a.pair_cus = 0;
+  if (p.ws && ctx->opt_ws_pair) {
+    // one round of the 2-waves/SIMD build: workgroups b and b + CUs share a CU (entropy_ws.hip)
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    const int64_t total = (int64_t)K * a.chunks;
+    if (ws_min_waves(p.DP, ws_ktmax_for(K), want_grad != 0) == 2 && total > cus && total <= 2 * (int64_t)cus)
+      a.pair_cus = cus;
+  }
   a.stride = 2 + 2 * D + K;
   const size_t n_part = (size_t)K * a.chunks * a.stride;
   int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, n_part + n_table);

@@ -28,6 +28,10 @@ struct EntArgs {
   // sums -- and the host's share of them -- are done long before the entropy kernel ends.
   int gp_items = 0;
   PrepArgs gp;
+  // wave-split kernel only: > 0 = number of CUs; (j, chunk) items are then handed to workgroups so
+  // that the two workgroups of a CU read the same table row (entropy_ws.hip).  Set by entmc_plan for
+  // one-round grids of the 2-waves/SIMD builds.
+  int pair_cus = 0;
 };
 
 // register-array size (components per wave) the wave-split launcher picks, and the waves per SIMD

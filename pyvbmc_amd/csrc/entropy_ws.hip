@@ -141,7 +141,22 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   }
   const int D = a.ml.D, K = a.ml.K;
   const int KT = EXACT ? KTMAX : ((K + 3) >> 2), K4 = KT * 4;
-  const int j = (EXTRA_ROW && a.extra != nullptr) ? blockIdx.y - 1 : blockIdx.y, chunk = blockIdx.x;
+  int j = (EXTRA_ROW && a.extra != nullptr) ? blockIdx.y - 1 : blockIdx.y, chunk = blockIdx.x;
+  // Scalar-cache locality.  With two workgroups resident per CU and a grid of one round, workgroups
+  // b and b + CUs of a launch share a CU (tools/probes/placement.hip); in grid order they would read
+  // table rows j and j + CUs / chunks -- every CU (and the neighbour it shares its 16 KB scalar cache
+  // with) then sweeps distinct 6.6 KB rows 32 times each and the rows evict each other.  Hand the
+  // (j, chunk) items out so that co-resident workgroups take neighbouring items, i.e. the same j.
+  if (a.pair_cus > 0) {
+    const int total = a.ml.K * a.chunks, b = j * a.chunks + chunk;
+    const int paired = total - a.pair_cus;  // workgroups of the second round = pairs (b, b + pair_cus)
+    if (paired > 0 && b < 2 * a.pair_cus) {
+      const int m = b < a.pair_cus ? b : b - a.pair_cus;
+      const int item = m < paired ? 2 * m + (b >= a.pair_cus ? 1 : 0) : paired + m;
+      j = item / a.chunks;
+      chunk = item - j * a.chunks;
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
