@@ -132,6 +132,8 @@ int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
  *   "predict_dma"  [VBMC_PREDICT_DMA]: 1 = gp_predict's variance product for batches of > 32
  *                  points on Cholesky samples runs in the LDS-direct kernel (default), 0 = the
  *                  plain 64 x 64-tile kernel (cross-check)
+ *   "ws_pair"      [VBMC_WS_PAIR]: 1 = the wave-split entropy kernel hands its (component, chunk)
+ *                  items out so that the two workgroups of a CU read the same table row (default)
  * The results of an evaluation do not depend on any of these.  Unknown key -> VBMC_E_ARG. */
 int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value);
 

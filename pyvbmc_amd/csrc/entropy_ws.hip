@@ -105,6 +105,12 @@ constexpr int ws_epi_doubles(int dp, int ktmax, bool grad) {
   return n <= cap ? n : 0;
 }
 
+#if defined(WS_TIMES) && VBMC_DP == 10
+__device__ unsigned long long g_ws_times[1024 * 4];  // per workgroup: start, batch loop start, batch loop end, end
+#define WS_STAMP(i) do { if (threadIdx.x == 0) g_ws_times[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define WS_STAMP(i) (void)0
+#endif
 template <int DP, int KTMAX, bool GRAD, bool EXACT, bool PHILOX>
 __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_kernel(
     EntArgs a, const double* __restrict__ T) {
@@ -159,6 +165,7 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  WS_STAMP(0);
 
   const double sig_j = a.mix[a.ml.o_sig + j];
   const double sj2 = sig_j * sig_j;
@@ -180,6 +187,7 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   for (int kk = 0; kk < KTMAX; ++kk) Wacc[kk] = 0.0;
 
   const int rows_per_wg = a.rg * 64;
+  WS_STAMP(1);
   for (int it = 0; it < a.rg; ++it) {
     const int64_t i_loc = (int64_t)chunk * rows_per_wg + it * 64 + lane;
     const bool valid = i_loc < a.row_count;
@@ -345,6 +353,7 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
     }
   }
 
+  WS_STAMP(2);
   // ---- workgroup reduction ----
   if constexpr (EPI > 0) {
     constexpr int NI = 1 + 2 * DP + KTMAX, HALF = ws_epi_half(DP, KTMAX);
@@ -410,6 +419,7 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
     __syncthreads();
   }
 
+  WS_STAMP(3);
   double* out = a.partial + ((int64_t)j * a.chunks + chunk) * a.stride;
   for (int t = tid; t < a.stride; t += WG) {
     double v = 0.0;
@@ -484,3 +494,9 @@ void VBMC_CAT(launch_entmc_ws_dp, VBMC_DP)(hipStream_t st, const EntArgs& a, con
   else if (KT <= 25) launch_one<VBMC_DP, 25>(st, a, d_table, e0, e1);
   else launch_one<VBMC_DP, 32>(st, a, d_table, e0, e1);
 }
+
+#if defined(WS_TIMES) && VBMC_DP == 10
+extern "C" int vbmc_debug_ws_times(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ws_times), sizeof(unsigned long long) * n);
+}
+#endif
