@@ -18,7 +18,8 @@ from pyvbmc_amd.variational_optimization import _neg_elcbo  # noqa: E402
 
 ctx = _lib.Context(0)
 _lib.set_default_context(ctx)
-wl = synthetic.make_workload(3, S=1)
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+wl = synthetic.make_workload(cfg, S=1)
 gp = gpm.GP(wl.D, gpm.SquaredExponential(), gpm.NegativeQuadratic(),
             gpm.GaussianNoise(constant_add=True, user_provided_add=wl.s2 is not None))
 gp.update(X_new=wl.X, y_new=wl.y, s2_new=wl.s2, hyp=wl.hyp)
