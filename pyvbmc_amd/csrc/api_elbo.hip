@@ -186,24 +186,28 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   double* fg = (can_poll && ctx->opt_mix_bar) ? write_pack_to_device(ctx) : nullptr;
   bool gp_in_ws = false;
   if (fg) {
-    if (ctx->opt_gp_tail) {
+    // Where the GP sums run.  2: a last row of the entropy launch, if that grid leaves at least
+    // `chunks` workgroup slots free (one round: K * chunks <= CUs * resident workgroups per CU) --
+    // else they stay in the prep launch (measured at config 5, whose grid is two rounds: prep
+    // placement 215 us, finish placement 225 us); 1: the finish launch; 0: the prep launch.
+    bool in_ws = false;
+    if (ctx->opt_gp_tail == 2 && pa.n_glj > 0 && plan.ws && !entmc_small_applies(plan.a, plan.DP)) {
+      const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+      const int slots = cus * ws_min_waves(plan.DP, ws_ktmax_for(K), grad_flags != 0);
+      in_ws = slots - K * plan.a.chunks >= plan.a.chunks;
+    }
+    if (pa.n_glj > 0 && (in_ws || ctx->opt_gp_tail == 1)) {
       gp_tail = pa;
       gp_tail.n_table = 0;
       gp_tail.gen = GenSlice();
       gp_tail.mix = ctx->d_mix;
-      gp_in_tail = pa.n_glj > 0;
       pa.n_glj = 0;
-      // placement 2: a last row of the entropy launch, if that grid leaves at least `chunks`
-      // workgroup slots free (one round: K * chunks <= CUs * resident workgroups per CU)
-      if (gp_in_tail && ctx->opt_gp_tail == 2 && plan.ws && !entmc_small_applies(plan.a, plan.DP)) {
-        const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-        const int slots = cus * ws_min_waves(plan.DP, ws_ktmax_for(K), grad_flags != 0);
-        if (slots - K * plan.a.chunks >= plan.a.chunks) {
-          plan.a.gp = gp_tail;
-          plan.a.gp_items = gp_tail.n_glj;
-          gp_in_ws = true;
-          gp_in_tail = false;
-        }
+      if (in_ws) {
+        plan.a.gp = gp_tail;
+        plan.a.gp_items = gp_tail.n_glj;
+        gp_in_ws = true;
+      } else {
+        gp_in_tail = true;
       }
     }
     pa.mix = fg;
