@@ -263,7 +263,7 @@ def main():
     # (hipExtLaunchKernel: no barrier packet in the queue), read back on every SAMPLE_EVERY-th step
     # of the timed region together with the library's host-side breakdown; the other steps run
     # without any instrumentation call.
-    SAMPLE_EVERY = 8
+    SAMPLE_EVERY = 32
     kern_ms = []
     host_us = np.zeros(5)
     n_host = 0

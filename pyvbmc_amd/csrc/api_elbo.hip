@@ -66,11 +66,38 @@ extern "C" int vbmc_debug_clock_pair(vbmc_ctx* ctx, int64_t* host_before, int64_
 #define HSTAMP(i) (void)0
 #endif
 
+// ---- armed evaluation (common.h ArmedEval) ----------------------------------------------------
+static inline uint64_t* ctl_word(vbmc_ctx* ctx, uint64_t seq) { return ctx->d_ctl + ((seq & 1) ? 4 : 0); }
+
+// Cancel the queued launches of an armed evaluation: they return at once (the prep kernel on the
+// cancel value of its go word, the two behind it on the same word) and the host-side bookkeeping of
+// the speculative draws goes back to what it was before arming.  Does not wait for the stream.
+void spec_disarm(vbmc_ctx* ctx) {
+  vbmc_ctx::ArmedEval& sp = ctx->spec;
+  if (!sp.armed) return;
+  *(volatile uint64_t*)ctl_word(ctx, sp.seq) = ~(uint64_t)0;
+  __builtin_ia32_sfence();
+  sp.armed = false;
+  ++sp.cancels;
+  // the armed finish launch would have generated the draws of seed + 1 into the other buffer; its
+  // own draws (seed) are still where the previous evaluation put them
+  ctx->gen_cur = sp.gen_cur_before;
+  ctx->ahead.valid = sp.ahead_before_valid;
+  ctx->ahead.seed = sp.ahead_before_seed;
+  ctx->ahead.buf = sp.ahead_before_buf;
+  ctx->ahead.frac = sp.ahead_before_frac;
+}
+
 extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
                               const vbmc_elbo_opts* opts, double* F, double* dF, double* G,
                               double* H, double* mu_KxD, double* sigma_K, double* lambd_D,
                               double* w_K, double* eta_K) {
   if (!ctx || !theta || !opts) return VBMC_E_ARG;
+  struct KeepArmed {  // inner calls must not cancel the armed evaluation this call may be about to use
+    vbmc_ctx* c;
+    explicit KeepArmed(vbmc_ctx* c_) : c(c_) { c->spec.keep = true; }
+    ~KeepArmed() { c->spec.keep = false; }
+  } keep_armed(ctx);
   NEED_DEVICE(ctx);
   if (!ctx->mix_set) return vbmc_fail(ctx, VBMC_E_ARG, "neg_elcbo: mixture (D,K) not set");
   if (!ctx->gp.set) return vbmc_fail(ctx, VBMC_E_ARG, "neg_elcbo: GP not set");
@@ -147,136 +174,223 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
 
   ctx->host_us[0] = us_since(t_begin);
   const auto t_launch = clk::now();
-  PrepArgs pa;
-  glj_fill_prep(ctx, grad_flags != 0, res_out, nullptr, pa);
-  EntPlan plan;
-  if (mc) {
-    rc = entmc_plan(ctx, opts->ns_per_comp, opts->eps_mode, opts->seed, row_begin, row_count,
-                    grad_flags != 0, plan);
-    if (rc) return rc;
-    entmc_fill_prep(ctx, plan, pa);
-    rc = entmc_pregen(ctx, plan, pa);  // Philox draws generated by extra blocks of the prep launch
-    if (rc) return rc;
-  }
   // single GPU: the host polls completion words instead of waiting for the stream (see below); the
   // GP part gets one of its own so that G / dG are finalised while the entropy kernel runs.  With
   // Philox draws read from the ahead buffers the next evaluation's draws are generated speculatively.
   const bool can_poll = mc && !multi;
-  const bool ahead_ok = can_poll && opts->eps_mode == VBMC_EPS_PHILOX && ctx->opt_elbo_ahead &&
-                        plan.a.eps != nullptr && plan.a.eps == ctx->d_epsgen[ctx->gen_cur];
   double* stage = nullptr;  // device staging of both result blocks: [GP sums n_res | raw entropy n_raw]
   if (can_poll) {
     rc = ensure_dev(ctx, &ctx->d_stage, &ctx->d_stage_cap, n_res + (size_t)n_raw);
     if (rc) return rc;
     stage = ctx->d_stage;
-    pa.done.cnt = ctx->d_done_cnt + 8;
-    pa.done.flag = ctx->hd_done + 4;
-    pa.done.seq = ++ctx->done_seq;  // the finish kernel publishes the same number to its own word
-    // results leave through device memory: the last workgroup copies them to the pinned block in
-    // coalesced stores (DoneSignal; single 8-byte stores are one PCIe write each)
-    pa.done.host_out = res_out;
-    pa.done.host_n = (int)n_res;
-    pa.res = stage;
   }
-  // Polled step: the CPU writes the pack into device memory itself (no upload launch; the prep
-  // launch copies it on for the later kernels) and the GP blocks move from the prep launch -- in
-  // front of the entropy kernel -- into the finish launch behind it.
-  PrepArgs gp_tail;
-  bool gp_in_tail = false;
-  double* fg = (can_poll && ctx->opt_mix_bar) ? write_pack_to_device(ctx) : nullptr;
-  bool gp_in_ws = false;
-  if (fg) {
-    // Where the GP sums run.  2: a last row of the entropy launch, if that grid leaves at least
-    // `chunks` workgroup slots free (one round: K * chunks <= CUs * resident workgroups per CU) --
-    // else they stay in the prep launch (measured at config 5, whose grid is two rounds: prep
-    // placement 215 us, finish placement 225 us); 1: the finish launch; 0: the prep launch.
-    bool in_ws = false;
-    if (ctx->opt_gp_tail == 2 && pa.n_glj > 0 && plan.ws && !entmc_small_applies(plan.a, plan.DP)) {
-      const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-      const int slots = cus * ws_min_waves(plan.DP, ws_ktmax_for(K), grad_flags != 0);
-      in_ws = slots - K * plan.a.chunks >= plan.a.chunks;
-    }
-    if (pa.n_glj > 0 && (in_ws || ctx->opt_gp_tail == 1)) {
-      gp_tail = pa;
-      gp_tail.n_table = 0;
-      gp_tail.gen = GenSlice();
-      gp_tail.mix = ctx->d_mix;
-      pa.n_glj = 0;
-      if (in_ws) {
-        plan.a.gp = gp_tail;
-        plan.a.gp_items = gp_tail.n_glj;
-        gp_in_ws = true;
-      } else {
-        gp_in_tail = true;
-      }
-    }
-    pa.mix = fg;
-    pa.mix_copy = ctx->d_mix;
-    pa.mix_copy_n = ctx->ml.total;
-  } else {
-    rc = upload_packed_mixture(ctx);
-    if (rc) return rc;
-  }
-  HSTAMP(1);
-  rc = launch_prep(ctx, pa);  // (j,k) table rows (+ GP sums, + the draws when they are not ahead), one launch
-  if (rc) return rc;
+  vbmc_ctx::ArmedEval& sp = ctx->spec;
+  // (whether the next evaluation will be armed decides how the next draws are split, see ahead_pct)
+  const bool arm_next = can_poll && ctx->opt_elbo_arm && ctx->opt_mix_bar && !ctx->timing &&
+                        opts->eps_mode == VBMC_EPS_PHILOX && ctx->opt_ahead_pct > 0 && ctx->opt_ahead_pct <= 100 &&
+                        (ctx->opt_ahead_mode == 2 || ctx->opt_ahead_mode == 3);
+
+  // Plan and queue the launches of ONE evaluation with Philox seed `seed`.  spin = false: for this
+  // call's theta (the pack is in ctx->h_pack); spin = true: armed -- the prep kernel waits for the
+  // go word the NEXT call writes together with its pack.  Nothing here depends on theta.
   bool polled = false;
-  if (mc) {
-    rc = entmc_launch_main(ctx, plan);
-    if (rc) return rc;
-    // Philox draws: the next evaluation's (seed + 1) are generated right behind this evaluation's
-    // last launch, while the host finalises, returns and comes back with the next theta.  The
-    // host therefore does not wait for the stream: the finish kernel's last result wave stores a
-    // sequence number into pinned memory and the host polls that word.  (An event between the
-    // finish kernel and the generation was measured first: its barrier packet delays the wake-up
-    // by ~7 us.  Generating in spare workgroups of the finish launch itself: the 40 MB of stores
-    // next to the 611 latency-bound result waves stretch them to 39 us.)
-    GenSlice ahead_gen;
-    DoneSignal done;
+  uint64_t cur_seq = 0;
+  auto issue = [&](uint64_t seed, bool spin, bool& polled_out, uint64_t& seq_out) -> int {
+    int rc2;
+    PrepArgs pa;
+    glj_fill_prep(ctx, grad_flags != 0, res_out, nullptr, pa);
+    EntPlan plan;
+    if (mc) {
+      rc2 = entmc_plan(ctx, opts->ns_per_comp, opts->eps_mode, seed, row_begin, row_count, grad_flags != 0, plan);
+      if (rc2) return rc2;
+      entmc_fill_prep(ctx, plan, pa);
+      rc2 = entmc_pregen(ctx, plan, pa);  // Philox draws generated by extra blocks of the prep launch
+      if (rc2) return rc2;
+    }
+    const bool ahead_ok = can_poll && opts->eps_mode == VBMC_EPS_PHILOX && ctx->opt_elbo_ahead &&
+                          plan.a.eps != nullptr && plan.a.eps == ctx->d_epsgen[ctx->gen_cur];
+    if (spin && !(ahead_ok && plan.pregen_hit && plan.ws && !entmc_small_applies(plan.a, plan.DP)))
+      return -1000;  // (not a shape to arm: the caller restores the bookkeeping)
     if (can_poll) {
-      if (ahead_ok) ahead_gen = entmc_ahead_slice(ctx, plan);
-      done.cnt = ctx->d_done_cnt;
-      done.flag = ctx->hd_done;
-      done.seq = ctx->done_seq;
-      done.host_out = raw_out;
-      done.host_n = n_raw;
+      pa.done.cnt = ctx->d_done_cnt + 8;
+      pa.done.flag = ctx->hd_done + 4;
+      pa.done.seq = ++ctx->done_seq;  // the finish kernel publishes the same number to its own word
+      // results leave through device memory: the last workgroup copies them to the pinned block in
+      // coalesced stores (DoneSignal; single 8-byte stores are one PCIe write each)
+      pa.done.host_out = res_out;
+      pa.done.host_n = (int)n_res;
+      pa.res = stage;
+    }
+    seq_out = ctx->done_seq;
+    // Polled step: the CPU writes the pack into device memory itself (no upload launch; the prep
+    // launch copies it on for the later kernels).
+    PrepArgs gp_tail;
+    bool gp_in_tail = false;
+    double* fg = nullptr;
+    if (can_poll && ctx->opt_mix_bar) fg = spin ? ctx->d_mix_fg : write_pack_to_device(ctx);
+    if (spin && !fg) return -1000;
+    if (fg) {
+      // Where the GP sums run.  2: a last row of the entropy launch, if that grid leaves at least
+      // `chunks` workgroup slots free (one round: K * chunks <= CUs * resident workgroups per CU) --
+      // else they stay in the prep launch (measured at config 5, whose grid is two rounds: prep
+      // placement 215 us, finish placement 225 us); 1: the finish launch; 0: the prep launch.
+      bool in_ws = false;
+      if (ctx->opt_gp_tail == 2 && pa.n_glj > 0 && plan.ws && !entmc_small_applies(plan.a, plan.DP)) {
+        const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        const int slots = cus * ws_min_waves(plan.DP, ws_ktmax_for(K), grad_flags != 0);
+        in_ws = slots - K * plan.a.chunks >= plan.a.chunks;
+      }
+      if (pa.n_glj > 0 && (in_ws || ctx->opt_gp_tail == 1)) {
+        gp_tail = pa;
+        gp_tail.n_table = 0;
+        gp_tail.gen = GenSlice();
+        gp_tail.mix = ctx->d_mix;
+        pa.n_glj = 0;
+        if (in_ws) {
+          plan.a.gp = gp_tail;
+          plan.a.gp_items = gp_tail.n_glj;
+        } else {
+          gp_in_tail = true;
+        }
+      }
+      pa.mix = fg;
+      pa.mix_copy = ctx->d_mix;
+      pa.mix_copy_n = ctx->ml.total;
+    } else {
+      rc2 = upload_packed_mixture(ctx);
+      if (rc2) return rc2;
+    }
+    uint64_t* ctl = nullptr;
+    if (spin) {
+      ctl = ctl_word(ctx, seq_out);
+      *(volatile uint64_t*)ctl = 0;  // (the evaluation two back used this word; it has completed)
+      __builtin_ia32_sfence();
+      pa.go = ctl;
+      pa.go_seq = seq_out;
+      pa.dead = ctx->hd_done + 5;
+      plan.a.cancel = ctl;
+    }
+    HSTAMP(1);
+    rc2 = launch_prep(ctx, pa);  // (j,k) table rows (+ GP sums, + the draws when they are not ahead), one launch
+    if (rc2) return rc2;
+    polled_out = false;
+    if (mc) {
+      rc2 = entmc_launch_main(ctx, plan);
+      if (rc2) return rc2;
+      // Philox draws: the next evaluation's (seed + 1) are generated by spare workgroups of this
+      // evaluation's last launch, while the host finalises, returns and comes back with the next
+      // theta.  The host therefore does not wait for the stream: the finish launch's last result
+      // workgroup stores a sequence number into pinned memory and the host polls that word.
+      GenSlice ahead_gen;
+      DoneSignal done;
+      if (can_poll) {
+        if (ahead_ok) ahead_gen = entmc_ahead_slice(ctx, plan, arm_next ? 0.01 * ctx->opt_ahead_pct : 1.0);
+        done.cnt = ctx->d_done_cnt;
+        done.flag = ctx->hd_done;
+        done.seq = seq_out;
+        done.host_out = raw_out;
+        done.host_n = n_raw;
+        done.cancel = ctl;
+        polled_out = true;
+      }
+      // where the speculative generation goes: (2) spare workgroups of the finish launch itself,
+      // (1) its own stream, queued before the finish launch, (0) a launch of its own behind the
+      // finish kernel on the main stream
+      int gen_mode = ahead_gen.n_blocks > 0 ? ctx->opt_ahead_mode : -1;
+      if (spin && gen_mode != 2 && gen_mode != 3 && gen_mode != -1) gen_mode = 2;  // armed launches keep everything in three kernels
+      const bool defer = gen_mode == 2;  // (3 = the same placement with the generator's plain one-pair-per-thread form)
+      if (gen_mode == 3) gen_mode = 2;
+      if (defer) {  // 8 pairs per thread, stored after all are computed (philox.h)
+        ahead_gen.per_thread = 8;
+        ahead_gen.n_blocks = (int)((ahead_gen.item_count + 2047) / 2048);
+      }
+      if (gen_mode == 1) {
+        rc2 = entmc_launch_ahead(ctx, ahead_gen);
+        if (rc2) return rc2;
+      }
+      rc2 = entmc_launch_finish(ctx, plan, polled_out ? stage + n_res : raw_out, gen_mode == 2 ? &ahead_gen : nullptr,
+                                polled_out ? &done : nullptr, gp_in_tail ? &gp_tail : nullptr);
+      if (rc2) return rc2;
+      if (gen_mode == 0) {
+        rc2 = launch_eps_gen(ctx, ctx->stream, ahead_gen);
+        if (rc2) return rc2;
+      }
+      if (multi) {
+        rc2 = comm_allreduce_sum(ctx, raw_out, n_raw);
+        if (rc2) return rc2;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned + n_res, raw_out, sizeof(double) * n_raw,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+      }
+    } else if (lb_dev) {
+      rc2 = launch_entlb(ctx, raw_host);
+      if (rc2) return rc2;
+    }
+    return 0;
+  };
+
+  // An armed evaluation planned for exactly this call?  Then its launches are already queued: write
+  // the pack and the go word.  Otherwise cancel it (if any) and launch as usual.
+  bool used_armed = false;
+  if (sp.armed) {
+    const bool match = can_poll && sp.seed == opts->seed && sp.n_theta == n_theta && sp.mask == mask &&
+                       sp.grad_flags == grad_flags && sp.eps_mode == opts->eps_mode &&
+                       sp.ns_per_comp == opts->ns_per_comp && sp.row_begin == row_begin && sp.row_count == row_count &&
+                       !ctx->timing &&
+                       std::chrono::duration<double, std::milli>(clk::now() - sp.t_armed).count() < 10.0;
+    if (match) {
+      memcpy(ctx->d_mix_fg, ctx->h_pack, sizeof(double) * (size_t)ctx->ml.total);
+      __builtin_ia32_sfence();  // the pack before the go word (write-combined stores are not ordered otherwise)
+      *(volatile uint64_t*)ctl_word(ctx, sp.seq) = sp.seq;
+      __builtin_ia32_sfence();
+      ctx->pack_valid = true;
+      sp.armed = false;
+      ++sp.hits;
+      used_armed = true;
       polled = true;
+      cur_seq = sp.seq;
+      HSTAMP(1);
+    } else {
+      spec_disarm(ctx);
     }
-    (void)gp_in_ws;
-    if (gp_in_tail && !polled) {  // (no ahead slice after all: the GP blocks still need a launch)
-      gp_tail.done = DoneSignal();
-      gp_tail.res = res_out;
-    }
-    // where the speculative generation goes: (2) spare workgroups of the finish launch itself,
-    // (1) its own stream, queued before the finish launch, (0) a launch of its own behind the
-    // finish kernel on the main stream
-    int gen_mode = ahead_gen.n_blocks > 0 ? ctx->opt_ahead_mode : -1;
-    const bool defer = gen_mode == 2;  // (3 = the same placement with the generator's plain one-pair-per-thread form)
-    if (gen_mode == 3) gen_mode = 2;
-    if (defer) {  // 8 pairs per thread, stored after all are computed (philox.h)
-      ahead_gen.per_thread = 8;
-      ahead_gen.n_blocks = (int)((ahead_gen.item_count + 2047) / 2048);
-    }
-    if (gen_mode == 1) {
-      rc = entmc_launch_ahead(ctx, ahead_gen);
-      if (rc) return rc;
-    }
-    rc = entmc_launch_finish(ctx, plan, polled ? stage + n_res : raw_out, gen_mode == 2 ? &ahead_gen : nullptr, polled ? &done : nullptr,
-                             gp_in_tail ? &gp_tail : nullptr);
+  }
+  if (!used_armed) {
+    rc = issue(opts->seed, false, polled, cur_seq);
     if (rc) return rc;
-    if (gen_mode == 0) {
-      rc = launch_eps_gen(ctx, ctx->stream, ahead_gen);
-      if (rc) return rc;
+  }
+  // Arm the next evaluation (seed + 1, same shapes): its launches go into the queue now, behind this
+  // one's, and wait for the next call's theta.
+  if (polled && arm_next && ctx->d_ctl && ctx->d_mix_fg) {
+    sp.gen_cur_before = ctx->gen_cur;
+    sp.ahead_before_valid = ctx->ahead.valid;
+    sp.ahead_before_seed = ctx->ahead.seed;
+    sp.ahead_before_buf = ctx->ahead.buf;
+    sp.ahead_before_frac = ctx->ahead.frac;
+    const uint64_t seq_before = ctx->done_seq;
+    bool p2 = false;
+    uint64_t seq2 = 0;
+    const int rc2 = issue(opts->seed + 1, true, p2, seq2);
+    if (rc2 == 0 && p2) {
+      sp.armed = true;
+      sp.t_armed = clk::now();
+      sp.seq = seq2;
+      sp.seed = opts->seed + 1;
+      sp.n_theta = n_theta;
+      sp.mask = mask;
+      sp.grad_flags = grad_flags;
+      sp.eps_mode = opts->eps_mode;
+      sp.ns_per_comp = opts->ns_per_comp;
+      sp.row_begin = row_begin;
+      sp.row_count = row_count;
+    } else if (rc2 == -1000) {  // nothing was queued: undo the planning's bookkeeping
+      ctx->done_seq = seq_before;
+      ctx->gen_cur = sp.gen_cur_before;
+      ctx->ahead.valid = sp.ahead_before_valid;
+      ctx->ahead.seed = sp.ahead_before_seed;
+      ctx->ahead.buf = sp.ahead_before_buf;
+      ctx->ahead.frac = sp.ahead_before_frac;
+    } else if (rc2 != 0) {
+      return rc2;
     }
-    if (multi) {
-      rc = comm_allreduce_sum(ctx, raw_out, n_raw);
-      if (rc) return rc;
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned + n_res, raw_out, sizeof(double) * n_raw,
-                                  hipMemcpyDeviceToHost, ctx->stream));
-    }
-  } else if (lb_dev) {
-    rc = launch_entlb(ctx, raw_host);
-    if (rc) return rc;
   }
   // ---- soft bounds and weight penalty (:1195-1229, _vp_bound_loss :537-606) ----
   // They depend on theta and the new mixture only: evaluated here, while the device works.
@@ -410,13 +524,13 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   };
   bool gp_done = false;
   if (polled) {
-    bool ok = spin_on(ctx->h_done + 4, ctx->done_seq);
+    bool ok = spin_on(ctx->h_done + 4, cur_seq);
     HSTAMP(3);
     if (ok) {
       rc = finalize_gp();  // overlaps the entropy kernel
       if (rc) return rc;
       gp_done = true;
-      ok = spin_on(ctx->h_done, ctx->done_seq);
+      ok = spin_on(ctx->h_done, cur_seq);
     }
     if (!ok) HIP_TRY(ctx, stream_wait(ctx));
   } else {

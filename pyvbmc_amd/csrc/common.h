@@ -2,6 +2,7 @@
 // Not part of the ABI (that is include/vbmc_hip.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <cstdint>
 #include <cstdio>
@@ -95,6 +96,26 @@ struct vbmc_ctx {
   std::vector<double> mu, sigma, lambd, w, eta;  // mu is K x D
   MixLayout ml;
   double* d_mix = nullptr;
+  // Armed evaluation (api_elbo.hip): the three launches of the NEXT host-driven evaluation are queued
+  // while the current one runs; their prep kernel waits on a control word in host-written device
+  // memory, so when theta arrives the host only writes the pack and that word (no launch latency).
+  struct ArmedEval {
+    bool armed = false;
+    bool keep = false;        // set while vbmc_neg_elcbo itself runs (its inner calls must not disarm)
+    uint64_t seq = 0;         // completion sequence number the armed launches will publish
+    uint64_t seed = 0;        // the Philox seed they were planned for
+    int n_theta = 0, mask = 0, grad_flags = 0, eps_mode = 0;
+    int64_t ns_per_comp = 0, row_begin = 0, row_count = 0;
+    // state to restore when the armed launches are cancelled instead of run
+    int gen_cur_before = 0;
+    bool ahead_before_valid = false;
+    uint64_t ahead_before_seed = 0;
+    int ahead_before_buf = 0;
+    double ahead_before_frac = 1.0;
+    uint64_t hits = 0, cancels = 0;
+    std::chrono::steady_clock::time_point t_armed;  // the device gives up after 20 ms: the host does not use an armed evaluation older than 10 ms
+  } spec;
+  uint64_t* d_ctl = nullptr;   // fine-grained device memory, 8 words: go / cancel word of even ([0]) and odd ([4]) seq
   double* d_stage = nullptr;   // device staging of the results the polled step hands to the host (DoneSignal)
   size_t d_stage_cap = 0;
   double* d_mix_fg = nullptr;  // host-writable (fine-grained) device memory: the host-driven step writes the pack here itself
@@ -120,6 +141,7 @@ struct vbmc_ctx {
     uint64_t seed = 0;
     int K = 0, D = 0, buf = 0;
     int64_t rows = 0, n_half = 0, row_begin = 0;
+    double frac = 1.0;  // the part [0, frac) of the items is (being) generated; the consumer's prep launch adds the rest
   } ahead;
   // completion word of the fused objective: the finish kernel's last result wave stores the
   // evaluation's sequence number into pinned host memory and the host polls it -- the spare
@@ -156,6 +178,8 @@ struct vbmc_ctx {
   int opt_elbo_ahead = 1;   // ... and those of seed+1 speculatively behind the finish kernel
   int opt_predict_dma = 1;  // predict's variance product through the LDS-direct kernel (batches on Cholesky samples)
   int opt_ahead_mode = 2;   // speculative draws: 2 = spare workgroups of the finish launch, 0 = a launch of their own behind it, 1 = on their own stream (measured: slower)
+  int opt_ahead_pct = 100;  // armed evaluations: percent of the next draws generated in the finish launch (the rest in the armed prep launch, which runs them while it waits for theta)
+  int opt_elbo_arm = 1;     // queue the next host-driven evaluation's launches ahead of its theta (armed evaluation)
   int opt_ws_pair = 1;      // entropy kernel: co-resident workgroups take the same table row (scalar-cache locality)
   int opt_gp_tail = 2;      // with mix_bar: GP sums in a last row of the entropy launch (2; needs free workgroup slots, else 1), in the finish launch (1), in the prep launch (0)
   int opt_mix_bar = 1;      // host-driven step: pack written by the CPU into device memory (no upload launch), GP sums in the finish launch
@@ -193,12 +217,15 @@ extern thread_local std::string g_create_err;
   } while (0)
 
 // Entry points that launch kernels refuse a host-only context (device_id -1).
+// cancel an armed evaluation (api_elbo.hip): its queued kernels return at once, host state is restored
+void spec_disarm(vbmc_ctx* ctx);
 #define NEED_DEVICE(ctx)                                                                     \
   do {                                                                                       \
     if ((ctx)->device < 0)                                                                   \
       return vbmc_fail((ctx), VBMC_E_NODEV,                                                  \
                        "host-only context: this entry point needs a gfx950 device "          \
                        "(libvbmc_hip has no CPU fallback)");                                 \
+    if ((ctx)->spec.armed && !(ctx)->spec.keep) spec_disarm(ctx);                            \
   } while (0)
 
 void write_mixture_pack(const MixLayout& ml, const double* mu_KxD, const double* sigma,
@@ -233,6 +260,8 @@ struct DoneSignal {
   // each -- ~1700 of them per evaluation queue up for 9-14 us in front of the completion word.
   double* host_out = nullptr;
   int host_n = 0;
+  // armed evaluation: the finish kernel returns at once when *cancel == ~0 (ArmedEval)
+  const uint64_t* cancel = nullptr;
 };
 
 #ifdef __HIPCC__
@@ -280,6 +309,12 @@ struct PrepArgs {
   // hands the pack over in host-written device memory; the later launches read the ordinary copy)
   double* mix_copy = nullptr;
   int mix_copy_n = 0;
+  // armed evaluation (ArmedEval): every workgroup first waits until *go == go_seq (the host has
+  // written the pack) -- or leaves at once when it reads ~0 (cancelled); after ~20 ms without either
+  // it cancels by itself (*go = ~0 for the launches behind it, *dead = go_seq for the host)
+  uint64_t* go = nullptr;
+  uint64_t go_seq = 0;
+  uint64_t* dead = nullptr;
   // table part (n_table = K blocks, or 0)
   int n_table = 0, DP = 0, K4 = 0;
   double* table = nullptr;
@@ -306,6 +341,7 @@ GenSlice make_gen_slice(double* eps, int K, int D, int64_t rows, int64_t n_half,
                         uint64_t seed, const int* seed_add, double frac_begin, double frac_end);
 // wait for everything queued on the ctx stream (also: the pinned mixture pack is free again)
 inline hipError_t stream_wait(vbmc_ctx* ctx) {
+  if (ctx->spec.armed) spec_disarm(ctx);  // (launches waiting for a theta would make this wait last their time-out)
   if (ctx->gen_pending) {  // the speculative draws on their own stream
     const hipError_t eg = hipStreamSynchronize(ctx->gen_stream);
     if (eg != hipSuccess) return eg;
@@ -331,7 +367,7 @@ int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p);
 int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out, const GenSlice* gen = nullptr,
                         const DoneSignal* done = nullptr, const PrepArgs* gp = nullptr);
 // the slice of seed+1's draws the finish launch's spare workgroups should generate (n_blocks == 0: none)
-GenSlice entmc_ahead_slice(vbmc_ctx* ctx, const EntPlan& p);
+GenSlice entmc_ahead_slice(vbmc_ctx* ctx, const EntPlan& p, double frac_end = 1.0);
 // launch the speculative slice (on gen_stream when enabled) / wait until a pending one has completed
 int entmc_launch_ahead(vbmc_ctx* ctx, const GenSlice& g);
 int entmc_ahead_wait(vbmc_ctx* ctx);

@@ -62,6 +62,10 @@ static void options_from_env(vbmc_ctx* c) {
   c->opt_mix_kernel = !(e && e[0] == '0');
   e = getenv("VBMC_AHEAD_MODE");
   c->opt_ahead_mode = e ? atoi(e) : 2;
+  e = getenv("VBMC_AHEAD_PCT");
+  if (e) c->opt_ahead_pct = atoi(e);
+  e = getenv("VBMC_ELBO_ARM");
+  c->opt_elbo_arm = !(e && e[0] == '0');
   e = getenv("VBMC_WS_PAIR");
   c->opt_ws_pair = !(e && e[0] == '0');
   e = getenv("VBMC_GP_TAIL");
@@ -145,7 +149,10 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
     return;
   }
   (void)hipSetDevice(ctx->device);
+  spec_disarm(ctx);
+  if (getenv("VBMC_DEBUG_ARM")) fprintf(stderr, "[vbmc] armed evaluations: %llu used, %llu cancelled\n", (unsigned long long)ctx->spec.hits, (unsigned long long)ctx->spec.cancels);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_ctl) (void)hipFree(ctx->d_ctl);
   if (ctx->gen_stream) {
     (void)hipStreamSynchronize(ctx->gen_stream);
     (void)hipStreamDestroy(ctx->gen_stream);
@@ -199,6 +206,7 @@ int vbmc_synchronize(vbmc_ctx* ctx) {
 
 int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   if (!ctx || !key) return VBMC_E_ARG;
+  spec_disarm(ctx);
   if (!strcmp(key, "entmc_kernel")) ctx->opt_entmc_valu = value == 1;
   else if (!strcmp(key, "elbo_pregen")) ctx->opt_elbo_pregen = value != 0;
   else if (!strcmp(key, "elbo_ahead")) ctx->opt_elbo_ahead = value != 0;
@@ -207,6 +215,8 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "mix_bar")) ctx->opt_mix_bar = value != 0;
   else if (!strcmp(key, "gp_tail")) ctx->opt_gp_tail = value;
   else if (!strcmp(key, "ws_pair")) ctx->opt_ws_pair = value != 0;
+  else if (!strcmp(key, "elbo_arm")) ctx->opt_elbo_arm = value != 0;
+  else if (!strcmp(key, "ahead_pct")) ctx->opt_ahead_pct = value;
   else if (!strcmp(key, "ahead_mode")) {
     (void)entmc_ahead_wait(ctx);
     ctx->opt_ahead_mode = value;
@@ -389,6 +399,15 @@ double* write_pack_to_device(vbmc_ctx* ctx) {
     }
     ctx->d_mix_fg_cap = want;
   }
+  if (!ctx->d_ctl) {  // control words of the armed evaluation (common.h ArmedEval), same kind of memory
+    if (hipExtMallocWithFlags((void**)&ctx->d_ctl, 64, hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->d_ctl = nullptr;
+    } else {
+      memset(ctx->d_ctl, 0, 64);
+      __builtin_ia32_sfence();
+    }
+  }
   memcpy(ctx->d_mix_fg, ctx->h_pack, n * sizeof(double));
   __builtin_ia32_sfence();  // write-combined stores drained before the doorbell of the next launch
   ctx->pack_valid = true;   // (d_mix itself receives the pack from the prep launch's copy block)
@@ -397,6 +416,7 @@ double* write_pack_to_device(vbmc_ctx* ctx) {
 
 int upload_packed_mixture(vbmc_ctx* ctx) {
   if (ctx->device < 0) return 0;
+  if (ctx->spec.armed) spec_disarm(ctx);  // (queued behind launches that wait for a theta it would wait with them)
   if (ctx->opt_mix_kernel) {
     double* src = nullptr;
     if (ctx->h_pack_dev_of != ctx->h_pack) {

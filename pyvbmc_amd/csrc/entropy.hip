@@ -210,6 +210,8 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
                                                            double* __restrict__ raw, GenSlice gen,
                                                            DoneSignal done, PrepArgs gp) {
   extern __shared__ double fin_lds[];
+  if (done.cancel != nullptr && __hip_atomic_load(done.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ~(uint64_t)0)
+    return;  // armed evaluation that was cancelled (common.h ArmedEval)
   const int D = ml.D, K = ml.K;
 #ifdef FIN_TIMES
   if (blockIdx.x == 0 && threadIdx.x == 0) { g_fin_times[0] = wall_clock64(); g_fin_times[2] = 0; }
@@ -571,8 +573,12 @@ int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& pa) {
   int cur;
   if (ah.valid && ah.seed == p.a.seed && ah.K == K && ah.D == D && ah.rows == p.a.row_count &&
       ah.n_half == p.a.n_half && ah.row_begin == p.a.row_begin) {
-    // the previous evaluation already queued exactly these draws (entmc_launch_ahead)
+    // the previous evaluation already queued exactly these draws (entmc_launch_ahead) -- or the
+    // first part of them: the rest is generated by this evaluation's prep launch
     cur = ah.buf;
+    p.pregen_hit = true;
+    if (ah.frac < 1.0)
+      pa.gen = make_gen_slice(ctx->d_epsgen[cur], K, D, p.a.row_count, p.a.n_half, p.a.row_begin, p.a.seed, nullptr, ah.frac, 1.0);
   } else {
     cur = ah.valid ? 1 - ah.buf : 0;  // keep clear of a speculative buffer that is not the one wanted
     int rc = entmc_ahead_wait(ctx);  // (a generation still running on the other stream)
@@ -589,7 +595,7 @@ int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& pa) {
   return 0;
 }
 
-GenSlice entmc_ahead_slice(vbmc_ctx* ctx, const EntPlan& p) {
+GenSlice entmc_ahead_slice(vbmc_ctx* ctx, const EntPlan& p, double frac_end) {
   const EntArgs& a = p.a;
   GenSlice none;
   if (!ctx->opt_elbo_ahead || a.eps == nullptr || a.eps != ctx->d_epsgen[ctx->gen_cur]) return none;
@@ -609,8 +615,9 @@ GenSlice entmc_ahead_slice(vbmc_ctx* ctx, const EntPlan& p) {
   ah.n_half = a.n_half;
   ah.row_begin = a.row_begin;
   ah.buf = other;
+  ah.frac = frac_end;
   ah.valid = true;  // the caller launches the slice right away
-  return make_gen_slice(ctx->d_epsgen[other], K, D, a.row_count, a.n_half, a.row_begin, ah.seed, nullptr, 0.0, 1.0);
+  return make_gen_slice(ctx->d_epsgen[other], K, D, a.row_count, a.n_half, a.row_begin, ah.seed, nullptr, 0.0, frac_end);
 }
 
 int entmc_launch_ahead(vbmc_ctx* ctx, const GenSlice& g) {

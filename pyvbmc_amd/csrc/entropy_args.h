@@ -32,6 +32,8 @@ struct EntArgs {
   // that the two workgroups of a CU read the same table row (entropy_ws.hip).  Set by entmc_plan for
   // one-round grids of the 2-waves/SIMD builds.
   int pair_cus = 0;
+  // armed evaluation (common.h ArmedEval): every workgroup returns at once when *cancel == ~0
+  const uint64_t* cancel = nullptr;
 };
 
 // register-array size (components per wave) the wave-split launcher picks, and the waves per SIMD
@@ -50,6 +52,7 @@ constexpr int ws_min_waves(int dp, int ktmax, bool grad) {
 
 struct EntPlan {
   EntArgs a;
+  bool pregen_hit = false;  // the draws come from a speculative generation (entmc_pregen)
   bool ws = false;
   int DP = 0;
   double inv_ns = 0.0;

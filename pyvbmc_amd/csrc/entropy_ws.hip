@@ -136,6 +136,8 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
       return;
     }
   }
+  // armed evaluation that the host cancelled (common.h ArmedEval): nothing to do
+  if (a.cancel != nullptr && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ~(uint64_t)0) return;
   // Host-driven step (api_elbo.hip): the LAST grid row works through the GP expected-log-joint
   // items in the workgroup slots this launch's entropy rows leave free (entropy_args.h)
   if (a.gp_items > 0 && blockIdx.y == gridDim.y - 1) {

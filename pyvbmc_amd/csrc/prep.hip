@@ -31,6 +31,35 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
 #endif
   const int D = a.ml.D, K = a.ml.K;
   const int tid = threadIdx.x;
+  if (a.gen.n_blocks > 0 && (int)blockIdx.x >= a.n_table + a.n_glj && (int)blockIdx.x < a.n_table + a.n_glj + a.gen.n_blocks) {
+    // ---- draw-generation block (philox.h): depends on the seed only, never waits for theta ----
+    gen_slice_block(a.gen, blockIdx.x - a.n_table - a.n_glj, tid);
+    return;
+  }
+  if (a.go) {
+    // ---- armed launch: wait for the host's theta (the pack in a.mix and the go word) ----
+    __shared__ int s_go;
+    if (tid == 0) {
+      const unsigned long long t0 = wall_clock64();
+      int st = 0;
+      for (;;) {
+        const uint64_t v = __hip_atomic_load(a.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (v == a.go_seq) { st = 1; break; }
+        if (v == ~(uint64_t)0) break;
+        if (wall_clock64() - t0 > 2000000ull) {  // 20 ms at 100 MHz: give up
+          if (blockIdx.x == 0 && blockIdx.y == 0) {
+            __hip_atomic_store(a.go, ~(uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.dead, a.go_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(16);
+      }
+      s_go = st;
+    }
+    __syncthreads();
+    if (!s_go) return;
+  }
   if (a.mix_copy && blockIdx.x == gridDim.x - 1) {
     // ---- copy block: the pack for the launches behind this one ----
     for (int i = tid; i < a.mix_copy_n; i += 256) a.mix_copy[i] = a.mix[i];
@@ -76,11 +105,6 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
     return;
   }
 
-  if ((int)blockIdx.x >= a.n_table + a.n_glj) {
-    // ---- draw-generation block (philox.h) ----
-    gen_slice_block(a.gen, blockIdx.x - a.n_table - a.n_glj, tid);
-    return;
-  }
 
   // ---- GP expected-log-joint block (s,k): glj_block.h ----
   glj_block(a, blockIdx.x - a.n_table, lds);

@@ -255,7 +255,11 @@ def test_step_pipeline_variants_bit_identical(ctx, S):
     def run(mix_bar, ahead_mode):
         # (ahead_mode + 10 * k: GP sums in the finish launch (k = 1) / the prep launch (k = 0) instead of
         # the entropy launch's last row)
+        arm = 1
+        if ahead_mode >= 100:  # 100 + m: without the armed evaluation
+            arm, ahead_mode = 0, ahead_mode - 100
         gp_tail, ahead_mode = (ahead_mode // 10 - 1, ahead_mode % 10) if ahead_mode >= 10 else (2, ahead_mode)
+        ctx.set_option("elbo_arm", arm)
         ctx.set_option("mix_bar", mix_bar)
         ctx.set_option("gp_tail", gp_tail)
         ctx.set_option("ahead_mode", ahead_mode)
@@ -270,10 +274,11 @@ def test_step_pipeline_variants_bit_identical(ctx, S):
             ctx.set_option("mix_bar", 1)
             ctx.set_option("gp_tail", 2)
             ctx.set_option("ahead_mode", 2)
+            ctx.set_option("elbo_arm", 1)
         return out
 
     base = run(1, 2)
-    for plan in [(1, 0), (1, 1), (1, 3), (0, 2), (0, 0), (0, 1), (1, 22), (1, 12)]:
+    for plan in [(1, 0), (1, 1), (1, 3), (0, 2), (0, 0), (0, 1), (1, 22), (1, 12), (1, 102), (1, 103)]:
         got = run(*plan)
         for (F, dF, G, H), (F0, dF0, G0, H0) in zip(got, base):
             assert F == F0 and G == G0 and H == H0 and np.array_equal(dF, dF0), plan
@@ -284,3 +289,59 @@ def test_step_pipeline_variants_bit_identical(ctx, S):
     eps = philox_ref.eps_half(K, NsK // 2, D, 900 + len(thetas) - 1)
     Ho, _ = entropy_ref.entmc(mix, NsK, (True,) * 4, False, eps_half=eps)
     assert abs(base[-1][3] - Ho) <= 1e-10 * max(1.0, abs(Ho))
+
+
+def test_armed_evaluation_cancel_paths(ctx):
+    """The polled step queues the NEXT evaluation's launches ahead of its theta (`elbo_arm`, armed
+    evaluation): whatever comes between two evaluations -- nothing, another seed, another entry
+    point, a GP update, an option change, a pause longer than the device-side time-out -- the values
+    must be those of the plain sequence (bit-identical: same kernels, same inputs)."""
+    import time
+
+    from pyvbmc_amd import entmc_vbmc
+    from pyvbmc_amd.variational_optimization import _neg_elcbo
+
+    wl = synthetic.make_workload(3, S=1, N=120)
+    D, K = wl.D, wl.K
+    g = dict(D=D, K=K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,
+             s2=wl.s2 if wl.s2 is not None else np.zeros(0))
+    gp = make_gp(g, ctx, wl.hyp)
+    rng = np.random.default_rng(11)
+    th0 = make_vp(g, ctx).get_parameters()
+    thetas = [th0 + 0.05 * rng.standard_normal(th0.size) for _ in range(12)]
+    seeds = [500, 501, 502, 777, 778, 779, 780, 780, 781, 782, 783, 784]  # a jump and a repeat
+    NsK = 2 * 64 * 9
+
+    def run(arm, disturb):
+        ctx.set_option("elbo_arm", arm)
+        out = []
+        try:
+            vp = make_vp(g, ctx)
+            for i, (th, sd) in enumerate(zip(thetas, seeds)):
+                F, dF, G, H, _ = _neg_elcbo(th.copy(), gp, vp, 0.0, NsK, True, False, None, 0.0, False,
+                                            rng="philox", seed=sd)
+                out.append((F, dF.copy(), G, H))
+                if disturb:
+                    if i == 1:
+                        vp2 = make_vp(g, ctx)
+                        vp2.pdf(wl.X[:5])                      # another entry point on the same context
+                    elif i == 2:
+                        entmc_vbmc(make_vp(g, ctx), NsK, (True,) * 4, True, rng="philox", seed=3)
+                    elif i == 4:
+                        gp.update(X_new=wl.X, y_new=wl.y, s2_new=wl.s2, hyp=wl.hyp)  # same GP, new upload
+                    elif i == 5:
+                        ctx.set_option("ws_pair", 0)
+                        ctx.set_option("ws_pair", 1)
+                    elif i == 8:
+                        time.sleep(0.05)                       # longer than the armed launches wait
+                    elif i == 9:
+                        ctx.synchronize()
+        finally:
+            ctx.set_option("elbo_arm", 1)
+        return out
+
+    base = run(0, False)
+    for arm, disturb in ((1, False), (1, True), (0, True)):
+        got = run(arm, disturb)
+        for i, ((F, dF, G, H), (F0, dF0, G0, H0)) in enumerate(zip(got, base)):
+            assert F == F0 and G == G0 and H == H0 and np.array_equal(dF, dF0), (arm, disturb, i)
