@@ -43,28 +43,49 @@ __host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 
 __device__ inline void philox_normal_pair(uint64_t row, uint32_t pair, uint64_t seed, double& z0, double& z1);
 
-// workgroup `block` (0-based among the slice's n_blocks) of a 256-thread launch
-__device__ inline void gen_item(const GenSlice& g, int64_t local, double& z0, double& z1, double*& dst, bool& two) {
-  const int64_t t = g.item_begin + local;
-  const int np = (g.D + 1) / 2;
-  const int p = (int)(t % np);
-  const int64_t r = t / np;
-  const int64_t j = r / g.rows, i = r - j * g.rows;
-  const uint64_t grow = (uint64_t)j * (uint64_t)g.n_half + (uint64_t)(g.row_begin + i);
-  const uint64_t seed = g.seed + (g.seed_add ? (uint64_t)g.seed_add[0] : 0);
-  philox_normal_pair(grow, (uint32_t)p, seed, z0, z1);
-  dst = g.eps + r * g.D + 2 * p;
-  two = 2 * p + 1 < g.D;
+// Item t of a slice = (component j, row i of the slice, pair p): t = (j * rows + i) * np + p.
+// 64-bit division is ~50 instructions on this ISA and the generator needs two per item; items and
+// rows fit 32 bits in every case the library runs (checked per call), and a thread that generates
+// several items a fixed stride apart walks the position instead of dividing again.
+struct GenPos {
+  int64_t j, i;
+  int p;
+};
+__device__ inline GenPos gen_pos(const GenSlice& g, int64_t t, int np) {
+  GenPos q;
+  if (((uint64_t)t | (uint64_t)g.rows) >> 32) {
+    const int64_t r = t / np;
+    q.p = (int)(t - r * np);
+    q.j = r / g.rows;
+    q.i = r - q.j * g.rows;
+  } else {
+    const uint32_t tt = (uint32_t)t, r = tt / (uint32_t)np, rows = (uint32_t)g.rows;
+    q.p = (int)(tt - r * (uint32_t)np);
+    const uint32_t jj = r / rows;
+    q.j = jj;
+    q.i = r - jj * rows;
+  }
+  return q;
+}
+__device__ inline void gen_emit(const GenSlice& g, const GenPos& q, uint64_t seed, double& z0, double& z1, double*& dst,
+                                bool& two) {
+  const uint64_t grow = (uint64_t)q.j * (uint64_t)g.n_half + (uint64_t)(g.row_begin + q.i);
+  philox_normal_pair(grow, (uint32_t)q.p, seed, z0, z1);
+  dst = g.eps + (q.j * g.rows + q.i) * g.D + 2 * q.p;
+  two = 2 * q.p + 1 < g.D;
 }
 
+// workgroup `block` (0-based among the slice's n_blocks) of a 256-thread launch
 __device__ inline void gen_slice_block(const GenSlice& g, int block, int tid) {
+  const int np = (g.D + 1) / 2;
+  const uint64_t seed = g.seed + (g.seed_add ? (uint64_t)g.seed_add[0] : 0);
   if (g.per_thread <= 1) {
     const int64_t local = (int64_t)block * 256 + tid;
     if (local >= g.item_count) return;
     double z0, z1;
     double* dst;
     bool two;
-    gen_item(g, local, z0, z1, dst, two);
+    gen_emit(g, gen_pos(g, g.item_begin + local, np), seed, z0, z1, dst, two);
     dst[0] = z0;
     if (two) dst[1] = z1;
     return;
@@ -72,20 +93,35 @@ __device__ inline void gen_slice_block(const GenSlice& g, int block, int tid) {
   // Deferred-store form (the speculative generation inside the finish launch, api_elbo.hip): a
   // thread computes its 8 pairs (items block * 2048 + i * 256 + tid: every store instruction of a
   // wave still writes contiguous memory) and only then stores them.  The generation is arithmetic
-  // for its first two thirds, so the 40 MB of stores reach the memory system in the last third:
-  // the completion word the reduction workgroups of the same launch send to the host is not
-  // queued behind them (it arrived 14-17 us late otherwise).
+  // for its first two thirds, so the 40 MB of stores reach the memory system in the last third.
   constexpr int PT = 8;
   double z[PT][2];
   double* dst[PT];
   bool two[PT];
   const int64_t base = (int64_t)block * (256 * PT) + tid;
+  GenPos q = gen_pos(g, g.item_begin + base, np);
+  const int step_r = 256 / np, step_p = 256 - step_r * np;  // 256 items further
+  const bool walk = g.rows > step_r + 1;
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
     const int64_t local = base + (int64_t)i * 256;
     dst[i] = nullptr;
     two[i] = false;
-    if (local < g.item_count) gen_item(g, local, z[i][0], z[i][1], dst[i], two[i]);
+    if (local < g.item_count) gen_emit(g, q, seed, z[i][0], z[i][1], dst[i], two[i]);
+    if (walk) {
+      q.p += step_p;
+      q.i += step_r;
+      if (q.p >= np) {
+        q.p -= np;
+        ++q.i;
+      }
+      if (q.i >= g.rows) {  // (rows > step_r + 1: at most one component boundary per step)
+        q.i -= g.rows;
+        ++q.j;
+      }
+    } else {
+      q = gen_pos(g, g.item_begin + local + 256, np);
+    }
   }
 #pragma unroll
   for (int i = 0; i < PT; ++i)
