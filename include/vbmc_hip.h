@@ -132,6 +132,11 @@ int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
  *   "predict_dma"  [VBMC_PREDICT_DMA]: 1 = gp_predict's variance product for batches of > 32
  *                  points on Cholesky samples runs in the LDS-direct kernel (default), 0 = the
  *                  plain 64 x 64-tile kernel (cross-check)
+ *   "elbo_arm"     [VBMC_ELBO_ARM]: 1 = after a polled Philox evaluation the launches of the next one
+ *                  (seed + 1, same shapes) are queued at once and wait on the device for the next
+ *                  call's theta (default); any other use of the context cancels them
+ *   "ahead_pct"    [VBMC_AHEAD_PCT]: with elbo_arm, percent of the speculative draws generated in the
+ *                  finish launch (rest: the armed prep launch); default 100
  *   "ws_pair"      [VBMC_WS_PAIR]: 1 = the wave-split entropy kernel hands its (component, chunk)
  *                  items out so that the two workgroups of a CU read the same table row (default)
  * The results of an evaluation do not depend on any of these.  Unknown key -> VBMC_E_ARG. */
