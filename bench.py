@@ -255,7 +255,7 @@ def main():
     # lasts >= MIN_TIMED_S whatever K is (a 20-step region is 3 ms: too short to mean anything).
     # All ranks must agree on R: take the maximum estimate.
     est = ctx.comm_max(est)
-    repeats = max(1, int(np.ceil(1.1 * MIN_TIMED_S / max(a.steps * est, 1e-9))))
+    repeats = max(1, int(np.ceil(1.3 * MIN_TIMED_S / max(a.steps * est, 1e-9))))
     n_timed = repeats * a.steps
     ctx.comm_barrier()
     ctx.synchronize()
