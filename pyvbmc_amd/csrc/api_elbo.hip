@@ -67,7 +67,12 @@ extern "C" int vbmc_debug_clock_pair(vbmc_ctx* ctx, int64_t* host_before, int64_
 #endif
 
 // ---- armed evaluation (common.h ArmedEval) ----------------------------------------------------
-static inline uint64_t* ctl_word(vbmc_ctx* ctx, uint64_t seq) { return ctx->d_ctl + ((seq & 1) ? 4 : 0); }
+// One control word per evaluation out of a ring of eight.  A word is reset when evaluation seq + 8
+// is armed; by then the host has seen later evaluations complete, and the queue is in order, so
+// the launches of evaluation seq -- run or cancelled -- have left it.  (With two words a cancelled
+// evaluation whose launches had not started yet could read the reset word of its successor, run on
+// stale inputs and overwrite the speculative draws: one wrong value in ~6 000 evaluations of a soak.)
+static inline uint64_t* ctl_word(vbmc_ctx* ctx, uint64_t seq) { return ctx->d_ctl + (seq & 7); }
 
 // Cancel the queued launches of an armed evaluation: they return at once (the prep kernel on the
 // cancel value of its go word, the two behind it on the same word) and the host-side bookkeeping of
@@ -263,7 +268,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     uint64_t* ctl = nullptr;
     if (spin) {
       ctl = ctl_word(ctx, seq_out);
-      *(volatile uint64_t*)ctl = 0;  // (the evaluation two back used this word; it has completed)
+      *(volatile uint64_t*)ctl = 0;  // (its previous user, eight evaluations back, has left the queue)
       __builtin_ia32_sfence();
       pa.go = ctl;
       pa.go_seq = seq_out;

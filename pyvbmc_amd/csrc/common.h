@@ -115,7 +115,7 @@ struct vbmc_ctx {
     uint64_t hits = 0, cancels = 0;
     std::chrono::steady_clock::time_point t_armed;  // the device gives up after 20 ms: the host does not use an armed evaluation older than 10 ms
   } spec;
-  uint64_t* d_ctl = nullptr;   // fine-grained device memory, 8 words: go / cancel word of even ([0]) and odd ([4]) seq
+  uint64_t* d_ctl = nullptr;   // fine-grained device memory, 8 words: go / cancel word of evaluation seq is [seq & 7]
   double* d_stage = nullptr;   // device staging of the results the polled step hands to the host (DoneSignal)
   size_t d_stage_cap = 0;
   double* d_mix_fg = nullptr;  // host-writable (fine-grained) device memory: the host-driven step writes the pack here itself

@@ -345,3 +345,42 @@ def test_armed_evaluation_cancel_paths(ctx):
         got = run(arm, disturb)
         for i, ((F, dF, G, H), (F0, dF0, G0, H0)) in enumerate(zip(got, base)):
             assert F == F0 and G == G0 and H == H0 and np.array_equal(dF, dF0), (arm, disturb, i)
+
+
+def test_armed_evaluation_soak(ctx):
+    """A few thousand evaluations with seeds that repeat, jump and follow on, other entry points,
+    pauses and stream waits thrown in at random: every repeat of a (theta, seed) pair must reproduce
+    its first value bit for bit.  (This is the test that found the control-word reuse race of the
+    armed evaluation: one wrong value in ~6 000 evaluations.)"""
+    import time
+
+    from pyvbmc_amd.variational_optimization import _neg_elcbo
+
+    wl = synthetic.make_workload(3, S=1, N=100)
+    g = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,
+             s2=wl.s2 if wl.s2 is not None else np.zeros(0))
+    gp = make_gp(g, ctx, wl.hyp)
+    vp = make_vp(g, ctx)
+    th = vp.get_parameters()
+    rng = np.random.default_rng(0)
+    NsK = 2 * 64 * 9
+    ref = {}
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < 4.0:
+        sd = int(rng.integers(0, 6)) if rng.random() < 0.2 else (n % 6)
+        F, dF, _, _, _ = _neg_elcbo(th + 0.01 * (sd + 1), gp, vp, 0.0, NsK, True, False, None, 0.0, False,
+                                    rng="philox", seed=1000 + sd)
+        if sd in ref:
+            assert ref[sd][0] == F and np.array_equal(ref[sd][1], dF), (n, sd)
+        else:
+            ref[sd] = (F, dF.copy())
+        r = rng.random()
+        if r < 0.02:
+            time.sleep(0.03)
+        elif r < 0.04:
+            vp.pdf(wl.X[:3])
+        elif r < 0.05:
+            ctx.synchronize()
+        n += 1
+    assert n > 1000
