@@ -349,11 +349,30 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
       __builtin_ia32_sfence();
       ctx->pack_valid = true;
       sp.armed = false;
-      ++sp.hits;
-      used_armed = true;
-      polled = true;
-      cur_seq = sp.seq;
-      HSTAMP(1);
+      const bool force_late = ctx->opt_arm_late_test > 0 && --ctx->opt_arm_late_test == 0;  // test hook
+      if (!force_late && std::chrono::duration<double, std::milli>(clk::now() - sp.t_armed).count() < 15.0) {
+        ++sp.hits;
+        used_armed = true;
+        polled = true;
+        cur_seq = sp.seq;
+        HSTAMP(1);
+      } else {
+        // This thread lost the CPU between the age check and the go word: the prep kernel's 20 ms
+        // time-out may have fired around the same moment.  Whatever ran is discarded: drain the
+        // queue, clear the completion counters, put the speculative-draw bookkeeping back to what it
+        // was before arming (still true: that evaluation only READ the draws it was planned on)
+        // and evaluate as usual.
+        *(volatile uint64_t*)ctl_word(ctx, sp.seq) = ~(uint64_t)0;
+        __builtin_ia32_sfence();
+        HIP_TRY(ctx, stream_wait(ctx));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_done_cnt, 0, sizeof(int) * 16, ctx->stream));
+        ctx->gen_cur = sp.gen_cur_before;
+        ctx->ahead.valid = sp.ahead_before_valid;
+        ctx->ahead.seed = sp.ahead_before_seed;
+        ctx->ahead.buf = sp.ahead_before_buf;
+        ctx->ahead.frac = sp.ahead_before_frac;
+        ++sp.cancels;
+      }
     } else {
       spec_disarm(ctx);
     }

@@ -206,6 +206,10 @@ int vbmc_synchronize(vbmc_ctx* ctx) {
 
 int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   if (!ctx || !key) return VBMC_E_ARG;
+  if (!strcmp(key, "arm_late_test")) {  // test hook of the armed evaluation's recovery path: must not cancel it
+    ctx->opt_arm_late_test = value;
+    return VBMC_OK;
+  }
   spec_disarm(ctx);
   if (!strcmp(key, "entmc_kernel")) ctx->opt_entmc_valu = value == 1;
   else if (!strcmp(key, "elbo_pregen")) ctx->opt_elbo_pregen = value != 0;

@@ -336,6 +336,8 @@ def test_armed_evaluation_cancel_paths(ctx):
                         time.sleep(0.05)                       # longer than the armed launches wait
                     elif i == 9:
                         ctx.synchronize()
+                    elif i == 10:
+                        ctx.set_option("arm_late_test", 1)     # the next armed use takes the late-go recovery
         finally:
             ctx.set_option("elbo_arm", 1)
         return out
