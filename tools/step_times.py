@@ -2,7 +2,7 @@
 """GPU-clock timeline of consecutive host-driven evaluations without a tracer: prep start / end,
 finish start / publish / end (library with prep.hip and entropy.hip built with -DFIN_TIMES), read
 back after each call WITHOUT synchronising in between (the stamps of the call before last).
-    VBMC_HIP_LIB=variants/libvbmc_st.so python tools/step_times.py"""
+    tools/build_times_variant.sh && VBMC_HIP_LIB=$PWD/variants/libvbmc_st.so python tools/step_times.py [config]"""
 import ctypes as C
 import sys
 import time
