@@ -425,3 +425,38 @@ def test_full_size_fused_step_vs_oracle(ctx):
               f"H rel {abs(H - Ho) / abs(Ho):.2e}")
         assert abs(F - Fo) <= 1e-10 * abs(Fo) and abs(G - Go) <= 1e-10 * abs(Go) and abs(H - Ho) <= 1e-10 * abs(Ho)
         assert dF.size == 610 and err < 1e-9
+
+
+def test_armed_evaluation_problem_switches(ctx):
+    """Four problems of different (D, K, N, Ns) evaluated in turns on one context, switching at random
+    (every switch re-uploads the GP and the mixture shape and cancels an armed evaluation): every
+    repeat of (problem, theta, seed) reproduces its first value bit for bit."""
+    import time
+
+    from pyvbmc_amd.variational_optimization import _neg_elcbo
+
+    cases = []
+    for (D, K, N, ns) in ((10, 50, 120, 2 * 64 * 9), (4, 13, 60, 2 * 64 * 40), (10, 50, 200, 2 * 64 * 9),
+                          (6, 20, 80, 2 * 64 * 30)):
+        wl = synthetic.make_workload(3, S=1, D=D, K=K, N=N)
+        g = dict(D=D, K=K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,
+                 s2=np.zeros(0))
+        vp = make_vp(g, ctx)
+        cases.append((make_gp(g, ctx, wl.hyp), vp, vp.get_parameters(), ns))
+    rng = np.random.default_rng(1)
+    ref = {}
+    t0 = time.time()
+    n = c = 0
+    while time.time() - t0 < 3.0:
+        if rng.random() < 0.1:
+            c = int(rng.integers(0, len(cases)))
+        gp, vp, th, ns = cases[c]
+        sd = n % 5
+        F, dF, _, _, _ = _neg_elcbo(th + 0.01 * (sd + 1), gp, vp, 0.0, ns, True, False, None, 0.0, False,
+                                    rng="philox", seed=50 + sd)
+        if (c, sd) in ref:
+            assert ref[(c, sd)][0] == F and np.array_equal(ref[(c, sd)][1], dF), (n, c, sd)
+        else:
+            ref[(c, sd)] = (F, dF.copy())
+        n += 1
+    assert n > 5000
