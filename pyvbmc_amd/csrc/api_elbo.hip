@@ -179,10 +179,14 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
 
   ctx->host_us[0] = us_since(t_begin);
   const auto t_launch = clk::now();
-  // single GPU: the host polls completion words instead of waiting for the stream (see below); the
-  // GP part gets one of its own so that G / dG are finalised while the entropy kernel runs.  With
-  // Philox draws read from the ahead buffers the next evaluation's draws are generated speculatively.
-  const bool can_poll = mc && !multi;
+  // The host polls completion words instead of waiting for the stream (see below); the GP part gets
+  // one of its own so that G / dG are finalised while the entropy kernel runs.  With Philox draws read
+  // from the ahead buffers the next evaluation's draws are generated speculatively.  With a
+  // communicator the raw entropy vector is all-reduced in-stream between the finish launch and a
+  // small publish launch that hands it to the host (and generates the next draws); evaluations
+  // are then never armed -- whether an armed evaluation is used or cancelled depends on host timing,
+  // and every rank has to queue the same collectives.
+  const bool can_poll = mc;
   double* stage = nullptr;  // device staging of both result blocks: [GP sums n_res | raw entropy n_raw]
   if (can_poll) {
     rc = ensure_dev(ctx, &ctx->d_stage, &ctx->d_stage_cap, n_res + (size_t)n_raw);
@@ -191,7 +195,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   }
   vbmc_ctx::ArmedEval& sp = ctx->spec;
   // (whether the next evaluation will be armed decides how the next draws are split, see ahead_pct)
-  const bool arm_next = can_poll && ctx->opt_elbo_arm && ctx->opt_mix_bar && !ctx->timing &&
+  const bool arm_next = can_poll && !multi && ctx->opt_elbo_arm && ctx->opt_mix_bar && !ctx->timing &&
                         opts->eps_mode == VBMC_EPS_PHILOX && ctx->opt_ahead_pct > 0 && ctx->opt_ahead_pct <= 100 &&
                         (ctx->opt_ahead_mode == 2 || ctx->opt_ahead_mode == 3);
 
@@ -313,18 +317,28 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
         rc2 = entmc_launch_ahead(ctx, ahead_gen);
         if (rc2) return rc2;
       }
-      rc2 = entmc_launch_finish(ctx, plan, polled_out ? stage + n_res : raw_out, gen_mode == 2 ? &ahead_gen : nullptr,
-                                polled_out ? &done : nullptr, gp_in_tail ? &gp_tail : nullptr);
-      if (rc2) return rc2;
-      if (gen_mode == 0) {
-        rc2 = launch_eps_gen(ctx, ctx->stream, ahead_gen);
+      if (!multi) {
+        rc2 = entmc_launch_finish(ctx, plan, polled_out ? stage + n_res : raw_out, gen_mode == 2 ? &ahead_gen : nullptr,
+                                  polled_out ? &done : nullptr, gp_in_tail ? &gp_tail : nullptr);
         if (rc2) return rc2;
-      }
-      if (multi) {
+        if (gen_mode == 0) {
+          rc2 = launch_eps_gen(ctx, ctx->stream, ahead_gen);
+          if (rc2) return rc2;
+        }
+      } else {
+        // finish (this rank's rows) -> all-reduce -> publish (+ the next draws): raw_out is device memory
+        rc2 = entmc_launch_finish(ctx, plan, raw_out, nullptr, nullptr, gp_in_tail ? &gp_tail : nullptr);
+        if (rc2) return rc2;
         rc2 = comm_allreduce_sum(ctx, raw_out, n_raw);
         if (rc2) return rc2;
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned + n_res, raw_out, sizeof(double) * n_raw,
-                                    hipMemcpyDeviceToHost, ctx->stream));
+        if (polled_out) {
+          done.host_out = raw_host;
+          rc2 = entmc_launch_publish(ctx, raw_out, done, (gen_mode == 2 || gen_mode == 0) ? &ahead_gen : nullptr);
+          if (rc2) return rc2;
+        } else {
+          HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned + n_res, raw_out, sizeof(double) * n_raw,
+                                      hipMemcpyDeviceToHost, ctx->stream));
+        }
       }
     } else if (lb_dev) {
       rc2 = launch_entlb(ctx, raw_host);

@@ -367,6 +367,9 @@ int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p);
 // gp: optional GP blocks (glj_block.h) appended to the finish launch's grid
 int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out, const GenSlice* gen = nullptr,
                         const DoneSignal* done = nullptr, const PrepArgs* gp = nullptr);
+// multi-GPU step: hand the all-reduced raw vector (device memory) to the host and publish done.seq;
+// spare workgroups generate `gen` (entropy.hip)
+int entmc_launch_publish(vbmc_ctx* ctx, const double* d_raw, const DoneSignal& done, const GenSlice* gen);
 // the slice of seed+1's draws the finish launch's spare workgroups should generate (n_blocks == 0: none)
 GenSlice entmc_ahead_slice(vbmc_ctx* ctx, const EntPlan& p, double frac_end = 1.0);
 // launch the speculative slice (on gen_stream when enabled) / wait until a pending one has completed

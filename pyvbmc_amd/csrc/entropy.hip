@@ -716,6 +716,28 @@ GenSlice make_gen_slice(double* eps, int K, int D, int64_t rows, int64_t n_half,
   return g;
 }
 
+namespace {
+// Multi-GPU step: the all-reduced raw vector (device memory, written by the collective in front of
+// this launch) goes to the pinned block in one coalesced copy and the sequence number is published;
+// the other workgroups generate the next evaluation's draws.
+__global__ __launch_bounds__(256) void entmc_publish_kernel(const double* __restrict__ src, DoneSignal done, GenSlice gen) {
+  if (blockIdx.x > 0) {
+    gen_slice_block(gen, blockIdx.x - 1, threadIdx.x);
+    return;
+  }
+  staged_copy_to_host(src, done.host_out, done.host_n);
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+int entmc_launch_publish(vbmc_ctx* ctx, const double* d_raw, const DoneSignal& done, const GenSlice* gen) {
+  const GenSlice g = gen ? *gen : GenSlice();
+  hipLaunchKernelGGL(entmc_publish_kernel, dim3(1 + g.n_blocks), dim3(256), 0, ctx->stream, d_raw, done, g);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
 int launch_eps_gen(vbmc_ctx* ctx, hipStream_t st, const GenSlice& g) {
   if (g.n_blocks <= 0) return 0;
   hipLaunchKernelGGL(eps_gen_kernel, dim3((unsigned)g.n_blocks), dim3(256), 0, st, g);
