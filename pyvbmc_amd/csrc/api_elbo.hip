@@ -355,7 +355,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
                        sp.grad_flags == grad_flags && sp.eps_mode == opts->eps_mode &&
                        sp.ns_per_comp == opts->ns_per_comp && sp.row_begin == row_begin && sp.row_count == row_count &&
                        !ctx->timing &&
-                       std::chrono::duration<double, std::milli>(clk::now() - sp.t_armed).count() < 10.0;
+                       std::chrono::duration<double, std::milli>(clk::now() - sp.t_armed).count() < 1.0;
     if (match) {
       memcpy(ctx->d_mix_fg, ctx->h_pack, sizeof(double) * (size_t)ctx->ml.total);
       __builtin_ia32_sfence();  // the pack before the go word (write-combined stores are not ordered otherwise)
@@ -364,14 +364,14 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
       ctx->pack_valid = true;
       sp.armed = false;
       const bool force_late = ctx->opt_arm_late_test > 0 && --ctx->opt_arm_late_test == 0;  // test hook
-      if (!force_late && std::chrono::duration<double, std::milli>(clk::now() - sp.t_armed).count() < 15.0) {
+      if (!force_late && std::chrono::duration<double, std::milli>(clk::now() - sp.t_armed).count() < 1.5) {
         ++sp.hits;
         used_armed = true;
         polled = true;
         cur_seq = sp.seq;
         HSTAMP(1);
       } else {
-        // This thread lost the CPU between the age check and the go word: the prep kernel's 20 ms
+        // This thread lost the CPU between the age check and the go word: the prep kernel's 2 ms
         // time-out may have fired around the same moment.  Whatever ran is discarded: drain the
         // queue, clear the completion counters, put the speculative-draw bookkeeping back to what it
         // was before arming (still true: that evaluation only READ the draws it was planned on)

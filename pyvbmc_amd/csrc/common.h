@@ -113,7 +113,7 @@ struct vbmc_ctx {
     int ahead_before_buf = 0;
     double ahead_before_frac = 1.0;
     uint64_t hits = 0, cancels = 0;
-    std::chrono::steady_clock::time_point t_armed;  // the device gives up after 20 ms: the host does not use an armed evaluation older than 10 ms
+    std::chrono::steady_clock::time_point t_armed;  // the device gives up after 2 ms: the host does not use an armed evaluation older than 1 ms
   } spec;
   uint64_t* d_ctl = nullptr;   // fine-grained device memory, 8 words: go / cancel word of evaluation seq is [seq & 7]
   double* d_stage = nullptr;   // device staging of the results the polled step hands to the host (DoneSignal)
@@ -311,7 +311,7 @@ struct PrepArgs {
   double* mix_copy = nullptr;
   int mix_copy_n = 0;
   // armed evaluation (ArmedEval): every workgroup first waits until *go == go_seq (the host has
-  // written the pack) -- or leaves at once when it reads ~0 (cancelled); after ~20 ms without either
+  // written the pack) -- or leaves at once when it reads ~0 (cancelled); after ~2 ms without either
   // it cancels by itself (*go = ~0 for the launches behind it, *dead = go_seq for the host)
   uint64_t* go = nullptr;
   uint64_t go_seq = 0;

@@ -409,7 +409,7 @@ def test_full_size_fused_step_vs_oracle(ctx):
     rng = np.random.default_rng(21)
     th0 = vp.get_parameters()
     thetas = [th0 + 0.02 * rng.standard_normal(th0.size) for _ in range(3)]
-    # the three device evaluations back to back (an armed evaluation is only used within 10 ms) ...
+    # the three device evaluations back to back (an armed evaluation is only used within 1 ms) ...
     got = []
     for i, theta in enumerate(thetas):
         F, dF, G, H, _ = _neg_elcbo(theta.copy(), gp, vp, 0.0, NsK, True, False, bnd, 0.0, False,
