@@ -1,6 +1,7 @@
 // The fused objective: one call = one evaluation of the negative ELBO
 // (reference vbmc/variational_optimization.py:991-1235 _neg_elcbo) with a single
 // host<->device round trip.
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cmath>
@@ -198,6 +199,9 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   const bool arm_next = can_poll && !multi && ctx->opt_elbo_arm && ctx->opt_mix_bar && !ctx->timing &&
                         opts->eps_mode == VBMC_EPS_PHILOX && ctx->opt_ahead_pct > 0 && ctx->opt_ahead_pct <= 100 &&
                         (ctx->opt_ahead_mode == 2 || ctx->opt_ahead_mode == 3);
+  // an armed evaluation is used within max(1 ms, 2.5 x the last evaluation's duration) of its arming; its prep
+  // kernel waits twice that before it gives up by itself
+  const double arm_limit_ms = std::max(1.0, 2.5e-3 * ctx->host_us[4]);
 
   // Plan and queue the launches of ONE evaluation with Philox seed `seed`.  spin = false: for this
   // call's theta (the pack is in ctx->h_pack); spin = true: armed -- the prep kernel waits for the
@@ -276,6 +280,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
       __builtin_ia32_sfence();
       pa.go = ctl;
       pa.go_seq = seq_out;
+      pa.go_timeout = (uint64_t)(2.0 * arm_limit_ms * 1e5);  // ticks of 10 ns
       pa.dead = ctx->hd_done + 5;
       plan.a.cancel = ctl;
     }
@@ -355,7 +360,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
                        sp.grad_flags == grad_flags && sp.eps_mode == opts->eps_mode &&
                        sp.ns_per_comp == opts->ns_per_comp && sp.row_begin == row_begin && sp.row_count == row_count &&
                        !ctx->timing &&
-                       std::chrono::duration<double, std::milli>(clk::now() - sp.t_armed).count() < 1.0;
+                       std::chrono::duration<double, std::milli>(clk::now() - sp.t_armed).count() < sp.limit_ms;
     if (match) {
       memcpy(ctx->d_mix_fg, ctx->h_pack, sizeof(double) * (size_t)ctx->ml.total);
       __builtin_ia32_sfence();  // the pack before the go word (write-combined stores are not ordered otherwise)
@@ -364,7 +369,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
       ctx->pack_valid = true;
       sp.armed = false;
       const bool force_late = ctx->opt_arm_late_test > 0 && --ctx->opt_arm_late_test == 0;  // test hook
-      if (!force_late && std::chrono::duration<double, std::milli>(clk::now() - sp.t_armed).count() < 1.5) {
+      if (!force_late && std::chrono::duration<double, std::milli>(clk::now() - sp.t_armed).count() < 1.5 * sp.limit_ms) {
         ++sp.hits;
         used_armed = true;
         polled = true;
@@ -409,6 +414,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     const int rc2 = issue(opts->seed + 1, true, p2, seq2);
     if (rc2 == 0 && p2) {
       sp.armed = true;
+      sp.limit_ms = arm_limit_ms;
       sp.t_armed = clk::now();
       sp.seq = seq2;
       sp.seed = opts->seed + 1;

@@ -113,6 +113,7 @@ struct vbmc_ctx {
     int ahead_before_buf = 0;
     double ahead_before_frac = 1.0;
     uint64_t hits = 0, cancels = 0;
+    double limit_ms = 1.0;  // use it within this time of arming (>= 1 ms, 2.5 x the last evaluation's duration); the device waits twice as long
     std::chrono::steady_clock::time_point t_armed;  // the device gives up after 2 ms: the host does not use an armed evaluation older than 1 ms
   } spec;
   uint64_t* d_ctl = nullptr;   // fine-grained device memory, 8 words: go / cancel word of evaluation seq is [seq & 7]
@@ -315,6 +316,7 @@ struct PrepArgs {
   // it cancels by itself (*go = ~0 for the launches behind it, *dead = go_seq for the host)
   uint64_t* go = nullptr;
   uint64_t go_seq = 0;
+  uint64_t go_timeout = 200000;  // wall-clock ticks (100 MHz) the launch waits for the go word
   uint64_t* dead = nullptr;
   // table part (n_table = K blocks, or 0)
   int n_table = 0, DP = 0, K4 = 0;

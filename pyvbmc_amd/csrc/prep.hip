@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
         const uint64_t v = __hip_atomic_load(a.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (v == a.go_seq) { st = 1; break; }
         if (v == ~(uint64_t)0) break;
-        if (wall_clock64() - t0 > 200000ull) {  // 2 ms at 100 MHz: give up
+        if (wall_clock64() - t0 > a.go_timeout) {  // (2 ms by default: twice the host's limit) give up
           if (blockIdx.x == 0 && blockIdx.y == 0) {
             __hip_atomic_store(a.go, ~(uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(a.dead, a.go_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
