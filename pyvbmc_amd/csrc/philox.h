@@ -43,35 +43,48 @@ __host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 
 __device__ inline void philox_normal_pair(uint64_t row, uint32_t pair, uint64_t seed, double& z0, double& z1);
 
-// Item t of a slice = (component j, row i of the slice, pair p): t = (j * rows + i) * np + p.
-// 64-bit division is ~50 instructions on this ISA and the generator needs two per item; items and
-// rows fit 32 bits in every case the library runs (checked per call), and a thread that generates
-// several items a fixed stride apart walks the position instead of dividing again.
+// Item t of a slice = (component j, row i of the slice, pair p): t = (j * rows + i) * np + p, so
+// r = t / np = j * rows + i is the row of the slice's eps block, the pair's normals go to
+// eps[r * D + 2p (+1)], and its Philox row is j * n_half + row_begin + i.
+// 64-bit division and multiplication are tens of instructions each on this ISA -- 32-bit integer
+// multiplies issue at a quarter of the rate, and this index arithmetic cost as much as the ten
+// Philox rounds -- so when items, rows and offsets fit 32 bits (checked per call, every case the
+// library runs) the position is derived with 32-bit operations, and a thread that generates several
+// items a fixed stride apart walks it with additions.
 struct GenPos {
-  int64_t j, i;
+  uint64_t grow;  // Philox row
+  int64_t off;    // element offset of the pair's first normal in eps
+  int64_t i;      // row within the component's slice
   int p;
 };
-__device__ inline GenPos gen_pos(const GenSlice& g, int64_t t, int np) {
+__device__ inline bool gen_fits32(const GenSlice& g, int np) {
+  const uint64_t items = (uint64_t)(g.item_begin + g.item_count), elems = (uint64_t)g.K * (uint64_t)g.rows * (uint64_t)g.D;
+  return ((items | elems | (uint64_t)g.rows | (uint64_t)g.n_half) >> 32) == 0;
+}
+__device__ inline GenPos gen_pos(const GenSlice& g, int64_t t, int np, bool fits32) {
   GenPos q;
-  if (((uint64_t)t | (uint64_t)g.rows) >> 32) {
+  if (!fits32) {
     const int64_t r = t / np;
     q.p = (int)(t - r * np);
-    q.j = r / g.rows;
-    q.i = r - q.j * g.rows;
+    const int64_t j = r / g.rows;
+    q.i = r - j * g.rows;
+    q.grow = (uint64_t)j * (uint64_t)g.n_half + (uint64_t)(g.row_begin + q.i);
+    q.off = r * g.D + 2 * q.p;
   } else {
     const uint32_t tt = (uint32_t)t, r = tt / (uint32_t)np, rows = (uint32_t)g.rows;
-    q.p = (int)(tt - r * (uint32_t)np);
-    const uint32_t jj = r / rows;
-    q.j = jj;
-    q.i = r - jj * rows;
+    const uint32_t p = tt - r * (uint32_t)np;
+    const uint32_t j = r / rows, i = r - j * rows;
+    q.p = (int)p;
+    q.i = i;
+    q.grow = (uint64_t)j * (uint64_t)(uint32_t)g.n_half + ((uint64_t)g.row_begin + i);  // one 32 x 32 -> 64 multiply-add
+    q.off = (int64_t)(r * (uint32_t)g.D + 2 * p);
   }
   return q;
 }
 __device__ inline void gen_emit(const GenSlice& g, const GenPos& q, uint64_t seed, double& z0, double& z1, double*& dst,
                                 bool& two) {
-  const uint64_t grow = (uint64_t)q.j * (uint64_t)g.n_half + (uint64_t)(g.row_begin + q.i);
-  philox_normal_pair(grow, (uint32_t)q.p, seed, z0, z1);
-  dst = g.eps + (q.j * g.rows + q.i) * g.D + 2 * q.p;
+  philox_normal_pair(q.grow, (uint32_t)q.p, seed, z0, z1);
+  dst = g.eps + q.off;
   two = 2 * q.p + 1 < g.D;
 }
 
@@ -79,13 +92,14 @@ __device__ inline void gen_emit(const GenSlice& g, const GenPos& q, uint64_t see
 __device__ inline void gen_slice_block(const GenSlice& g, int block, int tid) {
   const int np = (g.D + 1) / 2;
   const uint64_t seed = g.seed + (g.seed_add ? (uint64_t)g.seed_add[0] : 0);
+  const bool fits32 = gen_fits32(g, np);
   if (g.per_thread <= 1) {
     const int64_t local = (int64_t)block * 256 + tid;
     if (local >= g.item_count) return;
     double z0, z1;
     double* dst;
     bool two;
-    gen_emit(g, gen_pos(g, g.item_begin + local, np), seed, z0, z1, dst, two);
+    gen_emit(g, gen_pos(g, g.item_begin + local, np, fits32), seed, z0, z1, dst, two);
     dst[0] = z0;
     if (two) dst[1] = z1;
     return;
@@ -95,32 +109,46 @@ __device__ inline void gen_slice_block(const GenSlice& g, int block, int tid) {
   // wave still writes contiguous memory) and only then stores them.  The generation is arithmetic
   // for its first two thirds, so the 40 MB of stores reach the memory system in the last third.
   constexpr int PT = 8;
+  const int64_t base = (int64_t)block * (256 * PT) + tid;
+  const int step_r = 256 / np, step_p = 256 - step_r * np;  // 256 items further
+  if (g.rows <= step_r + 1) {  // slices too small to walk (more than one component boundary per step): item by item
+    for (int i = 0; i < PT; ++i) {
+      const int64_t local = base + (int64_t)i * 256;
+      if (local >= g.item_count) break;
+      double z0, z1;
+      double* dst;
+      bool two;
+      gen_emit(g, gen_pos(g, g.item_begin + local, np, fits32), seed, z0, z1, dst, two);
+      dst[0] = z0;
+      if (two) dst[1] = z1;
+    }
+    return;
+  }
   double z[PT][2];
   double* dst[PT];
   bool two[PT];
-  const int64_t base = (int64_t)block * (256 * PT) + tid;
-  GenPos q = gen_pos(g, g.item_begin + base, np);
-  const int step_r = 256 / np, step_p = 256 - step_r * np;  // 256 items further
-  const bool walk = g.rows > step_r + 1;
+  GenPos q = gen_pos(g, g.item_begin + base, np, fits32);
+  const int64_t step_off = (int64_t)step_r * g.D + 2 * step_p, wrap_off = (int64_t)g.D - 2 * np;
+  const uint64_t next_comp = (uint64_t)(g.n_half - g.rows);
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
     const int64_t local = base + (int64_t)i * 256;
     dst[i] = nullptr;
     two[i] = false;
     if (local < g.item_count) gen_emit(g, q, seed, z[i][0], z[i][1], dst[i], two[i]);
-    if (walk) {
-      q.p += step_p;
-      q.i += step_r;
-      if (q.p >= np) {
-        q.p -= np;
-        ++q.i;
-      }
-      if (q.i >= g.rows) {  // (rows > step_r + 1: at most one component boundary per step)
-        q.i -= g.rows;
-        ++q.j;
-      }
-    } else {
-      q = gen_pos(g, g.item_begin + local + 256, np);
+    q.p += step_p;
+    q.i += step_r;
+    q.grow += (uint64_t)step_r;
+    q.off += step_off;
+    if (q.p >= np) {
+      q.p -= np;
+      ++q.i;
+      ++q.grow;
+      q.off += wrap_off;
+    }
+    if (q.i >= g.rows) {  // (rows > step_r + 1: at most one component boundary per step)
+      q.i -= g.rows;
+      q.grow += next_comp;
     }
   }
 #pragma unroll

@@ -18,7 +18,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._duck import ctx_of, optimize_mask, store_mixture, upload_vp
+from ._duck import ctx_of, optimize_mask, upload_vp
 from .entropy import DEFAULT_RNG, _even_ns, draw_eps_half, entlb_vbmc, entmc_vbmc, philox_seed
 from .gp import upload_gp
 
@@ -192,7 +192,12 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
     if rc != 0:
         ctx.check(rc)
     # mirror the reference's side effects on vp and on the caller's theta
-    store_mixture(vp, fc.mu, fc.sg, fc.lm, fc.w, fc.eta if vp.optimize_weights else None)
+    # (store_mixture() through views shaped once: this sits between two evaluations of the optimiser)
+    vp.mu, vp.sigma, vp.lambd, vp.w = fc.mu_T.copy(), fc.sg_row.copy(), fc.lm_col.copy(), fc.w_row.copy()
+    if vp.optimize_weights:
+        vp.eta = fc.eta_row.copy()
+    if hasattr(vp, "_mode"):
+        vp._mode = None  # set_parameters drops the cached mode (variational_posterior.py:759)
     if vp.optimize_weights and type(theta) is np.ndarray and theta.dtype == fc.th.dtype:
         theta[-K:] = fc.th[-K:]
     return fc.F.value, (fc.dF.copy() if compute_grad else None), fc.G.value, fc.H.value, 0
@@ -239,6 +244,9 @@ class _FusedCall:
         self.dF = np.empty(n_theta)
         self.mu = np.empty((K, D))
         self.sg, self.lm, self.w, self.eta = np.empty(K), np.empty(D), np.empty(K), np.empty(K)
+        # the reference's attribute shapes as views of the buffers the library fills
+        self.mu_T, self.sg_row, self.lm_col = self.mu.T, self.sg.reshape(1, -1), self.lm.reshape(-1, 1)
+        self.w_row, self.eta_row = self.w.reshape(1, -1), self.eta.reshape(1, -1)
         self.F, self.G, self.H = C.c_double(), C.c_double(), C.c_double()
         o = self.opts = _lib.ElboOpts()
         o.row_begin, o.row_count, o.seed = 0, -1, 0

@@ -25,7 +25,7 @@ vp.mu, vp.sigma, vp.lambd = wl.mu.copy(), wl.sigma.reshape(1, -1), wl.lambd.resh
 vp.w, vp.eta = wl.w.reshape(1, -1), wl.eta.reshape(1, -1)
 theta = vp.get_parameters()
 lib = C.CDLL(str(_lib.LIB_PATH))
-buf = (C.c_ulonglong * 4)()
+buf = (C.c_ulonglong * (4 + 3 * 64))()
 import time
 rows = []
 for i in range(40):

@@ -76,4 +76,5 @@ names = ["entry -> prep launch issued (theta->pack, plan, CPU pack write)", "pre
 print("call period through the Python mirror %.1f us" % dt)
 for i, nm in enumerate(names):
     print("%-70s %6.1f us" % (nm, np.median(r[:, i])))
+print("finish start -> its last workgroup ends (last launch; generation of the next draws) %.1f us" % ((fb[2] - fb[0]) / 100.0))
 print("exit -> next entry (Python mirror) %.1f us" % np.median((h[3:-1, 0] - h[2:-2, 5]) / 1e3))
