@@ -241,9 +241,32 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
   const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (t >= n && !done.flag) return;  // (with a completion word every wave of the block meets at the barrier below)
   double v = 0.0;
+  // v = step(v, coef(i), partial[at(i)]) for i = lane, lane + 64, ... < total, in that order -- with the
+  // loads of four steps issued together (indices clamped, coefficients zeroed past the end, which
+  // leaves v unchanged): a wave's 8 steps at K * chunks = 500 cost two memory latencies instead of
+  // eight, and this reduction is on the path between the entropy kernel and the completion word
+  // (32-bit element offsets: the launcher refuses a partial block of 2^31 elements or more)
+  auto fold = [&](double acc, int total, auto&& coef, auto&& at, auto&& step) {
+    for (int b = 0; b < total; b += 4 * 64) {
+      double c[4], x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = b + 64 * u + lane;
+        const int ic = min(i, total - 1);
+        x[u] = partial[at(ic)];
+        c[u] = coef(ic);
+        if (i >= total) c[u] = 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = step(acc, c[u], x[u]);
+    }
+    return acc;
+  };
+  const auto add_prod = [](double a, double c, double x) { return a + c * x; };
   if (t >= n) {
   } else if (t == 0) {
-    for (int i = lane; i < K * chunks; i += 64) v -= w[i / chunks] * partial[(int64_t)i * stride];
+    v = fold(0.0, K * chunks, [&](int i) { return w[i / chunks]; }, [&](int i) { return (unsigned)(i * stride); },
+             [](double a, double c, double x) { return a - c * x; });
     v = wave_sum(v) * inv_ns;
   } else if (want_grad) {
     int u = t - 1;
@@ -256,27 +279,26 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
         const double* mup = mix + ml.o_mup;
         const double* is2 = mix + ml.o_is2;
         // lanes run over k within one partial row (coalesced), then over the chunks
-        for (int i = lane; i < K * chunks; i += 64) {
-          const int c = i / K, k = i - c * K;
-          const double Wjk = partial[((int64_t)j * chunks + c) * stride + 2 + 2 * D + k];
-          v = fma(w[k] * is2[k] * (mup[j * D + d] - mup[k * D + d]), Wjk, v);
-        }
+        const double mjd = mup[j * D + d];
+        v = fold(v, K * chunks,
+                 [&](int i) { const int k = i % K; return w[k] * is2[k] * (mjd - mup[k * D + d]); },
+                 [&](int i) { const int c = i / K, k = i - c * K; return (unsigned)((j * chunks + c) * stride + 2 + 2 * D + k); },
+                 [](double a, double c, double x) { return fma(c, x, a); });
       }
       v = wave_sum(v) * w[j] * inv_ns * ilam[d];
     } else if ((u -= D * K) < K) {
       for (int c = lane; c < chunks; c += 64) v += partial[((int64_t)u * chunks + c) * stride + 1 + D];
       v = wave_sum(v) * w[u] * inv_ns;
     } else if ((u -= K) < D) {
-      for (int i = lane; i < K * chunks; i += 64) {
-        const int j = i / chunks;
-        v += w[j] * sig[j] * partial[(int64_t)i * stride + 2 + D + u];
-      }
+      v = fold(0.0, K * chunks, [&](int i) { const int j = i / chunks; return w[j] * sig[j]; },
+               [&](int i) { return (unsigned)(i * stride + 2 + D + u); }, add_prod);
       v = wave_sum(v) * inv_ns * ilam[u];
     } else {
       u -= D;
-      double s = 0.0, sl = 0.0;
-      for (int i = lane; i < K * chunks; i += 64) s += w[i / chunks] * partial[(int64_t)i * stride + 2 + 2 * D + u];
+      double sl = 0.0;
       for (int c = lane; c < chunks; c += 64) sl += partial[((int64_t)u * chunks + c) * stride];
+      double s = fold(0.0, K * chunks, [&](int i) { return w[i / chunks]; },
+                      [&](int i) { return (unsigned)(i * stride + 2 + 2 * D + u); }, add_prod);
       s = wave_sum(s);
       sl = wave_sum(sl);
       v = -inv_ns * (sl + s);
@@ -748,6 +770,8 @@ int launch_eps_gen(vbmc_ctx* ctx, hipStream_t st, const GenSlice& g) {
 int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out, const GenSlice* gen,
                         const DoneSignal* done, const PrepArgs* gp) {
   const int n_out = raw_len(ctx->D, ctx->K);
+  if ((uint64_t)ctx->K * (uint64_t)p.a.chunks * (uint64_t)p.a.stride >= ((uint64_t)1 << 31))
+    return vbmc_fail(ctx, VBMC_E_UNSUP, "entropy: partial block of %d x %d rows too large", ctx->K, p.a.chunks);
   const GenSlice g = gen ? *gen : GenSlice();
   const DoneSignal ds = done ? *done : DoneSignal();
   PrepArgs ga;
