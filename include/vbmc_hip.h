@@ -193,6 +193,24 @@ int vbmc_mixture_pdf(vbmc_ctx* ctx, int64_t n, const double* x_nxD, int log_flag
 int vbmc_set_eps(vbmc_ctx* ctx, int K, int64_t n_half, int D, const double* eps_half,
                  int64_t row_begin, int64_t row_count);
 
+/* The reference's draw stream on the host cores (no device, no ctx): the next `n` values
+ * np.random.randn would return from NumPy's legacy global state -- MT19937 words, 53-bit
+ * uniforms, polar method (the eps of entmc_vbmc.py:67) -- bit for bit, with the state advanced
+ * exactly as NumPy would leave it.  `key[624], pos, has_gauss, gauss` are the fields of
+ * np.random.get_state(legacy=True) (in/out).  n_threads <= 0: all host cores (at most 64).
+ * The MT19937 recurrence runs on one thread; the polar method's attempts, each a pure
+ * function of its word position, on all of them (csrc/host_randn.hip). */
+int vbmc_mt19937_randn(uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out,
+                       int64_t n, int n_threads);
+
+/* vbmc_mt19937_randn + vbmc_set_eps in one call: the next K*n_half*D values of NumPy's legacy
+ * stream (= np.random.randn(n_half, D) for j = 0..K-1, the reference's draw order) are generated
+ * into a pinned buffer the ctx keeps and rows [row_begin, +row_count) of every component are
+ * uploaded as the resident draws.  The generator state advances by the whole job's values on
+ * every rank. */
+int vbmc_set_eps_numpy(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double* gauss, int K,
+                       int64_t n_half, int D, int64_t row_begin, int64_t row_count, int n_threads);
+
 /* Monte-Carlo entropy and its reparameterisation gradient.
  *   ns_per_comp : the reference's (even-rounded) Ns = 2*n_half.
  *   eps_mode    : VBMC_EPS_RESIDENT or VBMC_EPS_PHILOX (`seed` used by the latter).

@@ -72,6 +72,15 @@ SIGNATURES = {
     "vbmc_theta_to_mixture": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "vbmc_mixture_pdf": (C.c_int, [_vp, C.c_int64, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp]),
     "vbmc_set_eps": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, _dp, C.c_int64, C.c_int64]),
+    "vbmc_mt19937_randn": (
+        C.c_int,
+        [C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp, C.c_int64, C.c_int],
+    ),
+    "vbmc_set_eps_numpy": (
+        C.c_int,
+        [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_int, C.c_int64, C.c_int,
+         C.c_int64, C.c_int64, C.c_int],
+    ),
     "vbmc_entmc": (
         C.c_int,
         [_vp, C.c_int64, C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_int, _dp, _dp, _dp],
@@ -263,6 +272,25 @@ class Context:
         if row_count is None:
             row_count = h - row_begin
         self.check(self._lib.vbmc_set_eps(self._h, K, h, D, ptr(eps_half), row_begin, row_count))
+
+    def set_eps_numpy(self, K, n_half, D, row_begin=0, row_count=None, threads=0):
+        """Draw the reference's eps (the next K*n_half*D values of np.random.randn, NumPy's global
+        state advanced accordingly) and make this context's rows of them the resident draws --
+        without the values ever becoming a NumPy array.  False when NumPy's global generator is not
+        MT19937 (the caller then draws with NumPy and uses set_eps)."""
+        st = np.random.get_state(legacy=True)
+        if st[0] != "MT19937":
+            return False
+        if row_count is None:
+            row_count = n_half - row_begin
+        key = np.array(st[1], dtype=np.uint32)
+        pos, has_gauss, gauss = C.c_int(int(st[2])), C.c_int(int(st[3])), C.c_double(float(st[4]))
+        rc = self._lib.vbmc_set_eps_numpy(self._h, key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos),
+                                          C.byref(has_gauss), C.byref(gauss), K, n_half, D, row_begin, row_count, threads)
+        # (the state is written back even on an upload error: the values have been drawn)
+        np.random.set_state(("MT19937", key, pos.value, has_gauss.value, gauss.value))
+        self.check(rc)
+        return True
 
     def comm_init(self, uid_bytes, rank, world):
         buf = (C.c_uint8 * 128).from_buffer_copy(uid_bytes)

@@ -30,6 +30,7 @@ SOURCES = [
     "api_acq_is.hip",
     "sample.hip",
     "comm.hip",
+    "host_randn.hip",
 ]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [

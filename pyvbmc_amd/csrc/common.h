@@ -164,6 +164,8 @@ struct vbmc_ctx {
   double* d_out = nullptr;  // small result vectors
   size_t d_out_cap = 0;
   double* h_pinned = nullptr;  // pinned host staging for results (also written directly by kernels)
+  double* h_eps = nullptr;     // pinned host buffer the reference-stream draws are generated into (vbmc_set_eps_numpy)
+  size_t h_eps_cap = 0;
   size_t h_pinned_cap = 0;
   double* h_pack = nullptr;    // pinned source of the mixture pack upload
   size_t h_pack_cap = 0;

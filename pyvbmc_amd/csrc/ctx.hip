@@ -171,6 +171,7 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   if (ctx->h_done) (void)hipHostFree(ctx->h_done);
   if (ctx->d_done_cnt) (void)hipFree(ctx->d_done_cnt);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  if (ctx->h_eps) (void)hipHostFree(ctx->h_eps);
   if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
 
   for (hipEvent_t e : ctx->ev)
@@ -515,13 +516,8 @@ int vbmc_theta_to_mixture(vbmc_ctx* ctx, const double* theta, int n_theta, int o
   return VBMC_OK;
 }
 
-int vbmc_set_eps(vbmc_ctx* ctx, int K, int64_t n_half, int D, const double* eps_half,
-                 int64_t row_begin, int64_t row_count) {
-  if (!ctx || !eps_half || K < 1 || D < 1 || n_half < 0) return VBMC_E_ARG;
-  if (row_begin < 0 || row_count < 0 || row_begin + row_count > n_half)
-    return vbmc_fail(ctx, VBMC_E_ARG, "set_eps: rows [%lld,+%lld) outside [0,%lld)",
-                     (long long)row_begin, (long long)row_count, (long long)n_half);
-  NEED_DEVICE(ctx);
+static int upload_eps(vbmc_ctx* ctx, int K, int64_t n_half, int D, const double* eps_half, int64_t row_begin,
+                      int64_t row_count) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   size_t n = (size_t)K * (size_t)row_count * (size_t)D;
   int rc = ensure_dev(ctx, &ctx->d_eps, &ctx->d_eps_cap, n ? n : 1);
@@ -539,6 +535,42 @@ int vbmc_set_eps(vbmc_ctx* ctx, int K, int64_t n_half, int D, const double* eps_
   ctx->eps_row_begin = row_begin;
   ctx->eps_n_half = n_half;
   return VBMC_OK;
+}
+
+int vbmc_set_eps(vbmc_ctx* ctx, int K, int64_t n_half, int D, const double* eps_half,
+                 int64_t row_begin, int64_t row_count) {
+  if (!ctx || !eps_half || K < 1 || D < 1 || n_half < 0) return VBMC_E_ARG;
+  if (row_begin < 0 || row_count < 0 || row_begin + row_count > n_half)
+    return vbmc_fail(ctx, VBMC_E_ARG, "set_eps: rows [%lld,+%lld) outside [0,%lld)",
+                     (long long)row_begin, (long long)row_count, (long long)n_half);
+  NEED_DEVICE(ctx);
+  return upload_eps(ctx, K, n_half, D, eps_half, row_begin, row_count);
+}
+
+int vbmc_set_eps_numpy(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double* gauss, int K,
+                       int64_t n_half, int D, int64_t row_begin, int64_t row_count, int n_threads) {
+  if (!ctx || !key || !pos || !has_gauss || !gauss || K < 1 || D < 1 || n_half < 0) return VBMC_E_ARG;
+  if (row_begin < 0 || row_count < 0 || row_begin + row_count > n_half)
+    return vbmc_fail(ctx, VBMC_E_ARG, "set_eps_numpy: rows [%lld,+%lld) outside [0,%lld)",
+                     (long long)row_begin, (long long)row_count, (long long)n_half);
+  NEED_DEVICE(ctx);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // every rank draws the whole job's values (the reference's stream has one order) and ships its rows
+  const size_t n_all = (size_t)K * (size_t)n_half * (size_t)D;
+  if (ctx->h_eps_cap < n_all || !ctx->h_eps) {
+    if (ctx->h_eps) {
+      HIP_TRY(ctx, stream_wait(ctx));
+      HIP_TRY(ctx, hipHostFree(ctx->h_eps));
+      ctx->h_eps = nullptr;
+      ctx->h_eps_cap = 0;
+    }
+    const size_t want = n_all + n_all / 8 + 64;
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_eps, want * sizeof(double), hipHostMallocDefault));
+    ctx->h_eps_cap = want;
+  }
+  const int rc = vbmc_mt19937_randn(key, pos, has_gauss, gauss, ctx->h_eps, (int64_t)n_all, n_threads);
+  if (rc) return vbmc_fail(ctx, rc, "set_eps_numpy: generator state rejected");
+  return upload_eps(ctx, K, n_half, D, ctx->h_eps, row_begin, row_count);
 }
 
 }  // extern "C"

@@ -35,8 +35,53 @@ def _even_ns(Ns):
     return math.ceil(Ns / 2) * 2
 
 
+def host_randn(n, threads=0):
+    """The next ``n`` values of ``np.random.randn`` -- same values, same state left behind -- drawn
+    by the library's multi-threaded restatement of NumPy's legacy stream (csrc/host_randn.hip);
+    ``None`` when the global generator is not the MT19937 one that restatement covers."""
+    st = np.random.get_state(legacy=True)
+    if st[0] != "MT19937":
+        return None
+    key = np.array(st[1], dtype=np.uint32)
+    pos, has_gauss, gauss = C.c_int(int(st[2])), C.c_int(int(st[3])), C.c_double(float(st[4]))
+    out = np.empty(int(n))
+    rc = _lib.load().vbmc_mt19937_randn(key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), C.byref(has_gauss),
+                                        C.byref(gauss), _lib.ptr(out), int(n), int(threads))
+    if rc != 0:
+        raise RuntimeError(f"vbmc_mt19937_randn failed ({rc})")
+    np.random.set_state(("MT19937", key, pos.value, has_gauss.value, gauss.value))
+    return out
+
+
+_HOST_RANDN_MIN = 1 << 16  # below this np.random.randn itself is as fast as the call's fixed costs
+
+
+def upload_reference_eps(ctx, K, D, ns, eps_half=None):
+    """Make the reference's draws (or the caller's ``eps_half``) the context's resident eps: this
+    rank's share of the antithetic-pair rows of every component.  Drawn inside the library --
+    multi-threaded, straight into pinned memory -- when the job is large enough to pay for it."""
+    h = ns // 2
+    r0 = h * ctx.rank // ctx.world
+    r1 = h * (ctx.rank + 1) // ctx.world
+    if eps_half is None:
+        if K * h * D >= _HOST_RANDN_MIN and ctx.set_eps_numpy(K, h, D, r0, r1 - r0):
+            return
+        eps_half = draw_eps_half(K, D, ns)
+    eps_half = np.ascontiguousarray(eps_half, dtype=np.float64)
+    if eps_half.shape != (K, h, D):
+        raise ValueError(f"eps_half must have shape {(K, h, D)}, got {eps_half.shape}")
+    ctx.set_eps(eps_half, r0, r1 - r0)
+
+
 def draw_eps_half(K, D, Ns):
+    """The eps the reference draws (entmc_vbmc.py:67): ``np.random.randn(Ns/2, D)`` for j = 0..K-1, in
+    that order, i.e. the next K*Ns/2*D values of the global stream in C order."""
     h = _even_ns(Ns) // 2
+    n = K * h * D
+    if n >= _HOST_RANDN_MIN:
+        flat = host_randn(n)
+        if flat is not None:
+            return flat.reshape(K, h, D)
     eps = np.empty((K, h, D))
     for j in range(K):
         eps[j] = np.random.randn(h, D)
@@ -100,12 +145,7 @@ def entmc_vbmc(vp, Ns, grad_flags=tuple([True] * 4), jacobian_flag=True, *, rng=
     r0 = h * ctx.rank // ctx.world
     r1 = h * (ctx.rank + 1) // ctx.world
     if eps_half is not None or rng == "numpy":
-        if eps_half is None:
-            eps_half = draw_eps_half(K, D, ns)
-        eps_half = np.ascontiguousarray(eps_half, dtype=np.float64)
-        if eps_half.shape != (K, h, D):
-            raise ValueError(f"eps_half must have shape {(K, h, D)}, got {eps_half.shape}")
-        ctx.set_eps(eps_half, r0, r1 - r0)
+        upload_reference_eps(ctx, K, D, ns, eps_half)
         mode, seed = _lib.EPS_RESIDENT, 0
     elif rng == "philox":
         if seed is None:

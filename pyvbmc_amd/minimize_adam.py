@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _lib
 from ._duck import ctx_of, optimize_mask, store_mixture, upload_vp
-from .entropy import _even_ns, draw_eps_half, philox_seed
+from .entropy import _even_ns, philox_seed, upload_reference_eps
 from .gp import upload_gp
 
 BATCH_SIZE = 20  # minimize_adam.py:66
@@ -118,11 +118,7 @@ def minimize_adam_elbo(theta0, gp, vp, Ns, theta_bnd=None, beta=0.0, lb=None, ub
         opts.weight_penalty = float(theta_bnd.get("weight_penalty", 0.0))
     mode = "philox" if rng is None else rng  # fresh draws per iteration need the in-kernel generator
     if eps_half is not None or mode == "numpy":
-        if eps_half is None:
-            eps_half = draw_eps_half(K, D, ns)
-        h = ns // 2
-        r0, r1 = h * ctx.rank // ctx.world, h * (ctx.rank + 1) // ctx.world
-        ctx.set_eps(np.ascontiguousarray(eps_half, dtype=np.float64), r0, r1 - r0)
+        upload_reference_eps(ctx, K, D, ns, eps_half)
         opts.eps_mode, opts.seed = _lib.EPS_RESIDENT, 0
     elif mode == "philox":
         if seed is None:

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _lib
 from ._duck import ctx_of, optimize_mask, upload_vp
-from .entropy import DEFAULT_RNG, _even_ns, draw_eps_half, entlb_vbmc, entmc_vbmc, philox_seed
+from .entropy import DEFAULT_RNG, _even_ns, entlb_vbmc, entmc_vbmc, philox_seed, upload_reference_eps
 from .gp import upload_gp
 
 
@@ -175,12 +175,7 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
     if ns > 0:
         mode = DEFAULT_RNG if rng is None else rng
         if eps_half is not None or mode == "numpy":
-            if eps_half is None:
-                eps_half = draw_eps_half(K, D, ns)
-            h = ns // 2
-            r0 = h * ctx.rank // ctx.world
-            r1 = h * (ctx.rank + 1) // ctx.world
-            ctx.set_eps(np.ascontiguousarray(eps_half, dtype=np.float64), r0, r1 - r0)
+            upload_reference_eps(ctx, K, D, ns, eps_half)
             opts.eps_mode, opts.seed = _lib.EPS_RESIDENT, 0
         elif mode == "philox":
             if seed is None:
