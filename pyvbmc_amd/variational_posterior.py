@@ -26,6 +26,17 @@ import numpy as np
 
 from . import _lib
 from ._duck import upload_vp
+from .entropy import _HOST_RANDN_MIN, host_randn
+
+
+def _randn(n, d):
+    """``np.random.randn(n, d)`` -- the same values and generator state; large requests through the
+    library's multi-threaded restatement of NumPy's stream (csrc/host_randn.hip)."""
+    if n * d >= _HOST_RANDN_MIN:
+        flat = host_randn(n * d)
+        if flat is not None:
+            return flat.reshape(n, d)
+    return np.random.randn(n, d)
 
 
 class IdentityTransformer:
@@ -186,15 +197,15 @@ class VariationalPosterior:
                 i = np.random.choice(range(self.K), size=N, p=self.w.ravel())
             if heavy:
                 t = df / 2 / np.sqrt(np.random.gamma(df / 2, df / 2, (N, 1)))
-                x = self.mu.T[i] + lam * np.random.randn(N, self.D) * t * self.sigma[:, i].T
+                x = self.mu.T[i] + lam * _randn(N, self.D) * t * self.sigma[:, i].T
             else:
-                x = self.mu.T[i] + lam * np.random.randn(N, self.D) * self.sigma[:, i].T
+                x = self.mu.T[i] + lam * _randn(N, self.D) * self.sigma[:, i].T
         else:
             if heavy:
                 t = df / 2 / np.sqrt(np.random.gamma(df / 2, df / 2, (N, 1)))
-                x = self.mu.T + lam * t * np.random.randn(N, self.D) * self.sigma
+                x = self.mu.T + lam * t * _randn(N, self.D) * self.sigma
             else:
-                x = self.mu.T + lam * np.random.randn(N, self.D) * self.sigma
+                x = self.mu.T + lam * _randn(N, self.D) * self.sigma
             i = np.zeros(N)
         if orig_flag:
             x = self.parameter_transformer.inverse(x)

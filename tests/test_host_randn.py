@@ -60,3 +60,26 @@ def test_host_randn_declines_other_generators(monkeypatch):
     # a global state that is not MT19937 cannot be restated: the caller falls back to NumPy's own draw
     monkeypatch.setattr(np.random, "get_state", lambda legacy=True: ("PCG64", None, 0, 0, 0.0))
     assert ent.host_randn(10) is None
+
+
+def test_vp_sample_numpy_path_keeps_the_reference_stream():
+    """``vp.sample`` on the NumPy stream (variational_posterior.py:296-327) draws its N x D normals
+    through the restated generator once the request is large: same samples, same state after."""
+    from pyvbmc_amd import VariationalPosterior
+
+    np.random.seed(3)
+    vp = VariationalPosterior(4, 3)
+    vp.mu = np.random.randn(4, 3)
+    vp.sigma = np.exp(0.3 * np.random.randn(1, 3))
+    vp.lambd = np.exp(0.2 * np.random.randn(4, 1))
+    vp.w = np.array([[0.2, 0.5, 0.3]])
+    N = 30_000  # 120 000 normals: above the threshold
+    np.random.seed(8)
+    i_want = np.random.choice(range(3), size=N, p=vp.w.ravel())
+    x_want = vp.mu.T[i_want] + vp.lambd.reshape(1, -1) * np.random.randn(N, 4) * vp.sigma[:, i_want].T
+    after = np.random.rand(2)
+    np.random.seed(8)
+    x, i = vp.sample(N, orig_flag=False, rng="numpy")
+    assert np.array_equal(i, i_want)
+    assert np.array_equal(x, x_want)
+    assert np.array_equal(after, np.random.rand(2))
