@@ -43,6 +43,11 @@ rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_LDS_predict -o p -- $P > /dev/null 2>&1
 # the host-driven step's timeline
 bash $REPO/tools/step_timeline.sh $OUT/timeline --no-secondary > $OUT/timeline_stdout.txt 2>&1
+# the same statistics with the launches an armed evaluation cancelled told apart (tools/trace_stats.py)
+for d in stats stats_res stats_c2 stats_c5; do
+  t=$(find $OUT/$d -name "*_kernel_trace.csv" | head -1)
+  [ -n "$t" ] && python $REPO/tools/trace_stats.py "$t" $OUT/$d/completed_stats.csv
+done
 # keep only the small per-pass summaries (the raw traces exceed what gpurun copies back)
 find $OUT -name "*_kernel_trace.csv" -delete
 find $OUT -name "*_agent_info.csv" -delete

@@ -26,6 +26,9 @@ for mode, d in (("philox", "stats"), ("resident", "stats_res"), ("adam_loop", "s
     f = src / d / "s_kernel_stats.csv"
     if f.exists():
         shutil.copy(f, out / f"{tag}_kernel_stats_{mode}.csv")
+    f = src / d / "completed_stats.csv"  # tools/trace_stats.py: cancelled launches told apart
+    if f.exists():
+        shutil.copy(f, out / f"{tag}_kernel_stats_{mode}_completed.csv")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for p in sorted(src.glob("pmc_*/p_counter_collection.csv")):
     if "rows_mfma" in p.parent.name:
