@@ -18,7 +18,10 @@
 // entmc_finish_kernel with mu_from_w = 1 is unchanged) is
 //     mu_d  = sigma_j sum_k A_d(k)
 //     lam_d = sigma_j sum_k B_d(k) + sum_k Delta_kd A_d(k),   sig = sum_d lam_d,   W_k.
-// Used when the draws come from memory, K <= 64, at most 64 rows per component and D <= 16.
+// Used when the draws come from memory, K <= 64, at most 16 rows per component (the kernel handles up
+// to 64; above 16 the wave-split kernel is as fast or faster, entmc_small_applies) and D <= 16.
+#include <cstdlib>
+
 #include "adam_dev.h"
 #include "common.h"
 #include "entropy_args.h"
@@ -179,7 +182,13 @@ void launch_small(hipStream_t st, const EntArgs& a, const double* d_table) {
 }  // namespace
 
 bool entmc_small_applies(const EntArgs& a, int DP) {
-  return a.eps_mode != VBMC_EPS_PHILOX && a.eps != nullptr && a.ml.K <= 64 && a.row_count <= 64 && DP <= 16 &&
+  static const int max_rows = [] {
+    // measured in the optimiser loop (K = 50, D = 10, per iteration): this kernel 31.0 us at 14 rows
+    // per component, 31.8 at 24, 37.5 at 50, 40.6 at 64; the wave-split kernel 31.3-31.5 us at all of them
+    const char* e = getenv("VBMC_SMALL_MAX_ROWS");  // experiments
+    return e ? atoi(e) : 16;
+  }();
+  return a.eps_mode != VBMC_EPS_PHILOX && a.eps != nullptr && a.ml.K <= 64 && a.row_count <= max_rows && DP <= 16 &&
          a.chunks == 1;
 }
 

@@ -76,6 +76,24 @@ def test_entropy_sample_counts(ctx, NsK):
     assert rel_err(dH, dHo) < 1e-8
 
 
+@pytest.mark.parametrize("NsK,kernel", [(28, "small"), (32, "small"), (34, "ws"), (100, "ws")])
+def test_entropy_small_sample_counts_from_uploaded_draws(ctx, NsK, kernel):
+    """The optimiser's default sample counts (ns_ent = 100 K^(2/3) in total: 28 per component at
+    K = 50) with draws from memory: up to 16 antithetic rows per component take the row-split small
+    kernel (csrc/entropy_small.hip), more the wave-split one -- both against the oracle on the same
+    draws, and the choice asserted."""
+    from pyvbmc_amd import entmc_vbmc
+
+    wl, wd = case(6, 9, 20, NsK)
+    vp, _ = objects(wd, ctx)
+    eps = np.random.default_rng(NsK).standard_normal((9, NsK // 2, 6))
+    H, dH = entmc_vbmc(vp, NsK, (True,) * 4, True, eps_half=eps)
+    assert ctx.last_entmc_plan()["kernel"] == kernel
+    Ho, dHo = entropy_ref.entmc(oracle_mix(wd), NsK, (True,) * 4, True, eps_half=eps)
+    assert abs(H - Ho) <= 1e-10 * max(1.0, abs(Ho))
+    assert rel_err(dH, dHo) < 1e-8
+
+
 def test_entropy_far_apart_components(ctx):
     """Components hundreds of widths apart: cross densities underflow to exactly 0, sigma
     ratios of 1e3; the value stays finite and equals the oracle's."""
