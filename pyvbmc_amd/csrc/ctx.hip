@@ -522,11 +522,15 @@ static int upload_eps(vbmc_ctx* ctx, int K, int64_t n_half, int D, const double*
   size_t n = (size_t)K * (size_t)row_count * (size_t)D;
   int rc = ensure_dev(ctx, &ctx->d_eps, &ctx->d_eps_cap, n ? n : 1);
   if (rc) return rc;
-  for (int j = 0; j < K && row_count > 0; ++j) {
-    const double* src = eps_half + ((size_t)j * (size_t)n_half + (size_t)row_begin) * D;
-    double* dst = ctx->d_eps + (size_t)j * (size_t)row_count * D;
-    HIP_TRY(ctx, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)row_count * D,
-                                hipMemcpyHostToDevice, ctx->stream));
+  if (row_begin == 0 && row_count == n_half && n > 0) {  // the whole job: one contiguous block
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_eps, eps_half, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    for (int j = 0; j < K && row_count > 0; ++j) {
+      const double* src = eps_half + ((size_t)j * (size_t)n_half + (size_t)row_begin) * D;
+      double* dst = ctx->d_eps + (size_t)j * (size_t)row_count * D;
+      HIP_TRY(ctx, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)row_count * D,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    }
   }
   HIP_TRY(ctx, stream_wait(ctx));
   ctx->eps_K = K;

@@ -31,6 +31,8 @@
 
 #include "../../include/vbmc_hip.h"
 
+#ifndef __HIP_DEVICE_COMPILE__  // host code only (x86 dispatch builtins): nothing here for the gfx950 pass
+
 namespace {
 
 constexpr int MT_N = 624, MT_M = 397;
@@ -41,13 +43,24 @@ inline uint32_t twist(uint32_t hi, uint32_t lo) {
 }
 
 // d = the state after one regeneration of s (NumPy's mt19937_gen, written out of place so that each
-// of the three runs is a loop without a carried dependence shorter than 227 elements)
-void mt_next_block(const uint32_t* __restrict__ s, uint32_t* __restrict__ d) {
-  for (int i = 0; i < MT_N - MT_M; ++i) d[i] = s[i + MT_M] ^ twist(s[i], s[i + 1]);
-  for (int i = MT_N - MT_M; i < 2 * (MT_N - MT_M); ++i) d[i] = d[i - (MT_N - MT_M)] ^ twist(s[i], s[i + 1]);
-  for (int i = 2 * (MT_N - MT_M); i < MT_N - 1; ++i) d[i] = d[i - (MT_N - MT_M)] ^ twist(s[i], s[i + 1]);
+// of the three runs is a loop without a carried dependence shorter than 227 elements: the compiler
+// vectorises them).  Integer work only, so the 8-wide AVX2 build of the same source gives the same
+// words; it is chosen once at run time when the CPU has it.
+#define VBMC_MT_BLOCK_BODY                                                                                   \
+  for (int i = 0; i < MT_N - MT_M; ++i) d[i] = s[i + MT_M] ^ twist(s[i], s[i + 1]);                           \
+  for (int i = MT_N - MT_M; i < 2 * (MT_N - MT_M); ++i) d[i] = d[i - (MT_N - MT_M)] ^ twist(s[i], s[i + 1]);  \
+  for (int i = 2 * (MT_N - MT_M); i < MT_N - 1; ++i) d[i] = d[i - (MT_N - MT_M)] ^ twist(s[i], s[i + 1]);     \
   d[MT_N - 1] = d[MT_M - 1] ^ twist(s[MT_N - 1], d[0]);
+void mt_next_block_base(const uint32_t* __restrict__ s, uint32_t* __restrict__ d) { VBMC_MT_BLOCK_BODY }
+__attribute__((target("avx2"))) void mt_next_block_avx2(const uint32_t* __restrict__ s, uint32_t* __restrict__ d) {
+  VBMC_MT_BLOCK_BODY
 }
+#undef VBMC_MT_BLOCK_BODY
+using BlockFn = void (*)(const uint32_t*, uint32_t*);
+const BlockFn mt_next_block = [] {
+  __builtin_cpu_init();
+  return __builtin_cpu_supports("avx2") ? (BlockFn)mt_next_block_avx2 : (BlockFn)mt_next_block_base;
+}();
 
 inline uint32_t temper(uint32_t y) {
   y ^= y >> 11;
@@ -281,3 +294,5 @@ extern "C" int vbmc_mt19937_randn(uint32_t* key, int* pos, int* has_gauss, doubl
     return VBMC_E_ARG;  // unreachable: total >= pairs means some range completed the request
   }
 }
+
+#endif  // !__HIP_DEVICE_COMPILE__
