@@ -42,7 +42,8 @@ enum {
   VBMC_E_RCCL = -3,    /* RCCL error                                        */
   VBMC_E_NODEV = -4,   /* no usable gfx950 device                           */
   VBMC_E_UNSUP = -5,   /* combination the reference raises NotImplemented on */
-  VBMC_E_NONFINITE = -6 /* non-finite input where the path needs finite     */
+  VBMC_E_NONFINITE = -6, /* non-finite input where the path needs finite    */
+  VBMC_E_NOMEM = -7     /* host allocation failed (vbmc_mt19937_randn)       */
 };
 
 /* GP mean functions understood by the path

@@ -573,7 +573,7 @@ int vbmc_set_eps_numpy(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, d
     ctx->h_eps_cap = want;
   }
   const int rc = vbmc_mt19937_randn(key, pos, has_gauss, gauss, ctx->h_eps, (int64_t)n_all, n_threads);
-  if (rc) return vbmc_fail(ctx, rc, "set_eps_numpy: generator state rejected");
+  if (rc) return vbmc_fail(ctx, rc, rc == VBMC_E_NOMEM ? "set_eps_numpy: out of host memory" : "set_eps_numpy: generator state rejected");
   return upload_eps(ctx, K, n_half, D, ctx->h_eps, row_begin, row_count);
 }
 

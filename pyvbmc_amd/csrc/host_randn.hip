@@ -141,8 +141,21 @@ template <class F> void walk_attempts(const uint32_t* state, int64_t skip, int64
 
 }  // namespace
 
+static int randn_impl(uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out, int64_t n, int n_threads);
+
 extern "C" int vbmc_mt19937_randn(uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out, int64_t n,
                                   int n_threads) {
+  // no exception crosses the C boundary: every allocation below happens before the first thread is
+  // started, so an allocation failure unwinds with nothing running (thread creation failures are
+  // handled where they occur)
+  try {
+    return randn_impl(key, pos, has_gauss, gauss, out, n, n_threads);
+  } catch (const std::exception&) {
+    return VBMC_E_NOMEM;
+  }
+}
+
+static int randn_impl(uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out, int64_t n, int n_threads) {
   if (!key || !pos || !has_gauss || !gauss || n < 0 || (n > 0 && !out) || *pos < 0 || *pos > MT_N) return VBMC_E_ARG;
   int64_t produced = 0;
   if (n > 0 && *has_gauss) {  // the second value of the last accepted attempt comes first
