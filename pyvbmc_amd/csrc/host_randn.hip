@@ -3,7 +3,7 @@
 // The reference draws the Monte-Carlo entropy's eps with np.random.randn (entmc_vbmc.py:67): NumPy's
 // legacy global RandomState, i.e. MT19937 words -> 53-bit uniforms -> Marsaglia's polar method.  The
 // drop-in default (rng="numpy") reproduces those values draw for draw, and np.random.randn itself is
-// the cost of that mode: ~8 ns per normal on one core, 40 ms for the 5e6 of config 3 against a
+// the cost of that mode: ~10 ns per normal on one core, 48 ms for the 5e6 of config 3 against a
 // 0.1 ms evaluation.  The stream is sequential only in the MT19937 recurrence (cheap integer work,
 // one 624-word block from the one before); everything expensive is a pure function of the word
 // position: attempt t of the polar method always consumes words [4t, 4t+4) -- two doubles of two
@@ -91,9 +91,7 @@ inline Attempt attempt_at(const uint32_t* u) {  // legacy_gauss's loop body on w
 
 }  // namespace
 
-// Values [o0, o0 + n) ... see vbmc_mt19937_randn (include/vbmc_hip.h).
-//
-// Layout of the work.  Stream word w (w = 0 at key[pos]) is word pos + w of the block sequence
+// vbmc_mt19937_randn (include/vbmc_hip.h): layout of the work.  Stream word w (w = 0 at key[pos]) is word pos + w of the block sequence
 // 0 = the current key, 1 = its successor, ...; attempt t reads stream words [4t, 4t + 4).  The calling
 // thread runs the recurrence once over all blocks the request can need WITHOUT storing the stream --
 // two blocks ping-pong in its L1, 0.15 ns per word -- and keeps only one checkpoint (a 2.5 KB state)
