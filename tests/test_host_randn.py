@@ -83,3 +83,47 @@ def test_vp_sample_numpy_path_keeps_the_reference_stream():
     assert np.array_equal(i, i_want)
     assert np.array_equal(x, x_want)
     assert np.array_equal(after, np.random.rand(2))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pyvbmc_amd import _lib
+
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,h,D", [(3, 40, 4), (7, 3000, 5)])
+def test_set_eps_numpy_uploads_the_reference_draws(ctx, K, h, D):
+    """vbmc_set_eps_numpy = np.random.randn + vbmc_set_eps: the device ends up with the same resident
+    draws (checked through the raw entropy accumulator of a row shard and of the whole job) and
+    NumPy's state where randn would leave it -- the whole job's values are consumed on every rank."""
+    import ctypes as C
+
+    from pyvbmc_amd import _lib
+
+    rng = np.random.default_rng(K)
+    mu, sigma = rng.standard_normal((D, K)), np.exp(0.3 * rng.standard_normal(K))
+    lambd, w = np.exp(0.2 * rng.standard_normal(D)), rng.dirichlet(np.ones(K))
+    ctx.set_mixture(mu, sigma, lambd, w, np.log(w))
+    n = 1 + D * K + 2 * K + D
+
+    def raw(r0, rows):
+        H, out = C.c_double(), np.empty(n)
+        ctx.check(ctx._lib.vbmc_entmc(ctx._h, 2 * h, _lib.EPS_RESIDENT, 0, r0, rows, 15, 1, C.byref(H), None, _lib.ptr(out)))
+        return out
+
+    for r0, rows in ((0, h), (h // 3, h - h // 3)):
+        np.random.seed(21)
+        np.random.randn(1)  # a cached value going in
+        want_eps = np.stack([np.random.randn(h, D) for _ in range(K)])
+        want_after = np.random.rand(3)
+        ctx.set_eps(want_eps, r0, rows)
+        want = raw(r0, rows)
+        np.random.seed(21)
+        np.random.randn(1)
+        assert ctx.set_eps_numpy(K, h, D, r0, rows)
+        assert np.array_equal(want_after, np.random.rand(3))
+        assert np.array_equal(raw(r0, rows), want)
