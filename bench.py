@@ -227,18 +227,21 @@ def main():
         }
         if world == 1:
             # Secondary figure (never `value`): the drop-in's DEFAULT draw source, rng="numpy" -- the
-            # reference's MT19937 stream drawn on the host and shipped over PCIe every evaluation
-            # (bit-identical inputs to the reference's).  The headline needs rng="philox".
+            # reference's MT19937 stream drawn on the host cores (csrc/host_randn.hip) and shipped over
+            # PCIe every evaluation (bit-identical inputs to the reference's).  The headline needs
+            # rng="philox".
             _neg_elcbo(theta.copy(), gp, vp, 0.0, nsk_job, True, False, bnd, rng="numpy")
-            n_ref = 3
+            n_ref = 10
             t1 = time.perf_counter()
             for _ in range(n_ref):
                 _neg_elcbo(theta.copy(), gp, vp, 0.0, nsk_job, True, False, bnd, rng="numpy")
             dt_ref = (time.perf_counter() - t1) / n_ref
             reference_stream = {
                 "evals_per_s": 1.0 / dt_ref, "ms_per_eval": 1e3 * dt_ref, "evals": n_ref,
-                "what": "rng='numpy' (the default): host np.random.randn of K*NsK/2*D normals + H2D copy per "
-                        "evaluation, PCIe-inclusive; dominated by the host generator",
+                "what": "rng='numpy' (the default): the reference's np.random.randn stream of K*NsK/2*D normals, "
+                        "restated bit for bit on the host cores (vbmc_set_eps_numpy: MT19937 recurrence on one "
+                        "thread, polar method on all) + H2D copy per evaluation, PCIe-inclusive; dominated by "
+                        "the host generator",
             }
     for _ in range(a.warmup):
         out = step()
