@@ -244,6 +244,10 @@ int set_mixture_host(vbmc_ctx* ctx, int D, int K, const double* mu_KxD, const do
 // buffer helpers (ctx.hip) --------------------------------------------------
 int ensure_dev(vbmc_ctx* ctx, double** p, size_t* cap, size_t n_doubles);
 int ensure_pinned(vbmc_ctx* ctx, size_t n_doubles);
+// csrc/host_randn.hip: vbmc_mt19937_randn with progress(user, m) = "out[0 .. m) is final", called from
+// the calling thread while the worker threads still write the rest
+int randn_with_progress(uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out, int64_t n, int n_threads,
+                        void (*progress)(void*, int64_t), void* user);
 
 // raw-vector length of the entropy accumulator
 static inline int raw_len(int D, int K) { return 1 + D * K + 2 * K + D; }

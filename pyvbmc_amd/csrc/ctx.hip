@@ -572,9 +572,38 @@ int vbmc_set_eps_numpy(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, d
     HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_eps, want * sizeof(double), hipHostMallocDefault));
     ctx->h_eps_cap = want;
   }
-  const int rc = vbmc_mt19937_randn(key, pos, has_gauss, gauss, ctx->h_eps, (int64_t)n_all, n_threads);
+  // this context holds all rows (one GPU): the finished prefix of the draws goes up while the rest is
+  // still being generated; a row shard is uploaded afterwards, component by component
+  struct Up {
+    vbmc_ctx* ctx;
+    int64_t sent;
+    hipError_t err;
+  } up{ctx, 0, hipSuccess};
+  const bool whole = row_begin == 0 && row_count == n_half && n_all > 0;
+  if (whole) {
+    const int erc = ensure_dev(ctx, &ctx->d_eps, &ctx->d_eps_cap, n_all);
+    if (erc) return erc;
+  }
+  auto progress = [](void* user, int64_t m) {
+    Up* u = (Up*)user;
+    if (m <= u->sent || u->err != hipSuccess) return;
+    u->err = hipMemcpyAsync(u->ctx->d_eps + u->sent, u->ctx->h_eps + u->sent, sizeof(double) * (size_t)(m - u->sent),
+                            hipMemcpyHostToDevice, u->ctx->stream);
+    u->sent = m;
+  };
+  const int rc = randn_with_progress(key, pos, has_gauss, gauss, ctx->h_eps, (int64_t)n_all, n_threads,
+                                     whole ? +progress : nullptr, &up);
   if (rc) return vbmc_fail(ctx, rc, rc == VBMC_E_NOMEM ? "set_eps_numpy: out of host memory" : "set_eps_numpy: generator state rejected");
-  return upload_eps(ctx, K, n_half, D, ctx->h_eps, row_begin, row_count);
+  if (!whole) return upload_eps(ctx, K, n_half, D, ctx->h_eps, row_begin, row_count);
+  progress(&up, (int64_t)n_all);  // whatever the generator did not report
+  HIP_TRY(ctx, up.err);
+  HIP_TRY(ctx, stream_wait(ctx));
+  ctx->eps_K = K;
+  ctx->eps_D = D;
+  ctx->eps_rows = row_count;
+  ctx->eps_row_begin = row_begin;
+  ctx->eps_n_half = n_half;
+  return VBMC_OK;
 }
 
 }  // extern "C"

@@ -140,7 +140,11 @@ template <class F> void walk_attempts(const uint32_t* state, int64_t skip, int64
 
 }  // namespace
 
-static int randn_impl(uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out, int64_t n, int n_threads);
+// progress(user, m): out[0 .. m) is final (called from the calling thread while the team still writes
+// the rest; m grows; the caller handles whatever is left after the return)
+using RandnProgress = void (*)(void* user, int64_t m);
+static int randn_impl(uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out, int64_t n, int n_threads,
+                      RandnProgress progress, void* user);
 
 extern "C" int vbmc_mt19937_randn(uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out, int64_t n,
                                   int n_threads) {
@@ -148,13 +152,25 @@ extern "C" int vbmc_mt19937_randn(uint32_t* key, int* pos, int* has_gauss, doubl
   // started, so an allocation failure unwinds with nothing running (thread creation failures are
   // handled where they occur)
   try {
-    return randn_impl(key, pos, has_gauss, gauss, out, n, n_threads);
+    return randn_impl(key, pos, has_gauss, gauss, out, n, n_threads, nullptr, nullptr);
   } catch (const std::exception&) {
     return VBMC_E_NOMEM;
   }
 }
 
-static int randn_impl(uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out, int64_t n, int n_threads) {
+// the same with the progress callback (declared in common.h; vbmc_set_eps_numpy uploads the finished
+// prefix of the draws while the rest is generated)
+int randn_with_progress(uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out, int64_t n, int n_threads,
+                        void (*progress)(void*, int64_t), void* user) {
+  try {
+    return randn_impl(key, pos, has_gauss, gauss, out, n, n_threads, progress, user);
+  } catch (const std::exception&) {
+    return VBMC_E_NOMEM;
+  }
+}
+
+static int randn_impl(uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out, int64_t n, int n_threads,
+                      RandnProgress progress, void* user) {
   if (!key || !pos || !has_gauss || !gauss || n < 0 || (n > 0 && !out) || *pos < 0 || *pos > MT_N) return VBMC_E_ARG;
   int64_t produced = 0;
   if (n > 0 && *has_gauss) {  // the second value of the last accepted attempt comes first
@@ -195,9 +211,12 @@ static int randn_impl(uint32_t* key, int* pos, int* has_gauss, double* gauss, do
     };
     std::unique_ptr<Flag[]> ready(new Flag[R]);
     std::atomic<int> next_count{0}, next_value{0}, counted{0}, phase2{0};
-    auto wait_for = [](auto&& cond) {
-      for (int spins = 0; !cond(); ++spins)
-        if (spins > 64) std::this_thread::yield();
+    static const bool backoff = !getenv("VBMC_RANDN_NOSLEEP");  // experiments
+    auto wait_for = [](auto&& cond) {  // short waits spin, long ones get out of the way of the threads that work
+      for (int spins = 0; !cond(); ++spins) {
+        if (spins > 2000 && backoff) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        else if (spins > 64) std::this_thread::yield();
+      }
     };
     auto count_range = [&](int r) {
       Range& g = rg[r];
@@ -235,7 +254,10 @@ static int randn_impl(uint32_t* key, int* pos, int* has_gauss, double* gauss, do
       }
       wait_for([&] { return phase2.load(std::memory_order_acquire) != 0; });
       if (phase2.load(std::memory_order_relaxed) < 0) return;
-      for (int r; (r = next_value.fetch_add(1, std::memory_order_relaxed)) < R;) value_range(r);
+      for (int r; (r = next_value.fetch_add(1, std::memory_order_relaxed)) < R;) {
+        value_range(r);
+        ready[r].v.store(2, std::memory_order_release);  // this range's values are in place
+      }
     };
     // the team is started by its first member (creating 64 threads takes the calling thread ~1.5 ms,
     // as long as its pass over the recurrence)
@@ -283,6 +305,21 @@ static int randn_impl(uint32_t* key, int* pos, int* has_gauss, double* gauss, do
     phase2.store(total < pairs ? -1 : 1, std::memory_order_release);
     if (alone && total >= pairs)
       for (int r = 0; r < R; ++r) value_range(r);
+    if (!alone && total >= pairs && progress) {
+      // hand the finished prefix of the output to the caller while the rest is being written (the
+      // upload of the draws then runs beside their generation): ranges are taken in order
+      int64_t reported = 0;
+      for (int r = 0; r < R;) {
+        wait_for([&] { return ready[r].v.load(std::memory_order_acquire) == 2; });
+        while (r < R && ready[r].v.load(std::memory_order_acquire) == 2) ++r;
+        const int64_t pairs_done = r < R ? std::min(rg[r].first_pair, pairs) : pairs;
+        const int64_t m = produced + std::min(2 * pairs_done, rest);
+        if (m - reported >= ((int64_t)1 << 19) || r == R) {  // >= 4 MB at a time
+          progress(user, m);
+          reported = m;
+        }
+      }
+    }
     if (starter.joinable()) starter.join();  // (its team is complete once it has returned)
     for (auto& th : team) th.join();
     if (total < pairs) continue;
