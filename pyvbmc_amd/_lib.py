@@ -279,7 +279,7 @@ class Context:
         without the values ever becoming a NumPy array.  False when NumPy's global generator is not
         MT19937 (the caller then draws with NumPy and uses set_eps)."""
         st = np.random.get_state(legacy=True)
-        if st[0] != "MT19937":
+        if not isinstance(st, tuple) or st[0] != "MT19937":  # (a replaced bit generator reports a dict)
             return False
         if row_count is None:
             row_count = n_half - row_begin

@@ -40,7 +40,7 @@ def host_randn(n, threads=0):
     by the library's multi-threaded restatement of NumPy's legacy stream (csrc/host_randn.hip);
     ``None`` when the global generator is not the MT19937 one that restatement covers."""
     st = np.random.get_state(legacy=True)
-    if st[0] != "MT19937":
+    if not isinstance(st, tuple) or st[0] != "MT19937":  # (a replaced bit generator reports a dict)
         return None
     key = np.array(st[1], dtype=np.uint32)
     pos, has_gauss, gauss = C.c_int(int(st[2])), C.c_int(int(st[3])), C.c_double(float(st[4]))

@@ -60,6 +60,8 @@ def test_host_randn_declines_other_generators(monkeypatch):
     # a global state that is not MT19937 cannot be restated: the caller falls back to NumPy's own draw
     monkeypatch.setattr(np.random, "get_state", lambda legacy=True: ("PCG64", None, 0, 0, 0.0))
     assert ent.host_randn(10) is None
+    monkeypatch.setattr(np.random, "get_state", lambda legacy=True: {"bit_generator": "PCG64", "state": {}})
+    assert ent.host_randn(10) is None
 
 
 def test_vp_sample_numpy_path_keeps_the_reference_stream():
