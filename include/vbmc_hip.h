@@ -150,6 +150,13 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value);
  * generated in-line.  Lets the parity tests assert which code path they exercised. */
 int vbmc_last_entmc_plan(const vbmc_ctx* ctx, int out[4]);
 
+/* The raw (pre-Jacobian) entropy accumulator [H | mu (K x D) | sigma (K) | lambda (D) | w (K)] of
+ * the most recent Monte-Carlo vbmc_neg_elcbo of this ctx -- the vector the sharded job all-reduces
+ * (additive over disjoint row slices; with a communicator: the sum over the ranks).  n must be
+ * 1 + D*K + 2K + D.  VBMC_E_ARG when the last evaluation had none.  Lets the parity tests add up
+ * the slices of virtual ranks (row_begin/row_count of vbmc_elbo_opts) on one GPU. */
+int vbmc_last_elbo_raw(const vbmc_ctx* ctx, double* out, int n);
+
 /* ---- mixture state: VariationalPosterior attributes --------------------- */
 
 /* Upload the mixture (variational_posterior.py:106-138: mu (D,K), sigma (1,K),

@@ -65,6 +65,7 @@ SIGNATURES = {
     "vbmc_synchronize": (C.c_int, [_vp]),
     "vbmc_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "vbmc_last_entmc_plan": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "vbmc_last_elbo_raw": (C.c_int, [_vp, _dp, C.c_int]),
     "vbmc_set_timing": (C.c_int, [_vp, C.c_int]),
     "vbmc_last_kernel_ms": (C.c_int, [_vp, C.c_int, _dp]),
     "vbmc_last_host_us": (C.c_int, [_vp, _dp]),
@@ -244,6 +245,13 @@ class Context:
         self.check(self._lib.vbmc_last_entmc_plan(self._h, out))
         return {"kernel": ("valu", "ws", "small")[out[0]] if out[0] >= 0 else None, "rg": out[1],
                 "chunks": out[2], "resident_draws": bool(out[3])}
+
+    def last_elbo_raw(self, D, K):
+        """Raw entropy accumulator of the most recent Monte-Carlo ``vbmc_neg_elcbo`` (additive over
+        row slices; see include/vbmc_hip.h)."""
+        out = np.empty(1 + D * K + 2 * K + D)
+        self.check(self._lib.vbmc_last_elbo_raw(self._h, ptr(out), out.size))
+        return out
 
     def last_kernel_ms(self, which=0):
         v = C.c_double()

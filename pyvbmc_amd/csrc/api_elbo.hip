@@ -598,6 +598,8 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     rc = vbmc_entlb(ctx, grad_flags, 1, &Hv, grad_flags ? dHv.data() : nullptr);  // K == 1 closed form
     if (rc) return rc;
   }
+  ctx->last_raw_off = n_res;
+  ctx->last_raw_n = mc ? n_raw : 0;
   double Fv = -Gv - Hv;
   std::vector<double>& dFv = sc.dF;
   dFv.assign((size_t)n_theta, 0.0);
@@ -618,6 +620,12 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   if (G) *G = Gv;
   if (H) *H = Hv;
   if (dF && grad_flags) memcpy(dF, dFv.data(), sizeof(double) * n_theta);
+  return VBMC_OK;
+}
+
+extern "C" int vbmc_last_elbo_raw(const vbmc_ctx* ctx, double* out, int n) {
+  if (!ctx || !out || ctx->last_raw_n <= 0 || n != ctx->last_raw_n || !ctx->h_pinned) return VBMC_E_ARG;
+  memcpy(out, ctx->h_pinned + ctx->last_raw_off, sizeof(double) * (size_t)n);
   return VBMC_OK;
 }
 

@@ -195,6 +195,8 @@ struct vbmc_ctx {
   double exp_eta_sum = 0.0;
   bool exp_eta_valid = false;
   int last_plan[4] = {-1, 0, 0, 0};  // see vbmc_last_entmc_plan
+  size_t last_raw_off = 0;           // see vbmc_last_elbo_raw: offset into h_pinned, length (0: none)
+  int last_raw_n = 0;
 
   GpState gp;
 

@@ -133,8 +133,12 @@ def _n_grad(vp, bits):
 
 
 def entmc_vbmc(vp, Ns, grad_flags=tuple([True] * 4), jacobian_flag=True, *, rng=None, seed=None,
-               eps_half=None, ctx=None, return_raw=False):
-    """Monte-Carlo entropy of the variational posterior and its gradient."""
+               eps_half=None, ctx=None, return_raw=False, rows=None):
+    """Monte-Carlo entropy of the variational posterior and its gradient.
+
+    ``rows=(begin, count)`` (Philox draws only) evaluates that slice of every component's
+    antithetic-pair rows instead of the context's own share -- the contribution of one rank of a
+    sharded job, so the slices of "virtual ranks" can be added up on one GPU."""
     ctx = ctx_of(vp, ctx)
     upload_vp(vp, ctx)
     D, K = vp.D, vp.K
@@ -144,6 +148,10 @@ def entmc_vbmc(vp, Ns, grad_flags=tuple([True] * 4), jacobian_flag=True, *, rng=
     # this context's share of the antithetic-pair rows (all of them on one GPU)
     r0 = h * ctx.rank // ctx.world
     r1 = h * (ctx.rank + 1) // ctx.world
+    if rows is not None:
+        if eps_half is not None or rng != "philox":
+            raise ValueError("rows= needs rng='philox' (uploaded draws follow the context's own share)")
+        r0, r1 = int(rows[0]), int(rows[0]) + int(rows[1])
     if eps_half is not None or rng == "numpy":
         upload_reference_eps(ctx, K, D, ns, eps_half)
         mode, seed = _lib.EPS_RESIDENT, 0

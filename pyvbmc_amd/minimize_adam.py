@@ -83,7 +83,7 @@ def minimize_adam(f, x0, lb=None, ub=None, tol_fun=0.001, max_iter=10000, master
 def minimize_adam_elbo(theta0, gp, vp, Ns, theta_bnd=None, beta=0.0, lb=None, ub=None, tol_fun=0.001,
                        max_iter=10000, master_min=0.001, master_max=0.1, master_decay=200,
                        use_early_stopping=True, *, rng=None, seed=None, eps_half=None, ctx=None,
-                       return_parts=False):
+                       return_parts=False, rows=None):
     """``minimize_adam(lambda t: _neg_elcbo(t, gp, vp, beta, Ns, True, theta_bnd=theta_bnd)[:2],
     theta0, lb, ub, ...)`` with the whole inner loop on the device.
 
@@ -107,7 +107,8 @@ def minimize_adam_elbo(theta0, gp, vp, Ns, theta_bnd=None, beta=0.0, lb=None, ub
     upload_gp(gp, ctx)
     opts = _lib.ElboOpts()
     opts.ns_per_comp, opts.compute_grad, opts.optimize_mask = ns, 1, optimize_mask(vp)
-    opts.row_begin, opts.row_count = 0, -1
+    # rows=(begin, count): one (virtual) rank's slice of every component's antithetic-pair rows
+    opts.row_begin, opts.row_count = (0, -1) if rows is None else (int(rows[0]), int(rows[1]))
     keep = []
     if theta_bnd is not None:
         blb, bub = _lib.f64(theta_bnd["lb"].ravel()), _lib.f64(theta_bnd["ub"].ravel())

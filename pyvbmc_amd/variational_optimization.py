@@ -129,13 +129,17 @@ def _gp_log_joint(vp, gp, grad_flags, avg_flag=True, jacobian_flag=True, compute
 
 
 def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=None, theta_bnd=None,
-               _entropy_alpha=0.0, separate_K=False, *, rng=None, seed=None, eps_half=None, ctx=None):
+               _entropy_alpha=0.0, separate_K=False, *, rng=None, seed=None, eps_half=None, ctx=None,
+               rows=None):
     """Negative evidence lower (confidence) bound and its gradient.
 
     Same positional signature, mutation of ``vp`` (and of the caller's ``theta``
     eta tail, :1082-1085) and return arity as the reference: ``(F, dF, G, H, varF)``
     or the 11-tuple when ``separate_K``.  Keyword-only extras select the source of
-    the Monte-Carlo draws (see pyvbmc_amd.entropy).
+    the Monte-Carlo draws (see pyvbmc_amd.entropy); ``rows=(begin, count)`` (fused path, Philox
+    draws) evaluates that slice of every component's antithetic-pair rows instead of the context's
+    own share -- one rank's part of a sharded job (``ctx.last_elbo_raw`` then holds its additive
+    entropy accumulator).
     """
     if not math.isfinite(beta):
         beta = 0
@@ -154,6 +158,8 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
     K, D = vp.K, vp.D
 
     if separate_K or compute_var or beta != 0:
+        if rows is not None:
+            raise ValueError("rows= is only supported by the fused evaluation")
         return _neg_elcbo_composed(theta, gp, vp, beta, Ns, compute_grad, compute_var, theta_bnd,
                                    separate_K, rng, seed, eps_half, ctx)
 
@@ -172,8 +178,11 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
     opts.ns_per_comp = ns
     opts.compute_grad = 1 if compute_grad else 0
     opts.optimize_mask = mask
+    opts.row_begin, opts.row_count = (0, -1) if rows is None else (int(rows[0]), int(rows[1]))
     if ns > 0:
         mode = DEFAULT_RNG if rng is None else rng
+        if rows is not None and (eps_half is not None or mode != "philox"):
+            raise ValueError("rows= needs rng='philox' (uploaded draws follow the context's own share)")
         if eps_half is not None or mode == "numpy":
             upload_reference_eps(ctx, K, D, ns, eps_half)
             opts.eps_mode, opts.seed = _lib.EPS_RESIDENT, 0
