@@ -145,7 +145,8 @@ def spawn_ranks(a):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(a.gpus),
-               TORCHELASTIC_RUN_ID=f"bench{os.getpid()}", HSA_ENABLE_IPC_MODE_LEGACY="0")
+               TORCHELASTIC_RUN_ID=f"bench{os.getpid()}", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               VBMC_LAUNCH_NONCE=os.urandom(8).hex())
     argv = [sys.executable, str(Path(__file__).resolve())] + [x for x in sys.argv[1:] if x != "--spawn"]
     procs = [subprocess.Popen(argv, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True)

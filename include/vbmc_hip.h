@@ -135,7 +135,11 @@ int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
  *                  plain 64 x 64-tile kernel (cross-check)
  *   "elbo_arm"     [VBMC_ELBO_ARM]: 1 = after a polled Philox evaluation the launches of the next one
  *                  (seed + 1, same shapes) are queued at once and wait on the device for the next
- *                  call's theta (default); any other use of the context cancels them
+ *                  call's theta (default); any other use of the context cancels them.  Never after an
+ *                  evaluation that took more than 1 ms, and the device-side wait is at most 5 ms.
+ *   "arm_late_test" / "ident_test": test hooks -- the n-th use of an armed evaluation from now takes
+ *                  the late-go recovery path / the n-th identity check of a result block from now
+ *                  fails (the evaluation is repeated unarmed); see vbmc_armed_stats
  *   "ahead_pct"    [VBMC_AHEAD_PCT]: with elbo_arm, percent of the speculative draws generated in the
  *                  finish launch (rest: the armed prep launch); default 100
  *   "ws_pair"      [VBMC_WS_PAIR]: 1 = the wave-split entropy kernel hands its (component, chunk)
@@ -149,6 +153,21 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value);
  * out[2] = workgroups per component, out[3] = 1 if the draws were read from HBM, 0 if
  * generated in-line.  Lets the parity tests assert which code path they exercised. */
 int vbmc_last_entmc_plan(const vbmc_ctx* ctx, int out[4]);
+
+/* Host utility (no device, no ctx): a 64-bit checksum over n blocks of doubles,
+ * sum_a (sum_i bits(v_ai) * odd_i + len_a) * odd_a mod 2^64 -- any change of a single element changes
+ * it.  The Python mirror keys its "is this GP already on the device" test on it (every posterior's
+ * alpha and hyp in full: an in-place edit anywhere in them is seen; ~1 us + 0.05 us per KB). */
+int vbmc_host_checksum(const double* const* ptrs, const int64_t* lens, int n, uint64_t* out);
+
+/* Counters of the polled host-driven step (vbmc_neg_elcbo) since the context was created:
+ * out[0] armed evaluations used, out[1] cancelled, out[2] of those: late go word (recovery path),
+ * out[3] result blocks whose identity was checked -- the finish launch publishes, next to the
+ * sequence number, the checksum of the mixture pack the device actually read and the Philox seed
+ * its launches were planned for, and the host compares both with what it sent -- out[4] checks
+ * that failed (the evaluation was repeated), out[5] evaluations whose completion word never came
+ * (the armed launches had given up, or a stuck device) and that were repeated. */
+int vbmc_armed_stats(const vbmc_ctx* ctx, uint64_t out[6]);
 
 /* The raw (pre-Jacobian) entropy accumulator [H | mu (K x D) | sigma (K) | lambda (D) | w (K)] of
  * the most recent Monte-Carlo vbmc_neg_elcbo of this ctx -- the vector the sharded job all-reduces

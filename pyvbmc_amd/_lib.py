@@ -66,6 +66,8 @@ SIGNATURES = {
     "vbmc_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "vbmc_last_entmc_plan": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "vbmc_last_elbo_raw": (C.c_int, [_vp, _dp, C.c_int]),
+    "vbmc_armed_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "vbmc_host_checksum": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_uint64)]),
     "vbmc_set_timing": (C.c_int, [_vp, C.c_int]),
     "vbmc_last_kernel_ms": (C.c_int, [_vp, C.c_int, _dp]),
     "vbmc_last_host_us": (C.c_int, [_vp, _dp]),
@@ -246,6 +248,14 @@ class Context:
         return {"kernel": ("valu", "ws", "small")[out[0]] if out[0] >= 0 else None, "rg": out[1],
                 "chunks": out[2], "resident_draws": bool(out[3])}
 
+    def armed_stats(self):
+        """Counters of the polled step: armed evaluations used / cancelled / recovered from a late go
+        word, identity checks of result blocks done / failed, evaluations repeated because their
+        completion word never came (vbmc_armed_stats)."""
+        out = (C.c_uint64 * 6)()
+        self.check(self._lib.vbmc_armed_stats(self._h, out))
+        return dict(zip(("hits", "cancels", "late", "ident_checked", "ident_bad", "lost"), (int(v) for v in out)))
+
     def last_elbo_raw(self, D, K):
         """Raw entropy accumulator of the most recent Monte-Carlo ``vbmc_neg_elcbo`` (additive over
         row slices; see include/vbmc_hip.h)."""
@@ -286,17 +296,19 @@ class Context:
         state advanced accordingly) and make this context's rows of them the resident draws --
         without the values ever becoming a NumPy array.  False when NumPy's global generator is not
         MT19937 (the caller then draws with NumPy and uses set_eps)."""
-        st = np.random.get_state(legacy=True)
-        if not isinstance(st, tuple) or st[0] != "MT19937":  # (a replaced bit generator reports a dict)
-            return False
         if row_count is None:
             row_count = n_half - row_begin
-        key = np.array(st[1], dtype=np.uint32)
-        pos, has_gauss, gauss = C.c_int(int(st[2])), C.c_int(int(st[3])), C.c_double(float(st[4]))
-        rc = self._lib.vbmc_set_eps_numpy(self._h, key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos),
-                                          C.byref(has_gauss), C.byref(gauss), K, n_half, D, row_begin, row_count, threads)
-        # (the state is written back even on an upload error: the values have been drawn)
-        np.random.set_state(("MT19937", key, pos.value, has_gauss.value, gauss.value))
+        with NP_STREAM_LOCK:
+            st = np.random.get_state(legacy=True)
+            if not isinstance(st, tuple) or st[0] != "MT19937":  # (a replaced bit generator reports a dict)
+                return False
+            key = np.array(st[1], dtype=np.uint32)
+            pos, has_gauss, gauss = C.c_int(int(st[2])), C.c_int(int(st[3])), C.c_double(float(st[4]))
+            rc = self._lib.vbmc_set_eps_numpy(self._h, key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos),
+                                              C.byref(has_gauss), C.byref(gauss), K, n_half, D, row_begin, row_count,
+                                              threads or host_threads())
+            # (the state is written back even on an upload error: the values have been drawn)
+            np.random.set_state(("MT19937", key, pos.value, has_gauss.value, gauss.value))
         self.check(rc)
         return True
 
@@ -326,6 +338,24 @@ def comm_unique_id():
     if rc != 0:
         raise VbmcHipError(rc, (load().vbmc_last_error(None) or b"").decode())
     return bytes(buf)
+
+
+# The library's restatement of np.random.randn (vbmc_mt19937_randn / vbmc_set_eps_numpy) advances
+# NumPy's global stream as get_state -> C call (GIL released) -> set_state.  The lock serialises
+# those sections among this package's own callers; it cannot include other threads that call
+# np.random.* directly in that window (NumPy's own lock is not reachable from here): such draws
+# would be overwritten and replayed -- do not draw from the global generator concurrently.
+NP_STREAM_LOCK = threading.Lock()
+
+
+def host_threads():
+    """Worker threads for the host draw stream: the cores this process may run on (cgroup /
+    affinity aware, unlike hardware_concurrency()), at most 64."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    return max(1, min(64, n))
 
 
 _default_ctx = None

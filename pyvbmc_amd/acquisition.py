@@ -184,7 +184,11 @@ class _QuantileAcq(AbstractAcqFcn):
         return out
 
     def _upload_state(self, gp, ais, ctx):
-        key = (id(ais), id(ais.get("X")), id(ais.get("f_s2")), id(ais.get("ln_weights")), id(gp.posteriors))
+        # every array the device state is built from, and the content-aware key of the GP that
+        # upload_gp (called just before) left in the context: a posterior record replaced in place
+        # (active_importance_sampling.py:207-209) or a re-bound ais["C_tmp"] uploads the state again
+        parts = tuple(ais.get(k) for k in ("X", "f_s2", "ln_weights", "C_tmp", "K_Xa_X"))
+        key = (id(ais),) + tuple(id(a) for a in parts) + tuple(ctx.__dict__.get("_gp_key") or ())
         if ctx.__dict__.get("_acq_is_key") == key:
             return
         Xa = _lib.f64(ais["X"])
@@ -195,7 +199,8 @@ class _QuantileAcq(AbstractAcqFcn):
         lnw = None if self.acq_info.get("variational_importance_sampling") else _lib.f64(ais["ln_weights"])
         ctx.check(ctx._lib.vbmc_acq_is_set(ctx._h, Na, _lib.ptr(Xa), int(per_sample), _lib.ptr(ctmp),
                                            _lib.ptr(fs2a), _lib.ptr(lnw)))
-        ctx.__dict__["_acq_is_key"], ctx.__dict__["_acq_is_ref"] = key, (ais, gp.posteriors)
+        # (the held references keep every keyed object alive, so an id cannot be recycled)
+        ctx.__dict__["_acq_is_key"], ctx.__dict__["_acq_is_ref"] = key, (ais, gp.posteriors, parts)
 
     def __call__(self, Xs, gp, vp, function_logger, optim_state):
         Xs = np.asarray(Xs, dtype=np.float64)

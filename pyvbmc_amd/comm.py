@@ -74,12 +74,32 @@ def _launcher_start_time():
         return time.time() - 5.0
 
 
+def _own_start_time():
+    try:
+        fields = Path("/proc/self/stat").read_text().rsplit(")", 1)[1].split()
+        btime = next(int(l.split()[1]) for l in Path("/proc/stat").read_text().splitlines() if l.startswith("btime"))
+        return btime + int(fields[19]) / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, IndexError, StopIteration):
+        return time.time()
+
+
+def _launch_nonce():
+    """What tells this launch from an earlier one that reused the same key: VBMC_LAUNCH_NONCE when the
+    launcher sets one (bench.py's own spawner and the test harness do: random per launch), and the
+    launcher's pid and start time (every launch under torchrun has its own agent process)."""
+    return f"{os.environ.get('VBMC_LAUNCH_NONCE', '')}|{os.getppid()}|{_launcher_start_time():.2f}".encode()
+
+
 def exchange_unique_id(rank, world, make_id, timeout=300.0):
     """Rank 0 creates the id and publishes it atomically (exclusive create in a private
-    directory, then rename); the others poll for a file newer than the launcher."""
+    directory, then rename) followed by the launch nonce; the others poll for a file that is newer
+    than the launcher, not older than a minute before their own start (ranks started by hand from one
+    long-lived shell share the launcher: a leftover of a crashed earlier launch must not be joined)
+    and carries their own nonce."""
     path = _rendezvous_path()
     t0 = time.time()
-    not_before = _launcher_start_time() - 1.0
+    nonce = _launch_nonce()
+    not_before = max(_launcher_start_time() - 1.0, _own_start_time() - 60.0)
     if rank == 0:
         uid = make_id()
         tmp = path.with_suffix(".tmp%d" % os.getpid())
@@ -90,14 +110,16 @@ def exchange_unique_id(rank, world, make_id, timeout=300.0):
                 pass
         fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
         with os.fdopen(fd, "wb") as f:
-            f.write(uid)
+            f.write(uid + nonce)
         os.replace(tmp, path)
         return uid
     while True:
         try:
             st = os.lstat(path)
-            if st.st_size == 128 and st.st_uid == os.getuid() and st.st_mtime >= not_before:
-                return path.read_bytes()
+            if st.st_size == 128 + len(nonce) and st.st_uid == os.getuid() and st.st_mtime >= not_before:
+                blob = path.read_bytes()
+                if len(blob) == 128 + len(nonce) and blob[128:] == nonce:
+                    return blob[:128]
         except FileNotFoundError:
             pass
         if time.time() - t0 > timeout:

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void is_reduce_kernel(const double* __restrict
   const double iy = 1.0 / (fs2[m] + sn2[m]);
   const double lsf2 = 2.0 * hyp[D];
   double mx = -INFINITY, sm = 0.0;  // per-lane running log-sum-exp
+  bool bad = false;
   for (int64_t a = lane; a < Na; a += 64) {
     double d2 = 0.0;
     for (int d = 0; d < D; ++d) {
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(256) void is_reduce_kernel(const double* __restrict
     const double sp = sqrt(fmax(fs2a[a] - tau2, 0.0));
     double zz = u * sp + log1p(-exp(-2.0 * u * sp));
     if (lnw) zz += lnw[a];
+    bad |= zz != zz;  // a NaN integrand (NaN f_s2, C_tmp, sn2 ...) makes the reference's logsumexp NaN: so here
     if (zz > -INFINITY) {
       if (zz > mx) {
         sm = sm * exp(mx - zz) + 1.0;
@@ -142,9 +144,11 @@ __global__ __launch_bounds__(256) void is_reduce_kernel(const double* __restrict
   double gm = mx;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_xor(gm, off, 64));
-  double part = (mx > -INFINITY) ? sm * exp(mx - gm) : 0.0;
+  double part = (mx > -INFINITY && gm < INFINITY) ? sm * exp(mx - gm) : 0.0;
   part = fm::wave_sum_dpp(part);
-  if (lane == 0) out[m] = (gm > -INFINITY) ? gm + log(part) : -INFINITY;
+  const bool any_bad = __any(bad ? 1 : 0) != 0;
+  if (lane == 0)
+    out[m] = any_bad ? (double)NAN : gm == INFINITY ? (double)INFINITY : (gm > -INFINITY) ? gm + log(part) : -INFINITY;
 }
 
 // acq[m] = logsumexp_s acq_s[s][m] - log S   (acq_fcn_viqr.py:152-158)

@@ -196,18 +196,25 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   }
   vbmc_ctx::ArmedEval& sp = ctx->spec;
   // (whether the next evaluation will be armed decides how the next draws are split, see ahead_pct)
+  // Not for long evaluations: what arming saves is ~10 us of launch latency, under 1 % of a step of a
+  // millisecond, while a queued prep kernel that nobody releases keeps the device busy until its
+  // time-out -- which every device-wide wait elsewhere in the process (another library's hipFree,
+  // process teardown) then has to sit through.  So: no arming after an evaluation of more than
+  // ARM_MAX_EVAL_US, and the wait is capped whatever the evaluation took.
+  constexpr double ARM_MAX_EVAL_US = 1000.0, ARM_MAX_LIMIT_MS = 2.5;
   const bool arm_next = can_poll && !multi && ctx->opt_elbo_arm && ctx->opt_mix_bar && !ctx->timing &&
                         opts->eps_mode == VBMC_EPS_PHILOX && ctx->opt_ahead_pct > 0 && ctx->opt_ahead_pct <= 100 &&
-                        (ctx->opt_ahead_mode == 2 || ctx->opt_ahead_mode == 3);
-  // an armed evaluation is used within max(1 ms, 2.5 x the last evaluation's duration) of its arming; its prep
-  // kernel waits twice that before it gives up by itself
-  const double arm_limit_ms = std::max(1.0, 2.5e-3 * ctx->host_us[4]);
+                        (ctx->opt_ahead_mode == 2 || ctx->opt_ahead_mode == 3) && ctx->host_us[4] <= ARM_MAX_EVAL_US;
+  // an armed evaluation is used within max(1 ms, 2.5 x the last evaluation's duration) -- at most
+  // ARM_MAX_LIMIT_MS -- of its arming; its prep kernel waits twice that before it gives up by itself
+  const double arm_limit_ms = std::min(ARM_MAX_LIMIT_MS, std::max(1.0, 2.5e-3 * ctx->host_us[4]));
 
   // Plan and queue the launches of ONE evaluation with Philox seed `seed`.  spin = false: for this
   // call's theta (the pack is in ctx->h_pack); spin = true: armed -- the prep kernel waits for the
   // go word the NEXT call writes together with its pack.  Nothing here depends on theta.
   bool polled = false;
   uint64_t cur_seq = 0;
+  bool ident_out_flag = false;  // the launches just issued carry an identity (set by issue)
   auto issue = [&](uint64_t seed, bool spin, bool& polled_out, uint64_t& seq_out) -> int {
     int rc2;
     PrepArgs pa;
@@ -235,6 +242,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
       pa.res = stage;
     }
     seq_out = ctx->done_seq;
+    ident_out_flag = false;
     // Polled step: the CPU writes the pack into device memory itself (no upload launch; the prep
     // launch copies it on for the later kernels).
     PrepArgs gp_tail;
@@ -242,6 +250,8 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     double* fg = nullptr;
     if (can_poll && ctx->opt_mix_bar) fg = spin ? ctx->d_mix_fg : write_pack_to_device(ctx);
     if (spin && !fg) return -1000;
+    const bool ident = fg != nullptr && mc;  // self-identifying results (DoneSignal): the copy block exists
+    if (ident) pa.ident_out = (uint64_t*)(ctx->d_done_cnt + 12);
     if (fg) {
       // Where the GP sums run.  2: a last row of the entropy launch, if that grid leaves at least
       // `chunks` workgroup slots free (one round: K * chunks <= CUs * resident workgroups per CU) --
@@ -305,7 +315,13 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
         done.host_out = raw_out;
         done.host_n = n_raw;
         done.cancel = ctl;
+        if (ident) {
+          done.ident_src = (const uint64_t*)(ctx->d_done_cnt + 12);
+          done.ident_dst = ctx->hd_done + 1;
+          done.ident_seed = seed;
+        }
         polled_out = true;
+        ident_out_flag = ident;
       }
       // where the speculative generation goes: (2) spare workgroups of the finish launch itself,
       // (1) its own stream, queued before the finish launch, (0) a launch of its own behind the
@@ -352,6 +368,9 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     return 0;
   };
 
+  // What the result block must identify as (DoneSignal): the pack this call writes and its seed.
+  const uint64_t want_ck = (mc && can_poll && ctx->opt_mix_bar) ? pack_checksum(ctx->h_pack, (size_t)ctx->ml.total) : 0;
+  bool check_ident = false;
   // An armed evaluation planned for exactly this call?  Then its launches are already queued: write
   // the pack and the go word.  Otherwise cancel it (if any) and launch as usual.
   bool used_armed = false;
@@ -374,6 +393,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
         used_armed = true;
         polled = true;
         cur_seq = sp.seq;
+        check_ident = sp.ident;
         HSTAMP(1);
       } else {
         // This thread lost the CPU between the age check and the go word: the prep kernel's 2 ms
@@ -391,6 +411,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
         ctx->ahead.buf = sp.ahead_before_buf;
         ctx->ahead.frac = sp.ahead_before_frac;
         ++sp.cancels;
+        ++sp.late;
       }
     } else {
       spec_disarm(ctx);
@@ -399,6 +420,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   if (!used_armed) {
     rc = issue(opts->seed, false, polled, cur_seq);
     if (rc) return rc;
+    check_ident = polled && ident_out_flag;
   }
   // Arm the next evaluation (seed + 1, same shapes): its launches go into the queue now, behind this
   // one's, and wait for the next call's theta.
@@ -411,11 +433,19 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     const uint64_t seq_before = ctx->done_seq;
     bool p2 = false;
     uint64_t seq2 = 0;
+    // The host's clock for this armed evaluation starts BEFORE its launches are queued: the prep
+    // kernel's own time-out (2 x the limit, counted from when it starts to run) can then never fire
+    // before the host's cut-off (1.5 x the limit from here).  Taken after issue() it could -- a host
+    // thread that lost the CPU between the two for longer than the device waits came back, found the
+    // evaluation "fresh", wrote a go word nobody was waiting for any more and polled for 5 s before
+    // returning the PREVIOUS evaluation's block (found by the soak under a CPU hog, round 3).
+    const auto t_arm0 = clk::now();
     const int rc2 = issue(opts->seed + 1, true, p2, seq2);
     if (rc2 == 0 && p2) {
       sp.armed = true;
+      sp.ident = ident_out_flag;
       sp.limit_ms = arm_limit_ms;
-      sp.t_armed = clk::now();
+      sp.t_armed = t_arm0;
       sp.seq = seq2;
       sp.seed = opts->seed + 1;
       sp.n_theta = n_theta;
@@ -527,17 +557,38 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   ctx->host_us[1] = us_since(t_launch);
   HSTAMP(2);
   const auto t_wait = clk::now();
-  auto spin_on = [&](const volatile uint64_t* f, uint64_t want) {
-    // spin on a completion word (the GPU is <= ~100 us away); a stuck device falls back to the
-    // stream wait, which reports the error
+  // spin on a completion word (the GPU is <= ~100 us away).  0: the word arrived; 1: the armed prep
+  // kernel reported that it gave up on this evaluation (its time-out: the launches behind it returned
+  // at once and nothing will ever publish this sequence number); 2: no word after 5 s (a stuck device)
+  auto spin_on = [&](const volatile uint64_t* f, uint64_t want) -> int {
+    const volatile uint64_t* dead = ctx->h_done + 5;
     unsigned spins = 0;
     for (;;) {
       if (*f == want) break;
+      if (*dead == want) return 1;
       __builtin_ia32_pause();
-      if ((++spins & 0xFFFF) == 0 && us_since(t_wait) > 5e6) return false;
+      if ((++spins & 0xFFFF) == 0 && us_since(t_wait) > 5e6) return 2;
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    return true;
+    return 0;
+  };
+  // Whatever this evaluation's launches produced is discarded: drain the queue (that cancels what was
+  // just armed), clear the completion counters, forget the speculative draws and evaluate again,
+  // unarmed.  A result block is NEVER used unless its own completion word arrived and (when the
+  // launches carry one) its identity matches.
+  auto redo_unarmed = [&](const char* why) -> int {
+    HIP_TRY(ctx, stream_wait(ctx));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_done_cnt, 0, sizeof(int) * 16, ctx->stream));
+    ctx->ahead.valid = false;
+    if (ctx->ident_retry) return vbmc_fail(ctx, VBMC_E_HIP, "neg_elcbo: %s, twice in a row", why);
+    ctx->ident_retry = true;
+    const int arm_was = ctx->opt_elbo_arm;
+    ctx->opt_elbo_arm = 0;
+    const int rc3 = vbmc_neg_elcbo(ctx, theta, n_theta, opts, F, dF, G, H, mu_KxD, sigma_K, lambd_D, w_K, eta_K);
+    ctx->opt_elbo_arm = arm_was;
+    ctx->ident_retry = false;
+    ctx->spec.keep = true;  // (the inner call's guard cleared it; ours clears it again on return)
+    return rc3;
   };
   // ---- host finalisation, GP part (as soon as the prep launch's sums have landed) ----
   GljHost& o = sc.glj;
@@ -568,15 +619,30 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   };
   bool gp_done = false;
   if (polled) {
-    bool ok = spin_on(ctx->h_done + 4, cur_seq);
+    int st_w = spin_on(ctx->h_done + 4, cur_seq);
     HSTAMP(3);
-    if (ok) {
+    if (st_w == 0) {
       rc = finalize_gp();  // overlaps the entropy kernel
       if (rc) return rc;
       gp_done = true;
-      ok = spin_on(ctx->h_done, cur_seq);
+      st_w = spin_on(ctx->h_done, cur_seq);
     }
-    if (!ok) HIP_TRY(ctx, stream_wait(ctx));
+    if (st_w != 0) {
+      ++sp.lost;
+      return redo_unarmed(st_w == 1 ? "the armed launches gave up before the go word reached them"
+                                    : "no completion word from the device after 5 s");
+    }
+    if (check_ident) {
+      // the block that carries this sequence number says what it was computed from
+      const volatile uint64_t* id = ctx->h_done + 1;
+      ++sp.ident_checked;
+      const bool force_bad = ctx->opt_ident_test > 0 && --ctx->opt_ident_test == 0;  // test hook
+      if (force_bad || id[0] != want_ck || id[1] != opts->seed) {
+        // not this evaluation's result: a stale pack or another evaluation's launches
+        ++sp.ident_bad;
+        return redo_unarmed("the result block does not identify as this evaluation");
+      }
+    }
   } else {
     HIP_TRY(ctx, stream_wait(ctx));
   }
@@ -620,6 +686,18 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   if (G) *G = Gv;
   if (H) *H = Hv;
   if (dF && grad_flags) memcpy(dF, dFv.data(), sizeof(double) * n_theta);
+  return VBMC_OK;
+}
+
+extern "C" int vbmc_armed_stats(const vbmc_ctx* ctx, uint64_t out[6]) {
+  if (!ctx || !out) return VBMC_E_ARG;
+  const vbmc_ctx::ArmedEval& sp = ctx->spec;
+  out[0] = sp.hits;
+  out[1] = sp.cancels;
+  out[2] = sp.late;
+  out[3] = sp.ident_checked;
+  out[4] = sp.ident_bad;
+  out[5] = sp.lost;
   return VBMC_OK;
 }
 

@@ -112,7 +112,8 @@ struct vbmc_ctx {
     uint64_t ahead_before_seed = 0;
     int ahead_before_buf = 0;
     double ahead_before_frac = 1.0;
-    uint64_t hits = 0, cancels = 0;
+    uint64_t hits = 0, cancels = 0, late = 0, ident_checked = 0, ident_bad = 0, lost = 0;  // see vbmc_armed_stats
+    bool ident = false;       // its launches carry an identity (DoneSignal)
     double limit_ms = 1.0;  // use it within this time of arming (>= 1 ms, 2.5 x the last evaluation's duration); the device waits twice as long
     std::chrono::steady_clock::time_point t_armed;  // the device gives up after 2 ms: the host does not use an armed evaluation older than 1 ms
   } spec;
@@ -183,6 +184,8 @@ struct vbmc_ctx {
   int opt_ahead_mode = 2;   // speculative draws: 2 = spare workgroups of the finish launch, 0 = a launch of their own behind it, 1 = on their own stream (measured: slower)
   int opt_ahead_pct = 100;  // armed evaluations: percent of the next draws generated in the finish launch (the rest in the armed prep launch, which runs them while it waits for theta)
   int opt_arm_late_test = 0;  // test hook: n > 0 = the n-th use of an armed evaluation from now takes the late-go recovery path
+  int opt_ident_test = 0;     // test hook: n > 0 = the n-th identity check from now fails (the recovery path runs)
+  bool ident_retry = false;   // inside the re-evaluation after a failed identity check
   int opt_elbo_arm = 1;     // queue the next host-driven evaluation's launches ahead of its theta (armed evaluation)
   int opt_ws_pair = 1;      // entropy kernel: co-resident workgroups take the same table row (scalar-cache locality)
   int opt_gp_tail = 2;      // with mix_bar: GP sums in a last row of the entropy launch (2; needs free workgroup slots, else 1), in the finish launch (1), in the prep launch (0)
@@ -272,7 +275,38 @@ struct DoneSignal {
   int host_n = 0;
   // armed evaluation: the finish kernel returns at once when *cancel == ~0 (ArmedEval)
   const uint64_t* cancel = nullptr;
+  // Self-identifying results (optional): next to the sequence number the publishing workgroup hands
+  // the host WHAT was evaluated -- ident_dst[0] = *ident_src, the checksum the prep launch's copy
+  // block took of the mixture pack it actually read (pack_checksum below), ident_dst[1] = ident_seed,
+  // the Philox seed these launches were planned for.  The host compares both with what it sent
+  // before it accepts the result block (api_elbo.hip): a result computed on a stale pack or by the
+  // launches of another evaluation cannot pass for this one's.
+  const uint64_t* ident_src = nullptr;
+  uint64_t* ident_dst = nullptr;
+  uint64_t ident_seed = 0;
 };
+
+// Order-independent 64-bit checksum of a block of doubles: sum_i bits(v_i) * (odd_i) mod 2^64.  Every
+// multiplier is odd, hence invertible: any change of a single element changes the sum.  The same
+// terms are added up by the host (over its pinned pack) and by the 256 threads of the prep launch's
+// copy block (over the pack as the device reads it).
+__host__ __device__ inline uint64_t pack_ck_term(double v, uint32_t i) {
+  uint64_t b;
+  __builtin_memcpy(&b, &v, 8);
+  return b * (0x9E3779B97F4A7C15ull + 2ull * i);
+}
+inline uint64_t pack_checksum(const double* p, size_t n) {
+  uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  size_t i = 0;
+  for (; i + 4 <= n; i += 4) {
+    s0 += pack_ck_term(p[i], (uint32_t)i);
+    s1 += pack_ck_term(p[i + 1], (uint32_t)i + 1);
+    s2 += pack_ck_term(p[i + 2], (uint32_t)i + 2);
+    s3 += pack_ck_term(p[i + 3], (uint32_t)i + 3);
+  }
+  for (; i < n; ++i) s0 += pack_ck_term(p[i], (uint32_t)i);
+  return (s0 + s1) + (s2 + s3);
+}
 
 #ifdef __HIPCC__
 // The staged hand-over's copy (DoneSignal): n doubles from device memory written by other workgroups
@@ -319,6 +353,7 @@ struct PrepArgs {
   // hands the pack over in host-written device memory; the later launches read the ordinary copy)
   double* mix_copy = nullptr;
   int mix_copy_n = 0;
+  uint64_t* ident_out = nullptr;  // optional: that workgroup also stores pack_checksum(mix[0 .. mix_copy_n)) here (DoneSignal)
   // armed evaluation (ArmedEval): every workgroup first waits until *go == go_seq (the host has
   // written the pack) -- or leaves at once when it reads ~0 (cancelled); after ~2 ms without either
   // it cancels by itself (*go = ~0 for the launches behind it, *dead = go_seq for the host)

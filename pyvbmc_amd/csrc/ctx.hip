@@ -211,6 +211,10 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
     ctx->opt_arm_late_test = value;
     return VBMC_OK;
   }
+  if (!strcmp(key, "ident_test")) {  // test hook of the identity check's recovery path: must not cancel an armed evaluation either
+    ctx->opt_ident_test = value;
+    return VBMC_OK;
+  }
   spec_disarm(ctx);
   if (!strcmp(key, "entmc_kernel")) ctx->opt_entmc_valu = value == 1;
   else if (!strcmp(key, "elbo_pregen")) ctx->opt_elbo_pregen = value != 0;
@@ -227,6 +231,17 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
     ctx->opt_ahead_mode = value;
   }
   else return vbmc_fail(ctx, VBMC_E_ARG, "vbmc_set_option: unknown key '%s'", key);
+  return VBMC_OK;
+}
+
+int vbmc_host_checksum(const double* const* ptrs, const int64_t* lens, int n, uint64_t* out) {
+  if (!ptrs || !lens || n < 0 || !out) return VBMC_E_ARG;
+  uint64_t s = 0;
+  for (int a = 0; a < n; ++a) {
+    if (!ptrs[a] || lens[a] < 0) return VBMC_E_ARG;
+    s += (pack_checksum(ptrs[a], (size_t)lens[a]) + (uint64_t)lens[a]) * (0xD1B54A32D192ED03ull + 2ull * (uint64_t)a);
+  }
+  *out = s;
   return VBMC_OK;
 }
 

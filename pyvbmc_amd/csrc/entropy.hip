@@ -329,10 +329,15 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
   }
   __syncthreads();
   if (!s_last) return;
+  if (done.ident_dst && threadIdx.x == 255) {  // what this result block was computed from (DoneSignal)
+    __hip_atomic_store(done.ident_dst, *done.ident_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(done.ident_dst + 1, done.ident_seed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!staged) __builtin_amdgcn_s_waitcnt(0x0F70);  // (the staged copy below drains them with its own stores)
+  }
   if (staged) {  // one coalesced copy to the host instead of n single PCIe writes (DoneSignal)
     staged_copy_to_host(raw, done.host_out, done.host_n);
-    __syncthreads();
   }
+  if (staged || done.ident_dst) __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_store(done.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -746,6 +751,10 @@ __global__ __launch_bounds__(256) void entmc_publish_kernel(const double* __rest
   if (blockIdx.x > 0) {
     gen_slice_block(gen, blockIdx.x - 1, threadIdx.x);
     return;
+  }
+  if (done.ident_dst && threadIdx.x == 255) {
+    __hip_atomic_store(done.ident_dst, *done.ident_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(done.ident_dst + 1, done.ident_seed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   staged_copy_to_host(src, done.host_out, done.host_n);
   __syncthreads();

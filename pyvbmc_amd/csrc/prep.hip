@@ -61,8 +61,21 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
     if (!s_go) return;
   }
   if (a.mix_copy && blockIdx.x == gridDim.x - 1) {
-    // ---- copy block: the pack for the launches behind this one ----
-    for (int i = tid; i < a.mix_copy_n; i += 256) a.mix_copy[i] = a.mix[i];
+    // ---- copy block: the pack for the launches behind this one (+ its checksum, DoneSignal) ----
+    uint64_t ck = 0;
+    for (int i = tid; i < a.mix_copy_n; i += 256) {
+      const double v = a.mix[i];
+      a.mix_copy[i] = v;
+      ck += pack_ck_term(v, (uint32_t)i);
+    }
+    if (a.ident_out) {
+      __shared__ unsigned long long s_ck;
+      if (tid == 0) s_ck = 0;
+      __syncthreads();
+      atomicAdd(&s_ck, (unsigned long long)ck);
+      __syncthreads();
+      if (tid == 0) *a.ident_out = s_ck;
+    }
     return;
   }
   a.mix += (size_t)blockIdx.y * a.mix_stride;  // batched sieve: one candidate mixture per grid.y

@@ -39,17 +39,18 @@ def host_randn(n, threads=0):
     """The next ``n`` values of ``np.random.randn`` -- same values, same state left behind -- drawn
     by the library's multi-threaded restatement of NumPy's legacy stream (csrc/host_randn.hip);
     ``None`` when the global generator is not the MT19937 one that restatement covers."""
-    st = np.random.get_state(legacy=True)
-    if not isinstance(st, tuple) or st[0] != "MT19937":  # (a replaced bit generator reports a dict)
-        return None
-    key = np.array(st[1], dtype=np.uint32)
-    pos, has_gauss, gauss = C.c_int(int(st[2])), C.c_int(int(st[3])), C.c_double(float(st[4]))
     out = np.empty(int(n))
-    rc = _lib.load().vbmc_mt19937_randn(key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), C.byref(has_gauss),
-                                        C.byref(gauss), _lib.ptr(out), int(n), int(threads))
-    if rc != 0:
-        raise RuntimeError(f"vbmc_mt19937_randn failed ({rc})")
-    np.random.set_state(("MT19937", key, pos.value, has_gauss.value, gauss.value))
+    with _lib.NP_STREAM_LOCK:  # get_state -> draw -> set_state is one section (see _lib.NP_STREAM_LOCK)
+        st = np.random.get_state(legacy=True)
+        if not isinstance(st, tuple) or st[0] != "MT19937":  # (a replaced bit generator reports a dict)
+            return None
+        key = np.array(st[1], dtype=np.uint32)
+        pos, has_gauss, gauss = C.c_int(int(st[2])), C.c_int(int(st[3])), C.c_double(float(st[4]))
+        rc = _lib.load().vbmc_mt19937_randn(key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), C.byref(has_gauss),
+                                            C.byref(gauss), _lib.ptr(out), int(n), int(threads) or _lib.host_threads())
+        if rc != 0:
+            raise RuntimeError(f"vbmc_mt19937_randn failed ({rc})")
+        np.random.set_state(("MT19937", key, pos.value, has_gauss.value, gauss.value))
     return out
 
 
@@ -88,23 +89,50 @@ def draw_eps_half(K, D, Ns):
     return eps
 
 
-def _np_fingerprint_reader():
-    """A cheap fingerprint of NumPy's global MT19937 state (its position and first two key
-    words), read in place: ``np.random.get_state()`` copies 2.5 KB and costs ~35 us, more than
-    the host has per evaluation.  The layout (``uint32 key[624]; int pos``) is checked against
-    ``get_state`` once; on any mismatch there is no fingerprint and every call draws afresh."""
-    try:
-        addr = np.random.mtrand._rand._bit_generator.ctypes.state_address
-        words = (C.c_uint32 * 625).from_address(addr)
-        st = np.random.get_state()
-        if st[0] != "MT19937" or (words[0], words[1], words[624]) != (int(st[1][0]), int(st[1][1]), int(st[2])):
+class _NpFingerprint:
+    """A cheap fingerprint of NumPy's global MT19937 state (its position and first two key words),
+    read in place: ``np.random.get_state()`` copies 2.5 KB and costs ~35 us, more than the host has
+    per evaluation.  The words are read through the bit generator's public ctypes interface
+    (``BitGenerator.ctypes.state_address``); the struct layout behind it (``uint32 key[624]; int
+    pos``) is checked against ``get_state`` whenever a generator is bound, and the generator object
+    itself is HELD -- its memory cannot be freed under the view -- and compared by identity on every
+    read: after ``np.random.set_bit_generator`` the reader re-binds to the new generator (or, if that
+    is not an MT19937 / the layout check fails, reports no fingerprint and every call draws a fresh
+    seed).  Any consumption of the stream moves ``pos`` or refills the key, so the cached second
+    value of ``randn`` (``has_gauss``) cannot change without the fingerprint changing."""
+
+    def __init__(self):
+        self._get = getattr(np.random, "get_bit_generator", None) or (lambda: np.random.mtrand._rand._bit_generator)
+        self._bg = self._words = None
+        self._bind()
+
+    def _bind(self):
+        self._bg = self._words = None
+        try:
+            bg = self._get()
+            if type(bg).__name__ != "MT19937":
+                return
+            words = (C.c_uint32 * 625).from_address(bg.ctypes.state_address)
+            st = np.random.get_state(legacy=True)
+            if (not isinstance(st, tuple) or st[0] != "MT19937"
+                    or (words[0], words[1], words[624]) != (int(st[1][0]), int(st[1][1]), int(st[2]))):
+                return
+            self._bg, self._words = bg, words  # the generator is held as long as its memory is viewed
+        except Exception:
+            self._bg = self._words = None
+
+    def __call__(self):
+        try:
+            cur = self._get()
+        except Exception:
             return None
-        return lambda: (words[0], words[1], words[624])
-    except Exception:
-        return None
+        if cur is not self._bg:
+            self._bind()  # the global generator was replaced: view the new one (after the layout check)
+        w = self._words
+        return None if w is None else (w[0], w[1], w[624])
 
 
-_np_fingerprint = _np_fingerprint_reader()
+_np_fingerprint = _NpFingerprint()
 
 
 def philox_seed(ctx):
@@ -117,12 +145,12 @@ def philox_seed(ctx):
     what lets the library generate the next evaluation's draws while the host is busy with
     this one's result (``vbmc_neg_elcbo``, option ``elbo_ahead``)."""
     st = ctx.__dict__.get("_philox_seq")
-    fp = _np_fingerprint() if _np_fingerprint is not None else None
+    fp = _np_fingerprint()
     if st is not None and fp is not None and st[1] == fp:
         seed = (st[0] + 1) & 0x3FFFFFFFFFFFFFFF
     else:
         seed = int(np.random.randint(0, 2**62, dtype=np.int64))
-        fp = _np_fingerprint() if _np_fingerprint is not None else None
+        fp = _np_fingerprint()
     ctx.__dict__["_philox_seq"] = (seed, fp)
     return seed
 

@@ -103,36 +103,72 @@ def mean_kind_of(gp):
     return _MEAN_KINDS[name]
 
 
-def _gp_fingerprint(gp):
-    """Cheap state key of a GP duck type: identities of X, of the posteriors array, of every
-    posterior record and of its alpha / L / hyp arrays, plus the end elements of each array.
-    It catches what the reference does to a GP between two calls -- ``gp.posteriors[s] = ...``
-    (active_importance_sampling.py:207-209), attribute re-binding, ``gp.X`` replaced or
-    extended by ``gp.update`` (active_sample.py:584) -- and in-place edits that reach an
-    array's first or last element; an edit strictly inside an array needs ``invalidate_gp``.
-    ~1 us per posterior: this runs in front of every ELBO evaluation."""
+class _ChecksumPlan:
+    """The data pointers of every posterior's ``alpha`` and ``hyp`` (float64, contiguous), laid out
+    for ONE library call that checksums all of them (vbmc_host_checksum).  Built when the identities
+    of those arrays change and reused while they stay the same -- the objects are held, so an
+    unchanged ``id`` is the same array with the same buffer."""
+
+    __slots__ = ("ids", "held", "ptrs", "lens", "n", "out", "slow", "fn")
+
+    def __init__(self, ids, held, arrays):
+        self.ids, self.held = ids, held
+        fast = [a for a in arrays if isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags["C_CONTIGUOUS"] and a.size > 0]
+        self.slow = [a for a in arrays if not any(a is f for f in fast)]  # other dtypes / layouts: hashed through a copy
+        self.n = len(fast)
+        self.ptrs = (C.c_void_p * max(self.n, 1))(*[a.ctypes.data for a in fast])
+        self.lens = (C.c_int64 * max(self.n, 1))(*[a.size for a in fast])
+        self.out = C.c_uint64()
+        self.fn = _lib.load().vbmc_host_checksum
+
+    def checksum(self):
+        self.fn(self.ptrs, self.lens, self.n, self.out)
+        v = self.out.value
+        for a in self.slow:
+            v ^= hash(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+        return v
+
+
+def _gp_fingerprint(gp, ctx=None):
+    """State key of a GP duck type: identities of X, of the posteriors array, of every posterior
+    record and of its alpha / L / hyp arrays, the end elements of X and L, and a checksum of EVERY
+    element of every alpha and hyp.  It catches what the reference does to a GP between two calls
+    -- ``gp.posteriors[s] = ...`` (active_importance_sampling.py:207-209), attribute re-binding,
+    ``gp.X`` replaced or extended by ``gp.update`` (active_sample.py:584) -- and any in-place edit
+    of alpha or hyp (alpha = (K + Sigma)^-1 (y - m) changes whenever anything about the GP does).
+    An in-place edit of X or of the interior of L that leaves alpha untouched still needs
+    ``invalidate_gp``.  Runs in front of every ELBO evaluation: ~1.5 us at S = 1, ~3 us at S = 8,
+    N = 800 (one library call for all the arrays)."""
     ps, X = gp.posteriors, gp.X
-    key = [id(ps), id(X), X.shape[0], X.item(0), X.item(-1)]
+    ids = [id(ps), id(X), X.shape[0]]
     held = [ps, X]
+    tail = [X.item(0), X.item(-1)]
+    arrays = []
     for p in ps:
         a, h, L = p.alpha, p.hyp, p.L
-        key += (id(p), id(a), id(L), id(h), a.item(0), a.item(-1), h.item(0), h.item(-1), L.item(-1),
-                p.L_chol)
+        ids += (id(p), id(a), id(L), id(h))
         held += (p, a, L, h)
-    return key, held
+        tail += (L.item(-1), p.L_chol)
+        arrays += (a, h)
+    plan = getattr(ctx, "_gp_ck", None) if ctx is not None else None
+    if plan is None or plan.ids != ids:
+        plan = _ChecksumPlan(ids, held, arrays)
+        if ctx is not None:
+            ctx._gp_ck = plan
+    return ids + tail + [plan.checksum()], held
 
 
 def invalidate_gp(ctx=None):
     """Forget the GP the context holds: the next call uploads it again.  Only needed after
     editing GP arrays in place in a way the fingerprint cannot see (see ``_gp_fingerprint``)."""
     ctx = _lib.default_context() if ctx is None else ctx
-    ctx._gp_key = ctx._gp_ref = None
+    ctx._gp_key = ctx._gp_ref = ctx._gp_ck = None
 
 
 def upload_gp(gp, ctx):
     """Ship X and the posterior records of ``gp`` to the context (skipped while the GP's
     fingerprint is the one already uploaded)."""
-    key, held = _gp_fingerprint(gp)
+    key, held = _gp_fingerprint(gp, ctx)
     if getattr(ctx, "_gp_key", None) == key:
         return
     X = _lib.f64(gp.X)

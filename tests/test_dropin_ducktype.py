@@ -183,6 +183,68 @@ def test_gp_overwritten_in_place_is_seen(ctx, golden):
     assert np.max(np.abs(fs2 - os2)) <= 1e-10 * float(np.exp(2 * hyp[0, int(g["D"])]))
 
 
+def test_gp_interior_edit_in_place_is_seen(ctx, golden):
+    """An in-place edit strictly INSIDE ``alpha`` (or ``hyp``) -- same objects, same ids, same first
+    and last elements -- must reach the device: the GP key carries a checksum of every element of
+    every posterior's alpha and hyp (round 2's key only saw the ends)."""
+    from pyvbmc_amd.gp import _gp_fingerprint
+    from pyvbmc_amd.variational_optimization import _gp_log_joint
+
+    g = golden("c2s")
+    ogp = oracle_gp(g, g["hyp"][:2])
+    gp = PlainGP(ogp)
+    vp = PlainVP(g)
+    G0 = _gp_log_joint(vp, gp, False, True, True, False, False)[0]
+    N = gp.X.shape[0]
+    k0 = _gp_fingerprint(gp, ctx)[0]
+    assert _gp_fingerprint(gp, ctx)[0] == k0  # stable while nothing changes
+    gp.posteriors[1].alpha[N // 2, 0] *= 1.5  # interior element of the second record
+    assert _gp_fingerprint(gp, ctx)[0] != k0
+    G1 = _gp_log_joint(vp, gp, False, True, True, False, False)[0]
+    ogp.posteriors[1].alpha[N // 2, 0] *= 1.5
+    G1_ref = gp_ref.gp_log_joint(oracle_mix(g), ogp, False, True, True, False, False)[0]
+    assert abs(G1 - G1_ref) <= 1e-10 * abs(G1_ref) and G1 != G0
+    D = int(g["D"])
+    gp.posteriors[0].hyp[D + 2] += 0.3  # interior hyper-parameter (the mean's m0): not an end element
+    ogp.posteriors[0].hyp[D + 2] += 0.3
+    G2 = _gp_log_joint(vp, gp, False, True, True, False, False)[0]
+    G2_ref = gp_ref.gp_log_joint(oracle_mix(g), ogp, False, True, True, False, False)[0]
+    assert abs(G2 - G2_ref) <= 1e-10 * abs(G2_ref) and G2 != G1
+    # non-contiguous / non-float64 arrays take the slow hash and are seen too
+    rec = gp.posteriors[0]
+    big = np.zeros((N, 2))
+    big[:, 0] = rec.alpha[:, 0]
+    rec.alpha = big[:, :1]  # strided view
+    assert not rec.alpha.flags["C_CONTIGUOUS"]
+    _gp_log_joint(vp, gp, False, True, True, False, False)
+    k3 = _gp_fingerprint(gp, ctx)[0]
+    rec.alpha[N // 3, 0] += 1.0
+    assert _gp_fingerprint(gp, ctx)[0] != k3
+    # cost of the key (host): stated in DESIGN 4.3b; generous bound here, the figure is printed
+    import time
+
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        _gp_fingerprint(PLAIN8, ctx)
+    dt = (time.perf_counter() - t0) / 2000
+    print(f"_gp_fingerprint at S=8, N=800: {1e6 * dt:.2f} us")
+    assert dt < 50e-6
+
+
+def _plain8():
+    from types import SimpleNamespace
+
+    rng = np.random.default_rng(0)
+    gp = SimpleNamespace(X=rng.standard_normal((800, 20)), posteriors=np.empty(8, dtype=object))
+    for s in range(8):
+        gp.posteriors[s] = SimpleNamespace(hyp=rng.standard_normal(63), alpha=rng.standard_normal((800, 1)),
+                                           L=rng.standard_normal((8, 8)), sW=np.ones(800), L_chol=True)
+    return gp
+
+
+PLAIN8 = _plain8()
+
+
 def test_theta_bnd_edited_in_place_is_seen(ctx, golden):
     """Reassigning / editing ``theta_bnd`` entries between calls (advisor finding): the cached
     argument block must not keep the old arrays or scalars."""

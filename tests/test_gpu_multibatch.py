@@ -350,10 +350,17 @@ def test_armed_evaluation_cancel_paths(ctx):
 
 
 def test_armed_evaluation_soak(ctx):
-    """A few thousand evaluations with seeds that repeat, jump and follow on, other entry points,
-    pauses and stream waits thrown in at random: every repeat of a (theta, seed) pair must reproduce
+    """VBMC_SOAK_S seconds (default 60) of evaluations with seeds that repeat, jump and follow on, other
+    entry points, pauses and stream waits thrown in at random -- under a CPU hog: a busy process pinned
+    to the SAME core as this one, so that this thread loses the CPU for milliseconds at arbitrary
+    points of the call (between arming and use, between the age check and the go word, while it
+    polls) -- and with the late-go recovery and the identity-check recovery forced every few dozen
+    evaluations, so both run thousands of times.  Every repeat of a (theta, seed) pair must reproduce
     its first value bit for bit.  (This is the test that found the control-word reuse race of the
     armed evaluation: one wrong value in ~6 000 evaluations.)"""
+    import os
+    import subprocess
+    import sys
     import time
 
     from pyvbmc_amd.variational_optimization import _neg_elcbo
@@ -367,25 +374,100 @@ def test_armed_evaluation_soak(ctx):
     rng = np.random.default_rng(0)
     NsK = 2 * 64 * 9
     ref = {}
-    t0 = time.time()
-    n = 0
-    while time.time() - t0 < 4.0:
-        sd = int(rng.integers(0, 6)) if rng.random() < 0.2 else (n % 6)
-        F, dF, _, _, _ = _neg_elcbo(th + 0.01 * (sd + 1), gp, vp, 0.0, NsK, True, False, None, 0.0, False,
-                                    rng="philox", seed=1000 + sd)
-        if sd in ref:
-            assert ref[sd][0] == F and np.array_equal(ref[sd][1], dF), (n, sd)
-        else:
-            ref[sd] = (F, dF.copy())
-        r = rng.random()
-        if r < 0.02:
-            time.sleep(0.03)
-        elif r < 0.04:
-            vp.pdf(wl.X[:3])
-        elif r < 0.05:
-            ctx.synchronize()
-        n += 1
-    assert n > 1000
+    soak_s = float(os.environ.get("VBMC_SOAK_S", "60"))
+    before = ctx.armed_stats()
+    aff = os.sched_getaffinity(0)
+    core = min(aff)
+    hog = None
+    try:
+        try:
+            os.sched_setaffinity(0, {core})
+        except OSError:
+            pass  # (no pinning allowed here: the hog then competes wherever the scheduler puts it)
+        hog = subprocess.Popen([sys.executable, "-c", "import os\nos.sched_setaffinity(0, {%d})\nwhile True: pass" % core])
+        t0 = time.time()
+        n = 0
+        while time.time() - t0 < soak_s:
+            sd = int(rng.integers(0, 6)) if rng.random() < 0.2 else (n % 6)
+            F, dF, _, _, _ = _neg_elcbo(th + 0.01 * (sd + 1), gp, vp, 0.0, NsK, True, False, None, 0.0, False,
+                                        rng="philox", seed=1000 + sd)
+            if sd in ref:
+                assert ref[sd][0] == F and np.array_equal(ref[sd][1], dF), (n, sd)
+            else:
+                ref[sd] = (F, dF.copy())
+            r = rng.random()
+            if r < 0.01:
+                time.sleep(0.003)
+            elif r < 0.02:
+                vp.pdf(wl.X[:3])
+            elif r < 0.025:
+                ctx.synchronize()
+            elif r < 0.055:
+                ctx.set_option("arm_late_test", 1)  # the next armed use takes the late-go recovery
+            elif r < 0.085:
+                ctx.set_option("ident_test", 1)     # the next identity check fails: evaluated again
+            n += 1
+    finally:
+        if hog is not None:
+            hog.kill()
+            hog.wait()
+        os.sched_setaffinity(0, aff)
+    st = {k: v - before[k] for k, v in ctx.armed_stats().items()}
+    print(f"soak: {n} evaluations in {soak_s:.0f} s under a CPU hog on core {core}: {st}")
+    assert n > 100 * soak_s / 4
+    assert st["ident_checked"] >= n and st["hits"] > n // 4
+    if soak_s >= 30:
+        assert st["late"] >= 500 and st["ident_bad"] >= 500, st
+    assert st["ident_bad"] <= 0.04 * n, st  # only the forced ones: a real mismatch would show up here
+
+
+def test_result_blocks_identify_themselves(ctx):
+    """Every polled evaluation's result block carries the checksum of the mixture pack the device read
+    and the seed its launches were planned for; the host compares them with what it sent.  Normal
+    runs: every check passes.  A forced failure (`ident_test`): the evaluation is repeated unarmed and
+    returns the same values."""
+    from pyvbmc_amd.variational_optimization import _neg_elcbo
+
+    wl = synthetic.make_workload(3, S=1, N=120)
+    g = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,
+             s2=wl.s2 if wl.s2 is not None else np.zeros(0))
+    gp = make_gp(g, ctx, wl.hyp)
+    vp = make_vp(g, ctx)
+    th = vp.get_parameters()
+    NsK = 2 * 64 * 9
+
+    def run(n, hook_at=()):
+        out = []
+        for i in range(n):
+            if i in hook_at:
+                ctx.set_option("ident_test", 1)
+            F, dF, G, H, _ = _neg_elcbo(th + 0.01 * i, gp, vp, 0.0, NsK, True, False, None, 0.0, False,
+                                        rng="philox", seed=7000 + i)
+            out.append((F, dF.copy(), G, H))
+        return out
+
+    s0 = ctx.armed_stats()
+    base = run(12)
+    s1 = ctx.armed_stats()
+    assert s1["ident_checked"] - s0["ident_checked"] == 12 and s1["ident_bad"] == s0["ident_bad"]
+    assert s1["hits"] - s0["hits"] >= 8  # consecutive seeds: the evaluations after the first are armed ones
+    got = run(12, hook_at=(0, 5, 6))
+    s2 = ctx.armed_stats()
+    assert s2["ident_bad"] - s1["ident_bad"] == 3
+    for (F, dF, G, H), (F0, dF0, G0, H0) in zip(got, base):
+        assert F == F0 and G == G0 and H == H0 and np.array_equal(dF, dF0)
+    # the multi-batch shape of the bench too (GP sums in the entropy launch's free slots)
+    for mb in (0, 1):
+        ctx.set_option("mix_bar", mb)
+        try:
+            s3 = ctx.armed_stats()
+            r = run(3)
+            s4 = ctx.armed_stats()
+            assert (s4["ident_checked"] - s3["ident_checked"] == 3) == bool(mb)  # the upload-kernel path has no copy block
+            for (F, dF, G, H), (F0, dF0, G0, H0) in zip(r, base):
+                assert F == F0 and np.array_equal(dF, dF0)
+        finally:
+            ctx.set_option("mix_bar", 1)
 
 
 def test_full_size_fused_step_vs_oracle(ctx):

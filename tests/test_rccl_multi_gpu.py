@@ -30,7 +30,8 @@ def test_sharded_objective_on_real_gpus(tmp_path, world):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
-               TORCHELASTIC_RUN_ID=f"pytest{os.getpid()}", HSA_ENABLE_IPC_MODE_LEGACY="0")
+               TORCHELASTIC_RUN_ID=f"pytest{os.getpid()}", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               VBMC_LAUNCH_NONCE=os.urandom(8).hex())
     procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "rccl_worker.py"), str(tmp_path)],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
              for r in range(world)]

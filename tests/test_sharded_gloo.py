@@ -67,3 +67,30 @@ def test_unique_id_file_rendezvous(tmp_path, monkeypatch):
     monkeypatch.setenv("MASTER_PORT", "29555")
     uid = comm.exchange_unique_id(0, 2, lambda: bytes(range(128)))
     assert comm.exchange_unique_id(1, 2, None, timeout=5) == uid == bytes(range(128))
+
+
+def test_stale_rendezvous_file_is_not_joined(tmp_path, monkeypatch):
+    """A leftover id file of an earlier launch that reused the key (same port, run id, launcher pid)
+    must not be joined: wrong nonce, or written long before this process started."""
+    import os
+    import time
+
+    import pytest
+
+    from pyvbmc_amd import comm
+
+    monkeypatch.setenv("VBMC_RDZV_DIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_PORT", "29556")
+    monkeypatch.setenv("VBMC_LAUNCH_NONCE", "launch-A")
+    comm.exchange_unique_id(0, 2, lambda: bytes(128))  # launch A's file stays behind (it "crashed")
+    monkeypatch.setenv("VBMC_LAUNCH_NONCE", "launch-B")
+    with pytest.raises(TimeoutError):
+        comm.exchange_unique_id(1, 2, None, timeout=0.3)
+    uid = comm.exchange_unique_id(0, 2, lambda: bytes(range(128)))  # launch B's rank 0 replaces it
+    assert comm.exchange_unique_id(1, 2, None, timeout=5) == uid
+    # same nonce, but the file is far older than this process
+    path = comm._rendezvous_path()
+    old = time.time() - 3600
+    os.utime(path, (old, old))
+    with pytest.raises(TimeoutError):
+        comm.exchange_unique_id(1, 2, None, timeout=0.3)
