@@ -119,8 +119,7 @@ int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
  *                  seed s+1 are generated speculatively while the host finalises (default),
  *                  0 = never
  *   "ahead_mode"   [VBMC_AHEAD_MODE]: where that speculative generation runs: 2 = spare
- *                  workgroups of the finish launch, eight pairs per thread stored after all are
- *                  computed (default), 3 = the same with one pair per thread, 0 = a launch of its
+ *                  workgroups of the finish launch (default; 3 = the same), 0 = a launch of its
  *                  own behind the finish kernel, 1 = a stream of its own (measured slower; kept as
  *                  the record)
  *   "mix_bar"      [VBMC_MIX_BAR]: 1 = in the polled host-driven step the CPU writes the mixture
@@ -142,6 +141,8 @@ int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
  *                  fails (the evaluation is repeated unarmed); see vbmc_armed_stats
  *   "ahead_pct"    [VBMC_AHEAD_PCT]: with elbo_arm, percent of the speculative draws generated in the
  *                  finish launch (rest: the armed prep launch); default 100
+ *   "gen_pt"       Philox blocks per thread of the speculative generation in the finish launch (1..16;
+ *                  default 1)
  *   "ws_pair"      [VBMC_WS_PAIR]: 1 = the wave-split entropy kernel hands its (component, chunk)
  *                  items out so that the two workgroups of a CU read the same table row (default)
  * The results of an evaluation do not depend on any of these.  Unknown key -> VBMC_E_ARG. */
@@ -254,6 +255,15 @@ int vbmc_set_eps_numpy(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, d
 int vbmc_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed,
                int64_t row_begin, int64_t row_count, int grad_flags, int jacobian_flag,
                double* H, double* dH, double* raw_out);
+
+/* The draws of VBMC_EPS_PHILOX mode themselves: out[K][row_count][D] = the standard normals the
+ * entropy kernels use for rows [row_begin, +row_count) of every component of a job with n_half
+ * antithetic pairs per component (counter-based: Philox4x32-10 keyed by seed on (global row, block),
+ * four normals per block; csrc/philox.h, restated by oracle/philox_ref.py).  Generated by the same
+ * kernel code as inside an evaluation.  For parity and distribution tests; no reference counterpart
+ * (the reference draws np.random.randn, entropy/entmc_vbmc.py:64-68). */
+int vbmc_philox_normals(vbmc_ctx* ctx, int K, int64_t n_half, int D, uint64_t seed, int64_t row_begin,
+                        int64_t row_count, double* out);
 
 /* Finalise a raw accumulator vector on the host (Jacobians + packing,
  * entmc_vbmc.py:114-132) with the ctx's current mixture: what every rank does

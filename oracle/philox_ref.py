@@ -1,10 +1,13 @@
 """Oracle: the device RNG, restated.  TEST INFRASTRUCTURE.
 
 NumPy restatement of pyvbmc_amd/csrc/philox.h (Philox4x32-10, Salmon et al.
-SC'11, + float64 Box-Muller) so that the Monte-Carlo entropy of the HIP kernel in
-VBMC_EPS_PHILOX mode can be checked against the oracle on the SAME draws.  There
-is no reference counterpart (the reference draws from NumPy's MT19937 stream).
-Integer side is bit-exact; the float side (log, sqrt, cos/sin) agrees to ~1 ulp.
+SC'11, + float64 Box-Muller on 32-bit words: one block = four normals of a row) so
+that the Monte-Carlo entropy of the HIP kernel in VBMC_EPS_PHILOX mode can be checked
+against the oracle on the SAME draws.  There is no reference counterpart (the
+reference draws from NumPy's MT19937 stream).  Integer side is bit-exact; the float
+side (log, sqrt, cos/sin by libm here, fitted polynomials on the device) agrees to
+<= 2e-13 absolute.  ``normals`` / ``uniform`` restate the sampler's streams
+(csrc/sample.hip: 53-bit uniforms, one block per pair).
 """
 import numpy as np
 
@@ -31,10 +34,21 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
+def box_muller32(xr, xa):
+    """Two standard normals from two 32-bit words, as csrc/philox.h philox_bm32 defines them:
+    u = (xr + 1/2) 2^-32 in (0, 1), angle = 2 pi xa 2^-32 (libm here; the device's fitted
+    polynomials agree to <= 2e-13 absolute)."""
+    u = (xr.astype(np.float64) + 0.5) * 2.0**-32
+    ang = 2.0 * np.pi * (xa.astype(np.float64) * 2.0**-32)
+    rad = np.sqrt(-2.0 * np.log(u))
+    return rad * np.cos(ang), rad * np.sin(ang)
+
+
 def eps_half(K, n_half, D, seed, row_begin=0, row_count=None):
-    """[K][row_count][D] standard normals exactly as the kernel generates them:
-    counter = (row_lo, row_hi, pair, 0), key = (seed_lo, seed_hi),
-    row = j * n_half + i (global antithetic-pair row index)."""
+    """[K][row_count][D] standard normals exactly as the kernels generate them (csrc/philox.h):
+    counter = (row_lo, row_hi, blk, 0), key = (seed_lo, seed_hi), row = j * n_half + i (global
+    antithetic-pair row index); block blk gives dimensions 4 blk .. 4 blk + 3: (x0, x1) the first
+    pair, (x2, x3) the second."""
     if row_count is None:
         row_count = n_half - row_begin
     seed = int(seed)
@@ -44,18 +58,16 @@ def eps_half(K, n_half, D, seed, row_begin=0, row_count=None):
     row = j * np.uint64(n_half) + i
     lo = (row & MASK).astype(np.uint32)
     hi = (row >> np.uint64(32)).astype(np.uint32)
-    for p in range((D + 1) // 2):
-        x0, x1, x2, x3 = philox4x32_10(
-            lo, hi, np.full_like(lo, p), np.zeros_like(lo), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
-        )
-        a = ((x0.astype(np.uint64) << np.uint64(32)) | x1.astype(np.uint64)) >> np.uint64(11)
-        b = ((x2.astype(np.uint64) << np.uint64(32)) | x3.astype(np.uint64)) >> np.uint64(11)
-        u1 = (a + np.uint64(1)).astype(np.float64) * 2.0**-53
-        u2 = b.astype(np.float64) * 2.0**-53
-        rad = np.sqrt(-2.0 * np.log(u1))
-        out[:, :, 2 * p] = rad * np.cos(2.0 * np.pi * u2)
-        if 2 * p + 1 < D:
-            out[:, :, 2 * p + 1] = rad * np.sin(2.0 * np.pi * u2)
+    for b in range((D + 3) // 4):
+        x = philox4x32_10(lo, hi, np.full_like(lo, b), np.zeros_like(lo), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+        for h in range(2):
+            d0 = 4 * b + 2 * h
+            if d0 >= D:
+                break
+            z0, z1 = box_muller32(x[2 * h], x[2 * h + 1])
+            out[:, :, d0] = z0
+            if d0 + 1 < D:
+                out[:, :, d0 + 1] = z1
     return out
 
 

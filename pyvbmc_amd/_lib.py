@@ -88,6 +88,7 @@ SIGNATURES = {
         C.c_int,
         [_vp, C.c_int64, C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_int, _dp, _dp, _dp],
     ),
+    "vbmc_philox_normals": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_int64, C.c_int64, _dp]),
     "vbmc_entmc_finalize": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, _dp]),
     "vbmc_entlb": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp]),
     "vbmc_set_gp": (
@@ -247,6 +248,13 @@ class Context:
         self.check(self._lib.vbmc_last_entmc_plan(self._h, out))
         return {"kernel": ("valu", "ws", "small")[out[0]] if out[0] >= 0 else None, "rg": out[1],
                 "chunks": out[2], "resident_draws": bool(out[3])}
+
+    def philox_normals(self, K, n_half, D, seed, row_begin=0, row_count=None):
+        """[K][row_count][D] draws of the device generator (vbmc_philox_normals)."""
+        row_count = n_half - row_begin if row_count is None else row_count
+        out = np.empty((K, row_count, D))
+        self.check(self._lib.vbmc_philox_normals(self._h, K, n_half, D, C.c_uint64(seed), row_begin, row_count, ptr(out)))
+        return out
 
     def armed_stats(self):
         """Counters of the polled step: armed evaluations used / cancelled / recovered from a late go

@@ -330,9 +330,9 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
       if (spin && gen_mode != 2 && gen_mode != 3 && gen_mode != -1) gen_mode = 2;  // armed launches keep everything in three kernels
       const bool defer = gen_mode == 2;  // (3 = the same placement with the generator's plain one-pair-per-thread form)
       if (gen_mode == 3) gen_mode = 2;
-      if (defer) {  // 8 pairs per thread, stored after all are computed (philox.h)
-        ahead_gen.per_thread = 8;
-        ahead_gen.n_blocks = (int)((ahead_gen.item_count + 2047) / 2048);
+      if (defer && ctx->opt_gen_pt > 1) {  // several items per thread (philox.h; "gen_pt")
+        ahead_gen.per_thread = ctx->opt_gen_pt;
+        ahead_gen.n_blocks = (int)((ahead_gen.item_count + 256 * (int64_t)ctx->opt_gen_pt - 1) / (256 * (int64_t)ctx->opt_gen_pt));
       }
       if (gen_mode == 1) {
         rc2 = entmc_launch_ahead(ctx, ahead_gen);

@@ -115,6 +115,27 @@ int vbmc_entmc(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
   return vbmc_entmc_finalize(ctx, ctx->h_pinned, grad_flags, jacobian_flag, H, dH);
 }
 
+int vbmc_philox_normals(vbmc_ctx* ctx, int K, int64_t n_half, int D, uint64_t seed, int64_t row_begin,
+                        int64_t row_count, double* out) {
+  if (!ctx || !out || K < 1 || D < 1 || n_half < 1) return VBMC_E_ARG;
+  NEED_DEVICE(ctx);
+  if (row_begin < 0 || row_count < 0 || row_begin + row_count > n_half)
+    return vbmc_fail(ctx, VBMC_E_ARG, "philox_normals: rows [%lld,+%lld) outside [0,%lld)", (long long)row_begin,
+                     (long long)row_count, (long long)n_half);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t n = (size_t)K * (size_t)row_count * (size_t)D;
+  if (n == 0) return VBMC_OK;
+  HIP_TRY(ctx, stream_wait(ctx));  // (the scratch buffer may be in use by queued launches)
+  int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, n);
+  if (rc) return rc;
+  const GenSlice g = make_gen_slice(ctx->d_scratch, K, D, row_count, n_half, row_begin, seed, nullptr, 0.0, 1.0);
+  rc = launch_eps_gen(ctx, ctx->stream, g);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_scratch, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
+  return VBMC_OK;
+}
+
 int vbmc_entlb(vbmc_ctx* ctx, int grad_flags, int jacobian_flag, double* H, double* dH) {
   if (!ctx) return VBMC_E_ARG;
   if (!ctx->mix_set) return vbmc_fail(ctx, VBMC_E_ARG, "entlb: mixture not set");

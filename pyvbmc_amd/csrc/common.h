@@ -184,6 +184,7 @@ struct vbmc_ctx {
   int opt_ahead_mode = 2;   // speculative draws: 2 = spare workgroups of the finish launch, 0 = a launch of their own behind it, 1 = on their own stream (measured: slower)
   int opt_ahead_pct = 100;  // armed evaluations: percent of the next draws generated in the finish launch (the rest in the armed prep launch, which runs them while it waits for theta)
   int opt_arm_late_test = 0;  // test hook: n > 0 = the n-th use of an armed evaluation from now takes the late-go recovery path
+  int opt_gen_pt = 1;         // speculative draws in the finish launch: Philox blocks per thread
   int opt_ident_test = 0;     // test hook: n > 0 = the n-th identity check from now fails (the recovery path runs)
   bool ident_retry = false;   // inside the re-evaluation after a failed identity check
   int opt_elbo_arm = 1;     // queue the next host-driven evaluation's launches ahead of its theta (armed evaluation)
@@ -260,8 +261,9 @@ static inline int raw_len(int D, int K) { return 1 + D * K + 2 * K + D; }
 // arguments of the prep launch (prep.hip): table rows for the wave-split entropy kernel
 // and/or the GP expected-log-joint sums
 // A slice of the draw buffer eps[K][rows][D] for other kernels' spare workgroups to fill: the
-// (row, pair) items [item_begin, item_begin + item_count) of the K * rows * ceil(D/2) items, 256 per
-// workgroup.  The values depend on (seed, row, pair) only, so any kernel may generate any slice.
+// (row, block) items [item_begin, item_begin + item_count) of the K * rows * ceil(D/4) items -- one
+// Philox block = up to four normals of a row (philox.h) -- 256 * per_thread per workgroup.  The values
+// depend on (seed, row, block) only, so any kernel may generate any slice.
 // completion signalling of entmc_finish_kernel (all null/0: none)
 struct DoneSignal {
   int* cnt = nullptr;        // device counter of finished result waves
@@ -337,13 +339,15 @@ __device__ __forceinline__ void staged_copy_to_host(const double* __restrict__ s
 struct GenSlice {
   double* eps = nullptr;
   int K = 0, D = 0;
+  int nb = 0;              // ceil(D / 4): Philox blocks per row
+  uint32_t nb_magic = 0, rows_magic = 0;  // min(floor(2^32 / d), 2^32 - 1) for the two 32-bit divisions (philox.h gen_div32)
   int64_t rows = 0;        // rows per component held in eps (this rank's slice of the n_half pairs)
   int64_t n_half = 0, row_begin = 0;
   uint64_t seed = 0;
   const int* seed_add = nullptr;  // optional device-side addend (the Adam loop's iteration base)
   int64_t item_begin = 0, item_count = 0;
   int n_blocks = 0;        // ceil(item_count / (256 * per_thread))
-  int per_thread = 1;      // items per thread; > 1: all of a thread's pairs are computed before the first is stored
+  int per_thread = 1;      // items per thread, 256 apart
 };
 
 struct PrepArgs {
@@ -382,7 +386,7 @@ struct PrepArgs {
   // host can finalise G / dG while the entropy kernel runs
   DoneSignal done;
 };
-// the slice [frac_begin, frac_end) of the K * rows * ceil(D/2) draw items of eps[K][rows][D]
+// the slice [frac_begin, frac_end) of the K * rows * ceil(D/4) draw items of eps[K][rows][D]
 GenSlice make_gen_slice(double* eps, int K, int D, int64_t rows, int64_t n_half, int64_t row_begin,
                         uint64_t seed, const int* seed_add, double frac_begin, double frac_end);
 // wait for everything queued on the ctx stream (also: the pinned mixture pack is free again)

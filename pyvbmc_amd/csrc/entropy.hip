@@ -13,6 +13,8 @@
 // that the host finalises (Jacobians) and that the multi-GPU path all-reduces.
 #include <cstdlib>
 
+#include <algorithm>
+
 #include "common.h"
 #include "fastmath.h"
 #include "entropy_args.h"
@@ -85,12 +87,13 @@ __global__ __launch_bounds__(WG) void entmc_valu_kernel(EntArgs a) {
     } else {
       const uint64_t grow = (uint64_t)j * (uint64_t)a.n_half + (uint64_t)(a.row_begin + i_loc);
 #pragma unroll
-      for (int p = 0; p < DP / 2; ++p) {
-        if (2 * p < D) {
-          double z0, z1;
-          philox_normal_pair(grow, (uint32_t)p, a.seed, z0, z1);
-          e[2 * p] = z0;
-          if (2 * p + 1 < D) e[2 * p + 1] = z1;
+      for (int b = 0; b < (DP + 3) / 4; ++b) {
+        if (4 * b < D) {
+          double z[4];
+          philox_normal_quad(grow, (uint32_t)b, a.seed, z);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (4 * b + q < DP && 4 * b + q < D) e[4 * b + q] = z[q];
         }
       }
     }
@@ -735,7 +738,11 @@ GenSlice make_gen_slice(double* eps, int K, int D, int64_t rows, int64_t n_half,
   g.row_begin = row_begin;
   g.seed = seed;
   g.seed_add = seed_add;
-  const int64_t total = (int64_t)K * rows * ((D + 1) / 2);
+  g.nb = (D + 3) / 4;
+  auto magic = [](uint64_t d) { return (uint32_t)std::min<uint64_t>(d ? 0x100000000ull / d : 0, 0xFFFFFFFFull); };
+  g.nb_magic = magic((uint64_t)g.nb);
+  g.rows_magic = magic((uint64_t)rows);
+  const int64_t total = (int64_t)K * rows * g.nb;
   const int64_t b = (int64_t)(frac_begin * (double)total), e = frac_end >= 1.0 ? total : (int64_t)(frac_end * (double)total);
   g.item_begin = b;
   g.item_count = e > b ? e - b : 0;

@@ -206,23 +206,24 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
           if (d < D) e[d] = rp[d];
       }
     } else {
-      // Every GB-th batch the four waves generate the Box-Muller pairs of the next GB
-      // batches together: (batch, pair) slots are dealt round-robin over the waves, so each
-      // pair is generated exactly once per workgroup and the waves stay balanced (D/2 pairs
-      // per batch do not divide by 4, GB*D/2 does).  LDS hands the normals to all waves.
+      // Every GB-th batch the four waves generate the Philox blocks (four normals each, philox.h)
+      // of the next GB batches together: (batch, block) slots are dealt round-robin over the waves,
+      // so each block is generated exactly once per workgroup and the waves stay balanced.  LDS
+      // hands the normals to all waves.
       constexpr int NP = DP / 2;
-      const int np = (D + 1) / 2;  // pairs actually needed
+      const int nbk = (D + 3) / 4;  // blocks actually needed
       if ((it % GB) == 0) {
         const int nb = min(GB, a.rg - it);
         __syncthreads();  // readers of the previous round are done with sE
-        for (int q = wave; q < nb * np; q += WAVES) {
-          const int bq = q / np, p = q - bq * np;
+        for (int q = wave; q < nb * nbk; q += WAVES) {
+          const int bq = q / nbk, blk = q - bq * nbk;
           const int64_t il = (int64_t)chunk * rows_per_wg + (it + bq) * 64 + lane;
           const uint64_t grow = (uint64_t)j * (uint64_t)a.n_half + (uint64_t)(a.row_begin + il);
-          double z0, z1;
-          philox_normal_pair(grow, (uint32_t)p, a.seed, z0, z1);
-          sE[bq][2 * p][lane] = z0;
-          if (2 * p + 1 < DP) sE[bq][2 * p + 1][lane] = z1;
+          double z[4];
+          philox_normal_quad(grow, (uint32_t)blk, a.seed, z);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (4 * blk + c < DP) sE[bq][4 * blk + c][lane] = z[c];
         }
         __syncthreads();
       }

@@ -1,14 +1,28 @@
-// Counter-based standard-normal generator used by the entropy kernels in
-// VBMC_EPS_PHILOX mode.  Philox4x32-10 (Salmon et al., SC'11) + Box-Muller in
-// float64.  oracle/philox_ref.py restates this bit-for-bit on the integer side so
-// the parity tests can evaluate the oracle on identical draws.
+// Counter-based standard-normal generator of the entropy kernels' VBMC_EPS_PHILOX mode.
+// Philox4x32-10 (Salmon et al., SC'11); ONE 128-bit block gives FOUR normals of a row through two
+// Box-Muller transforms on 32-bit words.  oracle/philox_ref.py restates it (integer side bit for bit,
+// float side with libm: the routines below agree with libm to <= 2e-13 absolute, far inside the
+// 1e-10 the parity tests ask of H), so the oracle is evaluated on the same draws.
 //
-//   counter = (row_lo, row_hi, pair, 0)   key = (seed_lo, seed_hi)
+//   counter = (row_lo, row_hi, blk, 0)   key = (seed_lo, seed_hi)
 //   row   = global antithetic-pair row index  j * n_half + i
-//   pair  = d / 2  (one Philox call yields the normals of dimensions 2p, 2p+1)
-//   u1 = (((x0<<32 | x1) >> 11) + 1) * 2^-53   in (0,1]
-//   u2 =  ((x2<<32 | x3) >> 11)      * 2^-53   in [0,1)
-//   z0 = sqrt(-2 ln u1) cos(2 pi u2),  z1 = sqrt(-2 ln u1) sin(2 pi u2)
+//   blk   = d / 4: the block's words (x0, x1) give the normals of dimensions 4 blk, 4 blk + 1,
+//           (x2, x3) those of 4 blk + 2, 4 blk + 3
+//   pair (xr, xa):  u  = (xr + 1/2) 2^-32  in (0, 1)           (never 0 or 1: no guards)
+//                   z0 = sqrt(-2 ln u) cos(2 pi xa 2^-32),  z1 = sqrt(-2 ln u) sin(2 pi xa 2^-32)
+//
+// Round 3.  Rounds 1-2 spent one Philox block and 53-bit uniforms on every pair,
+// <= 1 ulp log / sqrt / sincospi and 64-bit index arithmetic: ~240 vector instructions per pair
+// (PMC), 21 us for the 5e6 normals of BASELINE config 3 -- the largest piece of an evaluation after
+// the entropy kernel.  A random INPUT needs neither: 32-bit radius / angle words leave the normal
+// law intact to 2^-33 in distribution (max |z| 6.7), so one block serves two pairs; log, sin and cos
+// are degree-5 fits (tools/fit_polys.py --gen: <= 1e-14 / 4e-15 / 6e-14), sqrt is v_rsq_f64 + one
+// coupled Newton step, the quadrant comes from the angle word's top two bits and the sign flips are
+// integer xors; thread = block with 32-bit magic-number index arithmetic.  Measured back to back
+// (tools/ubench_gen2.hip): 21.2 -> 13.7 us; with seven Philox rounds 13.0 (the Crush-resistant
+// minimum; the three rounds kept are 0.25 us each and buy the generator's published safety margin);
+// conversions by integer tricks instead of v_cvt / v_frexp: slower (15.2); write-through (sc1) or
+// nt stores: slower (16.7); stores through an LDS image of the wave's span: slower (16.5).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -41,124 +55,127 @@ __host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
   return o;
 }
 
-__device__ inline void philox_normal_pair(uint64_t row, uint32_t pair, uint64_t seed, double& z0, double& z1);
-
-// Item t of a slice = (component j, row i of the slice, pair p): t = (j * rows + i) * np + p, so
-// r = t / np = j * rows + i is the row of the slice's eps block, the pair's normals go to
-// eps[r * D + 2p (+1)], and its Philox row is j * n_half + row_begin + i.
-// 64-bit division and multiplication are tens of instructions each on this ISA -- 32-bit integer
-// multiplies issue at a quarter of the rate, and this index arithmetic cost as much as the ten
-// Philox rounds -- so when items, rows and offsets fit 32 bits (checked per call, every case the
-// library runs) the position is derived with 32-bit operations, and a thread that generates several
-// items a fixed stride apart walks it with additions.
-struct GenPos {
-  uint64_t grow;  // Philox row
-  int64_t off;    // element offset of the pair's first normal in eps
-  int64_t i;      // row within the component's slice
-  int p;
-};
-__device__ inline bool gen_fits32(const GenSlice& g, int np) {
-  const uint64_t items = (uint64_t)(g.item_begin + g.item_count), elems = (uint64_t)g.K * (uint64_t)g.rows * (uint64_t)g.D;
-  return ((items | elems | (uint64_t)g.rows | (uint64_t)g.n_half) >> 32) == 0;
+// Box-Muller on two 32-bit words (see the header of this file).
+__device__ __forceinline__ void philox_bm32(uint32_t xr, uint32_t xa, double& z0, double& z1) {
+  // -2 ln u, u = f 2^-32, f = xr + 1/2 = m 2^e with m in [sqrt(1/2), sqrt(2)): ln m = 2 atanh((m-1)/(m+1))
+  const double f = (double)xr + 0.5;  // exact
+  double m = __builtin_amdgcn_frexp_mant(f);
+  int e = __builtin_amdgcn_frexp_exp(f);
+  const bool lo = m < 0x1.6a09e667f3bcdp-1;
+  m = __builtin_amdgcn_ldexp(m, lo ? 1 : 0);
+  e = lo ? e - 1 : e;
+  const double den = m + 1.0, num = m - 1.0;
+  double r = __builtin_amdgcn_rcp(den);  // ~24 bits
+  r = fma(fma(-den, r, 1.0), r, r);      // ~48 bits: one Newton step is enough here
+  const double s = num * r, u = s * s;
+  double p = 0x1.9192e478c4308p-4;       // atanh(s)/s in u = s^2, degree 5: ln m to 9.4e-15
+  p = fma(p, u, 0x1.c620ee6e2b4a3p-4);
+  p = fma(p, u, 0x1.2494381ee5869p-3);
+  p = fma(p, u, 0x1.9999962c06032p-3);
+  p = fma(p, u, 0x1.555555567148cp-2);
+  p = fma(p, u, 0x1.fffffffffff12p-1);
+  const double lm2 = s * p;              // ln(m) / 2
+  const double x2 = fma(-4.0, lm2, (double)(32 - e) * 0x1.62e42fefa39efp+0);  // in [2.3e-10, 45.8]
+  // sqrt(x2): v_rsq_f64 and one coupled Newton step
+  const double y = __builtin_amdgcn_rsq(x2);
+  double g = x2 * y;
+  g = fma(g, fma(-0.5 * y, g, 0.5), g);
+  // angle = pi (q/2 + 1/4 + t), q = the word's top two bits, t = v 2^-33 in [-1/4, 1/4); the
+  // polynomials in t^2 are evaluated in v^2 with the powers of 2^-33 folded into the coefficients
+  const double v = (double)(int)((xa << 2) ^ 0x80000000u);
+  const double w = v * v;
+  double ps = -0x1.dd54805f3f706p-8 * 0x1p-363;  // sin(pi t)/t, degree 5: 3.5e-15
+  ps = fma(ps, w, 0x1.5071ce4b47930p-4 * 0x1p-297);
+  ps = fma(ps, w, -0x1.32d2c644adc0bp-1 * 0x1p-231);
+  ps = fma(ps, w, 0x1.466bc67123fa1p+1 * 0x1p-165);
+  ps = fma(ps, w, -0x1.4abbce6257a2ap+2 * 0x1p-99);
+  ps = fma(ps, w, 0x1.921fb54442cfap+1 * 0x1p-33);
+  const double S = ps * v;
+  double pc = -0x1.a0ee132c60c1fp-6 * 0x1p-330;  // cos(pi t), degree 5: 5.6e-14
+  pc = fma(pc, w, 0x1.e1e7ccccb387ap-3 * 0x1p-264);
+  pc = fma(pc, w, -0x1.55d3ba300cd50p+0 * 0x1p-198);
+  pc = fma(pc, w, 0x1.03c1f074ded21p+2 * 0x1p-132);
+  pc = fma(pc, w, -0x1.3bd3cc9bd2c35p+2 * 0x1p-66);
+  const double C = fma(pc, w, 0x1.ffffffffffe0bp-1);
+  // cos(a + pi t) = ca C - sa S, sin(a + pi t) = sa C + ca S with a = (2q + 1) pi / 4:
+  // (ca, sa) = sqrt(1/2) x (+,+), (-,+), (-,-), (+,-) for q = 0..3 -- sign flips by integer xor
+  const uint32_t ms = xa & 0x80000000u, mc = ((xa << 1) ^ xa) & 0x80000000u;
+  auto flip = [](double d, uint32_t mask) { return __hiloint2double(__double2hiint(d) ^ (int)mask, __double2loint(d)); };
+  const double gh = g * 0x1.6a09e667f3bcdp-1;
+  z0 = gh * (flip(C, mc) - flip(S, ms));
+  z1 = gh * (flip(C, ms) + flip(S, mc));
 }
-__device__ inline GenPos gen_pos(const GenSlice& g, int64_t t, int np, bool fits32) {
-  GenPos q;
-  if (!fits32) {
-    const int64_t r = t / np;
-    q.p = (int)(t - r * np);
-    const int64_t j = r / g.rows;
-    q.i = r - j * g.rows;
-    q.grow = (uint64_t)j * (uint64_t)g.n_half + (uint64_t)(g.row_begin + q.i);
-    q.off = r * g.D + 2 * q.p;
-  } else {
-    const uint32_t tt = (uint32_t)t, r = tt / (uint32_t)np, rows = (uint32_t)g.rows;
-    const uint32_t p = tt - r * (uint32_t)np;
-    const uint32_t j = r / rows, i = r - j * rows;
-    q.p = (int)p;
-    q.i = i;
-    q.grow = (uint64_t)j * (uint64_t)(uint32_t)g.n_half + ((uint64_t)g.row_begin + i);  // one 32 x 32 -> 64 multiply-add
-    q.off = (int64_t)(r * (uint32_t)g.D + 2 * p);
-  }
+
+// the four normals of block `blk` of Philox row `row`
+__device__ __forceinline__ void philox_normal_quad(uint64_t row, uint32_t blk, uint64_t seed, double (&z)[4]) {
+  const Philox4 r = philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), blk, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+  philox_bm32(r.x[0], r.x[1], z[0], z[1]);
+  philox_bm32(r.x[2], r.x[3], z[2], z[3]);
+}
+
+// Item t of a slice = (component j, row i of the slice, block b): t = (j * rows + i) * nb + b with
+// nb = ceil(D / 4), so r = t / nb = j * rows + i is the row of the slice's eps block, the block's
+// normals go to eps[r * D + 4 b ...], and its Philox row is j * n_half + row_begin + i.  Items are
+// consecutive in memory.  When items, rows and offsets fit 32 bits (checked per call: every case
+// the library runs) the two divisions are a multiply-high by floor(2^32 / d) and one correction.
+__device__ __forceinline__ uint32_t gen_div32(uint32_t t, uint32_t d, uint32_t magic) {
+  uint32_t q = __umulhi(t, magic);  // t/d - 1 <= q <= t/d
+  if (t - q * d >= d) ++q;
   return q;
 }
-__device__ inline void gen_emit(const GenSlice& g, const GenPos& q, uint64_t seed, double& z0, double& z1, double*& dst,
-                                bool& two) {
-  philox_normal_pair(q.grow, (uint32_t)q.p, seed, z0, z1);
-  dst = g.eps + q.off;
-  two = 2 * q.p + 1 < g.D;
+__device__ inline bool gen_fits32(const GenSlice& g) {
+  const uint64_t items = (uint64_t)(g.item_begin + g.item_count), elems = (uint64_t)g.K * (uint64_t)g.rows * (uint64_t)g.D;
+  return ((items | elems | (uint64_t)g.rows | (uint64_t)g.n_half | (uint64_t)(g.row_begin + g.rows)) >> 32) == 0;
+}
+__device__ __forceinline__ void gen_item(const GenSlice& g, int64_t t, uint64_t seed, bool fits32) {
+  uint64_t grow;
+  int64_t off;
+  uint32_t b;
+  if (fits32) {
+    const uint32_t tt = (uint32_t)t, r = gen_div32(tt, (uint32_t)g.nb, g.nb_magic);
+    b = tt - r * (uint32_t)g.nb;
+    const uint32_t j = gen_div32(r, (uint32_t)g.rows, g.rows_magic), i = r - j * (uint32_t)g.rows;
+    grow = (uint64_t)j * (uint64_t)(uint32_t)g.n_half + ((uint64_t)g.row_begin + i);
+    off = (int64_t)(r * (uint32_t)g.D + 4 * b);
+  } else {
+    const int64_t r = t / g.nb;
+    b = (uint32_t)(t - r * g.nb);
+    const int64_t j = r / g.rows, i = r - j * g.rows;
+    grow = (uint64_t)j * (uint64_t)g.n_half + (uint64_t)(g.row_begin + i);
+    off = r * g.D + 4 * (int64_t)b;
+  }
+  double z[4];
+  philox_normal_quad(grow, b, seed, z);
+  double* dst = g.eps + off;
+  const int left = g.D - 4 * (int)b;  // normals of this block that exist (1..4 and more)
+  if ((g.D & 1) == 0) {  // rows start 16-byte aligned: one or two 16-byte stores
+    *reinterpret_cast<double2*>(dst) = make_double2(z[0], z[1]);
+    if (left > 2) *reinterpret_cast<double2*>(dst + 2) = make_double2(z[2], z[3]);
+  } else {
+    dst[0] = z[0];
+    if (left > 1) dst[1] = z[1];
+    if (left > 2) dst[2] = z[2];
+    if (left > 3) dst[3] = z[3];
+  }
 }
 
-// workgroup `block` (0-based among the slice's n_blocks) of a 256-thread launch
+// workgroup `block` (0-based among the slice's n_blocks) of a 256-thread launch; a thread takes
+// per_thread items, 256 apart (every store instruction of a wave writes one contiguous span)
 __device__ inline void gen_slice_block(const GenSlice& g, int block, int tid) {
-  const int np = (g.D + 1) / 2;
   const uint64_t seed = g.seed + (g.seed_add ? (uint64_t)g.seed_add[0] : 0);
-  const bool fits32 = gen_fits32(g, np);
-  if (g.per_thread <= 1) {
-    const int64_t local = (int64_t)block * 256 + tid;
-    if (local >= g.item_count) return;
-    double z0, z1;
-    double* dst;
-    bool two;
-    gen_emit(g, gen_pos(g, g.item_begin + local, np, fits32), seed, z0, z1, dst, two);
-    dst[0] = z0;
-    if (two) dst[1] = z1;
-    return;
+  const bool fits32 = gen_fits32(g);
+  const int pt = g.per_thread > 1 ? g.per_thread : 1;
+  const int64_t base = (int64_t)block * (256 * (int64_t)pt) + tid;
+  for (int u = 0; u < pt; ++u) {
+    const int64_t local = base + (int64_t)u * 256;
+    if (local >= g.item_count) break;
+    gen_item(g, g.item_begin + local, seed, fits32);
   }
-  // Deferred-store form (the speculative generation inside the finish launch, api_elbo.hip): a
-  // thread computes its 8 pairs (items block * 2048 + i * 256 + tid: every store instruction of a
-  // wave still writes contiguous memory) and only then stores them.  The generation is arithmetic
-  // for its first two thirds, so the 40 MB of stores reach the memory system in the last third.
-  constexpr int PT = 8;
-  const int64_t base = (int64_t)block * (256 * PT) + tid;
-  const int step_r = 256 / np, step_p = 256 - step_r * np;  // 256 items further
-  if (g.rows <= step_r + 1) {  // slices too small to walk (more than one component boundary per step): item by item
-    for (int i = 0; i < PT; ++i) {
-      const int64_t local = base + (int64_t)i * 256;
-      if (local >= g.item_count) break;
-      double z0, z1;
-      double* dst;
-      bool two;
-      gen_emit(g, gen_pos(g, g.item_begin + local, np, fits32), seed, z0, z1, dst, two);
-      dst[0] = z0;
-      if (two) dst[1] = z1;
-    }
-    return;
-  }
-  double z[PT][2];
-  double* dst[PT];
-  bool two[PT];
-  GenPos q = gen_pos(g, g.item_begin + base, np, fits32);
-  const int64_t step_off = (int64_t)step_r * g.D + 2 * step_p, wrap_off = (int64_t)g.D - 2 * np;
-  const uint64_t next_comp = (uint64_t)(g.n_half - g.rows);
-#pragma unroll
-  for (int i = 0; i < PT; ++i) {
-    const int64_t local = base + (int64_t)i * 256;
-    dst[i] = nullptr;
-    two[i] = false;
-    if (local < g.item_count) gen_emit(g, q, seed, z[i][0], z[i][1], dst[i], two[i]);
-    q.p += step_p;
-    q.i += step_r;
-    q.grow += (uint64_t)step_r;
-    q.off += step_off;
-    if (q.p >= np) {
-      q.p -= np;
-      ++q.i;
-      ++q.grow;
-      q.off += wrap_off;
-    }
-    if (q.i >= g.rows) {  // (rows > step_r + 1: at most one component boundary per step)
-      q.i -= g.rows;
-      q.grow += next_comp;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < PT; ++i)
-    if (dst[i]) {
-      dst[i][0] = z[i][0];
-      if (two[i]) dst[i][1] = z[i][1];
-    }
 }
 
+// The generator of rounds 1-2 (one block and 53-bit uniforms per pair, <= 1 ulp elementary
+// functions); no kernel of the library uses it any more -- kept for tools/ubench_gen*.hip, which
+// time the old form beside the new one.
 __device__ inline void philox_normal_pair(uint64_t row, uint32_t pair, uint64_t seed,
                                           double& z0, double& z1) {
   Philox4 r = philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), pair, 0u, (uint32_t)seed,

@@ -105,4 +105,118 @@ for what, call in calls.items():
     except _lib.NoDeviceError:
         assert not have_gpu
         print(f"{what}: reached the device boundary (NoDeviceError, no GPU here)")
+
+# ---- 4. pyvbmc_amd.patch(vo): the callers either side of the path -------------
+# The reference's OWN _sieve runs under the patch (its candidate generation, its np.random use, its
+# return tuple); only the per-candidate evaluation loop is deferred into one batched call.  Here that
+# call is served by the reference's own (saved) _neg_elcbo, candidate by candidate, so the patched
+# sieve must return EXACTLY what the un-patched reference returns: same candidates, same order.
+import copy  # noqa: E402
+import os  # noqa: E402
+
+from pyvbmc.vbmc import Options  # noqa: E402
+
+pyvbmc_amd.unpatch(vo)
+for name in ("entmc_vbmc", "entlb_vbmc", "_gp_log_joint", "_neg_elcbo"):  # undo section 1's verbatim patch
+    setattr(vo, name, ref_fns[name])
+_ref_neg_elcbo = vo._neg_elcbo
+
+
+def ref_neg_elcbo(*a, **kw):
+    """The reference's own _neg_elcbo with the reference's own leaves under it (it looks
+    _gp_log_joint / entlb_vbmc up in the module at call time), whatever is patched in meanwhile."""
+    cur = {n: getattr(vo, n) for n in ("entmc_vbmc", "entlb_vbmc", "_gp_log_joint")}
+    for n in cur:
+        setattr(vo, n, ref_fns[n])
+    try:
+        return _ref_neg_elcbo(*a, **kw)
+    finally:
+        for n, v in cur.items():
+            setattr(vo, n, v)
+
+
+def setup_options(D):
+    base = REF / "pyvbmc" / "vbmc" / "option_configs"
+    o = Options(str(base / "basic_vbmc_options.ini"), evaluation_parameters={"D": D}, user_options={})
+    o.load_options_file(str(base / "advanced_vbmc_options.ini"), evaluation_parameters={"D": D})
+    return o
+
+
+wl2 = synthetic.make_workload(2, D=3, K=4, N=60)
+gp2 = gpr.GP(D=wl2.D, covariance=gpr.covariance_functions.SquaredExponential(),
+             mean=gpr.mean_functions.NegativeQuadratic(), noise=gpr.noise_functions.GaussianNoise(constant_add=True))
+gp2.update(X_new=wl2.X, y_new=wl2.y, hyp=wl2.hyp)
+
+
+def fresh_vp():
+    v = RefVP(wl2.D, wl2.K)
+    v.mu = wl2.mu.copy()
+    v.sigma, v.lambd = wl2.sigma.reshape(1, -1).copy(), wl2.lambd.reshape(-1, 1).copy()
+    v.w, v.eta = wl2.w.reshape(1, -1).copy(), wl2.eta.reshape(1, -1).copy()
+    return v
+
+
+options = setup_options(wl2.D)
+optim_state = {"warmup": False, "entropy_switch": False, "delta": np.zeros((1, wl2.D))}
+for best_N in (1, 3):
+    np.random.seed(11)
+    ref_out = vo._sieve(options, optim_state, fresh_vp(), gp2, init_N=13, best_N=best_N)
+    calls_seen = []
+
+    def batch_by_reference(thetas, gp_, vp_, bnd):
+        calls_seen.append(len(thetas))
+        return [ref_neg_elcbo(t.copy(), gp_, copy.deepcopy(vp_), 0, 0, 0, False, bnd)[0] for t in thetas]
+
+    pyvbmc_amd.patch(vo, _batch_eval=batch_by_reference)
+    assert vo._sieve is not ref_fns.get("_sieve") and vo._neg_elcbo is avo._neg_elcbo
+    np.random.seed(11)
+    new_out = vo._sieve(options, optim_state, fresh_vp(), gp2, init_N=13, best_N=best_N)
+    assert vo._neg_elcbo is avo._neg_elcbo  # the recorder is gone again
+    pyvbmc_amd.unpatch(vo)
+    assert vo._neg_elcbo is _ref_neg_elcbo
+    assert calls_seen == [13], calls_seen  # ONE batched evaluation of all 13 candidates
+    assert np.array_equal(ref_out[1], new_out[1]) and ref_out[2:] == new_out[2:]
+    for a, b in zip(ref_out[0], new_out[0]):
+        for attr in ("mu", "sigma", "lambd", "w", "eta"):
+            assert np.array_equal(getattr(a, attr), getattr(b, attr)), attr
+    print(f"patch(vo): the reference's _sieve (best_N={best_N}) returned the same 13 candidates in the same order, "
+          f"one batched evaluation")
+
+# optimize_vp's stochastic branch: the reference's own minimize_adam call site hands the patched
+# minimize_adam its closure vb_train_mc_fun; it must be recognised and routed to the device loop with
+# the closure's own gp / vp0 / ns_ent_K / theta_bnd.
+seen = {}
+
+
+def fake_loop(theta0, gp_, vp0, ns, theta_bnd, beta, lb, ub, tol_fun, max_iter, master_min, master_max, master_decay,
+              use_early_stopping):
+    seen.update(theta0=theta0, gp=gp_, vp0=vp0, ns=ns, bnd=theta_bnd, beta=beta, tol_fun=tol_fun, max_iter=max_iter,
+                steps=(master_min, master_max, master_decay))
+    n = theta0.size
+    return theta0, 0.0, np.tile(theta0[:, None], (1, 2)), np.zeros(2), 2
+
+
+pyvbmc_amd.patch(vo, _batch_eval=lambda th, g_, v_, b_: [ref_neg_elcbo(t.copy(), g_, copy.deepcopy(v_), 0, 0, 0, False, b_)[0]
+                                                        for t in th], _loop=fake_loop)
+np.random.seed(3)
+try:
+    vo.optimize_vp(options, dict(optim_state), fresh_vp(), gp2, 6, 1)
+    raise AssertionError("optimize_vp returned without a device")
+except _lib.NoDeviceError:
+    pass  # _eval_full_elcbo behind the optimiser reached the device boundary
+finally:
+    pyvbmc_amd.unpatch(vo)
+import math  # noqa: E402
+
+assert seen and seen["gp"] is gp2 and isinstance(seen["vp0"], RefVP)
+assert seen["ns"] == math.ceil(options.eval("ns_ent", {"K": wl2.K}) / wl2.K) and seen["beta"] == 0.0
+assert set(seen["bnd"]) >= {"lb", "ub", "tol_con"} and seen["theta0"].size == np.size(seen["vp0"].get_parameters())
+assert seen["tol_fun"] == options["tol_fun_stochastic"] and seen["max_iter"] == min(10000, options["max_iter_stochastic"])
+print(f"patch(vo): optimize_vp's minimize_adam call was routed to the device loop (ns_ent_K={seen['ns']}, "
+      f"steps {seen['steps']})")
+# an arbitrary objective still takes the host loop
+pyvbmc_amd.patch(vo, _loop=fake_loop)
+x, y, _, _, it = vo.minimize_adam(lambda t: (float(np.sum(t**2)), 2 * t), np.ones(3), max_iter=40, use_early_stopping=False)
+pyvbmc_amd.unpatch(vo)
+assert it == 40 and abs(y) < 1.0
 print("OK")
