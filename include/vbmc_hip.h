@@ -14,7 +14,8 @@
  *   - matrices are row-major.  `mu_KxD` is K rows of D means, i.e. exactly
  *     theta[:D*K] / mu.ravel(order="F") of the reference's (D,K) array
  *     (variational_posterior/variational_posterior.py:653-676).
- *   - return value: 0 = ok, <0 = error (VBMC_E_*); text via vbmc_last_error().
+ *   - return value: 0 = ok, <0 = error (VBMC_E_*); text via vbmc_last_error().  One entry point
+ *     has a positive "do it again" code (VBMC_W_GP_CHANGED).
  *     No C++ exception crosses the boundary.
  *   - a vbmc_ctx owns one device, its HIP streams, device scratch and (optionally)
  *     one RCCL communicator.  A ctx is not thread-safe; distinct ctxs are
@@ -43,7 +44,10 @@ enum {
   VBMC_E_NODEV = -4,   /* no usable gfx950 device                           */
   VBMC_E_UNSUP = -5,   /* combination the reference raises NotImplemented on */
   VBMC_E_NONFINITE = -6, /* non-finite input where the path needs finite    */
-  VBMC_E_NOMEM = -7     /* host allocation failed (vbmc_mt19937_randn)       */
+  VBMC_E_NOMEM = -7,    /* host allocation failed (vbmc_mt19937_randn)       */
+  VBMC_W_GP_CHANGED = 1 /* vbmc_neg_elcbo only: the watched GP arrays changed (vbmc_set_gp_watch);
+                           the outputs were computed on the GP of the last vbmc_set_gp: discard them,
+                           upload the GP again and repeat the call                               */
 };
 
 /* GP mean functions understood by the path
@@ -160,6 +164,16 @@ int vbmc_last_entmc_plan(const vbmc_ctx* ctx, int out[4]);
  * it.  The Python mirror keys its "is this GP already on the device" test on it (every posterior's
  * alpha and hyp in full: an in-place edit anywhere in them is seen; ~1 us + 0.05 us per KB). */
 int vbmc_host_checksum(const double* const* ptrs, const int64_t* lens, int n, uint64_t* out);
+
+/* Watch the HOST arrays the device GP was uploaded from: n blocks of doubles (every posterior's alpha
+ * and hyp) whose vbmc_host_checksum was `expected` at upload time.  vbmc_neg_elcbo then recomputes
+ * that checksum itself -- after it has released its launches, while the device works and the host
+ * would only be polling -- and returns VBMC_W_GP_CHANGED when it differs.  This keeps the caller's
+ * "is this GP still the one on the device" test (the reference overwrites GP records in place,
+ * active_importance_sampling.py:207-209) off the path between two evaluations of the optimiser.
+ * The caller guarantees the blocks stay allocated while the watch is set; n = 0 or the next
+ * vbmc_set_gp clears it. */
+int vbmc_set_gp_watch(vbmc_ctx* ctx, const double* const* ptrs, const int64_t* lens, int n, uint64_t expected);
 
 /* Counters of the polled host-driven step (vbmc_neg_elcbo) since the context was created:
  * out[0] armed evaluations used, out[1] cancelled, out[2] of those: late go word (recovery path),

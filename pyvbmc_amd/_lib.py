@@ -17,6 +17,7 @@ LIB_PATH = Path(os.environ.get("VBMC_HIP_LIB", _HERE / "libvbmc_hip.so"))
 EPS_RESIDENT, EPS_PHILOX = 0, 1
 MEAN_ZERO, MEAN_CONST, MEAN_NEGQUAD = 0, 1, 2
 E_ARG, E_HIP, E_RCCL, E_NODEV, E_UNSUP, E_NONFINITE = -1, -2, -3, -4, -5, -6
+W_GP_CHANGED = 1  # vbmc_neg_elcbo: the watched GP arrays changed under it (vbmc_set_gp_watch)
 
 
 class VbmcHipError(RuntimeError):
@@ -67,6 +68,7 @@ SIGNATURES = {
     "vbmc_last_entmc_plan": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "vbmc_last_elbo_raw": (C.c_int, [_vp, _dp, C.c_int]),
     "vbmc_armed_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "vbmc_set_gp_watch": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_uint64]),
     "vbmc_host_checksum": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_uint64)]),
     "vbmc_set_timing": (C.c_int, [_vp, C.c_int]),
     "vbmc_last_kernel_ms": (C.c_int, [_vp, C.c_int, _dp]),

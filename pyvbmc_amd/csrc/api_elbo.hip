@@ -554,6 +554,14 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
       }
     }
   }
+  // The watched GP arrays (vbmc_set_gp_watch): checksummed here, with the launches released and the
+  // device at work -- off the path between two evaluations.
+  bool gp_changed = false;
+  if (!ctx->gp_watch_ptrs.empty()) {
+    uint64_t ck = 0;
+    vbmc_host_checksum(ctx->gp_watch_ptrs.data(), ctx->gp_watch_lens.data(), (int)ctx->gp_watch_ptrs.size(), &ck);
+    gp_changed = ck != ctx->gp_watch_ck;
+  }
   ctx->host_us[1] = us_since(t_launch);
   HSTAMP(2);
   const auto t_wait = clk::now();
@@ -686,7 +694,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   if (G) *G = Gv;
   if (H) *H = Hv;
   if (dF && grad_flags) memcpy(dF, dFv.data(), sizeof(double) * n_theta);
-  return VBMC_OK;
+  return gp_changed ? VBMC_W_GP_CHANGED : VBMC_OK;
 }
 
 extern "C" int vbmc_armed_stats(const vbmc_ctx* ctx, uint64_t out[6]) {

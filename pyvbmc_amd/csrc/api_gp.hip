@@ -19,6 +19,8 @@ extern "C" int vbmc_set_gp(vbmc_ctx* ctx, int N, int D, int S, int P, int mean_k
     return vbmc_fail(ctx, VBMC_E_ARG, "set_gp: P=%d does not match D+2+mean(%d)=%d", P, mean_kind,
                      D + 2 + mean_n);
   NEED_DEVICE(ctx);
+  ctx->gp_watch_ptrs.clear();  // (vbmc_set_gp_watch: the caller sets it again for the arrays of THIS upload)
+  ctx->gp_watch_lens.clear();
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, stream_wait(ctx));
   GpState& g = ctx->gp;

@@ -207,6 +207,11 @@ struct vbmc_ctx {
   ncclComm* comm = nullptr;
   int rank = 0, world = 1;
 
+  // host arrays the device GP came from, re-checksummed by vbmc_neg_elcbo while it waits (vbmc_set_gp_watch)
+  std::vector<const double*> gp_watch_ptrs;
+  std::vector<int64_t> gp_watch_lens;
+  uint64_t gp_watch_ck = 0;
+
   ElboScratch elbo;      // api_elbo.hip
   void* adam = nullptr;  // device-resident optimiser state (adam.hip)
   void* acq_is = nullptr;  // resident importance-sampling state of AcqFcnVIQR / IMIQR (api_acq_is.hip)

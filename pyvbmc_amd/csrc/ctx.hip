@@ -235,6 +235,14 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   return VBMC_OK;
 }
 
+int vbmc_set_gp_watch(vbmc_ctx* ctx, const double* const* ptrs, const int64_t* lens, int n, uint64_t expected) {
+  if (!ctx || n < 0 || (n > 0 && (!ptrs || !lens))) return VBMC_E_ARG;
+  ctx->gp_watch_ptrs.assign(ptrs, ptrs + n);
+  ctx->gp_watch_lens.assign(lens, lens + n);
+  ctx->gp_watch_ck = expected;
+  return VBMC_OK;
+}
+
 int vbmc_host_checksum(const double* const* ptrs, const int64_t* lens, int n, uint64_t* out) {
   if (!ptrs || !lens || n < 0 || !out) return VBMC_E_ARG;
   uint64_t s = 0;

@@ -129,6 +129,33 @@ class _ChecksumPlan:
         return v
 
 
+def _gp_ids(gp):
+    """The identity half of the GP key: ids of X, of the posteriors array, of every record and of its
+    alpha / L / hyp arrays, and the end elements of X and L."""
+    ps, X = gp.posteriors, gp.X
+    ids = [id(ps), id(X), X.shape[0]]
+    tail = [X.item(0), X.item(-1)]
+    for p in ps:
+        L = p.L
+        ids += (id(p), id(p.alpha), id(L), id(p.hyp))
+        tail += (L.item(-1), p.L_chol)
+    return ids, tail
+
+
+def _gp_plan(gp, ctx, ids):
+    plan = getattr(ctx, "_gp_ck", None) if ctx is not None else None
+    if plan is None or plan.ids != ids:
+        ps = gp.posteriors
+        held, arrays = [ps, gp.X], []
+        for p in ps:
+            held += (p, p.alpha, p.L, p.hyp)
+            arrays += (p.alpha, p.hyp)
+        plan = _ChecksumPlan(ids, held, arrays)
+        if ctx is not None:
+            ctx._gp_ck = plan
+    return plan
+
+
 def _gp_fingerprint(gp, ctx=None):
     """State key of a GP duck type: identities of X, of the posteriors array, of every posterior
     record and of its alpha / L / hyp arrays, the end elements of X and L, and a checksum of EVERY
@@ -137,24 +164,11 @@ def _gp_fingerprint(gp, ctx=None):
     ``gp.X`` replaced or extended by ``gp.update`` (active_sample.py:584) -- and any in-place edit
     of alpha or hyp (alpha = (K + Sigma)^-1 (y - m) changes whenever anything about the GP does).
     An in-place edit of X or of the interior of L that leaves alpha untouched still needs
-    ``invalidate_gp``.  Runs in front of every ELBO evaluation: ~2 us at S = 1, ~5 us at S = 8,
-    N = 800 (one library call checksums all the arrays: 55 KB there)."""
-    ps, X = gp.posteriors, gp.X
-    ids = [id(ps), id(X), X.shape[0]]
-    tail = [X.item(0), X.item(-1)]
-    for p in ps:
-        L = p.L
-        ids += (id(p), id(p.alpha), id(L), id(p.hyp))
-        tail += (L.item(-1), p.L_chol)
-    plan = getattr(ctx, "_gp_ck", None) if ctx is not None else None
-    if plan is None or plan.ids != ids:
-        held, arrays = [ps, X], []
-        for p in ps:
-            held += (p, p.alpha, p.L, p.hyp)
-            arrays += (p.alpha, p.hyp)
-        plan = _ChecksumPlan(ids, held, arrays)
-        if ctx is not None:
-            ctx._gp_ck = plan
+    ``invalidate_gp``.  ~2 us at S = 1, ~5 us at S = 8, N = 800 (one library call checksums all
+    the arrays: 55 KB there); the optimiser's inner loop does not pay it up front (``upload_gp``
+    with ``lazy``)."""
+    ids, tail = _gp_ids(gp)
+    plan = _gp_plan(gp, ctx, ids)
     return ids + tail + [plan.checksum()], plan.held
 
 
@@ -162,15 +176,33 @@ def invalidate_gp(ctx=None):
     """Forget the GP the context holds: the next call uploads it again.  Only needed after
     editing GP arrays in place in a way the fingerprint cannot see (see ``_gp_fingerprint``)."""
     ctx = _lib.default_context() if ctx is None else ctx
-    ctx._gp_key = ctx._gp_ref = ctx._gp_ck = None
+    ctx._gp_key = ctx._gp_ref = ctx._gp_ck = ctx._gp_quick = None
 
 
-def upload_gp(gp, ctx):
+def upload_gp(gp, ctx, lazy=False):
     """Ship X and the posterior records of ``gp`` to the context (skipped while the GP's
-    fingerprint is the one already uploaded)."""
-    key, held = _gp_fingerprint(gp, ctx)
+    fingerprint is the one already uploaded).
+
+    ``lazy`` (the fused objective only): when identities and end elements are unchanged the
+    checksum of the arrays' contents is NOT taken here -- ``vbmc_neg_elcbo`` takes it itself after it
+    has released its launches, while the device works (vbmc_set_gp_watch), and answers
+    ``W_GP_CHANGED`` if an array was edited in place; the caller then uploads and evaluates again.
+    The test stays complete, its cost moves off the path between two evaluations."""
+    if lazy:
+        # identities of what the watch covers (alpha, hyp of every record) and of the containers; L and the
+        # end elements are part of the full key only -- L never changes without alpha changing
+        ps, X = gp.posteriors, gp.X
+        quick = [id(ps), id(X), X.shape[0]]
+        for p in ps:
+            quick += (id(p), id(p.alpha), id(p.hyp))
+        if quick == getattr(ctx, "_gp_quick", None):
+            return
+    ids, tail = _gp_ids(gp)
+    plan = _gp_plan(gp, ctx, ids)
+    key = ids + tail + [plan.checksum()]
     if getattr(ctx, "_gp_key", None) == key:
         return
+    ctx._gp_quick = None
     X = _lib.f64(gp.X)
     N, D = X.shape
     posts = list(gp.posteriors)
@@ -181,7 +213,7 @@ def upload_gp(gp, ctx):
     sW = _lib.f64(np.stack([np.ravel(p.sW) * np.ones(N) for p in posts]))
     chol = np.ascontiguousarray([1 if p.L_chol else 0 for p in posts], dtype=np.int32)
     mult = _lib.f64([float(getattr(p, "sn2_mult", 1.0)) for p in posts])
-    ctx._gp_key = None
+    ctx._gp_key = ctx._gp_quick = None
     ctx.check(
         ctx._lib.vbmc_set_gp(
             ctx._h, N, D, S, hyp.shape[1], mean_kind_of(gp), _lib.ptr(X), _lib.ptr(hyp),
@@ -189,8 +221,15 @@ def upload_gp(gp, ctx):
             _lib.ptr(mult),
         )
     )
-    # the held references keep every fingerprinted object alive, so an id cannot be recycled
-    ctx._gp_key, ctx._gp_ref = key, held
+    # the held references keep every fingerprinted object alive, so an id cannot be recycled (and the
+    # watched buffers stay allocated)
+    ctx._gp_key, ctx._gp_ref = key, plan.held
+    if not plan.slow and plan.n > 0:
+        ctx.check(ctx._lib.vbmc_set_gp_watch(ctx._h, plan.ptrs, plan.lens, plan.n, C.c_uint64(key[-1])))
+        quick = [id(gp.posteriors), id(gp.X), gp.X.shape[0]]
+        for p in gp.posteriors:
+            quick += (id(p), id(p.alpha), id(p.hyp))
+        ctx._gp_quick = quick  # (set only while the library watches the arrays' contents)
 
 
 class GP:

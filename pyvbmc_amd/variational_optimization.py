@@ -164,46 +164,58 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
                                    separate_K, rng, seed, eps_half, ctx)
 
     # ---- fused path: one library call ---------------------------------------------------
+    # (this sits between two evaluations of the optimiser -- on the step's critical path, with the
+    # device idle: attribute reads and ctypes field writes are kept to what changes call to call)
     # theta overwrites every optimised block; the current attributes only need to be on
     # the device when some block is NOT optimised or the context holds another (D, K)
     mask = optimize_mask(vp)
     if mask != 15 or getattr(ctx, "D", None) != D or getattr(ctx, "K", None) != K:
         upload_vp(vp, ctx)
-    upload_gp(gp, ctx)
-    n_theta = np.size(theta)
+    upload_gp(gp, ctx, lazy=True)  # (content checksum: taken by the library while the device works)
+    n_theta = theta.size if type(theta) is np.ndarray else np.size(theta)
     fc = _fused_call(ctx, D, K, n_theta, theta_bnd)
     fc.th[:] = theta
     opts = fc.opts
     ns = _even_ns(Ns) if Ns > 0 else 0
-    opts.ns_per_comp = ns
-    opts.compute_grad = 1 if compute_grad else 0
-    opts.optimize_mask = mask
-    opts.row_begin, opts.row_count = (0, -1) if rows is None else (int(rows[0]), int(rows[1]))
+    mode = 0
     if ns > 0:
         mode = DEFAULT_RNG if rng is None else rng
         if rows is not None and (eps_half is not None or mode != "philox"):
             raise ValueError("rows= needs rng='philox' (uploaded draws follow the context's own share)")
         if eps_half is not None or mode == "numpy":
             upload_reference_eps(ctx, K, D, ns, eps_half)
-            opts.eps_mode, opts.seed = _lib.EPS_RESIDENT, 0
+            mode, seed = _lib.EPS_RESIDENT, 0
         elif mode == "philox":
             if seed is None:
                 seed = philox_seed(ctx)
-            opts.eps_mode, opts.seed = _lib.EPS_PHILOX, seed
+            mode = _lib.EPS_PHILOX
         else:
             raise ValueError(f"unknown rng {mode!r}")
+    shape = (ns, 1 if compute_grad else 0, mask, mode, rows)
+    if shape != fc.shape:  # the fields that stay the same through an optimisation
+        opts.ns_per_comp, opts.compute_grad, opts.optimize_mask = ns, shape[1], mask
+        opts.row_begin, opts.row_count = (0, -1) if rows is None else (int(rows[0]), int(rows[1]))
+        opts.eps_mode = mode
+        fc.shape = shape
+    if ns > 0:
+        opts.seed = seed
     rc = fc.fn(*fc.args)
     if rc != 0:
-        ctx.check(rc)
+        if rc == _lib.W_GP_CHANGED:
+            # a GP array was edited in place since the upload: what came back was computed on the old GP
+            upload_gp(gp, ctx)
+            rc = fc.fn(*fc.args)  # (theta's tail is already shifted: shifting it again changes nothing)
+        if rc != 0:
+            ctx.check(rc)
     # mirror the reference's side effects on vp and on the caller's theta
     # (store_mixture() through views shaped once: this sits between two evaluations of the optimiser)
     vp.mu, vp.sigma, vp.lambd, vp.w = fc.mu_T.copy(), fc.sg_row.copy(), fc.lm_col.copy(), fc.w_row.copy()
-    if vp.optimize_weights:
+    if mask & 8:
         vp.eta = fc.eta_row.copy()
+        if type(theta) is np.ndarray and theta.dtype == fc.th.dtype:
+            theta[-K:] = fc.th[-K:]
     if hasattr(vp, "_mode"):
         vp._mode = None  # set_parameters drops the cached mode (variational_posterior.py:759)
-    if vp.optimize_weights and type(theta) is np.ndarray and theta.dtype == fc.th.dtype:
-        theta[-K:] = fc.th[-K:]
     return fc.F.value, (fc.dF.copy() if compute_grad else None), fc.G.value, fc.H.value, 0
 
 
@@ -254,6 +266,7 @@ class _FusedCall:
         self.F, self.G, self.H = C.c_double(), C.c_double(), C.c_double()
         o = self.opts = _lib.ElboOpts()
         o.row_begin, o.row_count, o.seed = 0, -1, 0
+        self.shape = None  # (ns, compute_grad, mask, eps mode, rows) the option block currently holds
         self.lb_src = self.ub_src = self.lb = self.ub = None
         self.fn = ctx._lib.vbmc_neg_elcbo
         self.args = (
@@ -283,6 +296,11 @@ class _FusedCall:
 
 
 def _fused_call(ctx, D, K, n_theta, theta_bnd):
+    last = ctx.__dict__.get("_fused_last")
+    if last is not None and last[0] == D and last[1] == K and last[2] == n_theta:
+        fc = last[3]
+        fc.bind_bounds(theta_bnd)
+        return fc
     cache = ctx.__dict__.setdefault("_fused_cache", {})
     key = (D, K, n_theta)
     fc = cache.get(key)
@@ -290,6 +308,7 @@ def _fused_call(ctx, D, K, n_theta, theta_bnd):
         if len(cache) > 16:
             cache.clear()
         fc = cache[key] = _FusedCall(ctx, D, K, n_theta)
+    ctx.__dict__["_fused_last"] = (D, K, n_theta, fc)
     fc.bind_bounds(theta_bnd)
     return fc
 

@@ -231,6 +231,45 @@ def test_gp_interior_edit_in_place_is_seen(ctx, golden):
     assert dt < 50e-6
 
 
+def test_gp_edited_in_place_between_fused_evaluations(ctx, golden):
+    """The optimiser's inner call does not checksum the GP arrays up front: the library does it while
+    the device works and answers W_GP_CHANGED, and the mirror uploads and evaluates again.  An
+    interior in-place edit between two Monte-Carlo evaluations (consecutive seeds: the second one is
+    armed, i.e. already queued with the OLD GP on the device) must give the NEW GP's value."""
+    from pyvbmc_amd import synthetic as syn
+    from pyvbmc_amd.variational_optimization import _neg_elcbo
+
+    g = golden("c2s")
+    ogp = oracle_gp(g, g["hyp"][:1])
+    gp = PlainGP(ogp)
+    K, D = int(g["K"]), int(g["D"])
+    wl = syn.make_workload(int(g["cfg"]), S=1, D=D, K=K, N=int(g["N"]), Ns_total=int(g["Ns_total"]))
+    bnd = syn.default_theta_bnd(wl)
+    NsK = 2 * 64 * 4
+    from oracle import philox_ref
+
+    def oracle(seed):
+        eps = philox_ref.eps_half(K, NsK // 2, D, seed)
+        return elbo_ref.neg_elcbo(g["theta"].copy(), ogp, oracle_mix(g), 0.0, NsK, True, False, bnd, False, eps_half=eps)
+
+    vp = PlainVP(g)
+    for i in range(3):
+        F, dF, G, H, _ = _neg_elcbo(g["theta"].copy(), gp, vp, 0.0, NsK, True, False, bnd, rng="philox", seed=300 + i)
+    Fo = oracle(302)
+    assert abs(F - Fo[0]) <= 1e-10 * abs(Fo[0]) and abs(G - Fo[2]) <= 1e-10 * abs(Fo[2])
+    N = gp.X.shape[0]
+    for rec in (gp.posteriors[0], ogp.posteriors[0]):
+        rec.alpha[N // 2, 0] *= 1.25  # interior, in place: ids and end elements unchanged
+    F2, dF2, G2, H2, _ = _neg_elcbo(g["theta"].copy(), gp, vp, 0.0, NsK, True, False, bnd, rng="philox", seed=303)
+    Fo2 = oracle(303)
+    assert abs(G2 - Fo2[2]) <= 1e-10 * abs(Fo2[2]) and abs(G2 - G) > 1e-8 * abs(G)
+    assert abs(F2 - Fo2[0]) <= 1e-10 * abs(Fo2[0]) and rel_err(dF2, Fo2[1]) < 1e-9
+    # and the evaluations after it run on the new GP without another upload
+    F3, _, G3, _, _ = _neg_elcbo(g["theta"].copy(), gp, vp, 0.0, NsK, True, False, bnd, rng="philox", seed=304)
+    Fo3 = oracle(304)
+    assert abs(F3 - Fo3[0]) <= 1e-10 * abs(Fo3[0]) and abs(G3 - G2) <= 1e-12 * abs(G2)
+
+
 def _plain8():
     from types import SimpleNamespace
 
