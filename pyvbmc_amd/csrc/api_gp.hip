@@ -38,7 +38,8 @@ extern "C" int vbmc_set_gp(vbmc_ctx* ctx, int N, int D, int S, int P, int mean_k
     return 0;
   };
   int rc;
-  if ((rc = grow(&g.d_X, &g.cap_X, (size_t)N * D)) || (rc = grow(&g.d_alpha, &g.cap_alpha, (size_t)S * N)) ||
+  if ((rc = grow(&g.d_X, &g.cap_X, (size_t)N * D)) || (rc = grow(&g.d_XT, &g.cap_XT, (size_t)N * D)) ||
+      (rc = grow(&g.d_alpha, &g.cap_alpha, (size_t)S * N)) ||
       (rc = grow(&g.d_L, &g.cap_L, (size_t)S * nn)) || (rc = grow(&g.d_Linv, &g.cap_Linv, (size_t)S * nn)) ||
       (rc = grow(&g.d_LinvP, &g.cap_LinvP, (size_t)S * predict_ld(N) * predict_ld(N))) ||
       (rc = grow(&g.d_sW, &g.cap_sW, (size_t)S * N)) || (rc = grow(&g.d_hyp, &g.cap_hyp, (size_t)S * P)) ||
@@ -72,6 +73,10 @@ extern "C" int vbmc_set_gp(vbmc_ctx* ctx, int N, int D, int S, int P, int mean_k
   HIP_TRY(ctx, hipMemcpyAsync(g.d_smeta, smeta, sizeof(double) * 3 * S, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(g.d_L, L_SxNxN, sizeof(double) * S * nn, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(g.d_X, X_NxD, sizeof(double) * N * D, hipMemcpyHostToDevice, ctx->stream));
+  g.h_XT.resize((size_t)N * D);
+  for (int n = 0; n < N; ++n)
+    for (int d = 0; d < D; ++d) g.h_XT[(size_t)d * N + n] = X_NxD[(size_t)n * D + d];
+  HIP_TRY(ctx, hipMemcpyAsync(g.d_XT, g.h_XT.data(), sizeof(double) * N * D, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(g.d_alpha, alpha_SxN, sizeof(double) * S * N, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(g.d_sW, sW_SxN, sizeof(double) * S * N, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(g.d_hyp, hyp_SxP, sizeof(double) * S * P, hipMemcpyHostToDevice, ctx->stream));

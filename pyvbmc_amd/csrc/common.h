@@ -54,6 +54,7 @@ struct GpState {
   std::vector<double> sn2_eff;   // S  (1 / sW[0]^2)
   std::vector<double> sn2_mult;  // S
   double* d_X = nullptr;      // N x D
+  double* d_XT = nullptr;     // D x N: the same, transposed (glj_block.h reads a dimension of consecutive points)
   double* d_alpha = nullptr;  // S x N
   double* d_L = nullptr;      // S x N x N
   double* d_Linv = nullptr;   // S x N x N : inverse of the upper Cholesky factor (L_chol samples)
@@ -62,8 +63,9 @@ struct GpState {
   double* d_hyp = nullptr;    // S x P
   double* d_xc = nullptr;     // D : column means of X (centre of the pairwise-distance expansion)
   double* d_smeta = nullptr;  // S x 3 : (L_chol as 0/1, sn2_mult, 1/sn2_eff) per sample, for kernels batched over s
-  size_t cap_X = 0, cap_alpha = 0, cap_L = 0, cap_Linv = 0, cap_LinvP = 0, cap_sW = 0, cap_hyp = 0, cap_xc = 0, cap_smeta = 0;
+  size_t cap_X = 0, cap_XT = 0, cap_alpha = 0, cap_L = 0, cap_Linv = 0, cap_LinvP = 0, cap_sW = 0, cap_hyp = 0, cap_xc = 0, cap_smeta = 0;
   std::vector<double> h_small;  // host source of the xc / smeta uploads
+  std::vector<double> h_XT;     // host source of the d_XT upload
 };
 
 // per-sample results of the GP expected log joint on the host (api_gp.hip glj_finalize)
@@ -378,6 +380,7 @@ struct PrepArgs {
   int batch = 1;              // candidates (grid.y); candidate b uses mix + b*mix_stride, res + b*res_stride
   size_t mix_stride = 0, res_stride = 0;
   const double* X = nullptr;
+  const double* XT = nullptr;  // [D][N]
   const double* alpha = nullptr;
   const double* hyp = nullptr;
   double* res = nullptr;  // [S][K][1+2D]  (device or device-visible pinned host memory)

@@ -161,7 +161,7 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   vbmc_comm_destroy(ctx);
   adam_free(ctx);
   acq_is_free(ctx);
-  double* bufs[] = {ctx->d_mix, ctx->d_mix_fg, ctx->d_stage, ctx->d_eps, ctx->d_scratch, ctx->d_out, ctx->gp.d_X,
+  double* bufs[] = {ctx->d_mix, ctx->d_mix_fg, ctx->d_stage, ctx->d_eps, ctx->d_scratch, ctx->d_out, ctx->gp.d_X, ctx->gp.d_XT,
                     ctx->gp.d_alpha, ctx->gp.d_L, ctx->gp.d_Linv, ctx->gp.d_LinvP, ctx->gp.d_sW, ctx->gp.d_hyp,
                     ctx->gp.d_xc, ctx->gp.d_smeta};
   for (double* b : bufs)

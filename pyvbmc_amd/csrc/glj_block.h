@@ -43,15 +43,45 @@ __device__ __forceinline__ void glj_block(const PrepArgs& a, int b, double* lds)
   }
   __syncthreads();
   const double lnnf = sMisc[0];
-  for (int n = tid; n < N; n += 256) {
-    double d2 = 0.0;
-    for (int d = 0; d < D; ++d) {
-      const double dl = (sMu[d] - a.X[(size_t)n * D + d]) * sItau[d];
-      d2 = fma(dl, dl, d2);
+  // X is read through its transpose XT[d][n]: consecutive threads take consecutive points of one
+  // dimension (coalesced) -- the strided row reads of rounds 1-2 were this block's latency chain
+  // (13 us at N = 800, D = 20, on the critical path of config 5's step)
+  for (int nb = 0; nb < N; nb += 4 * 256) {  // four points per thread and pass, four dimensions per step: 16 loads in flight
+    int nn[4];
+    double d2[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      nn[p] = min(nb + tid + 256 * p, N - 1);
+      d2[p] = 0.0;
     }
-    const double z = fm::exp2_fast(0x1.71547652b82fep+0 * (lnnf - 0.5 * d2));  // exp(.)
-    sZa[n] = z * a.alpha[(size_t)s * N + n];
-    if (a.Z) a.Z[((size_t)s * K + k) * N + n] = z;
+    for (int d0 = 0; d0 < D; d0 += 4) {
+      double x[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double* col = a.XT + (size_t)min(d0 + u, D - 1) * N;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) x[p][u] = col[nn[p]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (d0 + u < D) {
+          const double m = sMu[d0 + u], it = sItau[d0 + u];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const double dl = (m - x[p][u]) * it;
+            d2[p] = fma(dl, dl, d2[p]);
+          }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int n = nb + tid + 256 * p;
+      if (n < N) {
+        const double z = fm::exp2_fast(0x1.71547652b82fep+0 * (lnnf - 0.5 * d2[p]));  // exp(.)
+        sZa[n] = z * a.alpha[(size_t)s * N + n];
+        if (a.Z) a.Z[((size_t)s * K + k) * N + n] = z;
+      }
+    }
   }
   __syncthreads();
   double* out = a.res + ((size_t)s * K + k) * (1 + 2 * D);
@@ -76,19 +106,20 @@ __device__ __forceinline__ void glj_block(const PrepArgs& a, int b, double* lds)
     for (int d = ds; d < D; d += 16) {
       const double m = sMu[d], itau = sItau[d];
       double au = 0.0, at = 0.0;
-      // eight points per step, their loads issued together (indices clamped, weights zeroed past the
-      // end): a step costs one memory latency instead of eight -- the loop was this block's time
-      // (N / 16 dependent round trips per dimension: 20 us at N = 800, D = 20)
-      for (int n0 = ns; n0 < N; n0 += 16 * 8) {
-        double x[8], za[8];
+      // sixteen points per step, their loads issued together (indices clamped, weights zeroed past
+      // the end): a step costs one memory latency instead of sixteen -- the loop was this block's
+      // time (N / 16 dependent round trips per dimension: 20 us at N = 800, D = 20)
+      constexpr int PS = 16;
+      for (int n0 = ns; n0 < N; n0 += 16 * PS) {
+        double x[PS], za[PS];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < PS; ++u) {
           const int n = min(n0 + 16 * u, N - 1);
-          x[u] = a.X[(size_t)n * D + d];
+          x[u] = a.XT[(size_t)d * N + n];
           za[u] = n0 + 16 * u < N ? sZa[n] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < PS; ++u) {
           const double dl = (m - x[u]) * itau;
           const double t = dl * za[u];
           au += t;

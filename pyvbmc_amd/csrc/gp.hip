@@ -726,7 +726,12 @@ __global__ __launch_bounds__(64 * NW) void predict_var_small_kernel(const double
 // Both sets are shifted by the column means of X first, as the reference's _sq_dist shifts by
 // a common mean.  Cancellation: |d2 error| <= ~1e-16 (|a|^2+|b|^2), i.e. a relative error of
 // the same size in Ks -- far inside the 1e-10 budget of the predictive variance.
-constexpr int KDP = 32 + 1;  // LDS row stride (max padded D = 32, +1 against bank conflicts)
+// LDS row stride of the staged coordinate tiles.  The MFMA fragments are read as ds_read_b64 with lane =
+// (row li = lane & 15, k-index lk = lane >> 4): a 32-lane group covers li = 0..15, lk = 0..1, dword bank
+// (2 (stride li + lk)) mod 64.  An ODD stride (33, rounds 1-2) always puts some (li, lk = 1) on the
+// bank of another (li', lk = 0) -- 38 % of the kernel's LDS cycles were conflict cycles (PMC, r02);
+// stride = 2 mod 4 gives banks 4 li + 2 lk: 32 distinct ones.
+constexpr int KDP = 32 + 2;
 __global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
     const double* __restrict__ X, const double* __restrict__ xs, const double* __restrict__ alpha,
     const double* __restrict__ sW, const double* __restrict__ hyp, const double* __restrict__ cen,
@@ -1041,6 +1046,7 @@ void glj_fill_prep(const vbmc_ctx* ctx, int want_grad, double* res, double* Z, P
   a.P = g.P;
   a.want_grad = want_grad;
   a.X = g.d_X;
+  a.XT = g.d_XT;
   a.alpha = g.d_alpha;
   a.hyp = g.d_hyp;
   a.res = res;
