@@ -117,6 +117,8 @@ int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
  * from the environment variable in brackets, read when the context is created.
  *   "entmc_kernel" [VBMC_ENTMC_KERNEL=valu -> 1]: 0 = pick the kernel by shape (default),
  *                  1 = always the generic thread-per-row kernel (on-device cross-check)
+ *   "entmc_mfma"   1 = shapes the FP64 matrix tile pads little (D = 20, 97 <= K <= 112: BASELINE config 5)
+ *                  take the matrix-pipe form of the entropy kernel (default), 0 = the wave-split kernel
  *   "elbo_pregen"  [VBMC_ELBO_PREGEN]: 1 = Philox draws generated ahead of the entropy
  *                  kernel (default), 0 = generated in-line by it; same values either way
  *   "elbo_ahead"   [VBMC_ELBO_AHEAD]: 1 = after a Philox evaluation with seed s the draws of
@@ -154,7 +156,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value);
 
 /* Launch geometry of the most recent Monte-Carlo entropy of this ctx (vbmc_entmc,
  * vbmc_neg_elcbo, the optimiser loop): out[0] = kernel (0 generic, 1 wave-split, 2 small-
- * sample), out[1] = 64-row batches per workgroup (the wave-split kernel's batch loop count),
+ * sample, 3 matrix-pipe form), out[1] = 64-row batches per workgroup (the wave-split kernel's batch loop count),
  * out[2] = workgroups per component, out[3] = 1 if the draws were read from HBM, 0 if
  * generated in-line.  Lets the parity tests assert which code path they exercised. */
 int vbmc_last_entmc_plan(const vbmc_ctx* ctx, int out[4]);

@@ -18,6 +18,7 @@ SOURCES = [
     "ctx.hip",
     "entropy.hip",
     "entropy_small.hip",
+    "entropy_mfma.hip",
     "prep.hip",
     "api_entropy.hip",
     "mixture.hip",

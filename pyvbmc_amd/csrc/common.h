@@ -180,6 +180,7 @@ struct vbmc_ctx {
   double host_us[5] = {0, 0, 0, 0, 0};  // see vbmc_last_host_us
   // vbmc_set_option switches (defaults from the environment at context creation)
   int opt_entmc_valu = 0;   // 1: always the generic entropy kernel
+  int opt_entmc_mfma = 1;   // the matrix-pipe form of the entropy kernel where its shape applies (entropy_mfma.hip)
   int opt_elbo_pregen = 1;  // Philox draws generated ahead of the entropy kernel
   int opt_elbo_ahead = 1;   // ... and those of seed+1 speculatively behind the finish kernel
   int opt_predict_dma = 1;  // predict's variance product through the LDS-direct kernel (batches on Cholesky samples)

@@ -217,6 +217,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   }
   spec_disarm(ctx);
   if (!strcmp(key, "entmc_kernel")) ctx->opt_entmc_valu = value == 1;
+  else if (!strcmp(key, "entmc_mfma")) ctx->opt_entmc_mfma = value != 0;
   else if (!strcmp(key, "elbo_pregen")) ctx->opt_elbo_pregen = value != 0;
   else if (!strcmp(key, "elbo_ahead")) ctx->opt_elbo_ahead = value != 0;
   else if (!strcmp(key, "mix_kernel")) ctx->opt_mix_kernel = value != 0;

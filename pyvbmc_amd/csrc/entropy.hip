@@ -558,10 +558,26 @@ int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
     if (rg > 16) rg = 16;
     a.rg = (int)rg;
     rows_per_wg = 64 * a.rg;
-    n_table = (size_t)K * (size_t)(((K + 3) / 4) * 4) * (size_t)(p.DP + 6);
+    n_table = (size_t)K * (size_t)ws_table_rows(K) * (size_t)(p.DP + 6);
   }
   a.chunks = (int)((row_count + rows_per_wg - 1) / rows_per_wg);
   if (a.chunks < 1) a.chunks = 1;
+  if (p.ws) {
+    // chunks are per component: rounding them up can push K * chunks just past one round of resident
+    // workgroups (K = 52, 10 000 rows: 10 chunks of 1 024 rows = 520 workgroups for 512 slots, a second
+    // round of 8).  A few more batches per workgroup keep the grid in one round.
+    const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    const int64_t slots = cus * ws_min_waves(p.DP, ws_ktmax_for(K), want_grad != 0);
+    const int64_t fit = slots / K;  // chunks per component that fit one round
+    if (fit >= 1 && a.chunks > fit && (int64_t)K * (a.chunks - 1) <= slots) {
+      const int64_t rg2 = (row_count + 64 * fit - 1) / (64 * fit);
+      if (rg2 <= 24) {
+        a.rg = (int)rg2;
+        rows_per_wg = 64 * a.rg;
+        a.chunks = (int)((row_count + rows_per_wg - 1) / rows_per_wg);
+      }
+    }
+  }
   a.pair_cus = 0;
   if (p.ws && ctx->opt_ws_pair) {
     // one round of the 2-waves/SIMD build: workgroups b and b + CUs share a CU (entropy_ws.hip)
@@ -585,7 +601,7 @@ void entmc_fill_prep(const vbmc_ctx* ctx, const EntPlan& p, PrepArgs& a) {
   if (p.ws) {
     a.n_table = ctx->K;
     a.DP = p.DP;
-    a.K4 = ((ctx->K + 3) / 4) * 4;
+    a.K4 = ws_table_rows(ctx->K);
     a.table = p.table;
   }
 }
@@ -687,7 +703,8 @@ int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p) {
   // kernel is bracketed by two records (each a barrier packet, ~6 us between dependent kernels)
   hipEvent_t e0 = ctx->timing ? ctx->ev[0] : nullptr, e1 = ctx->timing ? ctx->ev[1] : nullptr;
   const bool small = p.ws && entmc_small_applies(a, p.DP);
-  ctx->last_plan[0] = small ? 2 : (p.ws ? 1 : 0);
+  const bool mfma = p.ws && !small && ctx->opt_entmc_mfma && entmc_mfma_applies(a, p.DP);
+  ctx->last_plan[0] = small ? 2 : mfma ? 3 : (p.ws ? 1 : 0);
   ctx->last_plan[1] = a.rg;
   ctx->last_plan[2] = a.chunks;
   ctx->last_plan[3] = a.eps_mode == VBMC_EPS_RESIDENT ? 1 : 0;
@@ -695,6 +712,8 @@ int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p) {
   if (bracket) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   if (small) {
     launch_entmc_small(ctx->stream, a, p.DP, p.table);
+  } else if (mfma) {
+    launch_entmc_mfma(ctx->stream, a, p.DP, p.table, e0, e1);
   } else if (p.ws) {
     switch (p.DP) {
 #define VBMC_CASE_WS(dp) case dp: launch_entmc_ws_dp##dp(ctx->stream, a, p.table, e0, e1); break;

@@ -37,11 +37,18 @@ struct EntArgs {
 };
 
 // register-array size (components per wave) the wave-split launcher picks, and the waves per SIMD
-// its build runs at (= resident workgroups per CU: a workgroup is one wave on each SIMD)
+// its build runs at (= resident workgroups per CU: a workgroup is one wave on each SIMD).
+// The (j,k) table always carries 4 * ws_ktmax_for(K) rows per component j (ws_table_rows): the rows
+// beyond K are components of density exactly 0, so the kernel's loops run over whole register arrays
+// with no per-component guards.  (Rounds 1-2 padded to 4 ceil(K/4) only and kept a guarded variant for
+// ceil(K/4) < KTMAX; that variant ran 2-3.5x slower per evaluated pair than the guard-free one --
+// K = 48 against K = 50 at D = 10: 3 699 against 1 592 ps per pair, tools/ws_k_probe.py -- far more
+// than the padding costs.)
 constexpr int ws_ktmax_for(int K) {
   const int KT = (K + 3) / 4;
-  return KT <= 8 ? 8 : KT <= 13 ? 13 : KT <= 16 ? 16 : KT <= 25 ? 25 : 32;
+  return KT <= 4 ? 4 : KT <= 8 ? 8 : KT <= 10 ? 10 : KT <= 13 ? 13 : KT <= 16 ? 16 : KT <= 20 ? 20 : KT <= 25 ? 25 : 32;
 }
+constexpr int ws_table_rows(int K) { return 4 * ws_ktmax_for(K); }
 constexpr int ws_min_waves(int dp, int ktmax, bool grad) {
 #ifdef VBMC_WS_FORCE_WAVES
   return VBMC_WS_FORCE_WAVES;
@@ -60,7 +67,7 @@ struct EntPlan {
 };
 
 // padded-D instantiations of the wave-split kernel (entropy_ws.hip), one translation
-// unit each; d_table: K * 4*ceil(K/4) * (dp+6) doubles of scratch for the (j,k) table
+// unit each; d_table: K * ws_table_rows(K) * (dp+6) doubles of scratch for the (j,k) table
 #define VBMC_WS_DPS(X) X(2) X(4) X(6) X(8) X(10) X(12) X(16) X(20) X(24) X(32)
 // e0 / e1 (may be null): HIP events that take the start / stop timestamps of the dispatch itself
 // (hipExtLaunchKernel) -- unlike hipEventRecord they put no barrier packet between dependent kernels
@@ -68,6 +75,11 @@ struct EntPlan {
   void launch_entmc_ws_dp##dp(hipStream_t st, const EntArgs& a, const double* d_table, hipEvent_t e0, hipEvent_t e1);
 VBMC_WS_DPS(VBMC_DECL_WS)
 #undef VBMC_DECL_WS
+
+// matrix-pipe form for shapes the 16 x 16 x 4 tile pads little (entropy_mfma.hip: D = 20, K up to 112 -- BASELINE
+// config 5); same table, same partial rows
+bool entmc_mfma_applies(const EntArgs& a, int DP);
+void launch_entmc_mfma(hipStream_t st, const EntArgs& a, int DP, const double* d_table, hipEvent_t e0, hipEvent_t e1);
 
 // small sample counts: lane = component (entropy_small.hip); same table, same partial rows
 bool entmc_small_applies(const EntArgs& a, int DP);

@@ -1,0 +1,320 @@
+// Monte-Carlo entropy, main kernel in its MATRIX-PIPE form -- reference entropy/entmc_vbmc.py:64-112;
+// the same sums as entropy_ws.hip (same table, same partial rows, same finish kernel), for shapes
+// where the 16 x 16 x 4 tile of v_mfma_f64_16x16x4_f64 pads little: D a multiple of 4 and K close
+// below a multiple of 16 -- BASELINE config 5, D = 20, K = 100 (K -> 112: x1.12).
+//
+// Why only there.  FP64 matrix and vector instructions run on the same units at the same peak
+// (tools/ubench_fp64.hip); what the matrix form buys is issue efficiency: the wave-split kernel
+// <20,25> needs 512 registers, runs ONE wave per SIMD and issues a float64 instruction every ~6.9
+// cycles where the pipe could take one every 4 (tools/ubench_ops.hip), while matrix instructions
+// keep the pipe busy for 64 cycles each.  Its two D-deep contractions are 40 of its ~86 vector
+// instructions per (sample pair, component).  At config 3 (D = 10, K = 50) the tile pads those
+// products x1.54 / x1.66 and the form loses (profiles/r02_entropy_ablation.md); at config 5 the
+// prototype measured x1.26 on contraction + rest (tools/ubench_mfma_entropy.hip,
+// profiles/r03_entropy_ablation.md).
+//
+// Layout.  Workgroup = (component j, chunk of rows), four waves; a WAVE owns 16 rows of a 64-row
+// batch and ALL K components (the wave-split kernel: 64 rows, a quarter of the components).
+//   product 1   C'[k][row] = Delta_j[k][:] . e[row][:]      M = k (KTILES tiles of 16), N = 16 rows, D/4 steps
+//       A: Delta[k = 16 kt + li][d = 4 s + lk]  (registers, loaded once per workgroup)
+//       B: e[row = li][d = 4 s + lk]            (li = lane & 15, lk = lane >> 4)
+//       C' element r of lane: k = 16 kt + lk + 4 r, row = li
+//     so a lane holds 4 KTILES (row, k) pairs of ONE row: exponents, the two exp2, the density sums over
+//     k (in-lane, then two cross-lane steps over lk), the normalised terms g -- all per lane;
+//   product 2   Td[row][d] = sum_k gd[row][k] Delta_j[k][d]  M = 16 rows, N = d (tiles of 16), steps (kt, r)
+//       A: gd[row = li][k = 16 kt + lk + 4 r]   = the lane's own pass-2 value: no transpose between the products
+//       B: Delta[k = 16 kt + lk + 4 r][d = 16 nt + li]   (LDS)
+//       C element r' of lane: row = lk + 4 r', d = 16 nt + li
+// Delta_j and the per-k constants sit in LDS (the table row of component j as prep.hip wrote it,
+// padding components with density exactly 0).  No barrier inside the batch loop: nothing crosses waves
+// until the end-of-workgroup reduction.
+#include <hip/hip_ext.h>
+
+#include "common.h"
+#include "entropy_args.h"
+#include "fastmath.h"
+
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int WG = 256, WAVES = 4;
+
+// 2^x, degree 10 (4.1e-16): the entropy kernels' exp2 (entropy_ws.hip kExp2C), coefficients as literals
+__device__ __forceinline__ void exp2_pair(double x1, double x2, double& r1, double& r2) {
+  const double t1 = __builtin_rint(x1), t2 = __builtin_rint(x2);
+  const double f1 = x1 - t1, f2 = x2 - t2;
+  const int n1 = (int)t1, n2 = (int)t2;
+  constexpr double c[10] = {0x1.62e42fefa3a19p-1, 0x1.ebfbdff82c598p-3, 0x1.c6b08d703ce49p-5, 0x1.3b2ab6fba1ddap-7,
+                            0x1.5d87fe9d7a584p-10, 0x1.430913096fd9fp-13, 0x1.ffcb54062e698p-17, 0x1.62bfd47773353p-20,
+                            0x1.b675bca4eeebbp-24, 0x1.e6063f7217bc6p-28};
+  double p1 = c[9], p2 = c[9];
+#pragma unroll
+  for (int i = 8; i >= 0; --i) {
+    p1 = fma(p1, f1, c[i]);
+    p2 = fma(p2, f2, c[i]);
+  }
+  p1 = fma(p1, f1, 1.0);
+  p2 = fma(p2, f2, 1.0);
+  r1 = __builtin_amdgcn_ldexp(p1, n1);
+  r2 = __builtin_amdgcn_ldexp(p2, n2);
+}
+// sum over the four lanes li, li + 16, li + 32, li + 48 (the lk groups), result in all four
+__device__ __forceinline__ double sum_lk(double v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+template <int DP, int KTILES>
+__global__ __launch_bounds__(WG, 1) void entmc_mfma_kernel(EntArgs a, const double* __restrict__ T) {
+  constexpr int TS = DP + 6, NS = DP / 4, NT = (DP + 15) / 16, KP = 16 * KTILES;
+  static_assert(DP % 4 == 0, "D padded to a multiple of 4");
+  extern __shared__ double dyn[];
+  double* sT = dyn;              // [KP][TS]: the table row of component j
+  double* sMu = sT + KP * TS;    // [WAVES][DP]
+  double* sWk = sMu + WAVES * DP;  // [WAVES][KP]
+  __shared__ double sLam[WAVES][NT * 16];
+  __shared__ double sLog[WAVES];
+  if (a.cancel != nullptr && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ~(uint64_t)0) return;
+  const int D = a.ml.D, K = a.ml.K, K4 = ws_table_rows(K);  // table rows per component (entropy_args.h)
+  const int j = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const double sig_j = a.mix[a.ml.o_sig + j];
+  const double sj2 = sig_j * sig_j, two_sj = 2.0 * sig_j;
+  {
+    const double* Tj = T + (size_t)j * K4 * TS;
+    for (int i = tid; i < KP * TS; i += WG) {
+      const int k = i / TS, c = i - k * TS;
+      sT[i] = k < K4 ? Tj[i] : (c == DP ? -2000.0 : 0.0);  // beyond K4: a component of density exactly 0
+    }
+  }
+  __syncthreads();
+  double a1[KTILES][NS];
+#pragma unroll
+  for (int kt = 0; kt < KTILES; ++kt)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) a1[kt][s] = sT[(16 * kt + li) * TS + 4 * s + lk];
+
+  double slog = 0.0, mu_acc[NS], lam_acc[NT], Wacc[KTILES][4];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) mu_acc[s] = 0.0;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) lam_acc[nt] = 0.0;
+#pragma unroll
+  for (int kt = 0; kt < KTILES; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wacc[kt][r] = 0.0;
+
+  const int rows_per_wg = a.rg * 64;
+  const double* epj = a.eps + (int64_t)j * a.eps_rows * D;
+  for (int it = 0; it < a.rg; ++it) {
+    const int64_t row0 = (int64_t)chunk * rows_per_wg + it * 64 + wave * 16;
+    const int64_t rowA = row0 + li;
+    const bool valid = rowA < a.row_count;
+    // ---- this lane's normals: row li, dimensions 4 s + lk ----
+    double eb[NS], e2 = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      eb[s] = (valid && 4 * s + lk < D) ? epj[rowA * D + 4 * s + lk] : 0.0;
+      e2 = fma(eb[s], eb[s], e2);
+    }
+    const double b = sj2 * sum_lk(e2);  // sigma_j^2 |eps|^2 of row li
+    // The table does not depend on the batch: left alone the compiler hoists its ~170 LDS reads per
+    // lane out of the batch loop into registers and spills.  An opaque zero offset ties them to
+    // this iteration (the same device as entropy_ws.hip's scalar table loads).
+    int zoff;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zoff));
+    const double* sTb = sT + zoff;
+    // ---- product 1 and pass 1, one k-tile at a time: the lane's pairs (row li, k = 16 kt + lk + 4 r) ----
+    // One wave per SIMD: nothing else hides an LDS read's latency, so the per-k constants of tile kt + 1
+    // are requested BEFORE the matrix instructions and the exp2 chains of tile kt (LDS results return in
+    // order; the scheduling barriers keep the requests where they are written).
+    double rp[KTILES][4], rm[KTILES][4], qp = 0.0, qm = 0.0;
+    double cur[4][3], nxt[4][3];  // [r][c0 | a | w]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) cur[r][q] = sTb[(lk + 4 * r) * TS + DP + q];
+#pragma unroll
+    for (int kt = 0; kt < KTILES; ++kt) {
+      if (kt + 1 < KTILES) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) nxt[r][q] = sTb[(16 * (kt + 1) + lk + 4 * r) * TS + DP + q];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      double4_t c = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kt][s], eb[s], c, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double sp = fma(two_sj, c[r], b), sm = fma(-two_sj, c[r], b);
+        exp2_pair(fma(cur[r][1], sp, cur[r][0]), fma(cur[r][1], sm, cur[r][0]), rp[kt][r], rm[kt][r]);
+        qp = fma(cur[r][2], rp[kt][r], qp);
+        qm = fma(cur[r][2], rm[kt][r], qm);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) cur[r][q] = nxt[r][q];
+    }
+    // pass 2's first tile: requested before the cross-lane sums and the logarithm
+    double w2c[4], b2c[4][NT], w2n[4], b2n[4][NT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double* tk = sTb + (lk + 4 * r) * TS;
+      w2c[r] = tk[DP + 3];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b2c[r][nt] = tk[min(16 * nt + li, TS - 1)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    qp = sum_lk(qp);
+    qm = sum_lk(qm);
+    if (lk < 2) {  // log q: the lk = 0 lanes take the + samples, lk = 1 the - samples
+      const double lq = fm::log_fast(lk == 0 ? qp : qm);
+      slog += valid ? lq : 0.0;
+    }
+    // ---- pass 2: normalised terms (entropy_ws.hip, pass 2); every gd goes straight into product 2,
+    // Td[row][d] = sum_k gd[row][k] Delta[k][d], as its A operand ----
+    const double ip = valid ? fm::rcp_fast(qp) : 0.0, im = valid ? fm::rcp_fast(qm) : 0.0;
+    double sgs = 0.0, sgd = 0.0;
+    double4_t td2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) td2[nt] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kt = 0; kt < KTILES; ++kt) {
+      if (kt + 1 < KTILES) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double* tk = sTb + (16 * (kt + 1) + lk + 4 * r) * TS;
+          w2n[r] = tk[DP + 3];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) b2n[r][nt] = tk[min(16 * nt + li, TS - 1)];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double t1 = rp[kt][r] * ip, t2 = rm[kt][r] * im;
+        const double ts = t1 + t2, td = t1 - t2;
+        Wacc[kt][r] += ts;
+        sgs = fma(ts, w2c[r], sgs);
+        const double gd = td * w2c[r];
+        sgd += gd;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          // (columns d >= DP of the last tile read the row's constants instead of zeros: their outputs,
+          // Td[.][d >= DP], are never used -- the lam sums below take d < D only)
+          td2[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(gd, b2c[r][nt], td2[nt], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        w2c[r] = w2n[r];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b2c[r][nt] = b2n[r][nt];
+      }
+    }
+    const double cs = sig_j * sum_lk(sgs), cd = sig_j * sum_lk(sgd);  // of row li, in all four lk lanes
+#pragma unroll
+    for (int s = 0; s < NS; ++s) mu_acc[s] = fma(eb[s], cd, mu_acc[s]);
+    // lam += e_d (e_d cs + Td_d) over the rows, in product 2's layout: row = lk + 4 r, d = 16 nt + li
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rl = lk + 4 * r;
+      const double csr = __shfl(cs, rl, 64);
+      const int64_t rowC = row0 + rl;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int d = 16 * nt + li;
+        const double ec = (rowC < a.row_count && d < D) ? epj[rowC * D + d] : 0.0;
+        lam_acc[nt] = fma(ec, fma(ec, csr, td2[nt][r]), lam_acc[nt]);
+      }
+    }
+  }
+
+  // ---- workgroup reduction -> the partial row [Slog | mu (D) | sig | lam (D) | W (K)] ----
+  {
+    const double v = fm::wave_sum_dpp(slog);
+    if (lane == 0) sLog[wave] = v;
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const double v = fm::row16_sum_dpp(mu_acc[s]);  // over the rows li
+    if (li == 0) sMu[wave * DP + 4 * s + lk] = v;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const double v = sum_lk(lam_acc[nt]);  // over the row groups lk
+    if (lk == 0) sLam[wave][16 * nt + li] = v;
+  }
+#pragma unroll
+  for (int kt = 0; kt < KTILES; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double v = fm::row16_sum_dpp(Wacc[kt][r]);
+      if (li == 0) sWk[wave * KP + 16 * kt + lk + 4 * r] = v;
+    }
+  __syncthreads();
+  double* out = a.partial + ((int64_t)j * a.chunks + chunk) * a.stride;
+  for (int t = tid; t < a.stride; t += WG) {
+    double v = 0.0;
+    if (t == 0) {
+      for (int wv = 0; wv < WAVES; ++wv) v += sLog[wv];
+    } else if (t <= D) {
+      for (int wv = 0; wv < WAVES; ++wv) v += sMu[wv * DP + t - 1];
+    } else if (t == D + 1) {
+      for (int d = 0; d < D; ++d)
+        for (int wv = 0; wv < WAVES; ++wv) v += sLam[wv][d];
+    } else if (t < 2 * D + 2) {
+      for (int wv = 0; wv < WAVES; ++wv) v += sLam[wv][t - (D + 2)];
+    } else {
+      for (int wv = 0; wv < WAVES; ++wv) v += sWk[wv * KP + t - (2 * D + 2)];
+    }
+    out[t] = v;
+  }
+}
+
+template <int DP, int KTILES>
+void launch_mfma(hipStream_t st, const EntArgs& a, const double* d_table, hipEvent_t e0, hipEvent_t e1) {
+  constexpr int TS = DP + 6, KP = 16 * KTILES;
+  const size_t lds = sizeof(double) * ((size_t)KP * TS + WAVES * DP + WAVES * KP);
+  auto kern = entmc_mfma_kernel<DP, KTILES>;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (lds > 32 * 1024 && !attr_set[dev & 63]) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set[dev & 63] = true;
+  }
+  hipExtLaunchKernelGGL(kern, dim3(a.chunks, a.ml.K), dim3(WG), (std::uint32_t)lds, st, e0, e1, 0u, a, d_table);
+}
+
+}  // namespace
+
+// Shapes this form is built for: resident draws, value + gradient, no extra grid rows (the optimiser
+// loop's pre row, the GP sums' row), D padded to 20, and K within 12 components below a multiple of 16
+// (68..80, 84..96, 100..112, 116..128: the exp2 work is padded with the tile).
+static int mfma_ktiles(int K4) {
+  const int kt = (K4 + 15) / 16;
+  return (kt >= 5 && kt <= 8 && 16 * kt - K4 <= 12) ? kt : 0;
+}
+bool entmc_mfma_applies(const EntArgs& a, int DP) {
+  const int K4 = ((a.ml.K + 3) / 4) * 4;
+  return DP == 20 && mfma_ktiles(K4) != 0 && a.want_grad && a.eps_mode != VBMC_EPS_PHILOX && a.eps != nullptr &&
+         a.extra == nullptr && a.gp_items == 0;
+}
+
+void launch_entmc_mfma(hipStream_t st, const EntArgs& a, int DP, const double* d_table, hipEvent_t e0, hipEvent_t e1) {
+  (void)DP;
+  switch (mfma_ktiles(((a.ml.K + 3) / 4) * 4)) {
+    case 5: launch_mfma<20, 5>(st, a, d_table, e0, e1); break;
+    case 6: launch_mfma<20, 6>(st, a, d_table, e0, e1); break;
+    case 7: launch_mfma<20, 7>(st, a, d_table, e0, e1); break;
+    default: launch_mfma<20, 8>(st, a, d_table, e0, e1); break;
+  }
+}

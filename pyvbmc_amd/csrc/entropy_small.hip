@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64 * SW) void entmc_small_kernel(EntArgs a, const d
     return;
   }
   const int D = a.ml.D, K = a.ml.K;
-  const int K4 = ((K + 3) >> 2) * 4;
+  const int K4 = ws_table_rows(K);  // rows of the (j,k) table per component (entropy_args.h)
   const int j = (GRAD && a.extra != nullptr) ? blockIdx.y - 1 : blockIdx.y;
   const int tid = threadIdx.x, k = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

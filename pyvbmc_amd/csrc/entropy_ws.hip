@@ -82,8 +82,9 @@ constexpr int WAVES = WG / 64;
 
 __device__ __forceinline__ double wave_sum(double v) { return fm::wave_sum_dpp(v); }
 
-// The (j,k) table rows [Delta_jk (DP) | a | c | lrc | w | wis2 | pad] are written by prep.hip.
-// EXACT: ceil(K/4) == KTMAX (padding components have zero density): the per-component guards fold away.
+// The (j,k) table rows [Delta_jk (DP) | a | c | lrc | w | wis2 | pad] are written by prep.hip, always
+// 4 KTMAX of them per component j (padding components have zero density, entropy_args.h): the loops
+// over a wave's components carry no guards.
 // Per-lane state is ~(4 DP + 3 KTMAX) doubles with gradients.  Up to ~95 it fits the 256
 // registers of 2 waves/SIMD; beyond that one wave per SIMD with the 512-register budget
 // (AGPRs as spill space) beats spilling to scratch memory.
@@ -111,7 +112,7 @@ __device__ unsigned long long g_ws_times[1024 * 4];  // per workgroup: start, ba
 #else
 #define WS_STAMP(i) (void)0
 #endif
-template <int DP, int KTMAX, bool GRAD, bool EXACT, bool PHILOX>
+template <int DP, int KTMAX, bool GRAD, bool PHILOX>
 __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_kernel(
     EntArgs a, const double* __restrict__ T) {
   constexpr int TS = DP + 6;
@@ -147,8 +148,8 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
     }
     return;
   }
-  const int D = a.ml.D, K = a.ml.K;
-  const int KT = EXACT ? KTMAX : ((K + 3) >> 2), K4 = KT * 4;
+  const int D = a.ml.D;
+  constexpr int KT = KTMAX, K4 = KT * 4;
   int j = (EXTRA_ROW && a.extra != nullptr) ? blockIdx.y - 1 : blockIdx.y, chunk = blockIdx.x;
   // Scalar-cache locality.  With two workgroups resident per CU and a grid of one round, workgroups
   // b and b + CUs of a launch share a CU (tools/probes/placement.hip); in grid order they would read
@@ -259,11 +260,10 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
     }
 #pragma unroll
     for (int kk = 0; kk < KTMAX; ++kk) {
-      if (!EXACT) rp_[kk] = rm_[kk] = 0.0;
-      if (EXACT || kk < KT) {
+      {
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): row kk is in SGPRs
         __builtin_amdgcn_sched_barrier(0);
-        if (kk + 1 < KTMAX && (EXACT || kk + 1 < KT)) {
+        if (kk + 1 < KTMAX) {
           const double* tn = Tw + (size_t)(4 * (kk + 1)) * TS;  // wave-uniform
 #pragma unroll
           for (int i = 0; i < NR1; ++i) nxt[i] = tn[i];
@@ -324,10 +324,10 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
       }
 #pragma unroll
       for (int kk = 0; kk < KTMAX; ++kk) {
-        if (EXACT || kk < KT) {
+        {
           __builtin_amdgcn_s_waitcnt(0xC07F);
           __builtin_amdgcn_sched_barrier(0);
-          if (kk + 1 < KTMAX && (EXACT || kk + 1 < KT)) {
+          if (kk + 1 < KTMAX) {
             const double* tn = Tw + (size_t)(4 * (kk + 1)) * TS;
 #pragma unroll
             for (int d = 0; d < DP; ++d) n2[d] = tn[d];
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
             sRed[wv][it] = sum;
           } else {
             const int kk = it - 1 - 2 * DP;
-            if (4 * kk + wv < K4) sW[4 * kk + wv] = sum;
+            sW[4 * kk + wv] = sum;
           }
         }
       }
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
       }
 #pragma unroll
       for (int kk = 0; kk < KTMAX; ++kk)
-        if (EXACT || kk < KT) {
+        {
           const double v = wave_sum(Wacc[kk]);
           if (lane == 0) sW[4 * kk + wave] = v;
         }
@@ -448,11 +448,8 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
 template <int DP, int KTMAX>
 void launch_one(hipStream_t st, const EntArgs& a, const double* d_table, hipEvent_t e0, hipEvent_t e1) {
   const int K = a.ml.K;
-  const int K4 = ((K + 3) / 4) * 4;
+  const int K4 = 4 * KTMAX;  // the table carries zero-density padding rows up to 4 * KTMAX (entropy_args.h)
   size_t lds = sizeof(double) * ((size_t)K4 + ws_epi_doubles(DP, KTMAX, a.want_grad != 0));
-  // the table carries zero-density padding rows up to 4*ceil(K/4), so the guard-free
-  // variant applies whenever ceil(K/4) == KTMAX
-  const bool exact = ((K + 3) / 4 == KTMAX);
   const bool philox = a.eps_mode == VBMC_EPS_PHILOX;
   const bool extra_row = a.extra != nullptr && a.want_grad && !philox;  // see EXTRA_ROW in the kernel
   const dim3 grid(a.chunks, K + (extra_row ? 1 : 0) + (a.gp_items > 0 ? 1 : 0)), block(WG);
@@ -461,9 +458,9 @@ void launch_one(hipStream_t st, const EntArgs& a, const double* d_table, hipEven
   int dev = 0;
   if (lds > 32 * 1024) (void)hipGetDevice(&dev);
   // (the raised dynamic-LDS limit is set once per instantiation and size)
-#define VBMC_LAUNCH_WS(G, E, P)                                                                           \
+#define VBMC_LAUNCH_WS(G, P)                                                                              \
   do {                                                                                                    \
-    auto kern = entmc_ws_kernel<DP, KTMAX, G, E, P>;                                                      \
+    auto kern = entmc_ws_kernel<DP, KTMAX, G, P>;                                                         \
     static size_t lds_limit[64] = {};  /* per device: function attributes are per device */              \
     if (lds > 32 * 1024 && lds > lds_limit[dev & 63]) {                                                   \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -472,11 +469,9 @@ void launch_one(hipStream_t st, const EntArgs& a, const double* d_table, hipEven
     hipExtLaunchKernelGGL(kern, grid, block, (std::uint32_t)lds, st, e0, e1, 0u, a, d_table);             \
   } while (0)
   if (a.want_grad) {
-    if (exact) { if (philox) VBMC_LAUNCH_WS(true, true, true); else VBMC_LAUNCH_WS(true, true, false); }
-    else       { if (philox) VBMC_LAUNCH_WS(true, false, true); else VBMC_LAUNCH_WS(true, false, false); }
+    if (philox) VBMC_LAUNCH_WS(true, true); else VBMC_LAUNCH_WS(true, false);
   } else {
-    if (exact) { if (philox) VBMC_LAUNCH_WS(false, true, true); else VBMC_LAUNCH_WS(false, true, false); }
-    else       { if (philox) VBMC_LAUNCH_WS(false, false, true); else VBMC_LAUNCH_WS(false, false, false); }
+    if (philox) VBMC_LAUNCH_WS(false, true); else VBMC_LAUNCH_WS(false, false);
   }
 #undef VBMC_LAUNCH_WS
 }
@@ -487,15 +482,19 @@ void launch_one(hipStream_t st, const EntArgs& a, const double* d_table, hipEven
 #define VBMC_CAT(a, b) VBMC_CAT2(a, b)
 
 // one exported launcher per padded D; picks the smallest register-array size that holds KT.
-// d_table must hold K * 4*ceil(K/4) * (DP+6) doubles.
+// d_table must hold K * ws_table_rows(K) * (DP+6) doubles.
 void VBMC_CAT(launch_entmc_ws_dp, VBMC_DP)(hipStream_t st, const EntArgs& a, const double* d_table, hipEvent_t e0,
                                             hipEvent_t e1) {
-  const int KT = (a.ml.K + 3) / 4;
-  if (KT <= 8) launch_one<VBMC_DP, 8>(st, a, d_table, e0, e1);
-  else if (KT <= 13) launch_one<VBMC_DP, 13>(st, a, d_table, e0, e1);
-  else if (KT <= 16) launch_one<VBMC_DP, 16>(st, a, d_table, e0, e1);
-  else if (KT <= 25) launch_one<VBMC_DP, 25>(st, a, d_table, e0, e1);
-  else launch_one<VBMC_DP, 32>(st, a, d_table, e0, e1);
+  switch (ws_ktmax_for(a.ml.K)) {
+    case 4: launch_one<VBMC_DP, 4>(st, a, d_table, e0, e1); break;
+    case 8: launch_one<VBMC_DP, 8>(st, a, d_table, e0, e1); break;
+    case 10: launch_one<VBMC_DP, 10>(st, a, d_table, e0, e1); break;
+    case 13: launch_one<VBMC_DP, 13>(st, a, d_table, e0, e1); break;
+    case 16: launch_one<VBMC_DP, 16>(st, a, d_table, e0, e1); break;
+    case 20: launch_one<VBMC_DP, 20>(st, a, d_table, e0, e1); break;
+    case 25: launch_one<VBMC_DP, 25>(st, a, d_table, e0, e1); break;
+    default: launch_one<VBMC_DP, 32>(st, a, d_table, e0, e1); break;
+  }
 }
 
 #if defined(WS_TIMES) && VBMC_DP == 10

@@ -89,13 +89,14 @@ def test_entmc_virtual_ranks(ctx, cfg, W, inline):
     wl = synthetic.make_workload(cfg, Ns_total=vw.JOB_NS[cfg])
     D, K = wl.D, wl.K
     plan = r["plan"]
-    assert plan["kernel"] == "ws" and plan["resident_draws"] == (not inline), plan
+    ws_form = "mfma" if (cfg == 5 and not inline) else "ws"  # D = 20, K = 100 with resident draws: entropy_mfma.hip
+    assert plan["kernel"] == ws_form and plan["resident_draws"] == (not inline), plan
     if cfg == 4:
         assert wl.NsK == 160_000 and plan["chunks"] * K > 512 and plan["rg"] == 16, plan  # several grid rounds
     if cfg == 5:
         assert (D, K, wl.NsK) == (20, 100, 40_000) and plan["chunks"] * K > 512, plan
     for p in r["plans"]:
-        assert p["kernel"] == "ws" and p["resident_draws"] == (not inline), p
+        assert p["kernel"] == ws_form and p["resident_draws"] == (not inline), p
     err = additive_err(r["raw"], r["parts"], D, K)
     Ho, dHo = oracle_entropy(cfg, SEED + cfg, grad=(cfg == 3))
     print(f"cfg {cfg} W={W} {'inline' if inline else 'pregen'}: plan {plan}; |sum_r raw_r - raw| {err:.2e}; "
@@ -141,7 +142,7 @@ def test_fused_step_virtual_ranks(ctx, tmp_path, cfg, W):
     r = vw.run_elbo(ctx, cfg, W, seed)
     wl = synthetic.make_workload(cfg, Ns_total=vw.JOB_NS[cfg])
     D, K = wl.D, wl.K
-    assert r["plan"]["kernel"] == "ws"
+    assert r["plan"]["kernel"] == ("mfma" if cfg == 5 else "ws")
     if cfg in (4, 5):
         assert r["plan"]["chunks"] * K > 512, r["plan"]
     assert np.array_equal(r["parts"], r["cold"])  # armed + ahead-generated draws == cold evaluation
