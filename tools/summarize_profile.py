@@ -22,20 +22,25 @@ src, tag = Path(sys.argv[1]), sys.argv[2]
 out = Path(__file__).resolve().parent.parent / "profiles"
 out.mkdir(exist_ok=True)
 for mode, d in (("philox", "stats"), ("resident", "stats_res"), ("adam_loop", "stats_adam"), ("config2", "stats_c2"),
-                ("config5", "stats_c5"), ("predict", "stats_predict")):
+                ("config5", "stats_c5"), ("config4_job", "stats_c4job"), ("config5_job", "stats_c5job"),
+                ("predict", "stats_predict")):
     f = src / d / "s_kernel_stats.csv"
     if f.exists():
         shutil.copy(f, out / f"{tag}_kernel_stats_{mode}.csv")
     f = src / d / "completed_stats.csv"  # tools/trace_stats.py: cancelled launches told apart
     if f.exists():
         shutil.copy(f, out / f"{tag}_kernel_stats_{mode}_completed.csv")
+# counters per (workload, kernel): the pass directory's suffix names the workload (pmc_<counters>_<workload>), so the
+# same kernel launched at two sizes (config 3's share and config 4's job) is not averaged into one figure
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for p in sorted(src.glob("pmc_*/p_counter_collection.csv")):
     if "rows_mfma" in p.parent.name:
         continue  # tools/summarize_rows_pmc.py
+    wl = p.parent.name.rsplit("_", 1)[1]  # c3, c5, c2, c4job, c5job, predict
     for r in csv.DictReader(open(p)):
-        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for extra in ("timeline/timeline.txt", "gp_probe.txt", "adam_loop.txt", "rows.json"):
+        acc[(wl, r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for extra in ("timeline/timeline.txt", "gp_probe.txt", "adam_loop.txt", "rows.json", "ws_k_probe_d10.txt", "mfma_probe.txt",
+              "ubench_gen2.txt", "ubench_mfma_entropy.txt"):
     f = src / extra
     if f.exists():
         shutil.copy(f, out / f"{tag}_{Path(extra).name}")
@@ -43,18 +48,20 @@ for f in sorted(src.glob("bench_*.json")):
     shutil.copy(f, out / f"{tag}_{f.name}")
 rows = []
 summary = {}
-for k, v in acc.items():
+for (wl, k), v in acc.items():
     short = k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").strip() or k[:40]
     if "anonymous" in k and "::" in k:
         short = k.split("::")[1].split("(")[0].split("<")[0]
-    if "entmc_ws_kernel<" in k:  # keep <DP, KTMAX, GRAD, EXACT, PHILOX>: the draw source changes the traffic
-        short = "entmc_ws_kernel<" + k.split("entmc_ws_kernel<")[1].split(">")[0].replace(" ", "") + ">"
-    summary.setdefault(short, {})
+    for name in ("entmc_ws_kernel<", "entmc_mfma_kernel<"):  # keep the template arguments: <DP, KTMAX, GRAD, PHILOX> / <DP, KTILES>
+        if name in k:
+            short = name + k.split(name)[1].split(">")[0].replace(" ", "") + ">"
+    key = f"{wl}:{short}"
+    summary.setdefault(key, {})
     for c, vals in v.items():
         m = sum(vals) / len(vals)
-        rows.append((short, c, m, len(vals)))
-        summary[short][c] = m
-    s = summary[short]
+        rows.append((key, c, m, len(vals)))
+        summary[key][c] = m
+    s = summary[key]
     if "FETCH_SIZE" in s:
         s["hbm_read_bytes_corrected"] = s["FETCH_SIZE"] * 1024 * 2  # gfx950: x2 (MI355X_MICROARCH.md, HBM)
     if "WRITE_SIZE" in s:
@@ -65,3 +72,25 @@ with open(out / f"{tag}_pmc_summary.csv", "w", newline="") as f:
     w.writerows(rows)
 json.dump(summary, open(out / f"{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
 print("wrote", sorted(p.name for p in out.glob(f"{tag}_*")))
+
+# profiles/traffic.json: HBM bytes per launch of the entropy main kernel per workload, from THIS collection
+traffic = {"_comment": "HBM bytes per launch of the entropy main kernel from rocprofv3 PMC passes (FETCH_SIZE[KB]*1024*2 + "
+                       "WRITE_SIZE[KB]*1024; gfx950 correction per MI355X_MICROARCH.md), one counter per pass, `--pmc <counter> "
+                       "--kernel-trace` only, VBMC_ELBO_ARM=0 so that no cancelled launch enters the per-launch mean "
+                       "(tools/collect_profile.sh).  bench.py copies the entry matching its workload into roofline.traffic "
+                       "together with this provenance.  The Philox draws are generated ahead of the entropy kernel, which "
+                       "therefore runs in its resident-draw form in both modes: same traffic."}
+names = {"c3": "config3", "c5": "config5", "c2": "config2", "c4job": "config4", "c5job": "config5_job"}
+for wl, cfg in names.items():
+    best = None
+    for key, s in summary.items():
+        if key.startswith(wl + ":entmc_") and "finish" not in key and "hbm_read_bytes_corrected" in s and "hbm_write_bytes_uncalibrated" in s:
+            if best is None or s["hbm_read_bytes_corrected"] > best[1]["hbm_read_bytes_corrected"]:
+                best = (key, s)
+    if best:
+        ent = {"hbm_bytes_per_launch": best[1]["hbm_read_bytes_corrected"] + best[1]["hbm_write_bytes_uncalibrated"],
+               "read": best[1]["hbm_read_bytes_corrected"], "write": best[1]["hbm_write_bytes_uncalibrated"],
+               "source": f"profiles/{tag}_pmc_summary.json ({best[0]})", "collected": f"tools/collect_profile.sh {tag}, 1xMI355X"}
+        traffic[cfg] = {"philox": ent, "resident": ent}
+if len(traffic) > 1:
+    json.dump(traffic, open(out / "traffic.json", "w"), indent=1)
