@@ -30,6 +30,7 @@
 // until the end-of-workgroup reduction.
 #include <hip/hip_ext.h>
 
+#include "adam_dev.h"
 #include "common.h"
 #include "entropy_args.h"
 #include "fastmath.h"
@@ -75,9 +76,20 @@ __global__ __launch_bounds__(WG, 1) void entmc_mfma_kernel(EntArgs a, const doub
   double* sWk = sMu + WAVES * DP;  // [WAVES][KP]
   __shared__ double sLam[WAVES][NT * 16];
   __shared__ double sLog[WAVES];
+  // Adam loop (adam.hip): grid row 0 is not an entropy row -- its first workgroup computes the
+  // entropy-free part of the iteration's gradient beside the entropy workgroups (adam_dev.h), as in
+  // entropy_ws.hip
+  if (a.extra != nullptr && blockIdx.y == 0) {
+    if (blockIdx.x == 0) {
+      const adam_dev::AdamDev& pa = *(const adam_dev::AdamDev*)a.extra;
+      if (a.extra_lds > 0) adam_dev::adam_pre_body<true>(pa, dyn, &sLam[0][0]);
+      else adam_dev::adam_pre_body<false>(pa, nullptr, &sLam[0][0]);
+    }
+    return;
+  }
   if (a.cancel != nullptr && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ~(uint64_t)0) return;
   const int D = a.ml.D, K = a.ml.K, K4 = ws_table_rows(K);  // table rows per component (entropy_args.h)
-  const int j = blockIdx.y, chunk = blockIdx.x;
+  const int j = a.extra != nullptr ? blockIdx.y - 1 : blockIdx.y, chunk = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const double sig_j = a.mix[a.ml.o_sig + j];
@@ -282,22 +294,25 @@ __global__ __launch_bounds__(WG, 1) void entmc_mfma_kernel(EntArgs a, const doub
 template <int DP, int KTILES>
 void launch_mfma(hipStream_t st, const EntArgs& a, const double* d_table, hipEvent_t e0, hipEvent_t e1) {
   constexpr int TS = DP + 6, KP = 16 * KTILES;
-  const size_t lds = sizeof(double) * ((size_t)KP * TS + WAVES * DP + WAVES * KP);
+  size_t lds = sizeof(double) * ((size_t)KP * TS + WAVES * DP + WAVES * KP);
+  const bool extra_row = a.extra != nullptr;
+  if (extra_row && sizeof(double) * (size_t)a.extra_lds > lds) lds = sizeof(double) * (size_t)a.extra_lds;
   auto kern = entmc_mfma_kernel<DP, KTILES>;
-  static bool attr_set[64] = {};
+  static size_t lds_limit[64] = {};  // per device: function attributes are per device
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (lds > 32 * 1024 && !attr_set[dev & 63]) {
+  if (lds > 32 * 1024 && lds > lds_limit[dev & 63]) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set[dev & 63] = true;
+    lds_limit[dev & 63] = lds;
   }
-  hipExtLaunchKernelGGL(kern, dim3(a.chunks, a.ml.K), dim3(WG), (std::uint32_t)lds, st, e0, e1, 0u, a, d_table);
+  hipExtLaunchKernelGGL(kern, dim3(a.chunks, a.ml.K + (extra_row ? 1 : 0)), dim3(WG), (std::uint32_t)lds, st, e0, e1, 0u, a,
+                        d_table);
 }
 
 }  // namespace
 
-// Shapes this form is built for: resident draws, value + gradient, no extra grid rows (the optimiser
-// loop's pre row, the GP sums' row), D padded to 20, and K within 12 components below a multiple of 16
+// Shapes this form is built for: resident draws, value + gradient, no GP-sums grid row (the optimiser
+// loop's pre row is supported), D padded to 20, and K within 12 components below a multiple of 16
 // (68..80, 84..96, 100..112, 116..128: the exp2 work is padded with the tile).
 static int mfma_ktiles(int K4) {
   const int kt = (K4 + 15) / 16;
@@ -306,7 +321,7 @@ static int mfma_ktiles(int K4) {
 bool entmc_mfma_applies(const EntArgs& a, int DP) {
   const int K4 = ((a.ml.K + 3) / 4) * 4;
   return DP == 20 && mfma_ktiles(K4) != 0 && a.want_grad && a.eps_mode != VBMC_EPS_PHILOX && a.eps != nullptr &&
-         a.extra == nullptr && a.gp_items == 0;
+         a.gp_items == 0;
 }
 
 void launch_entmc_mfma(hipStream_t st, const EntArgs& a, int DP, const double* d_table, hipEvent_t e0, hipEvent_t e1) {
