@@ -102,3 +102,21 @@ class PlainGP:
                                                  L=p.L.copy(), sn2_mult=p.sn2_mult, L_chol=p.L_chol)
         self.mean = type(mean_name, (), {})()
         self.temporary_data = {}
+
+
+def entmc_extended(mix, NsK, eps_half, jacobian_flag=True):
+    """The oracle's Monte-Carlo entropy formulas (entropy_ref.entmc_partial: the reference's loops,
+    entmc_vbmc.py:64-112) evaluated in extended precision (np.longdouble: 64-bit mantissa on x86-64),
+    finalised in float64.  For mixtures whose far components nearly underflow, the reference's own
+    float64 arithmetic (lsum / q with q ~ 1e-300 relative weights) loses up to ~4e-5 on single gradient
+    entries; the device's per-component-centred form does not (tests/test_gpu_multibatch.py)."""
+    from types import SimpleNamespace
+
+    from oracle import entropy_ref
+
+    ld = np.longdouble
+    m = SimpleNamespace(D=mix.D, K=mix.K, mu=mix.mu.astype(ld), sigma=mix.sigma.astype(ld), lambd=mix.lambd.astype(ld),
+                        w=mix.w.astype(ld))
+    p = entropy_ref.entmc_partial(m, np.asarray(eps_half, dtype=ld), NsK, (True,) * 4)
+    p = {k: (float(v) if np.ndim(v) == 0 else np.asarray(v, dtype=np.float64)) for k, v in p.items()}
+    return entropy_ref.entmc_finalize(mix, p, (True,) * 4, jacobian_flag)
