@@ -117,8 +117,9 @@ int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
  * from the environment variable in brackets, read when the context is created.
  *   "entmc_kernel" [VBMC_ENTMC_KERNEL=valu -> 1]: 0 = pick the kernel by shape (default),
  *                  1 = always the generic thread-per-row kernel (on-device cross-check)
- *   "entmc_mfma"   1 = shapes the FP64 matrix tile pads little (D = 20, 97 <= K <= 112: BASELINE config 5)
- *                  take the matrix-pipe form of the entropy kernel (default), 0 = the wave-split kernel
+ *   "entmc_mfma"   1 = shapes the FP64 matrix tile pads little and the wave-split kernel runs one wave per SIMD on
+ *                  (D > 10 or K > 80, K within 12 below a multiple of 16: BASELINE config 5) take the matrix-pipe form
+ *                  of the entropy kernel (default), 0 = the wave-split kernel everywhere
  *   "elbo_pregen"  [VBMC_ELBO_PREGEN]: 1 = Philox draws generated ahead of the entropy
  *                  kernel (default), 0 = generated in-line by it; same values either way
  *   "elbo_ahead"   [VBMC_ELBO_AHEAD]: 1 = after a Philox evaluation with seed s the draws of

@@ -18,7 +18,6 @@ SOURCES = [
     "ctx.hip",
     "entropy.hip",
     "entropy_small.hip",
-    "entropy_mfma.hip",
     "prep.hip",
     "api_entropy.hip",
     "mixture.hip",
@@ -46,6 +45,7 @@ FLAGS = [
 
 
 WS_DPS = [2, 4, 6, 8, 10, 12, 16, 20, 24, 32]  # must match VBMC_WS_DPS in entropy_args.h
+MFMA_DPS = [12, 16, 20, 24, 32]  # padded D of the entropy kernel's matrix-pipe form (entropy_mfma.hip), one object each
 WS_EXTRA = os.environ.get("VBMC_WS_EXTRA_FLAGS", "").split()  # experiments on the entropy kernel only
 ALL_EXTRA = os.environ.get("VBMC_EXTRA_FLAGS", "").split()    # experiments: flags for every translation unit
 
@@ -60,6 +60,8 @@ def _jobs(bdir):
     jobs = [(src, bdir / (src.stem + ".o"), list(ALL_EXTRA)) for src in _sources()]
     for dp in WS_DPS:
         jobs.append((CSRC / "entropy_ws.hip", bdir / f"entropy_ws_dp{dp}.o", [f"-DVBMC_DP={dp}"] + WS_EXTRA))
+    for dp in MFMA_DPS:
+        jobs.append((CSRC / "entropy_mfma.hip", bdir / f"entropy_mfma_dp{dp}.o", [f"-DVBMC_MFMA_DP={dp}"] + ALL_EXTRA))
     return jobs
 
 
@@ -67,7 +69,7 @@ def needs_build():
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    deps = _sources() + [CSRC / "entropy_ws.hip"] + list(CSRC.glob("*.h")) + [HERE.parent / "include" / "vbmc_hip.h"]
+    deps = _sources() + [CSRC / "entropy_ws.hip", CSRC / "entropy_mfma.hip"] + list(CSRC.glob("*.h")) + [HERE.parent / "include" / "vbmc_hip.h"]
     return any(p.stat().st_mtime > t for p in deps)
 
 

@@ -30,6 +30,8 @@
 // until the end-of-workgroup reduction.
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 #include "adam_dev.h"
 #include "common.h"
 #include "entropy_args.h"
@@ -66,9 +68,12 @@ __device__ __forceinline__ double sum_lk(double v) {
   return v;
 }
 
-template <int DP, int KTILES>
+// DP: D padded to a multiple of 4 (the products' depth / width); TDP: the padded D of the (j,k) table in
+// memory (prep.hip: its rows are [Delta (TDP) | c0 | a | w | wis2 | pad pad]) -- equal except for D = 9, 10,
+// whose table is 10 wide and whose products are 12 deep.
+template <int DP, int KTILES, int TDP = DP>
 __global__ __launch_bounds__(WG, 1) void entmc_mfma_kernel(EntArgs a, const double* __restrict__ T) {
-  constexpr int TS = DP + 6, NS = DP / 4, NT = (DP + 15) / 16, KP = 16 * KTILES;
+  constexpr int TS = DP + 6, TTS = TDP + 6, NS = DP / 4, NT = (DP + 15) / 16, KP = 16 * KTILES;
   static_assert(DP % 4 == 0, "D padded to a multiple of 4");
   extern __shared__ double dyn[];
   double* sT = dyn;              // [KP][TS]: the table row of component j
@@ -95,10 +100,12 @@ __global__ __launch_bounds__(WG, 1) void entmc_mfma_kernel(EntArgs a, const doub
   const double sig_j = a.mix[a.ml.o_sig + j];
   const double sj2 = sig_j * sig_j, two_sj = 2.0 * sig_j;
   {
-    const double* Tj = T + (size_t)j * K4 * TS;
+    const double* Tj = T + (size_t)j * K4 * TTS;
     for (int i = tid; i < KP * TS; i += WG) {
       const int k = i / TS, c = i - k * TS;
-      sT[i] = k < K4 ? Tj[i] : (c == DP ? -2000.0 : 0.0);  // beyond K4: a component of density exactly 0
+      // LDS row [Delta (DP, zero beyond TDP) | c0 | a | w | wis2 | pad pad]; beyond K4: a component of density exactly 0
+      const int cs = c < TDP ? c : c < DP ? -1 : TDP + (c - DP);
+      sT[i] = k < K4 ? (cs >= 0 ? Tj[(size_t)k * TTS + cs] : 0.0) : (c == DP ? -2000.0 : 0.0);
     }
   }
   __syncthreads();
@@ -291,13 +298,13 @@ __global__ __launch_bounds__(WG, 1) void entmc_mfma_kernel(EntArgs a, const doub
   }
 }
 
-template <int DP, int KTILES>
+template <int DP, int KTILES, int TDP = DP>
 void launch_mfma(hipStream_t st, const EntArgs& a, const double* d_table, hipEvent_t e0, hipEvent_t e1) {
   constexpr int TS = DP + 6, KP = 16 * KTILES;
   size_t lds = sizeof(double) * ((size_t)KP * TS + WAVES * DP + WAVES * KP);
   const bool extra_row = a.extra != nullptr;
   if (extra_row && sizeof(double) * (size_t)a.extra_lds > lds) lds = sizeof(double) * (size_t)a.extra_lds;
-  auto kern = entmc_mfma_kernel<DP, KTILES>;
+  auto kern = entmc_mfma_kernel<DP, KTILES, TDP>;
   static size_t lds_limit[64] = {};  // per device: function attributes are per device
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -311,25 +318,74 @@ void launch_mfma(hipStream_t st, const EntArgs& a, const double* d_table, hipEve
 
 }  // namespace
 
+// One translation unit per padded D (build.py: -DVBMC_MFMA_DP=16 / 20 / 24 / 32), each with the k-tile counts 3..8.
+#ifndef VBMC_MFMA_DP
+#error "compile with -DVBMC_MFMA_DP=<padded D: 16, 20, 24 or 32>"
+#endif
+#define VBMC_CAT2(a, b) a##b
+#define VBMC_CAT(a, b) VBMC_CAT2(a, b)
+void VBMC_CAT(launch_entmc_mfma_dp, VBMC_MFMA_DP)(hipStream_t st, const EntArgs& a, int ktiles, const double* d_table, hipEvent_t e0,
+                                                   hipEvent_t e1) {
+#if VBMC_MFMA_DP == 12
+  if (a.ml.D <= 10) {  // the table of D = 9, 10 is 10 wide (entropy.hip padded_d)
+    switch (ktiles) {
+      case 3: launch_mfma<12, 3, 10>(st, a, d_table, e0, e1); break;
+      case 4: launch_mfma<12, 4, 10>(st, a, d_table, e0, e1); break;
+      case 5: launch_mfma<12, 5, 10>(st, a, d_table, e0, e1); break;
+      case 6: launch_mfma<12, 6, 10>(st, a, d_table, e0, e1); break;
+      case 7: launch_mfma<12, 7, 10>(st, a, d_table, e0, e1); break;
+      default: launch_mfma<12, 8, 10>(st, a, d_table, e0, e1); break;
+    }
+    return;
+  }
+#endif
+  switch (ktiles) {
+    case 3: launch_mfma<VBMC_MFMA_DP, 3>(st, a, d_table, e0, e1); break;
+    case 4: launch_mfma<VBMC_MFMA_DP, 4>(st, a, d_table, e0, e1); break;
+    case 5: launch_mfma<VBMC_MFMA_DP, 5>(st, a, d_table, e0, e1); break;
+    case 6: launch_mfma<VBMC_MFMA_DP, 6>(st, a, d_table, e0, e1); break;
+    case 7: launch_mfma<VBMC_MFMA_DP, 7>(st, a, d_table, e0, e1); break;
+    default: launch_mfma<VBMC_MFMA_DP, 8>(st, a, d_table, e0, e1); break;
+  }
+}
+
+#if VBMC_MFMA_DP == 20
+void launch_entmc_mfma_dp12(hipStream_t, const EntArgs&, int, const double*, hipEvent_t, hipEvent_t);
+void launch_entmc_mfma_dp16(hipStream_t, const EntArgs&, int, const double*, hipEvent_t, hipEvent_t);
+void launch_entmc_mfma_dp24(hipStream_t, const EntArgs&, int, const double*, hipEvent_t, hipEvent_t);
+void launch_entmc_mfma_dp32(hipStream_t, const EntArgs&, int, const double*, hipEvent_t, hipEvent_t);
+
 // Shapes this form is built for: resident draws, value + gradient, no GP-sums grid row (the optimiser
-// loop's pre row is supported), D padded to 20, and K within 12 components below a multiple of 16
-// (68..80, 84..96, 100..112, 116..128: the exp2 work is padded with the tile).
+// loop's pre row is supported); D padded to 12 (tables 10 or 12 wide), 16, 20, 24 or 32; K within 12
+// components below a multiple of 16 (the exp2 work is padded with the tile) and at least 36; and only
+// where the wave-split kernel would run one wave per SIMD -- the regime this form exists for
+// (D <= 10: from K = 81, the wave-split kernel's <10, 20> build is still quick: 29 against 38 us at K = 72;
+// tools/mfma_probe.py: 1.09-1.28x at D = 10, K = 96-128; 1.06-1.34x at D = 12, K = 56-128; 1.3-1.85x at D = 16; 1.1-1.35x at D = 20;
+// 1.6-2.1x at D = 24; 2.2-3.5x at D = 32).  In the two-waves regime it loses or ties (BASELINE config 3,
+// D = 10, K = 50: 105 against 88 us, tools/mfma_c3_probe.py with VBMC_MFMA_ANY=1 -- K = 50 pads the exp2
+// work itself by 28 %).
 static int mfma_ktiles(int K4) {
   const int kt = (K4 + 15) / 16;
-  return (kt >= 5 && kt <= 8 && 16 * kt - K4 <= 12) ? kt : 0;
+  return (kt >= 3 && kt <= 8 && 16 * kt - K4 <= 12) ? kt : 0;
 }
 bool entmc_mfma_applies(const EntArgs& a, int DP) {
   const int K4 = ((a.ml.K + 3) / 4) * 4;
-  return DP == 20 && mfma_ktiles(K4) != 0 && a.want_grad && a.eps_mode != VBMC_EPS_PHILOX && a.eps != nullptr &&
-         a.gp_items == 0;
+  static const bool any_regime = [] { const char* e = getenv("VBMC_MFMA_ANY"); return e && e[0] == '1'; }();  // experiments
+  const int dp4 = DP == 10 ? 12 : DP;
+  return (dp4 == 12 || DP == 16 || DP == 20 || DP == 24 || DP == 32) && mfma_ktiles(K4) != 0 &&
+         (any_regime || (ws_min_waves(DP, ws_ktmax_for(a.ml.K), true) == 1 && (DP != 10 || ws_ktmax_for(a.ml.K) >= 25))) && a.want_grad && a.eps_mode != VBMC_EPS_PHILOX &&
+         a.eps != nullptr && a.gp_items == 0;
 }
 
 void launch_entmc_mfma(hipStream_t st, const EntArgs& a, int DP, const double* d_table, hipEvent_t e0, hipEvent_t e1) {
-  (void)DP;
-  switch (mfma_ktiles(((a.ml.K + 3) / 4) * 4)) {
-    case 5: launch_mfma<20, 5>(st, a, d_table, e0, e1); break;
-    case 6: launch_mfma<20, 6>(st, a, d_table, e0, e1); break;
-    case 7: launch_mfma<20, 7>(st, a, d_table, e0, e1); break;
-    default: launch_mfma<20, 8>(st, a, d_table, e0, e1); break;
+  const int kt = mfma_ktiles(((a.ml.K + 3) / 4) * 4);
+  switch (DP) {
+    case 10:
+    case 12: launch_entmc_mfma_dp12(st, a, kt, d_table, e0, e1); break;
+    case 16: launch_entmc_mfma_dp16(st, a, kt, d_table, e0, e1); break;
+    case 20: launch_entmc_mfma_dp20(st, a, kt, d_table, e0, e1); break;
+    case 24: launch_entmc_mfma_dp24(st, a, kt, d_table, e0, e1); break;
+    default: launch_entmc_mfma_dp32(st, a, kt, d_table, e0, e1); break;
   }
 }
+#endif

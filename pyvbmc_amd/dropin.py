@@ -94,7 +94,12 @@ def make_sieve(vo, ref_sieve, batch_eval=None):
         vp0_vec, vp0_type = out[0], out[1]
         vps = [v for _, v in rec]
         # the reference sorted by the placeholders: its arrays are still in candidate order
-        assert len(vp0_vec) == len(rec) and all(a is b for a, b in zip(vp0_vec, vps))
+        if len(vp0_vec) != len(rec) or not all(a is b for a, b in zip(vp0_vec, vps)):
+            # not the loop this wrapper was written for (another version of the caller): evaluate what it
+            # returned, in the order it returned it
+            F = np.array([real(v.get_parameters(), state["gp"], v, 0, 0, 0, False, state["bnd"])[0] for v in vp0_vec])
+            order = np.argsort(F)
+            return (vp0_vec[order], vp0_type[order]) + tuple(out[2:])
         thetas = np.stack([t for t, _ in rec])
         if _same_fixed_blocks(vps):
             F = np.asarray(batch_eval(thetas, state["gp"], vps[0], state["bnd"]), dtype=np.float64)

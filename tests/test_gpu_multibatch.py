@@ -163,13 +163,15 @@ def test_multibatch_vs_oracle(ctx, D, K, rg, draws):
     assert max(errs) < 1e-9, errs
 
 
-@pytest.mark.parametrize("D,K,kernel", [(10, 14, "ws"), (10, 36, "ws"), (10, 40, "ws"), (4, 60, "ws"), (10, 77, "ws"), (6, 120, "ws"),
-                                        (20, 72, "mfma"), (20, 90, "mfma"), (20, 60, "ws"), (20, 97, "mfma"), (20, 120, "mfma"), (18, 100, "mfma")])
+@pytest.mark.parametrize("D,K,kernel", [(10, 14, "ws"), (10, 36, "ws"), (10, 40, "ws"), (4, 60, "ws"), (10, 77, "ws"), (10, 90, "mfma"), (8, 77, "ws"), (6, 120, "ws"),
+                                        (20, 72, "mfma"), (20, 90, "mfma"), (20, 60, "mfma"), (20, 97, "mfma"), (20, 120, "mfma"), (18, 100, "mfma"),
+                                        (16, 100, "mfma"), (13, 44, "mfma"), (16, 40, "ws"), (24, 60, "mfma"), (32, 100, "mfma"), (29, 48, "mfma"),
+                                        (10, 100, "mfma"), (9, 90, "mfma"), (12, 120, "mfma"), (11, 60, "mfma"), (11, 50, "ws")])
 def test_every_register_array_size_vs_oracle(ctx, D, K, kernel):
     """One case per register-array size of the wave-split kernel (4, 8, 10, 13, 16, 20, 25, 32 components
     per wave: the table is padded to the array size with zero-density components, entropy_args.h) and
-    per k-tile count of the matrix-pipe form (5, 6, 8 tiles; D = 18 padded to 20), K NOT a multiple of
-    the array size: H and every gradient entry against the oracle, several batches per workgroup."""
+    per padded D (12 with tables 10 and 12 wide, 16, 20, 24, 32) and k-tile count (3 to 8) of the matrix-pipe form,
+    K NOT a multiple of the array size: H and every gradient entry against the oracle, several batches per workgroup."""
     from pyvbmc_amd import VariationalPosterior, entmc_vbmc
 
     cus = ctx.device_info()["cu_count"]

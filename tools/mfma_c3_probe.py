@@ -1,5 +1,5 @@
-"""Entropy main kernel: the wave-split form against the matrix-pipe form (entropy_mfma.hip) over K.
-    python tools/mfma_probe.py [D ...]    -> kernel microseconds (HIP events on the kernel's own dispatch) per form"""
+"""BASELINE config 3's shape (and neighbours) through the matrix-pipe form (VBMC_MFMA_ANY=1 lifts the
+'only where the wave-split kernel runs one wave per SIMD' rule) against the wave-split kernel."""
 import sys
 from pathlib import Path
 
@@ -10,11 +10,10 @@ from pyvbmc_amd import VariationalPosterior, _lib, entmc_vbmc, synthetic  # noqa
 
 ctx = _lib.Context(0)
 _lib.set_default_context(ctx)
-Ds = [int(x) for x in sys.argv[1:]] or [20]
-for D in Ds:
-  for K in ((40, 44, 48, 56, 64, 72, 80, 96, 100, 112, 128) if D != 20 else (64, 72, 80, 88, 96, 100, 104, 112, 120, 128)):
-    wl = synthetic.make_workload(5, D=D, K=K, N=50, Ns_total=2500 * K)
-    vp = VariationalPosterior(wl.D, wl.K)  # noqa: E111
+for D, K, ns in ((10, 50, 1_000_000), (10, 64, 1_280_000), (10, 48, 960_000), (12, 50, 1_000_000), (10, 100, 2_000_000),
+                 (12, 100, 2_000_000), (8, 48, 960_000)):
+    wl = synthetic.make_workload(3, D=D, K=K, N=50, Ns_total=ns)
+    vp = VariationalPosterior(wl.D, wl.K)
     vp.mu, vp.sigma, vp.lambd = wl.mu.copy(), wl.sigma.reshape(1, -1), wl.lambd.reshape(-1, 1)
     vp.w, vp.eta = wl.w.reshape(1, -1), wl.eta.reshape(1, -1)
     out = {}
@@ -27,7 +26,7 @@ for D in Ds:
             if i >= 2:
                 ms.append(ctx.last_kernel_ms(0))
         ctx.set_timing(False)
-        out[form] = (float(np.median(ms)), ctx.last_entmc_plan()["kernel"], H, dH)
+        out[form] = (float(np.median(ms)), ctx.last_entmc_plan(), H, dH)
     d = float(np.max(np.abs(out[0][3] - out[1][3])) / np.max(np.abs(out[0][3])))
-    print(f"D={D:2d} K={K:4d} rows/comp={wl.NsK // 2}: {out[0][1]} {1e3 * out[0][0]:7.1f} us   {out[1][1]} {1e3 * out[1][0]:7.1f} us   "
-          f"ratio {out[0][0] / out[1][0]:.3f}   |dH diff| {d:.1e}")
+    print(f"D={D:2d} K={K:4d} NsK={wl.NsK}: {out[0][1]['kernel']} {1e3 * out[0][0]:7.1f} us   {out[1][1]['kernel']} {1e3 * out[1][0]:7.1f} us "
+          f"(rg {out[1][1]['rg']}, chunks {out[1][1]['chunks']})  ratio {out[0][0] / out[1][0]:.3f}   |dH diff| {d:.1e}")
