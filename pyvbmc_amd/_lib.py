@@ -248,7 +248,7 @@ class Context:
         64-row batches each workgroup looped over, workgroups per component, draw source."""
         out = (C.c_int * 4)()
         self.check(self._lib.vbmc_last_entmc_plan(self._h, out))
-        return {"kernel": ("valu", "ws", "small", "mfma")[out[0]] if out[0] >= 0 else None, "rg": out[1],
+        return {"kernel": ("valu", "ws", "small", "mfma", "adam_fused")[out[0]] if out[0] >= 0 else None, "rg": out[1],
                 "chunks": out[2], "resident_draws": bool(out[3])}
 
     def philox_normals(self, K, n_half, D, seed, row_begin=0, row_count=None):

@@ -26,6 +26,7 @@ SOURCES = [
     "api_elbo.hip",
     "api_batch.hip",
     "adam.hip",
+    "adam_fused.hip",
     "api_acq.hip",
     "api_acq_is.hip",
     "sample.hip",

@@ -37,109 +37,12 @@ using namespace adam_dev;
 
 namespace {
 
-// set_parameters(theta) + eta max-shift + mixture pack; theta's eta tail is shifted in
-// place.  theta / aux may live in LDS; the pack goes to a.mix.  Two reduction rounds:
-// (sum lambda^2, max eta), then (sum exp(eta - max), prod lambda); red needs 16 doubles.
-__device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, double* red) {
-  const int D = a.D, K = a.K, tid = threadIdx.x, n = a.n_theta;
-  const int lane = tid & 63, wave = tid >> 6;
-  const bool o_mu = a.mask & 1, o_sg = a.mask & 2, o_lm = a.mask & 4, o_w = a.mask & 8;
-  const int p_sg = o_mu ? D * K : 0, p_lm = p_sg + (o_sg ? K : 0), p_w = n - K;
-  double* mu = aux;
-  double* sg = mu + K * D;
-  double* lm = sg + K;
-  double* w = lm + D;
-  double* eta = w + K;
-  int bad = 0;
-  for (int i = tid; i < n; i += 256) bad |= !isfinite(theta[i]);
-  if (bad) atomicOr(a.status, 1);
-  // ---- round 1: raw lambda and its sum of squares; max of the eta tail ----
-  double s2 = 0.0, mx = -INFINITY;
-  for (int d = tid; d < D; d += 256) {
-    const double l = o_lm ? fm::exp2_fast(0x1.71547652b82fep+0 * theta[p_lm + d]) : lm[d];  // exp(.)
-    lm[d] = l;
-    s2 = fma(l, l, s2);
-  }
-  if (o_w)
-    for (int k = tid; k < K; k += 256) mx = fmax(mx, theta[p_w + k]);
-  s2 = wave_sum(s2);
-  mx = fm::wave_max_dpp(mx);
-  __syncthreads();
-  if (lane == 0) {
-    red[wave] = s2;
-    red[4 + wave] = mx;
-  }
-  __syncthreads();
-  s2 = (red[0] + red[1]) + (red[2] + red[3]);
-  mx = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
-  const double nl = sqrt(s2 / D);  // lambda -> unit RMS, sigma absorbs it
-  const double inl = 1.0 / nl;
-  // ---- round 2: unnormalised weights and their sum; product of the normalised lambdas ----
-  double wsum = 0.0, pr = 1.0;
-  if (o_w)
-    for (int k = tid; k < K; k += 256) {
-      const double e = theta[p_w + k] - mx;
-      theta[p_w + k] = e;
-      eta[k] = e;
-      const double we = fm::exp2_fast(0x1.71547652b82fep+0 * e);
-      w[k] = we;
-      wsum += we;
-    }
-  for (int d = tid; d < D; d += 256) pr *= lm[d] * inl;  // this thread's own entries of round 1
-  wsum = wave_sum(wsum);
-  pr = fm::wave_prod_dpp(pr);
-  if (lane == 0) {
-    red[8 + wave] = wsum;
-    red[12 + wave] = pr;
-  }
-  __syncthreads();
-  wsum = (red[8] + red[9]) + (red[10] + red[11]);
-  pr = (red[12] * red[13]) * (red[14] * red[15]);
-  const double nconst = a.c_norm / pr;  // 1 / (2 pi)^(D/2) / prod(lambda)   (entmc_vbmc.py:54-56)
-  const double l2n = 0x1.71547652b82fep+0 * fm::log_fast(nconst);
-  // ---- the pack and the final attributes (lm stays raw until every reader is through) ----
-  const MixLayout& ml = a.ml;
-  double* p = a.mix;
-  for (int i = tid; i < K * D; i += 256) {
-    const int d = i % D;
-    const double m = o_mu ? theta[i] : mu[i];
-    mu[i] = m;
-    p[ml.o_mu + i] = m;
-    p[ml.o_mup + i] = m * fm::rcp_fast(lm[d] * inl);
-  }
-  for (int k = tid; k < K; k += 256) {
-    const double s = (o_sg ? fm::exp2_fast(0x1.71547652b82fep+0 * theta[p_sg + k]) : sg[k]) * nl;
-    const double wk = o_w ? w[k] / wsum : w[k];
-    double sD = 1.0, b = s;  // sigma^D by repeated squaring, as the host pack (ctx.hip)
-    for (int e = D; e > 0; e >>= 1) {
-      if (e & 1) sD *= b;
-      b *= b;
-    }
-    sg[k] = s;
-    w[k] = wk;
-    const double rsD = nconst * fm::rcp_fast(sD);
-    p[ml.o_is2 + k] = fm::rcp_fast(s * s);
-    p[ml.o_rc + k] = rsD;
-    p[ml.o_lrc + k] = l2n - D * (0x1.71547652b82fep+0 * fm::log_fast(s));
-    p[ml.o_wc + k] = wk * rsD;
-    p[ml.o_sig + k] = s;
-    p[ml.o_w + k] = wk;
-  }
-  __syncthreads();
-  for (int d = tid; d < D; d += 256) {
-    const double l = lm[d] * inl;
-    lm[d] = l;
-    p[ml.o_lam + d] = l;
-    p[ml.o_ilam + d] = fm::rcp_fast(l);
-  }
-}
-
 // stand-alone launch of the pre workgroup, for entropy kernels without the extra row
 template <bool LDS>
 __global__ __launch_bounds__(256) void adam_pre_kernel(AdamDev a) {
   extern __shared__ double sh[];
   __shared__ double red[16];
-  adam_pre_body<LDS>(a, sh, red);
+  adam_pre_body<LDS>(a, sh, red, a.pre);
 }
 
 // ---------------------------------------------------------------------------
@@ -276,7 +179,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamDev a, int do_step, 
     __syncthreads();
   }
 
-  pack_from_theta(a, theta, aux, red);
+  pack_from_theta(a, theta, aux, red, a.mix);
   if (LDS) {  // write the mirrored, modified arrays back
     __syncthreads();
     for (int i = tid; i < L.o_hyp(); i += 256) a.state[i] = sh[i];  // theta | aux
@@ -317,6 +220,13 @@ struct AdamState {
   double* d_eps1 = nullptr;  // [K][row_count][D]
   size_t eps_cap = 0;        // doubles allocated
   bool eps_started = false;  // the buffer already holds the finish/step slices of the next iteration
+  // the fused loop (adam_fused.hip): one launch per batch at the reference's own sample counts
+  bool fused = false;
+  FusedArgs fz;
+  size_t fused_lds = 0;
+  double* d_xch = nullptr;
+  size_t xch_cap = 0;
+  unsigned long long* d_arrive = nullptr;
 };
 
 static AdamState* adam_of(vbmc_ctx* ctx) {
@@ -331,6 +241,8 @@ void adam_free(vbmc_ctx* ctx) {
   if (st->d_status) (void)hipFree(st->d_status);
   if (st->d_eps1) (void)hipFree(st->d_eps1);
   if (st->d_args) (void)hipFree(st->d_args);
+  if (st->d_xch) (void)hipFree(st->d_xch);
+  if (st->d_arrive) (void)hipFree(st->d_arrive);
   delete st;
   ctx->adam = nullptr;
 }
@@ -400,6 +312,7 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
   if (!opts->compute_grad) return vbmc_fail(ctx, VBMC_E_ARG, "adam_begin: compute_grad must be set");
   if ((lb == nullptr) != (ub == nullptr)) return vbmc_fail(ctx, VBMC_E_ARG, "adam_begin: lb/ub must both be given");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->spec.armed) spec_disarm(ctx);  // launches waiting for a theta would hold CUs the loop's workgroups need
   const int D = ctx->D, K = ctx->K, S = ctx->gp.S;
   const int mask = opts->optimize_mask;
   const int need = ((mask & 1) ? D * K : 0) + ((mask & 2) ? K : 0) + ((mask & 4) ? D : 0) +
@@ -530,6 +443,35 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
       st->eps_cap = st->n_eps;
     }
   }
+  // the fused loop where its shape applies (adam_fused.hip)
+  st->fused = false;
+  if (ctx->opt_adam_fused && ctx->world == 1 && st->row_begin == 0 && st->row_count == n_half) {
+    FusedArgs& f = st->fz;
+    f = FusedArgs();
+    f.a = a;
+    f.N = ctx->gp.N;
+    f.rows = (int)st->row_count;
+    const size_t lds = st->row_count <= 64 ? adam_fused_plan(f) : 0;
+    if (lds) {
+      const size_t rt = (size_t)K * (2 + 2 * D + K) + (size_t)S * K * (1 + 2 * D);
+      rc = ensure_dev(ctx, &st->d_xch, &st->xch_cap, 2 * rt);
+      if (rc) return rc;
+      if (!st->d_arrive) HIP_TRY(ctx, hipMalloc((void**)&st->d_arrive, sizeof(unsigned long long)));
+      f.XT = ctx->gp.d_XT;
+      f.alpha = ctx->gp.d_alpha;
+      f.eps_mode = st->eps_mode;
+      f.eps = ctx->d_eps;
+      f.eps_rows = st->row_count;
+      f.n_half = n_half;
+      f.row_begin = st->row_begin;
+      f.seed = st->seed;
+      f.inv_ns = 1.0 / (double)st->ns;
+      f.xch = st->d_xch;
+      f.arrive = st->d_arrive;
+      st->fused_lds = lds;
+      st->fused = true;
+    }
+  }
   st->active = true;
   return VBMC_OK;
 }
@@ -622,8 +564,47 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
   const int i0 = st->iter;
   int rc = 0;
   // the iteration base every kernel of this call adds its launch-constant offset to
-  hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, ctx->stream, st->d_status + 1, i0);
-  rc = enqueue_batch(ctx, st, i0, n_iters, multi);
+  if (st->fused && !multi && n_iters > 0) {
+    FusedArgs f = st->fz;
+    f.i0 = i0;
+    f.n_iters = n_iters;
+    HIP_TRY(ctx, hipMemsetAsync(st->d_arrive, 0, sizeof(unsigned long long), ctx->stream));
+    static const bool want_times = [] {
+      const char* e = getenv("VBMC_FUSED_TIMES");  // measurement aid: phase stamps of two workgroups to stderr
+      return e && e[0] == '1';
+    }();
+    unsigned long long* d_times = nullptr;
+    if (want_times) {
+      HIP_TRY(ctx, hipMalloc((void**)&d_times, sizeof(unsigned long long) * 2 * 64 * 10));
+      HIP_TRY(ctx, hipMemsetAsync(d_times, 0, sizeof(unsigned long long) * 2 * 64 * 10, ctx->stream));
+      f.times = d_times;
+    }
+    rc = adam_fused_launch(ctx, ctx->stream, f, st->fused_lds);
+    ctx->last_plan[0] = 4;  // vbmc_last_plan: the fused loop
+    if (want_times && !rc) {
+      std::vector<unsigned long long> tt(2 * 64 * 10);
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      HIP_TRY(ctx, hipMemcpy(tt.data(), d_times, sizeof(unsigned long long) * tt.size(), hipMemcpyDeviceToHost));
+      (void)hipFree(d_times);
+      const int nt = n_iters < 64 ? n_iters : 64;
+      for (int w = 0; w < 2; ++w) {
+        double acc[9] = {};
+        int cnt = 0;
+        for (int t = 2; t + 1 < nt; ++t, ++cnt) {
+          const unsigned long long* r = &tt[((size_t)w * 64 + t) * 10];
+          for (int p = 0; p < 8; ++p) acc[p] += (double)(r[p + 1] - r[p]) * 0.01;
+          acc[8] += (double)(tt[((size_t)w * 64 + t + 1) * 10] - r[0]) * 0.01;
+        }
+        if (cnt > 0)
+          fprintf(stderr, "fused loop, %s workgroup, us: phase A %.2f | drain %.2f | wait %.2f | gather %.2f | raw %.2f | pre %.2f | step %.2f | pack %.2f | iteration %.2f\n",
+                  w == 0 ? "entropy" : "GP-sum", acc[0] / cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[5] / cnt,
+                  acc[6] / cnt, acc[7] / cnt, acc[8] / cnt);
+      }
+    }
+  } else {
+    hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, ctx->stream, st->d_status + 1, i0);
+    rc = enqueue_batch(ctx, st, i0, n_iters, multi);
+  }
   if (rc) return rc;
   HIP_TRY(ctx, hipGetLastError());
   st->iter = i0 + n_iters;
@@ -642,6 +623,10 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
     if (y_tab_out) y_tab_out[it] = y3[3 * (size_t)it];
     if (G_out) G_out[it] = y3[3 * (size_t)it + 1];
     if (H_out) H_out[it] = y3[3 * (size_t)it + 2];
+  }
+  if (status & 4) {
+    st->active = false;
+    return vbmc_fail(ctx, VBMC_E_HIP, "adam_run: a workgroup of the fused loop did not arrive within 20 ms");
   }
   if (status) {
     st->active = false;

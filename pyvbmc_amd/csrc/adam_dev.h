@@ -51,6 +51,30 @@ struct AdamDev {
   int* status;    // != 0: a non-finite iterate was produced
 };
 
+// Argument block of the fused loop (adam_fused.hip): a batch of iterations in one launch.
+struct FusedArgs {
+  AdamDev a;
+  const double* XT = nullptr;     // [D][N]
+  const double* alpha = nullptr;  // [S][N]
+  int N = 0;
+  int eps_mode = 0;               // VBMC_EPS_PHILOX: Philox(seed + iteration), else the resident block eps
+  const double* eps = nullptr;    // [K][eps_rows][D]
+  long long eps_rows = 0, n_half = 0, row_begin = 0;
+  int rows = 0;                   // antithetic rows per component
+  unsigned long long seed = 0;
+  double inv_ns = 0.0;
+  double* xch = nullptr;                 // [2][K (2 + 2D + K) + S K (1 + 2D)] exchange records
+  unsigned long long* arrive = nullptr;  // zeroed before the launch; counts workgroup arrivals
+  unsigned long long timeout = 2000000;  // wall-clock ticks (100 MHz) a workgroup waits for the others: 20 ms
+  unsigned long long* times = nullptr;   // optional [2][64][10] phase stamps (VBMC_FUSED_TIMES=1)
+  int n_ent = 0, n_gp = 0;        // workgroups: K entropy + n_gp GP-sum workers
+  int i0 = 0, n_iters = 0;
+  int o_pre = 0, o_raw = 0, o_pack = 0, o_ee = 0, o_recs = 0, o_eps = 0, o_part = 0, o_out = 0, o_gp = 0, o_xt = 0,
+      o_alpha = 0;                // LDS carve, in doubles (adam_fused_plan)
+};
+size_t adam_fused_plan(FusedArgs& f);
+int adam_fused_launch(vbmc_ctx* ctx, hipStream_t st, const FusedArgs& f, size_t lds_bytes);
+
 __host__ __device__ inline size_t aux_len(int D, int K) { return (size_t)K * D + 3 * (size_t)K + D; }
 // scratch: ell2, iom2 [S][D] | gmu, tgs, tnu [K][D] | gsg, gw, ee [K] | glm, bl [D] | dL [n_bnd]
 __host__ __device__ inline size_t work_len(int D, int K, int S, int n_bnd) {
@@ -73,13 +97,15 @@ static __device__ __forceinline__ double wave_sum(double v) {
 // LDS = true: the state prefix [theta | aux | hyp | res | bounds] and the scratch live in LDS;
 // compile-time so that every access is a true ds_* or global access (a pointer that may be
 // either at run time makes the compiler emit flat_* instructions, several times slower on LDS).
-template <bool LDS>
-static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red) {
+// PRELOADED (with LDS): sh already holds the state prefix (the fused loop, adam_fused.hip, keeps it there
+// across iterations); pre_out: where the result goes (a.pre, or that loop's LDS copy).
+template <bool LDS, bool PRELOADED = false>
+static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red, double* pre_out) {
   const int D = a.D, K = a.K, S = a.S, tid = threadIdx.x, n = a.n_theta;
   const int lane = tid & 63, wave = tid >> 6;
   const int st = 1 + 2 * D;
   const AdamLayout& L = a.lay;
-  if (LDS) {
+  if (LDS && !PRELOADED) {
     const int cnt = L.o_raw();
     constexpr int U = 24;  // BASELINE config 3 (4 493 doubles) in one batch of loads
     for (int base = 0; base < cnt; base += 256 * U) {
@@ -299,11 +325,107 @@ static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red) 
       g = -ee[k] * sm_dot / (sm_s * sm_s) + ee[k] * gw[k] / sm_s;
       if (a.has_bnd) g += dL[a.n_bnd - K + k];
     }
-    a.pre[i] = g;
+    pre_out[i] = g;
   }
   if (tid == 0) {
-    a.pre[n] = G;
-    a.pre[n + 1] = loss;
+    pre_out[n] = G;
+    pre_out[n + 1] = loss;
+  }
+}
+
+// set_parameters(theta) + eta max-shift + mixture pack; theta's eta tail is shifted in
+// place.  theta / aux may live in LDS; the pack goes to p (a.mix, or the fused loop's LDS copy).  Two reduction rounds:
+// (sum lambda^2, max eta), then (sum exp(eta - max), prod lambda); red needs 16 doubles.
+static __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, double* red, double* p) {
+  const int D = a.D, K = a.K, tid = threadIdx.x, n = a.n_theta;
+  const int lane = tid & 63, wave = tid >> 6;
+  const bool o_mu = a.mask & 1, o_sg = a.mask & 2, o_lm = a.mask & 4, o_w = a.mask & 8;
+  const int p_sg = o_mu ? D * K : 0, p_lm = p_sg + (o_sg ? K : 0), p_w = n - K;
+  double* mu = aux;
+  double* sg = mu + K * D;
+  double* lm = sg + K;
+  double* w = lm + D;
+  double* eta = w + K;
+  int bad = 0;
+  for (int i = tid; i < n; i += 256) bad |= !isfinite(theta[i]);
+  if (bad) atomicOr(a.status, 1);
+  // ---- round 1: raw lambda and its sum of squares; max of the eta tail ----
+  double s2 = 0.0, mx = -INFINITY;
+  for (int d = tid; d < D; d += 256) {
+    const double l = o_lm ? fm::exp2_fast(0x1.71547652b82fep+0 * theta[p_lm + d]) : lm[d];  // exp(.)
+    lm[d] = l;
+    s2 = fma(l, l, s2);
+  }
+  if (o_w)
+    for (int k = tid; k < K; k += 256) mx = fmax(mx, theta[p_w + k]);
+  s2 = wave_sum(s2);
+  mx = fm::wave_max_dpp(mx);
+  __syncthreads();
+  if (lane == 0) {
+    red[wave] = s2;
+    red[4 + wave] = mx;
+  }
+  __syncthreads();
+  s2 = (red[0] + red[1]) + (red[2] + red[3]);
+  mx = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+  const double nl = sqrt(s2 / D);  // lambda -> unit RMS, sigma absorbs it
+  const double inl = 1.0 / nl;
+  // ---- round 2: unnormalised weights and their sum; product of the normalised lambdas ----
+  double wsum = 0.0, pr = 1.0;
+  if (o_w)
+    for (int k = tid; k < K; k += 256) {
+      const double e = theta[p_w + k] - mx;
+      theta[p_w + k] = e;
+      eta[k] = e;
+      const double we = fm::exp2_fast(0x1.71547652b82fep+0 * e);
+      w[k] = we;
+      wsum += we;
+    }
+  for (int d = tid; d < D; d += 256) pr *= lm[d] * inl;  // this thread's own entries of round 1
+  wsum = wave_sum(wsum);
+  pr = fm::wave_prod_dpp(pr);
+  if (lane == 0) {
+    red[8 + wave] = wsum;
+    red[12 + wave] = pr;
+  }
+  __syncthreads();
+  wsum = (red[8] + red[9]) + (red[10] + red[11]);
+  pr = (red[12] * red[13]) * (red[14] * red[15]);
+  const double nconst = a.c_norm / pr;  // 1 / (2 pi)^(D/2) / prod(lambda)   (entmc_vbmc.py:54-56)
+  const double l2n = 0x1.71547652b82fep+0 * fm::log_fast(nconst);
+  // ---- the pack and the final attributes (lm stays raw until every reader is through) ----
+  const MixLayout& ml = a.ml;
+  for (int i = tid; i < K * D; i += 256) {
+    const int d = i % D;
+    const double m = o_mu ? theta[i] : mu[i];
+    mu[i] = m;
+    p[ml.o_mu + i] = m;
+    p[ml.o_mup + i] = m * fm::rcp_fast(lm[d] * inl);
+  }
+  for (int k = tid; k < K; k += 256) {
+    const double s = (o_sg ? fm::exp2_fast(0x1.71547652b82fep+0 * theta[p_sg + k]) : sg[k]) * nl;
+    const double wk = o_w ? w[k] / wsum : w[k];
+    double sD = 1.0, b = s;  // sigma^D by repeated squaring, as the host pack (ctx.hip)
+    for (int e = D; e > 0; e >>= 1) {
+      if (e & 1) sD *= b;
+      b *= b;
+    }
+    sg[k] = s;
+    w[k] = wk;
+    const double rsD = nconst * fm::rcp_fast(sD);
+    p[ml.o_is2 + k] = fm::rcp_fast(s * s);
+    p[ml.o_rc + k] = rsD;
+    p[ml.o_lrc + k] = l2n - D * (0x1.71547652b82fep+0 * fm::log_fast(s));
+    p[ml.o_wc + k] = wk * rsD;
+    p[ml.o_sig + k] = s;
+    p[ml.o_w + k] = wk;
+  }
+  __syncthreads();
+  for (int d = tid; d < D; d += 256) {
+    const double l = lm[d] * inl;
+    lm[d] = l;
+    p[ml.o_lam + d] = l;
+    p[ml.o_ilam + d] = fm::rcp_fast(l);
   }
 }
 

@@ -1,0 +1,532 @@
+// The optimiser loop at the reference's OWN sample counts: one launch per batch of iterations.
+//
+// `optimize_vp` runs minimize_adam (vbmc/minimize_adam.py:84-137) around _neg_elcbo
+// (variational_optimization.py:238-249) with ns_ent = 100 K^(2/3) samples in total
+// (option_configs/advanced_vbmc_options.ini:43): 28 per component at K = 50, 14 antithetic rows.
+// At that size every kernel of the four-launch iteration (adam.hip) sits at its latency floor:
+// 7.5 + 11 + 5 + 7 = 30 us, of which hardly 5 are arithmetic.  Here a batch of iterations is ONE
+// launch of K + min(S K, 128) workgroups that stay resident and meet once per iteration:
+//
+//   phase A (workgroups side by side, from the mixture pack every workgroup holds in its LDS)
+//     workgroup j < K       Monte-Carlo entropy sums of component j (entropy_small.hip's form: lane =
+//                           component k, the four waves split the rows); its (j,k) table rows and
+//                           its rows' Philox normals are made in place; the entries of the raw
+//                           gradient that only need component j (mu_j, sigma_j) are finished here
+//     workgroup K + q       GP expected-log-joint sums of blocks (s,k) = q, q + n_gp, ... (the
+//                           arithmetic of glj_block.h) with X^T and alpha resident in its LDS
+//   exchange                every workgroup stores its record write-through (sc1), drains the
+//                           stores, counts itself on one monotonic word; everybody polls that word
+//                           and then reads ALL records (sc1 loads) into its own LDS: one all-gather of
+//                           K (2 + 2D + K) + S K (1 + 2D) doubles (37 KB at K = 50, D = 10), no fence,
+//                           two buffers alternating between iterations
+//   phase B (every workgroup, redundantly and identically, all operands in LDS / registers)
+//                           the sums over j (H, lambda, w), the entropy-free part of dF
+//                           (adam_dev::adam_pre_body), the Adam update with the moments in registers,
+//                           set_parameters + the pack of the next iterate (adam_dev::pack_from_theta)
+//
+// so an iteration has ONE inter-workgroup exchange (~2-3 us) and no launch boundary, no table in
+// memory, no draw buffer and no partial rows.  Workgroup 0 writes the iterate and (y, G, H) rows the
+// host's stopping rule reads, and the state back at the end of the batch.  Every spin is bounded
+// (a workgroup that never arrives -- it cannot happen with <= 192 workgroups on 256 CUs, but a hung
+// GPU is not an acceptable failure mode -- raises status bit 4 and every workgroup leaves).
+//
+// Used when the loop runs on one rank, K <= 64, D <= 16, at most 64 antithetic rows per component and
+// the LDS plan fits (adam_fused_plan); everything else keeps the four-launch iteration.  Same draws
+// (Philox(seed + i), philox.h), same formulas: tests/test_adam.py runs both against the oracle loop.
+#include <cstdlib>
+
+#include "adam_dev.h"
+#include "common.h"
+#include "entropy_args.h"
+#include "fastmath.h"
+#include "philox.h"
+
+using namespace adam_dev;
+
+namespace {
+
+constexpr int SW = 4;  // waves per workgroup
+constexpr double LOG2E = 0x1.71547652b82fep+0;
+
+__device__ __forceinline__ void st_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_wt(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0)
+
+template <int DP>
+__global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
+  extern __shared__ double sh[];
+  __shared__ double red[32];
+  __shared__ double red2[SW][128];
+  __shared__ int s_ok;
+  const AdamDev& a = f.a;
+  const AdamLayout& L = a.lay;
+  const MixLayout& ml = a.ml;
+  const int D = a.D, K = a.K, S = a.S, n = a.n_theta, N = f.N;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.x, G = gridDim.x;
+  const bool o_mu = a.mask & 1, o_sg = a.mask & 2, o_lm = a.mask & 4, o_w = a.mask & 8;
+  const int p_sg = o_mu ? D * K : 0, p_lm = p_sg + (o_sg ? K : 0), p_w = n - K;
+  const int f_w = 1 + D * K + K + D;  // weight block of the raw vector
+  const int RE = 2 + 2 * D + K;       // entropy record: slog | raw mu_j (D) | raw sigma_j | lam_j (D) | W_j (K)
+  const int RG = 1 + 2 * D;           // GP record
+  const int n_blocks = S * K;
+  const int RT = K * RE + n_blocks * RG;
+
+  // ---- LDS carve: [state prefix | pre-body scratch] is adam_pre_body's own layout ----
+  double* theta = sh + L.o_theta();
+  double* aux = sh + L.o_aux();
+  const double* hyp = sh + L.o_hyp();
+  double* pre = sh + f.o_pre;
+  double* raw = sh + f.o_raw;
+  double* pack = sh + f.o_pack;
+  double* ee = sh + f.o_ee;
+  double* recs = sh + f.o_recs;
+  double* sE = sh + f.o_eps;
+  double* part = sh + f.o_part;   // [SW][2 DP + 1] | W [SW][64]
+  double* out = sh + f.o_out;
+  double* gsc = sh + f.o_gp;
+  double* sXT = sh + f.o_xt;
+  double* sAl = sh + f.o_alpha;
+
+  // ---- what persists across the iterations of this launch ----
+  for (int i = tid; i < L.o_raw(); i += 256) sh[i] = a.state[i];
+  for (int i = tid; i < ml.total; i += 256) pack[i] = a.mix[i];
+  constexpr int U = 4;  // n_theta <= 1024 (adam_fused_plan)
+  double r_m[U], r_v[U], r_lo[U], r_hi[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int i = u * 256 + tid;
+    const bool in = i < n;
+    r_m[u] = in ? a.state[L.o_m() + i] : 0.0;
+    r_v[u] = in ? a.state[L.o_v() + i] : 0.0;
+    r_lo[u] = (in && a.has_box) ? a.state[L.o_xlb() + i] : 0.0;
+    r_hi[u] = (in && a.has_box) ? a.state[L.o_xub() + i] : 0.0;
+  }
+  if (g >= f.n_ent) {
+    for (int i = tid; i < D * N; i += 256) sXT[i] = f.XT[i];
+    for (int i = tid; i < S * N; i += 256) sAl[i] = f.alpha[i];
+  }
+  __syncthreads();
+
+  auto raw_index = [&](int i) -> int {
+    if (o_mu && i < D * K) return 1 + i;
+    if (o_sg && i >= p_sg && i < p_sg + K) return 1 + D * K + (i - p_sg);
+    if (o_lm && i >= p_lm && i < p_lm + D) return 1 + D * K + K + (i - p_lm);
+    return f_w + (i - p_w);
+  };
+
+  // phase stamps of workgroups 0 (entropy) and n_ent (GP sums), VBMC_FUSED_TIMES=1: a measurement aid
+  const int tslot = f.times == nullptr ? -1 : (g == 0 ? 0 : (g == f.n_ent ? 1 : -1));
+  auto stamp = [&](int t, int p) {
+    if (tslot >= 0 && tid == 0 && t < 64) f.times[((size_t)tslot * 64 + t) * 10 + p] = wall_clock64();
+  };
+
+  for (int t = 0; t < f.n_iters; ++t) {
+    const int iter = f.i0 + t;
+    double* xb = f.xch + (size_t)(t & 1) * RT;
+    stamp(t, 0);
+
+    if (g < f.n_ent) {
+      // ================= phase A, entropy of component j (entropy_small.hip; entmc_vbmc.py:64-112) =================
+      const int j = g, k = lane;
+      const bool live = k < K;
+      const int rows = f.rows;
+      if (f.eps_mode == VBMC_EPS_PHILOX) {
+        const int nb = (D + 3) >> 2;
+        const uint64_t seed = f.seed + (uint64_t)iter;
+        for (int it = tid; it < rows * nb; it += 256) {
+          const int i = it / nb, b = it - i * nb;
+          double z[4];
+          philox_normal_quad((uint64_t)j * (uint64_t)f.n_half + (uint64_t)(f.row_begin + i), (uint32_t)b, seed, z);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (4 * b + q < D) sE[i * D + 4 * b + q] = z[q];
+        }
+      } else if (t == 0) {  // resident draws: the same block every iteration
+        const double* src = f.eps + (int64_t)j * f.eps_rows * D;
+        for (int i = tid; i < rows * D; i += 256) sE[i] = src[i];
+      }
+      // the lane's table row (prep.hip's table block, from the pack in LDS)
+      const double* mup = pack + ml.o_mup;
+      const double sig_j = pack[ml.o_sig + j];
+      const double sj2 = sig_j * sig_j, two_sj = 2.0 * sig_j;
+      double dl[DP], d2s = 0.0;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        const double v = (d < D && live) ? (mup[j * D + d] - mup[k * D + d]) : 0.0;
+        dl[d] = v;
+        d2s += v * v;
+      }
+      double c0 = -2000.0, ak = 0.0, wk = 0.0, wis2 = 0.0;
+      if (live) {
+        const double is2 = pack[ml.o_is2 + k];
+        wk = pack[ml.o_w + k];
+        ak = -0.5 * LOG2E * is2;
+        c0 = fma(ak, d2s, pack[ml.o_lrc + k]);
+        wis2 = wk * is2;
+      }
+      double slog = 0.0, W = 0.0, A[DP], B[DP];
+#pragma unroll
+      for (int d = 0; d < DP; ++d) A[d] = B[d] = 0.0;
+      __syncthreads();
+      for (int i = wave; i < rows; i += SW) {
+        const double* rp = sE + i * D;
+        double e[DP], e2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+          e[d] = (d < D) ? rp[d] : 0.0;
+          e2 = fma(e[d], e[d], e2);
+        }
+        const double bq = sj2 * e2;
+        double c = 0.0;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) c = fma(dl[d], e[d], c);
+        const double sp = fma(two_sj, c, bq), sm = fma(-two_sj, c, bq);
+        const double r1 = fm::exp2_fast(fma(ak, sp, c0)), r2 = fm::exp2_fast(fma(ak, sm, c0));
+        const double qp = fm::wave_sum_dpp(wk * r1), qm = fm::wave_sum_dpp(wk * r2);
+        slog += fm::log_fast(qp) + fm::log_fast(qm);
+        const double t1 = r1 * fm::rcp_fast(qp), t2 = r2 * fm::rcp_fast(qm);
+        const double ts = t1 + t2, td = t1 - t2;
+        W += ts;
+        const double gs = ts * wis2, gd = td * wis2;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+          A[d] = fma(e[d], gd, A[d]);
+          B[d] = fma(e[d] * e[d], gs, B[d]);
+        }
+      }
+      // per wave: the sums over its lanes (= k) of what component j's entries need
+      //   mu_d  : sigma_j A_d(k) + w_k/sigma_k^2 Delta_jk,d W(k)       (entropy.hip finish, mu_from_w)
+      //   lam_d : sigma_j B_d(k) + Delta_jk,d A_d(k)
+      double* pw = part + wave * (2 * DP + 1);
+      if (lane == 0) pw[0] = slog;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        const double smu = fm::wave_sum_dpp(fma(sig_j, A[d], (wis2 * dl[d]) * W));
+        const double slm = fm::wave_sum_dpp(fma(sig_j, B[d], dl[d] * A[d]));
+        if (lane == 0) {
+          pw[1 + d] = smu;
+          pw[1 + DP + d] = slm;
+        }
+      }
+      part[SW * (2 * DP + 1) + wave * 64 + lane] = W;
+      __syncthreads();
+      if (wave == 0) {
+        auto tot = [&](int item) {
+          double v = 0.0;
+#pragma unroll
+          for (int wv = 0; wv < SW; ++wv) v += part[wv * (2 * DP + 1) + item];
+          return v;
+        };
+        const double w_j = pack[ml.o_w + j];
+        const double sc = w_j * f.inv_ns;
+        double Wk = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < SW; ++wv) Wk += part[SW * (2 * DP + 1) + wv * 64 + lane];
+        if (live) out[2 + 2 * D + lane] = Wk;
+        double slm = 0.0;
+        if (lane < D) {
+          slm = tot(1 + DP + lane);
+          out[1 + lane] = tot(1 + lane) * sc * pack[ml.o_ilam + lane];
+          out[2 + D + lane] = slm;
+        }
+        const double sg = fm::wave_sum_dpp(slm);
+        if (lane == 0) {
+          out[0] = tot(0);
+          out[1 + D] = sg * sc;
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < RE; i += 256) st_wt(xb + (size_t)j * RE + i, out[i]);
+    } else {
+      // ================= phase A, GP sums of blocks (s,k) (glj_block.h; variational_optimization.py:1400-1465) =================
+      double* sItau = gsc;
+      double* sMu = sItau + D;
+      double* sZa = sMu + D;
+      double* sPart = sZa + N;
+      double* sMisc = sPart + 4;
+      for (int b = g - f.n_ent; b < n_blocks; b += f.n_gp) {
+        const int s = b / K, k = b - s * K;
+        const double* h = hyp + (size_t)s * a.P;
+        const double sigk = pack[ml.o_sig + k];
+        if (tid < 64) {
+          double term = 0.0;
+          for (int d = tid; d < D; d += 64) {
+            const double ell = fm::exp2_fast(LOG2E * h[d]);
+            const double lam = pack[ml.o_lam + d];
+            const double tau2 = sigk * sigk * lam * lam + ell * ell;
+            sItau[d] = fm::rsqrt_fast(tau2);
+            sMu[d] = pack[ml.o_mu + k * D + d];
+            term += h[d] - 0.5 * fm::log_fast(tau2);
+          }
+          term = fm::wave_sum_dpp(term);
+          if (tid == 0) sMisc[0] = 2.0 * h[D] + term;
+        }
+        __syncthreads();
+        const double lnnf = sMisc[0];
+        for (int nn = tid; nn < N; nn += 256) {
+          double d2 = 0.0;
+          for (int d = 0; d < D; ++d) {
+            const double dlt = (sMu[d] - sXT[d * N + nn]) * sItau[d];
+            d2 = fma(dlt, dlt, d2);
+          }
+          const double z = fm::exp2_fast(LOG2E * (lnnf - 0.5 * d2));
+          sZa[nn] = z * sAl[s * N + nn];
+        }
+        __syncthreads();
+        {
+          double acc = 0.0;
+          for (int nn = tid; nn < N; nn += 256) acc += sZa[nn];
+          acc = fm::wave_sum_dpp(acc);
+          if (lane == 0) sPart[wave] = acc;
+        }
+        {
+          const int ns = tid & 15, ds = tid >> 4;
+          for (int d = ds; d < D; d += 16) {
+            const double m = sMu[d], itau = sItau[d];
+            double au = 0.0, at = 0.0;
+            for (int nn = ns; nn < N; nn += 16) {
+              const double dlt = (m - sXT[d * N + nn]) * itau;
+              const double tt = dlt * sZa[nn];
+              au += tt;
+              at = fma(dlt, tt, at);
+            }
+            au = fm::row16_sum_dpp(au);
+            at = fm::row16_sum_dpp(at);
+            if (ns == 0) {
+              out[1 + d] = au;
+              out[1 + D + d] = at;
+            }
+          }
+        }
+        __syncthreads();
+        if (tid == 0) out[0] = (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]);
+        __syncthreads();
+        if (tid < RG) st_wt(xb + (size_t)K * RE + (size_t)b * RG + tid, out[tid]);
+      }
+    }
+
+    // ================= exchange: drained write-through records, one count per workgroup, all-gather =================
+    stamp(t, 1);
+    drain();
+    __syncthreads();
+    stamp(t, 2);
+    if (tid == 0) {
+      __hip_atomic_fetch_add(f.arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long want = (unsigned long long)G * (unsigned long long)(t + 1);
+      const unsigned long long t0 = wall_clock64();
+      int ok = 1;
+      while (__hip_atomic_load(f.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (wall_clock64() - t0 > f.timeout) {
+          ok = 0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!ok) atomicOr(a.status, 4);
+      s_ok = ok;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    stamp(t, 3);
+    for (int base = 0; base < RT; base += 256 * 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld_wt(xb + min(base + u * 256 + tid, RT - 1));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * 256 + tid;
+        if (i < K * RE) recs[i] = v[u];
+        else if (i < RT) sh[L.o_res() + (i - K * RE)] = v[u];
+      }
+    }
+    __syncthreads();
+    stamp(t, 4);
+
+    // ================= phase B (every workgroup): the raw vector [H | mu | sigma | lambda | w] =================
+    for (int i = tid; i < K * (D + 1); i += 256) {
+      const int j = i / (D + 1), c = i - j * (D + 1);
+      if (c < D) raw[1 + j * D + c] = recs[j * RE + 1 + c];
+      else raw[1 + D * K + j] = recs[j * RE + 1 + D];
+    }
+    {
+      // outputs H, lambda_d, w_u (1 + D + K <= 81 of them): lane = output, the waves split the components j
+      const int n_out = 1 + D + K;
+      for (int o = lane; o < n_out; o += 64) {
+        const int col = o == 0 ? 0 : (o <= D ? 2 + D + (o - 1) : 2 + 2 * D + (o - 1 - D));
+        double acc = 0.0;
+        for (int j = wave; j < K; j += SW) {
+          const double wj = pack[ml.o_w + j];
+          const double cf = (o >= 1 && o <= D) ? wj * pack[ml.o_sig + j] : wj;
+          acc = fma(cf, recs[j * RE + col], acc);
+        }
+        red2[wave][o] = acc;
+      }
+      __syncthreads();
+      for (int o = tid; o < n_out; o += 256) {
+        const double sum = (red2[0][o] + red2[1][o]) + (red2[2][o] + red2[3][o]);
+        if (o == 0) raw[0] = -sum * f.inv_ns;
+        else if (o <= D) raw[1 + D * K + K + (o - 1)] = sum * f.inv_ns * pack[ml.o_ilam + (o - 1)];
+        else raw[f_w + (o - 1 - D)] = -f.inv_ns * (recs[(o - 1 - D) * RE] + sum);
+      }
+    }
+    __syncthreads();
+
+    // ---- the entropy-free part of dF ----
+    stamp(t, 5);
+    adam_pre_body<true, true>(a, sh, red, pre);
+    __syncthreads();
+    stamp(t, 6);
+
+    // ---- dF, Adam update (minimize_adam.py:89-105), as adam_step_kernel ----
+    {
+      const double it1 = (double)(iter + 1);
+      const double c1 = 1.0 / (1.0 - fm::exp2_fast(it1 * a.l2_beta1));
+      const double c2 = 1.0 / (1.0 - fm::exp2_fast(it1 * a.l2_beta2));
+      const double step = a.master_min + (a.master_max - a.master_min) * fm::exp2_fast(-it1 * a.l2e_over_decay);
+      const double* sg = aux + K * D;
+      const double* lm = sg + K;
+      const double* eta = lm + D + K;
+      double sm_s = 1.0, sm_dot = 0.0;
+      if (o_w) {
+        double ps = 0.0, pd = 0.0;
+        for (int k = tid; k < K; k += 256) {
+          const double e = fm::exp2_fast(LOG2E * eta[k]);
+          ee[k] = e;
+          ps += e;
+          pd += e * raw[f_w + k];
+        }
+        ps = fm::wave_sum_dpp(ps);
+        pd = fm::wave_sum_dpp(pd);
+        if (lane == 0) {
+          red[16 + wave] = ps;
+          red[20 + wave] = pd;
+        }
+        __syncthreads();
+        sm_s = (red[16] + red[17]) + (red[18] + red[19]);
+        sm_dot = (red[20] + red[21]) + (red[22] + red[23]);
+      }
+      if (g == 0 && tid == 0) {
+        const double Gv = pre[n], loss = pre[n + 1], H = raw[0];
+        double* y_out = a.y_tab + 3 * (size_t)iter;
+        y_out[0] = -Gv - H + loss;
+        y_out[1] = Gv;
+        y_out[2] = H;
+      }
+      double* x_row = a.x_tab + (size_t)iter * n;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = u * 256 + tid;
+        if (i >= n) continue;
+        const double rr = raw[raw_index(i)], rp = pre[i];
+        double gr;
+        if (o_mu && i < D * K) {
+          gr = rp - rr;
+        } else if (o_sg && i >= p_sg && i < p_sg + K) {
+          gr = rp - rr * sg[i - p_sg];
+        } else if (o_lm && i >= p_lm && i < p_lm + D) {
+          gr = rp - rr * lm[i - p_lm];
+        } else {
+          const double e = ee[i - p_w];
+          gr = rp + (e * sm_dot / (sm_s * sm_s) - e * rr / sm_s);
+        }
+        const double m = a.beta1 * r_m[u] + (1.0 - a.beta1) * gr;
+        const double v = a.beta2 * r_v[u] + (1.0 - a.beta2) * (gr * gr);
+        r_m[u] = m;
+        r_v[u] = v;
+        const double m_hat = m * c1, v_hat = v * c2;
+        double x = theta[i] - step * m_hat / (sqrt(v_hat) + a.fudge);
+        if (a.has_box) x = fmin(r_hi[u], fmax(r_lo[u], x));
+        theta[i] = x;
+        if (g == 0) x_row[i] = x;
+      }
+      __syncthreads();
+    }
+
+    // ---- set_parameters + the pack of the next iterate ----
+    stamp(t, 7);
+    pack_from_theta(a, theta, aux, red, pack);
+    __syncthreads();
+    stamp(t, 8);
+  }
+
+  if (g == 0) {  // the state the next batch (or vbmc_adam_end) starts from
+    for (int i = tid; i < L.o_hyp(); i += 256) a.state[i] = sh[i];  // theta | aux
+    for (int i = tid; i < ml.total; i += 256) a.mix[i] = pack[i];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = u * 256 + tid;
+      if (i < n) {
+        a.state[L.o_m() + i] = r_m[u];
+        a.state[L.o_v() + i] = r_v[u];
+      }
+    }
+  }
+}
+
+template <int DP>
+int launch_fused(vbmc_ctx* ctx, hipStream_t st, const FusedArgs& f, size_t lds) {
+  static size_t lds_limit[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (lds > 48 * 1024 && lds > lds_limit[dev & 63]) {
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)adam_fused_kernel<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_limit[dev & 63] = lds;
+  }
+  hipLaunchKernelGGL((adam_fused_kernel<DP>), dim3(f.n_ent + f.n_gp), dim3(64 * SW), lds, st, f);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int fused_dp(int D) { return D <= 2 ? 2 : D <= 4 ? 4 : D <= 6 ? 6 : D <= 8 ? 8 : D <= 10 ? 10 : D <= 12 ? 12 : 16; }
+
+}  // namespace
+
+namespace adam_dev {
+
+// Fills the workgroup split and the LDS carve of f (f.a, f.N, f.rows set by the caller); returns the
+// dynamic LDS bytes, or 0 when the fused loop does not apply to this shape.
+size_t adam_fused_plan(FusedArgs& f) {
+  const AdamDev& a = f.a;
+  const int D = a.D, K = a.K, S = a.S, N = f.N;
+  if (K > 64 || D > 16 || f.rows < 1 || f.rows > 64 || a.n_theta > 1024 || N < 1) return 0;
+  const int DP = fused_dp(D);
+  const int RE = 2 + 2 * D + K, RG = 1 + 2 * D;
+  f.n_ent = K;
+  f.n_gp = S * K < 128 ? S * K : 128;
+  size_t o = (size_t)a.lay.o_raw() + work_len(D, K, S, a.n_bnd);
+  auto take = [&](size_t cnt) {
+    const size_t at = o;
+    o += (cnt + 1) & ~(size_t)1;  // 16-byte granules
+    return (int)at;
+  };
+  o = (o + 1) & ~(size_t)1;
+  f.o_pre = take((size_t)a.n_theta + 2);
+  f.o_raw = take(raw_len(D, K));
+  f.o_pack = take(a.ml.total);
+  f.o_ee = take(K);
+  f.o_recs = take((size_t)K * RE);
+  f.o_eps = take((size_t)f.rows * D);
+  f.o_part = take((size_t)SW * (2 * DP + 1) + (size_t)SW * 64);
+  f.o_out = take(RE > RG ? RE : RG);
+  f.o_gp = take((size_t)2 * D + N + 8);
+  f.o_xt = take((size_t)D * N);
+  f.o_alpha = take((size_t)S * N);
+  const size_t bytes = o * sizeof(double);
+  return bytes <= 158 * 1024 ? bytes : 0;
+}
+
+int adam_fused_launch(vbmc_ctx* ctx, hipStream_t st, const FusedArgs& f, size_t lds) {
+  switch (fused_dp(f.a.D)) {
+    case 2: return launch_fused<2>(ctx, st, f, lds);
+    case 4: return launch_fused<4>(ctx, st, f, lds);
+    case 6: return launch_fused<6>(ctx, st, f, lds);
+    case 8: return launch_fused<8>(ctx, st, f, lds);
+    case 10: return launch_fused<10>(ctx, st, f, lds);
+    case 12: return launch_fused<12>(ctx, st, f, lds);
+    default: return launch_fused<16>(ctx, st, f, lds);
+  }
+}
+
+}  // namespace adam_dev

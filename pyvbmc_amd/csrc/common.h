@@ -187,6 +187,7 @@ struct vbmc_ctx {
   int opt_ahead_mode = 2;   // speculative draws: 2 = spare workgroups of the finish launch, 0 = a launch of their own behind it, 1 = on their own stream (measured: slower)
   int opt_ahead_pct = 100;  // armed evaluations: percent of the next draws generated in the finish launch (the rest in the armed prep launch, which runs them while it waits for theta)
   int opt_arm_late_test = 0;  // test hook: n > 0 = the n-th use of an armed evaluation from now takes the late-go recovery path
+  int opt_adam_fused = 1;     // the optimiser loop as one launch per batch where its shape applies (adam_fused.hip)
   int opt_gen_pt = 1;         // speculative draws in the finish launch: Philox blocks per thread
   int opt_ident_test = 0;     // test hook: n > 0 = the n-th identity check from now fails (the recovery path runs)
   bool ident_retry = false;   // inside the re-evaluation after a failed identity check

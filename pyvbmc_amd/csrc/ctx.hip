@@ -66,6 +66,8 @@ static void options_from_env(vbmc_ctx* c) {
   if (e) c->opt_ahead_pct = atoi(e);
   e = getenv("VBMC_ELBO_ARM");
   c->opt_elbo_arm = !(e && e[0] == '0');
+  e = getenv("VBMC_ADAM_FUSED");
+  c->opt_adam_fused = !(e && e[0] == '0');
   e = getenv("VBMC_WS_PAIR");
   c->opt_ws_pair = !(e && e[0] == '0');
   e = getenv("VBMC_GP_TAIL");
@@ -227,6 +229,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "ws_pair")) ctx->opt_ws_pair = value != 0;
   else if (!strcmp(key, "elbo_arm")) ctx->opt_elbo_arm = value != 0;
   else if (!strcmp(key, "ahead_pct")) ctx->opt_ahead_pct = value;
+  else if (!strcmp(key, "adam_fused")) ctx->opt_adam_fused = value != 0;
   else if (!strcmp(key, "gen_pt")) ctx->opt_gen_pt = value < 1 ? 1 : value > 16 ? 16 : value;
   else if (!strcmp(key, "ahead_mode")) {
     (void)entmc_ahead_wait(ctx);

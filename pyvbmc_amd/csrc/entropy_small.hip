@@ -43,8 +43,8 @@ __global__ __launch_bounds__(64 * SW) void entmc_small_kernel(EntArgs a, const d
   // Adam loop (adam.hip): grid row 0 is not an entropy row -- see entropy_ws.hip
   if (GRAD && a.extra != nullptr && blockIdx.y == 0) {
     const adam_dev::AdamDev& pa = *(const adam_dev::AdamDev*)a.extra;
-    if (a.extra_lds > 0) adam_dev::adam_pre_body<true>(pa, sh, red);
-    else adam_dev::adam_pre_body<false>(pa, nullptr, red);
+    if (a.extra_lds > 0) adam_dev::adam_pre_body<true>(pa, sh, red, pa.pre);
+    else adam_dev::adam_pre_body<false>(pa, nullptr, red, pa.pre);
     return;
   }
   const int D = a.ml.D, K = a.ml.K;

@@ -131,8 +131,8 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
     if (a.extra != nullptr && blockIdx.y == 0) {
       if (blockIdx.x == 0) {
         const adam_dev::AdamDev& pa = *(const adam_dev::AdamDev*)a.extra;
-        if (a.extra_lds > 0) adam_dev::adam_pre_body<true>(pa, dyn, &sRed[0][0]);
-        else adam_dev::adam_pre_body<false>(pa, nullptr, &sRed[0][0]);
+        if (a.extra_lds > 0) adam_dev::adam_pre_body<true>(pa, dyn, &sRed[0][0], pa.pre);
+        else adam_dev::adam_pre_body<false>(pa, nullptr, &sRed[0][0], pa.pre);
       }
       return;
     }

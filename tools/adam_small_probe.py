@@ -2,7 +2,8 @@
 NsK = 28 at K = 50; advanced_vbmc_options.ini:43) and at ns_ent_fine: microseconds per iteration.
 (Round 3 used it to A/B a build whose step workgroup reduced the K partial rows itself instead of a finish
 launch: 53.5 against 31.9 us at K = 50 -- one workgroup's chain of L2 reads for 500 x 50 terms costs far
-more than a 153-workgroup launch and its boundary; dropped)"""
+more than a 153-workgroup launch and its boundary; dropped, DESIGN section 7.  Then to A/B the fused loop,
+csrc/adam_fused.hip.)"""
 import os
 import subprocess
 import sys
@@ -33,9 +34,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             t0 = time.perf_counter()
             out = minimize_adam_elbo(wl.theta.copy(), g, vp, nsk, bnd, **kw)
             best = min(best, (time.perf_counter() - t0) / 400 * 1e6)
-        print(f"config {cfg} shape, NsK={nsk:5d}: {best:6.2f} us per iteration   F {out[3][0]:.6f} -> {out[3][-1]:.6f}  plan {ctx.last_entmc_plan()}")
+        print(f"config {cfg} shape, NsK={nsk:5d}: {best:6.2f} us per iteration   F {out[3][0]:.10f} -> {out[3][-1]:.10f}  "
+              f"|x| {np.linalg.norm(out[0]):.12f}  plan {ctx.last_entmc_plan()}")
 else:
-    for tag, env in (("default", {}),):
+    for tag, env in (("four launches per iteration (VBMC_ADAM_FUSED=0)", {"VBMC_ADAM_FUSED": "0"}),
+                     ("one launch per batch of 20 iterations (adam_fused.hip)", {})):
         print(tag)
         sys.stdout.flush()
         subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, **env))
