@@ -226,7 +226,7 @@ struct AdamState {
   size_t fused_lds = 0;
   double* d_xch = nullptr;
   size_t xch_cap = 0;
-  unsigned long long* d_arrive = nullptr;
+  unsigned long long* d_flags = nullptr;  // [256]
 };
 
 static AdamState* adam_of(vbmc_ctx* ctx) {
@@ -242,7 +242,7 @@ void adam_free(vbmc_ctx* ctx) {
   if (st->d_eps1) (void)hipFree(st->d_eps1);
   if (st->d_args) (void)hipFree(st->d_args);
   if (st->d_xch) (void)hipFree(st->d_xch);
-  if (st->d_arrive) (void)hipFree(st->d_arrive);
+  if (st->d_flags) (void)hipFree(st->d_flags);
   delete st;
   ctx->adam = nullptr;
 }
@@ -453,10 +453,10 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
     f.rows = (int)st->row_count;
     const size_t lds = st->row_count <= 64 ? adam_fused_plan(f) : 0;
     if (lds) {
-      const size_t rt = (size_t)K * (2 + 2 * D + K) + (size_t)S * K * (1 + 2 * D);
+      const size_t rt = (size_t)K * (2 + 2 * D + K) + (size_t)S * K * (2 * D + 4);
       rc = ensure_dev(ctx, &st->d_xch, &st->xch_cap, 2 * rt);
       if (rc) return rc;
-      if (!st->d_arrive) HIP_TRY(ctx, hipMalloc((void**)&st->d_arrive, sizeof(unsigned long long)));
+      if (!st->d_flags) HIP_TRY(ctx, hipMalloc((void**)&st->d_flags, 256 * sizeof(unsigned long long)));
       f.XT = ctx->gp.d_XT;
       f.alpha = ctx->gp.d_alpha;
       f.eps_mode = st->eps_mode;
@@ -467,7 +467,7 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
       f.seed = st->seed;
       f.inv_ns = 1.0 / (double)st->ns;
       f.xch = st->d_xch;
-      f.arrive = st->d_arrive;
+      f.flags = st->d_flags;
       st->fused_lds = lds;
       st->fused = true;
     }
@@ -568,37 +568,41 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
     FusedArgs f = st->fz;
     f.i0 = i0;
     f.n_iters = n_iters;
-    HIP_TRY(ctx, hipMemsetAsync(st->d_arrive, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(st->d_flags, 0, 256 * sizeof(unsigned long long), ctx->stream));
     static const bool want_times = [] {
       const char* e = getenv("VBMC_FUSED_TIMES");  // measurement aid: phase stamps of two workgroups to stderr
       return e && e[0] == '1';
     }();
     unsigned long long* d_times = nullptr;
     if (want_times) {
-      HIP_TRY(ctx, hipMalloc((void**)&d_times, sizeof(unsigned long long) * 2 * 64 * 10));
-      HIP_TRY(ctx, hipMemsetAsync(d_times, 0, sizeof(unsigned long long) * 2 * 64 * 10, ctx->stream));
+      HIP_TRY(ctx, hipMalloc((void**)&d_times, sizeof(unsigned long long) * 2 * 64 * 16));
+      HIP_TRY(ctx, hipMemsetAsync(d_times, 0, sizeof(unsigned long long) * 2 * 64 * 16, ctx->stream));
       f.times = d_times;
     }
     rc = adam_fused_launch(ctx, ctx->stream, f, st->fused_lds);
     ctx->last_plan[0] = 4;  // vbmc_last_plan: the fused loop
     if (want_times && !rc) {
-      std::vector<unsigned long long> tt(2 * 64 * 10);
+      std::vector<unsigned long long> tt(2 * 64 * 16);
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
       HIP_TRY(ctx, hipMemcpy(tt.data(), d_times, sizeof(unsigned long long) * tt.size(), hipMemcpyDeviceToHost));
       (void)hipFree(d_times);
       const int nt = n_iters < 64 ? n_iters : 64;
       for (int w = 0; w < 2; ++w) {
-        double acc[9] = {};
+        double acc[9] = {}, sub[4] = {};
         int cnt = 0;
         for (int t = 2; t + 1 < nt; ++t, ++cnt) {
-          const unsigned long long* r = &tt[((size_t)w * 64 + t) * 10];
+          const unsigned long long* r = &tt[((size_t)w * 64 + t) * 16];
           for (int p = 0; p < 8; ++p) acc[p] += (double)(r[p + 1] - r[p]) * 0.01;
-          acc[8] += (double)(tt[((size_t)w * 64 + t + 1) * 10] - r[0]) * 0.01;
+          acc[8] += (double)(tt[((size_t)w * 64 + t + 1) * 16] - r[0]) * 0.01;
+          if (w == 0) { sub[0] += (double)(r[9] - r[0]) * 0.01; sub[1] += (double)(r[10] - r[9]) * 0.01; sub[2] += (double)(r[11] - r[10]) * 0.01; sub[3] += (double)(r[1] - r[11]) * 0.01; }
         }
         if (cnt > 0)
           fprintf(stderr, "fused loop, %s workgroup, us: phase A %.2f | drain %.2f | wait %.2f | gather %.2f | raw %.2f | pre %.2f | step %.2f | pack %.2f | iteration %.2f\n",
                   w == 0 ? "entropy" : "GP-sum", acc[0] / cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[5] / cnt,
                   acc[6] / cnt, acc[7] / cnt, acc[8] / cnt);
+        if (cnt > 0 && w == 0)
+          fprintf(stderr, "   phase A of the entropy workgroup: draws + table row %.2f | row loop %.2f | wave sums %.2f | record %.2f\n",
+                  sub[0] / cnt, sub[1] / cnt, sub[2] / cnt, sub[3] / cnt);
       }
     }
   } else {
@@ -626,7 +630,7 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
   }
   if (status & 4) {
     st->active = false;
-    return vbmc_fail(ctx, VBMC_E_HIP, "adam_run: a workgroup of the fused loop did not arrive within 20 ms");
+    return vbmc_fail(ctx, VBMC_E_HIP, "adam_run: a workgroup of the fused loop did not publish within 20 ms");
   }
   if (status) {
     st->active = false;

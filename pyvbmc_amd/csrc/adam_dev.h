@@ -63,10 +63,10 @@ struct FusedArgs {
   int rows = 0;                   // antithetic rows per component
   unsigned long long seed = 0;
   double inv_ns = 0.0;
-  double* xch = nullptr;                 // [2][K (2 + 2D + K) + S K (1 + 2D)] exchange records
-  unsigned long long* arrive = nullptr;  // zeroed before the launch; counts workgroup arrivals
+  double* xch = nullptr;                 // [2][K (2 + 2D + K) + S K (2D + 4)] exchange records
+  unsigned long long* flags = nullptr;   // [n_ent + n_gp], zeroed before the launch: the iteration a workgroup has published
   unsigned long long timeout = 2000000;  // wall-clock ticks (100 MHz) a workgroup waits for the others: 20 ms
-  unsigned long long* times = nullptr;   // optional [2][64][10] phase stamps (VBMC_FUSED_TIMES=1)
+  unsigned long long* times = nullptr;   // optional [2][64][16] phase stamps (VBMC_FUSED_TIMES=1)
   int n_ent = 0, n_gp = 0;        // workgroups: K entropy + n_gp GP-sum workers
   int i0 = 0, n_iters = 0;
   int o_pre = 0, o_raw = 0, o_pack = 0, o_ee = 0, o_recs = 0, o_eps = 0, o_part = 0, o_out = 0, o_gp = 0, o_xt = 0,

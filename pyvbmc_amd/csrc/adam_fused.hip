@@ -69,14 +69,15 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
   const int p_sg = o_mu ? D * K : 0, p_lm = p_sg + (o_sg ? K : 0), p_w = n - K;
   const int f_w = 1 + D * K + K + D;  // weight block of the raw vector
   const int RE = 2 + 2 * D + K;       // entropy record: slog | raw mu_j (D) | raw sigma_j | lam_j (D) | W_j (K)
-  const int RG = 1 + 2 * D;           // GP record
+  const int RC = 2 * D + 4;           // GP contribution record: gmu (D) | glm (D) | gs | nu | b0 | qbar
   const int n_blocks = S * K;
-  const int RT = K * RE + n_blocks * RG;
+  const int RT = K * RE + n_blocks * RC;
 
   // ---- LDS carve: [state prefix | pre-body scratch] is adam_pre_body's own layout ----
   double* theta = sh + L.o_theta();
   double* aux = sh + L.o_aux();
   const double* hyp = sh + L.o_hyp();
+  double* work = sh + L.o_raw();  // phase B scratch
   double* pre = sh + f.o_pre;
   double* raw = sh + f.o_raw;
   double* pack = sh + f.o_pack;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
   // phase stamps of workgroups 0 (entropy) and n_ent (GP sums), VBMC_FUSED_TIMES=1: a measurement aid
   const int tslot = f.times == nullptr ? -1 : (g == 0 ? 0 : (g == f.n_ent ? 1 : -1));
   auto stamp = [&](int t, int p) {
-    if (tslot >= 0 && tid == 0 && t < 64) f.times[((size_t)tslot * 64 + t) * 10 + p] = wall_clock64();
+    if (tslot >= 0 && tid == 0 && t < 64) f.times[((size_t)tslot * 64 + t) * 16 + p] = wall_clock64();
   };
 
   for (int t = 0; t < f.n_iters; ++t) {
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
 #pragma unroll
       for (int d = 0; d < DP; ++d) A[d] = B[d] = 0.0;
       __syncthreads();
+      stamp(t, 9);
       for (int i = wave; i < rows; i += SW) {
         const double* rp = sE + i * D;
         double e[DP], e2 = 0.0;
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
       // per wave: the sums over its lanes (= k) of what component j's entries need
       //   mu_d  : sigma_j A_d(k) + w_k/sigma_k^2 Delta_jk,d W(k)       (entropy.hip finish, mu_from_w)
       //   lam_d : sigma_j B_d(k) + Delta_jk,d A_d(k)
+      stamp(t, 10);
       double* pw = part + wave * (2 * DP + 1);
       if (lane == 0) pw[0] = slog;
 #pragma unroll
@@ -212,6 +215,7 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
       }
       part[SW * (2 * DP + 1) + wave * 64 + lane] = W;
       __syncthreads();
+      stamp(t, 11);
       if (wave == 0) {
         auto tot = [&](int item) {
           double v = 0.0;
@@ -301,81 +305,259 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
           }
         }
         __syncthreads();
-        if (tid == 0) out[0] = (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]);
+        // this block's CONTRIBUTIONS to the entropy-free part of dF (adam_dev::adam_pre_body, phases 1-2: every term of
+        // it is linear in the per-(s,k) quantities, so the sums over s and k are left to phase B): lane = d
+        if (wave == 0) {
+          const double r0 = (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]);
+          const bool quad = a.mean_kind == VBMC_MEAN_NEGQUAD;
+          const double inv_S = 1.0 / S;
+          const double wk = pack[ml.o_w + k];
+          double c_gs = 0.0, c_nu = 0.0, c_qb = 0.0;
+          double* rec = xb + (size_t)K * RE + (size_t)b * RC;
+          if (lane < D) {
+            const int d = lane;
+            const double lam = pack[ml.o_lam + d], m = sMu[d];
+            const double ell2 = fm::exp2_fast(2.0 * LOG2E * h[d]);  // exp(2 h_d)
+            const double io = quad ? fm::exp2_fast(-2.0 * LOG2E * h[2 * D + 3 + d]) : 0.0;
+            const double tau2 = sigk * sigk * lam * lam + ell2;
+            const double rtau = fm::rsqrt_fast(tau2);
+            const double Ud = out[1 + d], T = out[1 + D + d] - r0;
+            double gm = wk * (-Ud * rtau);
+            c_gs = (lam * lam * (rtau * rtau)) * T * inv_S;
+            double gl = wk * (sigk * sigk * fm::rcp_fast(tau2)) * lam * T;
+            if (quad) {
+              const double xm = h[D + 3 + d];
+              gm -= wk * io * (m - xm);
+              c_nu = io * (m * m + sigk * sigk * lam * lam - 2.0 * m * xm + xm * xm) * inv_S;
+              gl -= wk * sigk * sigk * io * lam;
+              c_qb = io * lam * lam * inv_S;
+            }
+            st_wt(rec + d, gm * inv_S);
+            st_wt(rec + D + d, gl * inv_S);
+          }
+          c_gs = fm::wave_sum_dpp(c_gs);
+          c_nu = fm::wave_sum_dpp(c_nu);
+          c_qb = fm::wave_sum_dpp(c_qb);
+          if (lane == 0) {
+            st_wt(rec + 2 * D, c_gs);
+            st_wt(rec + 2 * D + 1, c_nu);
+            st_wt(rec + 2 * D + 2, (r0 + (a.mean_kind == VBMC_MEAN_ZERO ? 0.0 : h[D + 2])) * inv_S);
+            st_wt(rec + 2 * D + 3, c_qb);
+          }
+        }
         __syncthreads();
-        if (tid < RG) st_wt(xb + (size_t)K * RE + (size_t)b * RG + tid, out[tid]);
       }
     }
 
-    // ================= exchange: drained write-through records, one count per workgroup, all-gather =================
+    // ================= exchange: drained write-through records, one flag per workgroup, all-gather =================
     stamp(t, 1);
     drain();
     __syncthreads();
+    if (tid == 0) __hip_atomic_store(f.flags + g, (unsigned long long)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     stamp(t, 2);
-    if (tid == 0) {
-      __hip_atomic_fetch_add(f.arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long want = (unsigned long long)G * (unsigned long long)(t + 1);
+
+    // ---- while the flags travel: soft bounds (_vp_bound_loss :537-606), which need theta only ----
+    double* dL = work;              // [n_bnd]
+    double* gsg = dL + a.n_bnd;     // [K]
+    double* gw = gsg + K;           // [K]
+    double* glm = gw + K;           // [D]
+    double* bl = glm + D;           // [D]
+    const double* mu = aux;
+    const double* sg = mu + K * D;
+    const double* lm = sg + K;
+    const double* wv = lm + D;
+    const double* eta = wv + K;
+    double loss = 0.0;
+    if (a.has_bnd) {
+      const double* bnd_lb = sh + L.o_blb();
+      const double* bnd_ub = sh + L.o_bub();
+      const int n_mu = o_mu ? D * K : 0, n_sc = (o_sg || o_lm) ? D * K : 0;
+      for (int i = tid; i < a.n_bnd; i += 256) {
+        double x;
+        if (i < n_mu) {
+          x = theta[i];
+        } else if (i < n_mu + n_sc) {
+          const int q = i - n_mu, k = q / D, d = q - k * D;  // ravel('F') of the (D,K) array
+          const double ls = o_sg ? theta[p_sg + k] : log(sg[k]);
+          const double ll = o_lm ? theta[p_lm + d] : log(lm[d]);
+          x = ll + ls;
+        } else {
+          x = theta[p_w + (i - n_mu - n_sc)];
+        }
+        const double lb = bnd_lb[i], ub = bnd_ub[i];
+        const double ell = (ub - lb) * a.tol_con;
+        double gg = 0.0;
+        if (x < lb) {
+          const double tt = (lb - x) / ell;
+          loss += 0.5 * tt * tt;
+          gg = (x - lb) / (ell * ell);
+        }
+        if (x > ub) {
+          const double tt = (x - ub) / ell;
+          loss += 0.5 * tt * tt;
+          gg = (x - ub) / (ell * ell);
+        }
+        dL[i] = gg;
+      }
+    }
+
+    if (wave == 0) {
+      const unsigned long long want = (unsigned long long)(t + 1);
       const unsigned long long t0 = wall_clock64();
       int ok = 1;
-      while (__hip_atomic_load(f.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        if (wall_clock64() - t0 > f.timeout) {
+      for (;;) {
+        bool all = true;
+        for (int q = lane; q < G; q += 64)
+          all = all && __hip_atomic_load(f.flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+        if (__all(all)) break;
+        if (__builtin_amdgcn_readfirstlane((int)((wall_clock64() - t0) > f.timeout))) {
           ok = 0;
           break;
         }
         __builtin_amdgcn_s_sleep(1);
       }
-      if (!ok) atomicOr(a.status, 4);
-      s_ok = ok;
+      if (lane == 0) {
+        if (!ok) atomicOr(a.status, 4);
+        s_ok = ok;
+      }
     }
-    __syncthreads();
+    __syncthreads();  // (also: dL complete)
     if (!s_ok) return;
     stamp(t, 3);
-    for (int base = 0; base < RT; base += 256 * 8) {
-      double v[8];
+    for (int base = 0; base < RT; base += 256 * 10) {
+      double v[10];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ld_wt(xb + min(base + u * 256 + tid, RT - 1));
+      for (int u = 0; u < 10; ++u) v[u] = ld_wt(xb + min(base + u * 256 + tid, RT - 1));
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 10; ++u) {
         const int i = base + u * 256 + tid;
-        if (i < K * RE) recs[i] = v[u];
-        else if (i < RT) sh[L.o_res() + (i - K * RE)] = v[u];
+        if (i < RT) recs[i] = v[u];  // entropy records, then the GP contribution records
       }
     }
     __syncthreads();
     stamp(t, 4);
+    const double* crec = recs + K * RE;  // [S K][2D + 4]: gmu (D) | glm (D) | gs | nu | b0 | qbar
 
-    // ================= phase B (every workgroup): the raw vector [H | mu | sigma | lambda | w] =================
+    // ================= phase B (every workgroup): the raw vector [H | mu | sigma | lambda | w] and the
+    // entropy-free part of dF (the sums adam_pre_body's phase 2 makes, over the contribution records) =================
     for (int i = tid; i < K * (D + 1); i += 256) {
       const int j = i / (D + 1), c = i - j * (D + 1);
       if (c < D) raw[1 + j * D + c] = recs[j * RE + 1 + c];
       else raw[1 + D * K + j] = recs[j * RE + 1 + D];
     }
-    {
-      // outputs H, lambda_d, w_u (1 + D + K <= 81 of them): lane = output, the waves split the components j
-      const int n_out = 1 + D + K;
-      for (int o = lane; o < n_out; o += 64) {
-        const int col = o == 0 ? 0 : (o <= D ? 2 + D + (o - 1) : 2 + 2 * D + (o - 1 - D));
-        double acc = 0.0;
-        for (int j = wave; j < K; j += SW) {
-          const double wj = pack[ml.o_w + j];
-          const double cf = (o >= 1 && o <= D) ? wj * pack[ml.o_sig + j] : wj;
-          acc = fma(cf, recs[j * RE + col], acc);
-        }
-        red2[wave][o] = acc;
+    const int n_out = 1 + D + K;
+    for (int o = lane; o < n_out; o += 64) {
+      // outputs H, lambda_d, w_u: lane = output, the waves split the components j
+      const int col = o == 0 ? 0 : (o <= D ? 2 + D + (o - 1) : 2 + 2 * D + (o - 1 - D));
+      double acc = 0.0;
+      for (int j = wave; j < K; j += SW) {
+        const double wj = pack[ml.o_w + j];
+        const double cf = (o >= 1 && o <= D) ? wj * pack[ml.o_sig + j] : wj;
+        acc = fma(cf, recs[j * RE + col], acc);
       }
-      __syncthreads();
-      for (int o = tid; o < n_out; o += 256) {
-        const double sum = (red2[0][o] + red2[1][o]) + (red2[2][o] + red2[3][o]);
-        if (o == 0) raw[0] = -sum * f.inv_ns;
-        else if (o <= D) raw[1 + D * K + K + (o - 1)] = sum * f.inv_ns * pack[ml.o_ilam + (o - 1)];
-        else raw[f_w + (o - 1 - D)] = -f.inv_ns * (recs[(o - 1 - D) * RE] + sum);
+      red2[wave][o] = acc;
+    }
+    double gpart = 0.0, ps = 0.0, pd = 0.0;
+    for (int k = tid; k < K; k += 256) {
+      const double sgk = sg[k], wk = wv[k];
+      double gs = 0.0, nu = 0.0, b0 = 0.0, qbar = 0.0;
+      for (int sidx = 0; sidx < S; ++sidx) {
+        const double* c = crec + (size_t)(sidx * K + k) * RC + 2 * D;
+        gs += c[0];
+        nu += c[1];
+        b0 += c[2];
+        qbar += c[3];
+      }
+      const double wI = b0 - 0.5 * nu;  // mean over s of I_sk
+      gpart += wk * wI;
+      gsg[k] = wk * sgk * (gs - qbar);
+      double gg = -wI;  // d(-G)/dw_k; the entropy part is added below
+      if (a.has_bnd && o_w) {  // weight penalty (:1211-1229)
+        const bool small = wk < a.w_thresh;
+        loss += (small ? wk : a.w_thresh) * a.w_pen;
+        if (small) gg += a.w_pen;
+      }
+      gw[k] = gg;
+      if (o_w) {
+        const double e = fm::exp2_fast(LOG2E * eta[k]);
+        ee[k] = e;
+        ps += e;
+        pd += e * gg;
       }
     }
-    __syncthreads();
-
-    // ---- the entropy-free part of dF ----
+    {
+      const int ns = tid & 15, g16 = tid >> 4;
+      const int sc0 = o_mu ? D * K : 0;
+      for (int d = g16; d < D; d += 16) {
+        double acc = 0.0, accb = 0.0;
+        for (int idx = ns; idx < n_blocks; idx += 16) acc += crec[(size_t)idx * RC + D + d];
+        if (a.has_bnd && o_lm)
+          for (int k = ns; k < K; k += 16) accb += dL[sc0 + d * K + k];
+        acc = fm::row16_sum_dpp(acc);
+        accb = fm::row16_sum_dpp(accb);
+        if (ns == 0) {
+          glm[d] = acc;
+          bl[d] = accb;
+        }
+      }
+    }
+    gpart = fm::wave_sum_dpp(gpart);
+    loss = fm::wave_sum_dpp(loss);
+    ps = fm::wave_sum_dpp(ps);
+    pd = fm::wave_sum_dpp(pd);
+    if (lane == 0) {
+      red[wave] = gpart;
+      red[4 + wave] = loss;
+      red[8 + wave] = ps;
+      red[12 + wave] = pd;
+    }
     stamp(t, 5);
-    adam_pre_body<true, true>(a, sh, red, pre);
+    __syncthreads();
+    for (int o = tid; o < n_out; o += 256) {
+      const double sum = (red2[0][o] + red2[1][o]) + (red2[2][o] + red2[3][o]);
+      if (o == 0) raw[0] = -sum * f.inv_ns;
+      else if (o <= D) raw[1 + D * K + K + (o - 1)] = sum * f.inv_ns * pack[ml.o_ilam + (o - 1)];
+      else raw[f_w + (o - 1 - D)] = -f.inv_ns * (recs[(o - 1 - D) * RE] + sum);
+    }
+    {
+      const double Gv = (red[0] + red[1]) + (red[2] + red[3]);
+      const double lossv = (red[4] + red[5]) + (red[6] + red[7]);
+      const double pm_s = o_w ? (red[8] + red[9]) + (red[10] + red[11]) : 1.0;
+      const double pm_dot = o_w ? (red[12] + red[13]) + (red[14] + red[15]) : 0.0;
+      const int sc0 = o_mu ? D * K : 0;
+      for (int i = tid; i < n; i += 256) {
+        double gg;
+        if (o_mu && i < D * K) {
+          const int k = i / D, d = i - k * D;
+          double gm = 0.0;
+          for (int sidx = 0; sidx < S; ++sidx) gm += crec[(size_t)(sidx * K + k) * RC + d];
+          gg = -gm;
+          if (a.has_bnd) gg += dL[i];
+        } else if (o_sg && i >= p_sg && i < p_sg + K) {
+          const int k = i - p_sg;
+          gg = -gsg[k] * sg[k];
+          if (a.has_bnd) {
+            // the reference reshapes this block C-order (D,K) (:585-587); restated as-is
+            double acc = 0.0;
+            for (int d = 0; d < D; ++d) acc += dL[sc0 + d * K + k];
+            gg += acc;
+          }
+        } else if (o_lm && i >= p_lm && i < p_lm + D) {
+          const int d = i - p_lm;
+          gg = -glm[d] * lm[d];
+          if (a.has_bnd) gg += bl[d];
+        } else {
+          const int k = i - p_w;
+          gg = -ee[k] * pm_dot / (pm_s * pm_s) + ee[k] * gw[k] / pm_s;
+          if (a.has_bnd) gg += dL[a.n_bnd - K + k];
+        }
+        pre[i] = gg;
+      }
+      if (tid == 0) {
+        pre[n] = Gv;
+        pre[n + 1] = lossv;
+      }
+    }
     __syncthreads();
     stamp(t, 6);
 
@@ -492,10 +674,10 @@ size_t adam_fused_plan(FusedArgs& f) {
   const int D = a.D, K = a.K, S = a.S, N = f.N;
   if (K > 64 || D > 16 || f.rows < 1 || f.rows > 64 || a.n_theta > 1024 || N < 1) return 0;
   const int DP = fused_dp(D);
-  const int RE = 2 + 2 * D + K, RG = 1 + 2 * D;
+  const int RE = 2 + 2 * D + K, RG = 1 + 2 * D, RC = 2 * D + 4;
   f.n_ent = K;
   f.n_gp = S * K < 128 ? S * K : 128;
-  size_t o = (size_t)a.lay.o_raw() + work_len(D, K, S, a.n_bnd);
+  size_t o = (size_t)a.lay.o_raw() + (size_t)a.n_bnd + 2 * (size_t)K + 2 * (size_t)D;  // state prefix | phase B scratch
   auto take = [&](size_t cnt) {
     const size_t at = o;
     o += (cnt + 1) & ~(size_t)1;  // 16-byte granules
@@ -506,7 +688,7 @@ size_t adam_fused_plan(FusedArgs& f) {
   f.o_raw = take(raw_len(D, K));
   f.o_pack = take(a.ml.total);
   f.o_ee = take(K);
-  f.o_recs = take((size_t)K * RE);
+  f.o_recs = take((size_t)K * RE + (size_t)S * K * RC);
   f.o_eps = take((size_t)f.rows * D);
   f.o_part = take((size_t)SW * (2 * DP + 1) + (size_t)SW * 64);
   f.o_out = take(RE > RG ? RE : RG);
@@ -514,7 +696,7 @@ size_t adam_fused_plan(FusedArgs& f) {
   f.o_xt = take((size_t)D * N);
   f.o_alpha = take((size_t)S * N);
   const size_t bytes = o * sizeof(double);
-  return bytes <= 158 * 1024 ? bytes : 0;
+  return bytes <= 154 * 1024 ? bytes : 0;  // + 4.5 KB of static arrays <= 160 KB
 }
 
 int adam_fused_launch(vbmc_ctx* ctx, hipStream_t st, const FusedArgs& f, size_t lds) {
