@@ -335,8 +335,11 @@ static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red, 
 
 // set_parameters(theta) + eta max-shift + mixture pack; theta's eta tail is shifted in
 // place.  theta / aux may live in LDS; the pack goes to p (a.mix, or the fused loop's LDS copy).  Two reduction rounds:
-// (sum lambda^2, max eta), then (sum exp(eta - max), prod lambda); red needs 16 doubles.
+// (sum lambda^2, max eta), then (sum exp(eta - max), prod lambda); red needs 4 NT / 64 doubles.
+// NT: threads of the workgroup (256: the launches of adam.hip; 512: the fused loop).
+template <int NT = 256>
 static __device__ void pack_from_theta(const AdamDev& a, double* theta, double* aux, double* red, double* p) {
+  constexpr int NW = NT / 64;
   const int D = a.D, K = a.K, tid = threadIdx.x, n = a.n_theta;
   const int lane = tid & 63, wave = tid >> 6;
   const bool o_mu = a.mask & 1, o_sg = a.mask & 2, o_lm = a.mask & 4, o_w = a.mask & 8;
@@ -347,33 +350,37 @@ static __device__ void pack_from_theta(const AdamDev& a, double* theta, double* 
   double* w = lm + D;
   double* eta = w + K;
   int bad = 0;
-  for (int i = tid; i < n; i += 256) bad |= !isfinite(theta[i]);
+  for (int i = tid; i < n; i += NT) bad |= !isfinite(theta[i]);
   if (bad) atomicOr(a.status, 1);
   // ---- round 1: raw lambda and its sum of squares; max of the eta tail ----
   double s2 = 0.0, mx = -INFINITY;
-  for (int d = tid; d < D; d += 256) {
+  for (int d = tid; d < D; d += NT) {
     const double l = o_lm ? fm::exp2_fast(0x1.71547652b82fep+0 * theta[p_lm + d]) : lm[d];  // exp(.)
     lm[d] = l;
     s2 = fma(l, l, s2);
   }
   if (o_w)
-    for (int k = tid; k < K; k += 256) mx = fmax(mx, theta[p_w + k]);
+    for (int k = tid; k < K; k += NT) mx = fmax(mx, theta[p_w + k]);
   s2 = wave_sum(s2);
   mx = fm::wave_max_dpp(mx);
   __syncthreads();
   if (lane == 0) {
     red[wave] = s2;
-    red[4 + wave] = mx;
+    red[NW + wave] = mx;
   }
   __syncthreads();
   s2 = (red[0] + red[1]) + (red[2] + red[3]);
-  mx = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+  mx = fmax(fmax(red[NW], red[NW + 1]), fmax(red[NW + 2], red[NW + 3]));
+  if (NW == 8) {
+    s2 += (red[4] + red[5]) + (red[6] + red[7]);
+    mx = fmax(mx, fmax(fmax(red[NW + 4], red[NW + 5]), fmax(red[NW + 6], red[NW + 7])));
+  }
   const double nl = sqrt(s2 / D);  // lambda -> unit RMS, sigma absorbs it
   const double inl = 1.0 / nl;
   // ---- round 2: unnormalised weights and their sum; product of the normalised lambdas ----
   double wsum = 0.0, pr = 1.0;
   if (o_w)
-    for (int k = tid; k < K; k += 256) {
+    for (int k = tid; k < K; k += NT) {
       const double e = theta[p_w + k] - mx;
       theta[p_w + k] = e;
       eta[k] = e;
@@ -381,28 +388,32 @@ static __device__ void pack_from_theta(const AdamDev& a, double* theta, double* 
       w[k] = we;
       wsum += we;
     }
-  for (int d = tid; d < D; d += 256) pr *= lm[d] * inl;  // this thread's own entries of round 1
+  for (int d = tid; d < D; d += NT) pr *= lm[d] * inl;  // this thread's own entries of round 1
   wsum = wave_sum(wsum);
   pr = fm::wave_prod_dpp(pr);
   if (lane == 0) {
-    red[8 + wave] = wsum;
-    red[12 + wave] = pr;
+    red[2 * NW + wave] = wsum;
+    red[3 * NW + wave] = pr;
   }
   __syncthreads();
-  wsum = (red[8] + red[9]) + (red[10] + red[11]);
-  pr = (red[12] * red[13]) * (red[14] * red[15]);
+  wsum = (red[2 * NW] + red[2 * NW + 1]) + (red[2 * NW + 2] + red[2 * NW + 3]);
+  pr = (red[3 * NW] * red[3 * NW + 1]) * (red[3 * NW + 2] * red[3 * NW + 3]);
+  if (NW == 8) {
+    wsum += (red[2 * NW + 4] + red[2 * NW + 5]) + (red[2 * NW + 6] + red[2 * NW + 7]);
+    pr *= (red[3 * NW + 4] * red[3 * NW + 5]) * (red[3 * NW + 6] * red[3 * NW + 7]);
+  }
   const double nconst = a.c_norm / pr;  // 1 / (2 pi)^(D/2) / prod(lambda)   (entmc_vbmc.py:54-56)
   const double l2n = 0x1.71547652b82fep+0 * fm::log_fast(nconst);
   // ---- the pack and the final attributes (lm stays raw until every reader is through) ----
   const MixLayout& ml = a.ml;
-  for (int i = tid; i < K * D; i += 256) {
+  for (int i = tid; i < K * D; i += NT) {
     const int d = i % D;
     const double m = o_mu ? theta[i] : mu[i];
     mu[i] = m;
     p[ml.o_mu + i] = m;
     p[ml.o_mup + i] = m * fm::rcp_fast(lm[d] * inl);
   }
-  for (int k = tid; k < K; k += 256) {
+  for (int k = tid; k < K; k += NT) {
     const double s = (o_sg ? fm::exp2_fast(0x1.71547652b82fep+0 * theta[p_sg + k]) : sg[k]) * nl;
     const double wk = o_w ? w[k] / wsum : w[k];
     double sD = 1.0, b = s;  // sigma^D by repeated squaring, as the host pack (ctx.hip)
@@ -421,7 +432,7 @@ static __device__ void pack_from_theta(const AdamDev& a, double* theta, double* 
     p[ml.o_w + k] = wk;
   }
   __syncthreads();
-  for (int d = tid; d < D; d += 256) {
+  for (int d = tid; d < D; d += NT) {
     const double l = lm[d] * inl;
     lm[d] = l;
     p[ml.o_lam + d] = l;

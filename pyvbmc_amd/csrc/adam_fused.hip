@@ -45,24 +45,117 @@ using namespace adam_dev;
 
 namespace {
 
-constexpr int SW = 4;  // waves per workgroup
+constexpr int SW = 8;        // waves per workgroup: two per SIMD (a float64 instruction every ~4 cycles instead of ~7)
+constexpr int NT = 64 * SW;  // threads
 constexpr double LOG2E = 0x1.71547652b82fep+0;
 
 __device__ __forceinline__ void st_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_wt(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0)
 
+// the SW per-wave partials r[0 .. SW) in a fixed order
+__device__ __forceinline__ double sumw(const double* r) {
+  double v = (r[0] + r[1]) + (r[2] + r[3]);
+  if (SW == 8) v += (r[4] + r[5]) + (r[6] + r[7]);
+  return v;
+}
+
+// adam_dev::pack_from_theta for K <= 64, D <= 16: set_parameters (variational_posterior.py:680-759) with the
+// eta max-shift (variational_optimization.py:1082-1085) and the mixture pack.  EVERY wave computes the
+// per-component and per-dimension quantities itself (lane = k, lane = d) and so owns the four wave-wide
+// reductions: one barrier (before theta's eta tail is shifted in place) instead of five.  The waves share the
+// stores.  theta, aux and p are LDS arrays.
+__device__ void pack_waves(const AdamDev& a, double* theta, double* aux, double* p) {
+  const int D = a.D, K = a.K, tid = threadIdx.x, n = a.n_theta;
+  const int lane = tid & 63, wave = tid >> 6;
+  const bool o_mu = a.mask & 1, o_sg = a.mask & 2, o_lm = a.mask & 4, o_w = a.mask & 8;
+  const int p_sg = o_mu ? D * K : 0, p_lm = p_sg + (o_sg ? K : 0), p_w = n - K;
+  double* mu = aux;
+  double* sg = mu + K * D;
+  double* lm = sg + K;
+  double* w = lm + D;
+  double* eta = w + K;
+  const MixLayout& ml = a.ml;
+  int bad = 0;
+  for (int i = tid; i < n; i += NT) bad |= !isfinite(theta[i]);
+  if (bad) atomicOr(a.status, 1);
+  const bool isd = lane < D, isk = lane < K;
+  // raw lambda (lane = d), the eta tail (lane = k)
+  const double l_raw = isd ? (o_lm ? fm::exp2_fast(LOG2E * theta[p_lm + lane]) : lm[lane]) : 0.0;
+  const double th_w = (o_w && isk) ? theta[p_w + lane] : -INFINITY;
+  const double th_s = (o_sg && isk) ? theta[p_sg + lane] : 0.0;
+  const double sg_old = isk ? sg[lane] : 1.0, w_old = isk ? w[lane] : 0.0;
+  const double s2 = fm::wave_sum_dpp(l_raw * l_raw);
+  const double mx = fm::wave_max_dpp(th_w);
+  const double nl = sqrt(s2 / D);  // lambda -> unit RMS, sigma absorbs it
+  const double inl = 1.0 / nl;
+  const double e = th_w - mx;
+  const double we = (o_w && isk) ? fm::exp2_fast(LOG2E * e) : 0.0;
+  const double wsum = fm::wave_sum_dpp(we);
+  const double l_n = l_raw * inl;
+  const double pr = fm::wave_prod_dpp(isd ? l_n : 1.0);
+  const double nconst = a.c_norm / pr;  // 1 / (2 pi)^(D/2) / prod(lambda)   (entmc_vbmc.py:54-56)
+  const double l2n = LOG2E * fm::log_fast(nconst);
+  __syncthreads();  // every wave has read theta's eta tail and the old attributes
+  // per component (lane = k): wave 0 stores
+  if (wave == 0 && isk) {
+    const int k = lane;
+    const double s = (o_sg ? fm::exp2_fast(LOG2E * th_s) : sg_old) * nl;
+    const double wk = o_w ? we / wsum : w_old;
+    double sD = 1.0, b = s;  // sigma^D by repeated squaring, as the host pack (ctx.hip)
+    for (int ex = D; ex > 0; ex >>= 1) {
+      if (ex & 1) sD *= b;
+      b *= b;
+    }
+    if (o_w) {
+      theta[p_w + k] = e;
+      eta[k] = e;
+    }
+    sg[k] = s;
+    w[k] = wk;
+    const double rsD = nconst * fm::rcp_fast(sD);
+    p[ml.o_is2 + k] = fm::rcp_fast(s * s);
+    p[ml.o_rc + k] = rsD;
+    p[ml.o_lrc + k] = l2n - D * (LOG2E * fm::log_fast(s));
+    p[ml.o_wc + k] = wk * rsD;
+    p[ml.o_sig + k] = s;
+    p[ml.o_w + k] = wk;
+  }
+  // per dimension (lane = d): wave 1 stores
+  if (wave == 1 && isd) {
+    lm[lane] = l_n;
+    p[ml.o_lam + lane] = l_n;
+    p[ml.o_ilam + lane] = fm::rcp_fast(l_n);
+  }
+  // the means (K D entries): waves 2 .. SW - 1; 1 / lambda_d from the lane that holds dimension d
+  {
+    const double il = fm::rcp_fast(l_n);  // lane d: 1 / (lambda_d / nl)
+    for (int base = (wave - 2) * 64; wave >= 2 && base < K * D; base += (SW - 2) * 64) {
+      const int i = base + lane;
+      const int d = i % D;
+      const int ilo = __builtin_amdgcn_ds_bpermute(d << 2, __double2loint(il));
+      const int ihi = __builtin_amdgcn_ds_bpermute(d << 2, __double2hiint(il));
+      if (i < K * D) {
+        const double m = o_mu ? theta[i] : mu[i];
+        mu[i] = m;
+        p[ml.o_mu + i] = m;
+        p[ml.o_mup + i] = m * __hiloint2double(ihi, ilo);
+      }
+    }
+  }
+}
+
 template <int DP>
-__global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
+__global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
   extern __shared__ double sh[];
-  __shared__ double red[32];
+  __shared__ double red[8 * SW];
   __shared__ double red2[SW][128];
   __shared__ int s_ok;
   const AdamDev& a = f.a;
   const AdamLayout& L = a.lay;
   const MixLayout& ml = a.ml;
   const int D = a.D, K = a.K, S = a.S, n = a.n_theta, N = f.N;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = blockIdx.x, G = gridDim.x;
   const bool o_mu = a.mask & 1, o_sg = a.mask & 2, o_lm = a.mask & 4, o_w = a.mask & 8;
@@ -84,20 +177,20 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
   double* ee = sh + f.o_ee;
   double* recs = sh + f.o_recs;
   double* sE = sh + f.o_eps;
-  double* part = sh + f.o_part;   // [SW][2 DP + 1] | W [SW][64]
+  double* part = sh + f.o_part;   // entropy workgroups' reduction scratch, laid over recs | gsc | sXT | sAl (dead / unused there)
   double* out = sh + f.o_out;
   double* gsc = sh + f.o_gp;
   double* sXT = sh + f.o_xt;
   double* sAl = sh + f.o_alpha;
 
   // ---- what persists across the iterations of this launch ----
-  for (int i = tid; i < L.o_raw(); i += 256) sh[i] = a.state[i];
-  for (int i = tid; i < ml.total; i += 256) pack[i] = a.mix[i];
-  constexpr int U = 4;  // n_theta <= 1024 (adam_fused_plan)
+  for (int i = tid; i < L.o_raw(); i += NT) sh[i] = a.state[i];
+  for (int i = tid; i < ml.total; i += NT) pack[i] = a.mix[i];
+  constexpr int U = 1024 / NT;  // n_theta <= 1024 (adam_fused_plan)
   double r_m[U], r_v[U], r_lo[U], r_hi[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int i = u * 256 + tid;
+    const int i = u * NT + tid;
     const bool in = i < n;
     r_m[u] = in ? a.state[L.o_m() + i] : 0.0;
     r_v[u] = in ? a.state[L.o_v() + i] : 0.0;
@@ -105,8 +198,8 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
     r_hi[u] = (in && a.has_box) ? a.state[L.o_xub() + i] : 0.0;
   }
   if (g >= f.n_ent) {
-    for (int i = tid; i < D * N; i += 256) sXT[i] = f.XT[i];
-    for (int i = tid; i < S * N; i += 256) sAl[i] = f.alpha[i];
+    for (int i = tid; i < D * N; i += NT) sXT[i] = f.XT[i];
+    for (int i = tid; i < S * N; i += NT) sAl[i] = f.alpha[i];
   }
   __syncthreads();
 
@@ -123,7 +216,37 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
     if (tslot >= 0 && tid == 0 && t < 64) f.times[((size_t)tslot * 64 + t) * 16 + p] = wall_clock64();
   };
 
+  // the normals of component g's rows at iteration `it` (philox.h: row j n_half + row_begin + i, block d / 4)
+  auto make_draws = [&](int it) {
+    const int rows = f.rows;
+    if (f.eps_mode == VBMC_EPS_PHILOX) {
+      const int nb = (D + 3) >> 2;
+      const uint64_t seed = f.seed + (uint64_t)it;
+      // two threads per Philox block, one Box-Muller pair each (the block itself is computed twice: it is the short part)
+      for (int q = tid; q < 2 * rows * nb; q += NT) {
+        const int h = q & 1, ib = q >> 1, i = ib / nb, b = ib - i * nb;
+        const uint64_t row = (uint64_t)g * (uint64_t)f.n_half + (uint64_t)(f.row_begin + i);
+        const Philox4 r = philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)b, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+        double z0, z1;
+        philox_bm32(h ? r.x[2] : r.x[0], h ? r.x[3] : r.x[1], z0, z1);
+        const int d0 = 4 * b + 2 * h;
+        if (d0 < D) sE[i * D + d0] = z0;
+        if (d0 + 1 < D) sE[i * D + d0 + 1] = z1;
+      }
+    } else if (it == f.i0) {  // resident draws: the same block every iteration
+      const double* src = f.eps + (int64_t)g * f.eps_rows * D;
+      for (int i = tid; i < rows * D; i += NT) sE[i] = src[i];
+    }
+  };
+  if (g < f.n_ent) make_draws(f.i0);
+
+  const int tid_launch = tid;
   for (int t = 0; t < f.n_iters; ++t) {
+    // (an opaque zero ties everything derived from the thread index to the iteration: hoisted out of this long loop,
+    // the address arithmetic of its ~40 inner loops was worth 75 spilled registers)
+    int zoff;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zoff));
+    const int tid = tid_launch + zoff, lane = tid & 63;
     const int iter = f.i0 + t;
     double* xb = f.xch + (size_t)(t & 1) * RT;
     stamp(t, 0);
@@ -133,21 +256,6 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
       const int j = g, k = lane;
       const bool live = k < K;
       const int rows = f.rows;
-      if (f.eps_mode == VBMC_EPS_PHILOX) {
-        const int nb = (D + 3) >> 2;
-        const uint64_t seed = f.seed + (uint64_t)iter;
-        for (int it = tid; it < rows * nb; it += 256) {
-          const int i = it / nb, b = it - i * nb;
-          double z[4];
-          philox_normal_quad((uint64_t)j * (uint64_t)f.n_half + (uint64_t)(f.row_begin + i), (uint32_t)b, seed, z);
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (4 * b + q < D) sE[i * D + 4 * b + q] = z[q];
-        }
-      } else if (t == 0) {  // resident draws: the same block every iteration
-        const double* src = f.eps + (int64_t)j * f.eps_rows * D;
-        for (int i = tid; i < rows * D; i += 256) sE[i] = src[i];
-      }
       // the lane's table row (prep.hip's table block, from the pack in LDS)
       const double* mup = pack + ml.o_mup;
       const double sig_j = pack[ml.o_sig + j];
@@ -198,58 +306,63 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
           B[d] = fma(e[d] * e[d], gs, B[d]);
         }
       }
-      // per wave: the sums over its lanes (= k) of what component j's entries need
+      // component j's entries need, summed over the lanes (= k) and the waves (= rows):
       //   mu_d  : sigma_j A_d(k) + w_k/sigma_k^2 Delta_jk,d W(k)       (entropy.hip finish, mu_from_w)
       //   lam_d : sigma_j B_d(k) + Delta_jk,d A_d(k)
+      // every wave lays its 2D per-lane values down in LDS, then wave c % SW sums item c over the waves and its lanes
       stamp(t, 10);
-      double* pw = part + wave * (2 * DP + 1);
-      if (lane == 0) pw[0] = slog;
+      const int NI = 2 * D + 1;
+      double* pc = part;                      // [SW][2D + 1][K]
+      double* pW = pc + (size_t)SW * NI * K;  // [SW][64]
+      double* pS = pW + SW * 64;              // [SW] slog
+      if (live) {
+        double sl = 0.0;
 #pragma unroll
-      for (int d = 0; d < DP; ++d) {
-        const double smu = fm::wave_sum_dpp(fma(sig_j, A[d], (wis2 * dl[d]) * W));
-        const double slm = fm::wave_sum_dpp(fma(sig_j, B[d], dl[d] * A[d]));
-        if (lane == 0) {
-          pw[1 + d] = smu;
-          pw[1 + DP + d] = slm;
-        }
+        for (int d = 0; d < DP; ++d)
+          if (d < D) {
+            const double cl = fma(sig_j, B[d], dl[d] * A[d]);
+            pc[((size_t)wave * NI + d) * K + lane] = fma(sig_j, A[d], (wis2 * dl[d]) * W);
+            pc[((size_t)wave * NI + D + d) * K + lane] = cl;
+            sl += cl;
+          }
+        pc[((size_t)wave * NI + 2 * D) * K + lane] = sl;  // item 2D: sigma_j's entry is the sum of the lambda items
       }
-      part[SW * (2 * DP + 1) + wave * 64 + lane] = W;
+      pW[wave * 64 + lane] = W;
+      if (lane == 0) pS[wave] = slog;
       __syncthreads();
       stamp(t, 11);
-      if (wave == 0) {
-        auto tot = [&](int item) {
+      // item c is summed over the waves and the lanes by wave c % SW, whose lane 0 stores the record entry itself
+      {
+        double* rec = xb + (size_t)j * RE;
+        const double sc = pack[ml.o_w + j] * f.inv_ns;
+        for (int c = wave; c < NI; c += SW) {
           double v = 0.0;
+          if (live) {
 #pragma unroll
-          for (int wv = 0; wv < SW; ++wv) v += part[wv * (2 * DP + 1) + item];
-          return v;
-        };
-        const double w_j = pack[ml.o_w + j];
-        const double sc = w_j * f.inv_ns;
-        double Wk = 0.0;
+            for (int wv = 0; wv < SW; ++wv) v += pc[((size_t)wv * NI + c) * K + lane];
+          }
+          v = fm::wave_sum_dpp(v);
+          if (lane == 0) {
+            if (c < D) st_wt(rec + 1 + c, v * sc * pack[ml.o_ilam + c]);
+            else if (c < 2 * D) st_wt(rec + 2 + c, v);  // 2 + D + (c - D)
+            else st_wt(rec + 1 + D, v * sc);
+          }
+        }
+        if (wave == SW - 1 && live) {
+          double Wk = 0.0;
 #pragma unroll
-        for (int wv = 0; wv < SW; ++wv) Wk += part[SW * (2 * DP + 1) + wv * 64 + lane];
-        if (live) out[2 + 2 * D + lane] = Wk;
-        double slm = 0.0;
-        if (lane < D) {
-          slm = tot(1 + DP + lane);
-          out[1 + lane] = tot(1 + lane) * sc * pack[ml.o_ilam + lane];
-          out[2 + D + lane] = slm;
+          for (int wv = 0; wv < SW; ++wv) Wk += pW[wv * 64 + lane];
+          st_wt(rec + 2 + 2 * D + lane, Wk);
         }
-        const double sg = fm::wave_sum_dpp(slm);
-        if (lane == 0) {
-          out[0] = tot(0);
-          out[1 + D] = sg * sc;
-        }
+        if (wave == SW - 2 && lane == 0) st_wt(rec, sumw(pS));
       }
-      __syncthreads();
-      for (int i = tid; i < RE; i += 256) st_wt(xb + (size_t)j * RE + i, out[i]);
     } else {
       // ================= phase A, GP sums of blocks (s,k) (glj_block.h; variational_optimization.py:1400-1465) =================
       double* sItau = gsc;
       double* sMu = sItau + D;
       double* sZa = sMu + D;
       double* sPart = sZa + N;
-      double* sMisc = sPart + 4;
+      double* sMisc = sPart + SW;
       for (int b = g - f.n_ent; b < n_blocks; b += f.n_gp) {
         const int s = b / K, k = b - s * K;
         const double* h = hyp + (size_t)s * a.P;
@@ -269,7 +382,7 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
         }
         __syncthreads();
         const double lnnf = sMisc[0];
-        for (int nn = tid; nn < N; nn += 256) {
+        for (int nn = tid; nn < N; nn += NT) {
           double d2 = 0.0;
           for (int d = 0; d < D; ++d) {
             const double dlt = (sMu[d] - sXT[d * N + nn]) * sItau[d];
@@ -281,13 +394,13 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
         __syncthreads();
         {
           double acc = 0.0;
-          for (int nn = tid; nn < N; nn += 256) acc += sZa[nn];
+          for (int nn = tid; nn < N; nn += NT) acc += sZa[nn];
           acc = fm::wave_sum_dpp(acc);
           if (lane == 0) sPart[wave] = acc;
         }
         {
           const int ns = tid & 15, ds = tid >> 4;
-          for (int d = ds; d < D; d += 16) {
+          for (int d = ds; d < D; d += NT / 16) {
             const double m = sMu[d], itau = sItau[d];
             double au = 0.0, at = 0.0;
             for (int nn = ns; nn < N; nn += 16) {
@@ -308,7 +421,8 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
         // this block's CONTRIBUTIONS to the entropy-free part of dF (adam_dev::adam_pre_body, phases 1-2: every term of
         // it is linear in the per-(s,k) quantities, so the sums over s and k are left to phase B): lane = d
         if (wave == 0) {
-          const double r0 = (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]);
+          double r0 = (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]);
+          if (SW == 8) r0 += (sPart[4] + sPart[5]) + (sPart[6] + sPart[7]);
           const bool quad = a.mean_kind == VBMC_MEAN_NEGQUAD;
           const double inv_S = 1.0 / S;
           const double wk = pack[ml.o_w + k];
@@ -356,7 +470,9 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
     if (tid == 0) __hip_atomic_store(f.flags + g, (unsigned long long)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     stamp(t, 2);
 
-    // ---- while the flags travel: soft bounds (_vp_bound_loss :537-606), which need theta only ----
+    // ---- while the flags travel: the next iteration's normals, and the soft bounds (_vp_bound_loss :537-606),
+    // which need theta only ----
+    if (g < f.n_ent && t + 1 < f.n_iters) make_draws(iter + 1);
     double* dL = work;              // [n_bnd]
     double* gsg = dL + a.n_bnd;     // [K]
     double* gw = gsg + K;           // [K]
@@ -367,12 +483,17 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
     const double* lm = sg + K;
     const double* wv = lm + D;
     const double* eta = wv + K;
+    // (and the iteration's bias corrections and step size, minimize_adam.py:92-98: off the path behind the gather)
+    const double it1 = (double)(iter + 1);
+    const double c1 = 1.0 / (1.0 - fm::exp2_fast(it1 * a.l2_beta1));
+    const double c2 = 1.0 / (1.0 - fm::exp2_fast(it1 * a.l2_beta2));
+    const double step = a.master_min + (a.master_max - a.master_min) * fm::exp2_fast(-it1 * a.l2e_over_decay);
     double loss = 0.0;
     if (a.has_bnd) {
       const double* bnd_lb = sh + L.o_blb();
       const double* bnd_ub = sh + L.o_bub();
       const int n_mu = o_mu ? D * K : 0, n_sc = (o_sg || o_lm) ? D * K : 0;
-      for (int i = tid; i < a.n_bnd; i += 256) {
+      for (int i = tid; i < a.n_bnd; i += NT) {
         double x;
         if (i < n_mu) {
           x = theta[i];
@@ -424,13 +545,13 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
     __syncthreads();  // (also: dL complete)
     if (!s_ok) return;
     stamp(t, 3);
-    for (int base = 0; base < RT; base += 256 * 10) {
+    for (int base = 0; base < RT; base += NT * 10) {
       double v[10];
 #pragma unroll
-      for (int u = 0; u < 10; ++u) v[u] = ld_wt(xb + min(base + u * 256 + tid, RT - 1));
+      for (int u = 0; u < 10; ++u) v[u] = ld_wt(xb + min(base + u * NT + tid, RT - 1));
 #pragma unroll
       for (int u = 0; u < 10; ++u) {
-        const int i = base + u * 256 + tid;
+        const int i = base + u * NT + tid;
         if (i < RT) recs[i] = v[u];  // entropy records, then the GP contribution records
       }
     }
@@ -440,11 +561,6 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
 
     // ================= phase B (every workgroup): the raw vector [H | mu | sigma | lambda | w] and the
     // entropy-free part of dF (the sums adam_pre_body's phase 2 makes, over the contribution records) =================
-    for (int i = tid; i < K * (D + 1); i += 256) {
-      const int j = i / (D + 1), c = i - j * (D + 1);
-      if (c < D) raw[1 + j * D + c] = recs[j * RE + 1 + c];
-      else raw[1 + D * K + j] = recs[j * RE + 1 + D];
-    }
     const int n_out = 1 + D + K;
     for (int o = lane; o < n_out; o += 64) {
       // outputs H, lambda_d, w_u: lane = output, the waves split the components j
@@ -457,38 +573,51 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
       }
       red2[wave][o] = acc;
     }
-    double gpart = 0.0, ps = 0.0, pd = 0.0;
-    for (int k = tid; k < K; k += 256) {
-      const double sgk = sg[k], wk = wv[k];
-      double gs = 0.0, nu = 0.0, b0 = 0.0, qbar = 0.0;
-      for (int sidx = 0; sidx < S; ++sidx) {
-        const double* c = crec + (size_t)(sidx * K + k) * RC + 2 * D;
-        gs += c[0];
-        nu += c[1];
-        b0 += c[2];
-        qbar += c[3];
+    // the rest of this stage is three independent jobs, each a chain of LDS round trips: one per group of waves
+    if (wave == 0) {
+      // per component (lane = k; K <= 64): the sums over s, the entropy-free weight gradient, the softmax terms
+      double gpart = 0.0, ps = 0.0, pd = 0.0;
+      if (lane < K) {
+        const int k = lane;
+        const double sgk = sg[k], wk = wv[k];
+        double gs = 0.0, nu = 0.0, b0 = 0.0, qbar = 0.0;
+        for (int sidx = 0; sidx < S; ++sidx) {
+          const double* c = crec + (size_t)(sidx * K + k) * RC + 2 * D;
+          gs += c[0];
+          nu += c[1];
+          b0 += c[2];
+          qbar += c[3];
+        }
+        const double wI = b0 - 0.5 * nu;  // mean over s of I_sk
+        gpart = wk * wI;
+        gsg[k] = wk * sgk * (gs - qbar);
+        double gg = -wI;  // d(-G)/dw_k; the entropy part is added by the update below
+        if (a.has_bnd && o_w) {  // weight penalty (:1211-1229)
+          const bool small = wk < a.w_thresh;
+          loss += (small ? wk : a.w_thresh) * a.w_pen;
+          if (small) gg += a.w_pen;
+        }
+        gw[k] = gg;
+        if (o_w) {
+          const double e = fm::exp2_fast(LOG2E * eta[k]);
+          ee[k] = e;
+          ps = e;
+          pd = e * gg;
+        }
       }
-      const double wI = b0 - 0.5 * nu;  // mean over s of I_sk
-      gpart += wk * wI;
-      gsg[k] = wk * sgk * (gs - qbar);
-      double gg = -wI;  // d(-G)/dw_k; the entropy part is added below
-      if (a.has_bnd && o_w) {  // weight penalty (:1211-1229)
-        const bool small = wk < a.w_thresh;
-        loss += (small ? wk : a.w_thresh) * a.w_pen;
-        if (small) gg += a.w_pen;
+      gpart = fm::wave_sum_dpp(gpart);
+      ps = fm::wave_sum_dpp(ps);
+      pd = fm::wave_sum_dpp(pd);
+      if (lane == 0) {
+        red[0] = gpart;
+        red[2 * SW] = ps;
+        red[3 * SW] = pd;
       }
-      gw[k] = gg;
-      if (o_w) {
-        const double e = fm::exp2_fast(LOG2E * eta[k]);
-        ee[k] = e;
-        ps += e;
-        pd += e * gg;
-      }
-    }
-    {
-      const int ns = tid & 15, g16 = tid >> 4;
+    } else if (wave <= 4) {
+      // per dimension (one 16-lane group each; D <= 16): lambda's sums over (s, k), the soft bounds folded onto lambda
+      const int ns = tid & 15, d = (tid - 64) >> 4;
       const int sc0 = o_mu ? D * K : 0;
-      for (int d = g16; d < D; d += 16) {
+      if (d < D) {
         double acc = 0.0, accb = 0.0;
         for (int idx = ns; idx < n_blocks; idx += 16) acc += crec[(size_t)idx * RC + D + d];
         if (a.has_bnd && o_lm)
@@ -500,32 +629,47 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
           bl[d] = accb;
         }
       }
+    } else {
+      // component j's own entries of the raw vector were finished by its workgroup: copies
+      for (int i = tid - 5 * 64; i < K * (D + 1); i += NT - 5 * 64) {
+        const int j = i / (D + 1), c = i - j * (D + 1);
+        if (c < D) raw[1 + j * D + c] = recs[j * RE + 1 + c];
+        else raw[1 + D * K + j] = recs[j * RE + 1 + D];
+      }
     }
-    gpart = fm::wave_sum_dpp(gpart);
-    loss = fm::wave_sum_dpp(loss);
-    ps = fm::wave_sum_dpp(ps);
-    pd = fm::wave_sum_dpp(pd);
-    if (lane == 0) {
-      red[wave] = gpart;
-      red[4 + wave] = loss;
-      red[8 + wave] = ps;
-      red[12 + wave] = pd;
+    if (a.has_bnd) {
+      loss = fm::wave_sum_dpp(loss);
+      if (lane == 0) red[SW + wave] = loss;
     }
     stamp(t, 5);
     __syncthreads();
-    for (int o = tid; o < n_out; o += 256) {
-      const double sum = (red2[0][o] + red2[1][o]) + (red2[2][o] + red2[3][o]);
-      if (o == 0) raw[0] = -sum * f.inv_ns;
-      else if (o <= D) raw[1 + D * K + K + (o - 1)] = sum * f.inv_ns * pack[ml.o_ilam + (o - 1)];
-      else raw[f_w + (o - 1 - D)] = -f.inv_ns * (recs[(o - 1 - D) * RE] + sum);
+    {
+      double sd = 0.0;
+      const int o = tid;  // n_out <= 81
+      if (o < n_out) {
+        double sum = (red2[0][o] + red2[1][o]) + (red2[2][o] + red2[3][o]);
+        if (SW == 8) sum += (red2[4][o] + red2[5][o]) + (red2[6][o] + red2[7][o]);
+        if (o == 0) {
+          raw[0] = -sum * f.inv_ns;
+        } else if (o <= D) {
+          raw[1 + D * K + K + (o - 1)] = sum * f.inv_ns * pack[ml.o_ilam + (o - 1)];
+        } else {
+          const double rw = -f.inv_ns * (recs[(o - 1 - D) * RE] + sum);
+          raw[f_w + (o - 1 - D)] = rw;
+          if (o_w) sd = ee[o - 1 - D] * rw;  // the softmax Jacobian of the entropy's weight gradient needs sum_k e_k raw_k
+        }
+      }
+      if (wave < 2) {
+        sd = fm::wave_sum_dpp(sd);
+        if (lane == 0) red[6 * SW + wave] = sd;
+      }
     }
     {
-      const double Gv = (red[0] + red[1]) + (red[2] + red[3]);
-      const double lossv = (red[4] + red[5]) + (red[6] + red[7]);
-      const double pm_s = o_w ? (red[8] + red[9]) + (red[10] + red[11]) : 1.0;
-      const double pm_dot = o_w ? (red[12] + red[13]) + (red[14] + red[15]) : 0.0;
+      const double Gv = red[0], lossv = a.has_bnd ? sumw(red + SW) : 0.0;
+      const double pm_s = o_w ? red[2 * SW] : 1.0;
+      const double pm_dot = o_w ? red[3 * SW] : 0.0;
       const int sc0 = o_mu ? D * K : 0;
-      for (int i = tid; i < n; i += 256) {
+      for (int i = tid; i < n; i += NT) {
         double gg;
         if (o_mu && i < D * K) {
           const int k = i / D, d = i - k * D;
@@ -563,32 +707,8 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
 
     // ---- dF, Adam update (minimize_adam.py:89-105), as adam_step_kernel ----
     {
-      const double it1 = (double)(iter + 1);
-      const double c1 = 1.0 / (1.0 - fm::exp2_fast(it1 * a.l2_beta1));
-      const double c2 = 1.0 / (1.0 - fm::exp2_fast(it1 * a.l2_beta2));
-      const double step = a.master_min + (a.master_max - a.master_min) * fm::exp2_fast(-it1 * a.l2e_over_decay);
-      const double* sg = aux + K * D;
-      const double* lm = sg + K;
-      const double* eta = lm + D + K;
-      double sm_s = 1.0, sm_dot = 0.0;
-      if (o_w) {
-        double ps = 0.0, pd = 0.0;
-        for (int k = tid; k < K; k += 256) {
-          const double e = fm::exp2_fast(LOG2E * eta[k]);
-          ee[k] = e;
-          ps += e;
-          pd += e * raw[f_w + k];
-        }
-        ps = fm::wave_sum_dpp(ps);
-        pd = fm::wave_sum_dpp(pd);
-        if (lane == 0) {
-          red[16 + wave] = ps;
-          red[20 + wave] = pd;
-        }
-        __syncthreads();
-        sm_s = (red[16] + red[17]) + (red[18] + red[19]);
-        sm_dot = (red[20] + red[21]) + (red[22] + red[23]);
-      }
+      const double sm_s = o_w ? red[2 * SW] : 1.0;                      // sum_k e_k and sum_k e_k raw_k, from the stages above
+      const double sm_dot = o_w ? red[6 * SW] + red[6 * SW + 1] : 0.0;
       if (g == 0 && tid == 0) {
         const double Gv = pre[n], loss = pre[n + 1], H = raw[0];
         double* y_out = a.y_tab + 3 * (size_t)iter;
@@ -599,7 +719,7 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
       double* x_row = a.x_tab + (size_t)iter * n;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int i = u * 256 + tid;
+        const int i = u * NT + tid;
         if (i >= n) continue;
         const double rr = raw[raw_index(i)], rp = pre[i];
         double gr;
@@ -628,17 +748,17 @@ __global__ __launch_bounds__(64 * SW) void adam_fused_kernel(FusedArgs f) {
 
     // ---- set_parameters + the pack of the next iterate ----
     stamp(t, 7);
-    pack_from_theta(a, theta, aux, red, pack);
+    pack_waves(a, theta, aux, pack);
     __syncthreads();
     stamp(t, 8);
   }
 
   if (g == 0) {  // the state the next batch (or vbmc_adam_end) starts from
-    for (int i = tid; i < L.o_hyp(); i += 256) a.state[i] = sh[i];  // theta | aux
-    for (int i = tid; i < ml.total; i += 256) a.mix[i] = pack[i];
+    for (int i = tid; i < L.o_hyp(); i += NT) a.state[i] = sh[i];  // theta | aux
+    for (int i = tid; i < ml.total; i += NT) a.mix[i] = pack[i];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = u * 256 + tid;
+      const int i = u * NT + tid;
       if (i < n) {
         a.state[L.o_m() + i] = r_m[u];
         a.state[L.o_v() + i] = r_v[u];
@@ -688,13 +808,18 @@ size_t adam_fused_plan(FusedArgs& f) {
   f.o_raw = take(raw_len(D, K));
   f.o_pack = take(a.ml.total);
   f.o_ee = take(K);
-  f.o_recs = take((size_t)K * RE + (size_t)S * K * RC);
   f.o_eps = take((size_t)f.rows * D);
-  f.o_part = take((size_t)SW * (2 * DP + 1) + (size_t)SW * 64);
   f.o_out = take(RE > RG ? RE : RG);
-  f.o_gp = take((size_t)2 * D + N + 8);
+  // the entropy workgroups' reduction scratch lies over what they do not use in phase A: the gathered
+  // records (dead until the gather) and the GP workgroups' arrays
+  f.o_recs = take((size_t)K * RE + (size_t)S * K * RC);
+  f.o_part = f.o_recs;
+  f.o_gp = take((size_t)2 * D + N + SW + 4);
   f.o_xt = take((size_t)D * N);
   f.o_alpha = take((size_t)S * N);
+  const size_t need_part = (size_t)SW * (2 * D + 1) * K + (size_t)SW * 64 + SW + 2;
+  if (o - (size_t)f.o_recs < need_part) o = (size_t)f.o_recs + need_part;
+  (void)DP;
   const size_t bytes = o * sizeof(double);
   return bytes <= 154 * 1024 ? bytes : 0;  // + 4.5 KB of static arrays <= 160 KB
 }
