@@ -120,6 +120,10 @@ int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
  *   "entmc_mfma"   1 = shapes the FP64 matrix tile pads little and the wave-split kernel runs one wave per SIMD on
  *                  (D > 10 or K > 80, K within 12 below a multiple of 16: BASELINE config 5) take the matrix-pipe form
  *                  of the entropy kernel (default), 0 = the wave-split kernel everywhere
+ *   "adam_fused"   [VBMC_ADAM_FUSED]: 1 = vbmc_adam_run runs a batch of iterations as ONE launch where the shape allows
+ *                  (one rank, K <= 64, D <= 16, <= 64 antithetic rows per component, LDS plan fits; default),
+ *                  0 = always four launches per iteration; 2 = test hook (the launch also waits for a workgroup
+ *                  that does not exist and must end by its 20 ms limit with VBMC_E_HIP)
  *   "elbo_pregen"  [VBMC_ELBO_PREGEN]: 1 = Philox draws generated ahead of the entropy
  *                  kernel (default), 0 = generated in-line by it; same values either way
  *   "elbo_ahead"   [VBMC_ELBO_AHEAD]: 1 = after a Philox evaluation with seed s the draws of
@@ -157,7 +161,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value);
 
 /* Launch geometry of the most recent Monte-Carlo entropy of this ctx (vbmc_entmc,
  * vbmc_neg_elcbo, the optimiser loop): out[0] = kernel (0 generic, 1 wave-split, 2 small-
- * sample, 3 matrix-pipe form), out[1] = 64-row batches per workgroup (the wave-split kernel's batch loop count),
+ * sample, 3 matrix-pipe form, 4 the fused optimiser loop: no entropy launch of its own), out[1] = 64-row batches per workgroup (the wave-split kernel's batch loop count),
  * out[2] = workgroups per component, out[3] = 1 if the draws were read from HBM, 0 if
  * generated in-line.  Lets the parity tests assert which code path they exercised. */
 int vbmc_last_entmc_plan(const vbmc_ctx* ctx, int out[4]);
@@ -370,7 +374,9 @@ int vbmc_neg_elcbo_batch(vbmc_ctx* ctx, const double* thetas_BxN, int B, int n_t
  * vb_train_mc_fun = _neg_elcbo(theta, gp, vp0, beta, ns_ent_K, compute_grad=True,
  * theta_bnd=...) (vbmc/variational_optimization.py:238-249).  theta, the Adam moments and
  * the mixture stay on the device; one iteration is four kernel launches and no
- * synchronisation.  The early-stopping decision (minimize_adam.py:107-140) stays with the
+ * synchronisation -- or, at the sample counts optimize_vp really uses (ns_ent = 100 K^(2/3) in total,
+ * option_configs/advanced_vbmc_options.ini:43), a whole vbmc_adam_run is ONE launch of resident workgroups
+ * that exchange their results once per iteration (option "adam_fused").  The early-stopping decision (minimize_adam.py:107-140) stays with the
  * caller, who sees y_tab / x_tab after every vbmc_adam_run -- the reference only tests it
  * every 20 iterations.
  *
@@ -382,7 +388,8 @@ int vbmc_neg_elcbo_batch(vbmc_ctx* ctx, const double* thetas_BxN, int B, int n_t
  * vbmc_adam_run: the next n_iters iterations.  y_tab_out[n_iters] = objective values
  *   (minimize_adam's y_tab slice), x_tab_out[n_iters][n_theta] = iterates after each update
  *   (rows; the reference stores them as columns), G_out/H_out[n_iters] the two terms of the
- *   objective.  All nullable.  VBMC_E_NONFINITE if an iterate became non-finite.
+ *   objective.  All nullable.  VBMC_E_NONFINITE if an iterate became non-finite; VBMC_E_HIP if a
+ *   workgroup of the one-launch form did not publish its results within 20 ms (the run is over then).
  * vbmc_adam_end: ends the run; the ctx mixture becomes that of the last iterate (outputs as
  *   in vbmc_theta_to_mixture, nullable; theta_out = last x with its eta tail max-shifted).
  * Between begin and end no other entry point of the same ctx may be called. */

@@ -568,6 +568,7 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
     FusedArgs f = st->fz;
     f.i0 = i0;
     f.n_iters = n_iters;
+    f.test_absent = ctx->opt_adam_fused == 2 ? 1 : 0;
     HIP_TRY(ctx, hipMemsetAsync(st->d_flags, 0, 256 * sizeof(unsigned long long), ctx->stream));
     static const bool want_times = [] {
       const char* e = getenv("VBMC_FUSED_TIMES");  // measurement aid: phase stamps of two workgroups to stderr

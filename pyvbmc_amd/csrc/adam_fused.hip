@@ -528,7 +528,7 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
       int ok = 1;
       for (;;) {
         bool all = true;
-        for (int q = lane; q < G; q += 64)
+        for (int q = lane; q < G + f.test_absent; q += 64)
           all = all && __hip_atomic_load(f.flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
         if (__all(all)) break;
         if (__builtin_amdgcn_readfirstlane((int)((wall_clock64() - t0) > f.timeout))) {

@@ -229,7 +229,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "ws_pair")) ctx->opt_ws_pair = value != 0;
   else if (!strcmp(key, "elbo_arm")) ctx->opt_elbo_arm = value != 0;
   else if (!strcmp(key, "ahead_pct")) ctx->opt_ahead_pct = value;
-  else if (!strcmp(key, "adam_fused")) ctx->opt_adam_fused = value != 0;
+  else if (!strcmp(key, "adam_fused")) ctx->opt_adam_fused = value;  // 2: test hook, see FusedArgs::test_absent
   else if (!strcmp(key, "gen_pt")) ctx->opt_gen_pt = value < 1 ? 1 : value > 16 ? 16 : value;
   else if (!strcmp(key, "ahead_mode")) {
     (void)entmc_ahead_wait(ctx);

@@ -356,3 +356,134 @@ def test_device_loop_random_shapes(ctx):
         shape = dict(D=D, K=K, N=N, S=S, NsK=wl.NsK, cfg=cfg, it=n_it)
         assert got[4] == ref[4], shape
         assert rel_err(got[2], ref[2]) < 1e-8 and rel_err(got[3], ref[3]) < 1e-8, shape
+
+
+FUSED_SHAPES = [dict(cfg=3, D=10, K=50, N=400, S=1, NsK=28), dict(cfg=5, D=16, K=12, N=60, S=3, NsK=40),
+                dict(cfg=2, D=4, K=20, N=200, S=2, NsK=22), dict(cfg=3, D=7, K=64, N=90, S=1, NsK=2),
+                dict(cfg=5, D=11, K=1, N=50, S=1, NsK=128), dict(cfg=3, D=6, K=20, N=60, S=8, NsK=28)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", FUSED_SHAPES, ids=lambda s: "D%d-K%d-S%d-NsK%d" % (s["D"], s["K"], s["S"], s["NsK"]))
+def test_fused_loop_vs_four_launch_loop_and_oracle(ctx, shape):
+    """The loop at the reference's own sample counts (ns_ent = 100 K^(2/3) in total, advanced_vbmc_options.ini:43:
+    NsK = 28 at K = 50) as ONE launch per batch (csrc/adam_fused.hip) against the four-launch iteration and
+    against oracle Adam on the same Philox draws: the reference's default shape, three GP hyper-parameter
+    samples with the quadratic mean, more GP blocks than GP workgroups (S K > 128), K = 64 lanes full, K = 1,
+    one antithetic pair per component, 64 rows per component (the fused loop's limit)."""
+    from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+
+    wl = synthetic.make_workload(shape["cfg"], S=shape["S"], D=shape["D"], K=shape["K"], N=shape["N"],
+                                 Ns_total=shape["NsK"] * shape["K"])
+    wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,
+              hyp=wl.hyp, s2=np.zeros(0) if wl.s2 is None else wl.s2)
+    bnd = synthetic.default_theta_bnd(wl)
+    theta0 = wl.theta.copy()
+    theta0[0] += 4.0  # one coordinate outside its soft bound
+    kw = dict(tol_fun=1e-9, master_min=0.001, master_max=0.1, master_decay=200)
+    n_it = 47  # two full batches and a short one
+    runs = {}
+    for fused in (1, 0):
+        ctx.set_option("adam_fused", fused)
+        vp, gp = device_objects(wd, ctx)
+        runs[fused] = minimize_adam_elbo(theta0, gp, vp, wl.NsK, bnd, max_iter=n_it, seed=77, rng="philox",
+                                         return_parts=True, **kw)
+        assert (ctx.last_entmc_plan()["kernel"] == "adam_fused") == bool(fused), ctx.last_entmc_plan()
+        runs[fused, "vp"] = vp
+    ctx.set_option("adam_fused", 1)
+    a, b = runs[1], runs[0]
+    assert a[4] == b[4] == n_it
+    # the two device loops agree far inside what either owes the oracle (summation orders differ)
+    assert rel_err(a[2], b[2]) < 1e-10 and rel_err(a[3], b[3]) < 1e-10, (rel_err(a[2], b[2]), rel_err(a[3], b[3]))
+    assert rel_err(a[5], b[5]) < 1e-10 and rel_err(a[6], b[6]) < 1e-9  # G and H of every iteration
+    for name in ("mu", "sigma", "lambd", "w"):
+        assert rel_err(np.ravel(getattr(runs[1, "vp"], name)), np.ravel(getattr(runs[0, "vp"], name))) < 1e-10, name
+    ref = oracle_philox_run(wl, wd, theta0, bnd, 77, n_it, **kw)
+    assert a[4] == ref[4]
+    assert rel_err(a[2], ref[2]) < 1e-7 and rel_err(a[3], ref[3]) < 1e-7, (rel_err(a[2], ref[2]), rel_err(a[3], ref[3]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [(True, True, True, False), (True, True, False, True), (False, True, True, True)],
+                         ids=["warmup-no-weights", "no-lambda", "no-mu"])
+def test_fused_loop_partial_masks_box_and_resident_draws(ctx, flags):
+    """The fused loop with blocks that are not optimised, with box constraints, and with ONE resident set of
+    NumPy-stream draws reused by every iteration (rng="numpy"), each against the four-launch iteration."""
+    from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+
+    wl = synthetic.make_workload(3, S=2, D=6, K=18, N=70, Ns_total=18 * 30)
+    wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,
+              hyp=wl.hyp, s2=np.zeros(0))
+    mix = oracle_mix(wd)
+    mix.optimize_mu, mix.optimize_sigma, mix.optimize_lambd, mix.optimize_weights = flags
+    from oracle import mixture_ref
+
+    theta0 = mixture_ref.get_parameters(mix)
+    theta0[0] += 5.0
+    bnd = masked_bounds(wl, flags)
+    lb, ub = theta0 - 0.3, theta0 + 0.2
+    for extra in (dict(seed=3, rng="philox"), dict(rng="numpy"), dict(seed=3, rng="philox", lb=lb, ub=ub)):
+        out = {}
+        for fused in (1, 0):
+            ctx.set_option("adam_fused", fused)
+            vp, gp = device_objects(wd, ctx)
+            vp.optimize_mu, vp.optimize_sigma, vp.optimize_lambd, vp.optimize_weights = flags
+            if extra.get("rng") == "numpy":
+                np.random.seed(11)
+            out[fused] = minimize_adam_elbo(theta0, gp, vp, wl.NsK, bnd, max_iter=40, use_early_stopping=False, **extra)
+            assert (ctx.last_entmc_plan()["kernel"] == "adam_fused") == bool(fused)
+        ctx.set_option("adam_fused", 1)
+        assert rel_err(out[1][2], out[0][2]) < 1e-10 and rel_err(out[1][3], out[0][3]) < 1e-10, (flags, extra.keys())
+        if "lb" in extra:
+            assert np.all(out[1][2] >= lb[:, None]) and np.all(out[1][2] <= ub[:, None])
+
+
+@pytest.mark.gpu
+def test_fused_loop_applies_only_to_its_shapes(ctx):
+    """K > 64, D > 16, more than 64 rows per component, a row slice (virtual rank) or an LDS plan that does not
+    fit keep the four-launch iteration; a non-finite iterate is reported as before."""
+    from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+
+    for kwargs, fused in ((dict(D=10, K=50, N=400, NsK=28), True), (dict(D=10, K=65, N=100, NsK=28), False),
+                          (dict(D=17, K=10, N=100, NsK=28), False), (dict(D=10, K=20, N=100, NsK=130), False),
+                          (dict(D=16, K=40, N=1200, NsK=28), False)):
+        wl = synthetic.make_workload(3, S=1, D=kwargs["D"], K=kwargs["K"], N=kwargs["N"], Ns_total=kwargs["NsK"] * kwargs["K"])
+        wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,
+                  hyp=wl.hyp, s2=np.zeros(0))
+        vp, gp = device_objects(wd, ctx)
+        out = minimize_adam_elbo(wl.theta.copy(), gp, vp, wl.NsK, synthetic.default_theta_bnd(wl), max_iter=20, seed=1)
+        assert np.all(np.isfinite(out[3]))
+        assert (ctx.last_entmc_plan()["kernel"] == "adam_fused") == fused, (kwargs, ctx.last_entmc_plan())
+    # a row slice: one virtual rank's share
+    wl = synthetic.make_workload(3, S=1, D=10, K=50, N=400, Ns_total=50 * 28)
+    wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y, hyp=wl.hyp,
+              s2=np.zeros(0))
+    vp, gp = device_objects(wd, ctx)
+    minimize_adam_elbo(wl.theta.copy(), gp, vp, wl.NsK, synthetic.default_theta_bnd(wl), max_iter=20, seed=1, rows=(0, 7))
+    assert ctx.last_entmc_plan()["kernel"] != "adam_fused"
+
+
+@pytest.mark.gpu
+def test_fused_loop_bounded_wait(ctx):
+    """Every spin of the fused loop is bounded: made to wait for a workgroup that does not exist (test hook), the
+    launch ends after its 20 ms limit, the call reports it, and the context runs the next optimisation."""
+    import time
+
+    from pyvbmc_amd import _lib
+    from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+
+    wl, wd = workload_dict("c1")
+    wl = synthetic.make_workload(3, S=1, D=10, K=50, N=400, Ns_total=50 * 28)
+    wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y, hyp=wl.hyp,
+              s2=np.zeros(0))
+    vp, gp = device_objects(wd, ctx)
+    bnd = synthetic.default_theta_bnd(wl)
+    ctx.set_option("adam_fused", 2)
+    t0 = time.perf_counter()
+    with pytest.raises(_lib.VbmcHipError, match="did not publish"):
+        minimize_adam_elbo(wl.theta.copy(), gp, vp, wl.NsK, bnd, max_iter=40, seed=1)
+    assert time.perf_counter() - t0 < 5.0
+    ctx.set_option("adam_fused", 1)
+    vp, gp = device_objects(wd, ctx)
+    out = minimize_adam_elbo(wl.theta.copy(), gp, vp, wl.NsK, bnd, max_iter=40, seed=1)
+    assert out[4] == 40 and np.all(np.isfinite(out[3])) and ctx.last_entmc_plan()["kernel"] == "adam_fused"

@@ -195,6 +195,21 @@ def main():
     emit("8f-2 minimize_adam, device-resident loop (per iteration)", "vbmc/minimize_adam.py:84-105 + variational_optimization.py:238-249",
          f"NsK={wl1.NsK} K={K} N={N} iters={n_it}", t / n_it, tc_entmc_grad, "oracle entropy value+grad of one evaluation, scaled (the GP part and the update are negligible)",
          rel(out[3], oh[3]), {"host_loop_device_objective_ms_per_iter": 1e3 * th / n_it, "device_vs_host_loop": th / t})
+    # the same loop at the sample count optimize_vp really uses (ns_ent = 100 K^(2/3) in total, advanced_vbmc_options.ini:43:
+    # NsK = 28 at K = 50): one launch per batch of iterations (csrc/adam_fused.hip) against the four-launch iteration
+    nsk_ref = 2 * max(1, int(round(100.0 * K ** (2.0 / 3.0) / K / 2.0)))
+    kw2 = dict(max_iter=400, master_min=0.001, master_max=0.1, master_decay=200, use_early_stopping=False)
+    per = {}
+    for fused in (0, 1):
+        ctx.set_option("adam_fused", fused)
+        vv = mkvp(wl1)
+        tt, oo = med(lambda: minimize_adam_elbo(wl1.theta.copy(), g, vv, nsk_ref, bnd, seed=11, rng="philox", **kw2), reps=5, warm=1)
+        per[fused] = (tt / 400, oo, ctx.last_entmc_plan()["kernel"])
+    ctx.set_option("adam_fused", 1)
+    emit("8f-2b minimize_adam at the reference's ns_ent (per iteration)", "vbmc/minimize_adam.py:84-137; option_configs/advanced_vbmc_options.ini:43",
+         f"NsK={nsk_ref} K={K} N={N} iters=400", per[1][0], tc_entmc_grad * nsk_ref / wl1.NsK,
+         "oracle entropy value+grad of one evaluation, scaled to this NsK", rel(per[1][1][3], per[0][1][3]),
+         {"four_launch_iteration_ms": 1e3 * per[0][0], "fused_vs_four_launches": per[0][0] / per[1][0], "kernels": [per[0][2], per[1][2]]})
     # ---- 8f row 3: acquisition evaluation on the cached search batch (2^13 points) ------------
     from types import SimpleNamespace
     from oracle import acq_ref

@@ -43,6 +43,7 @@ done
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/pmc_MFMA_c5 -o p -- $B --config 5 --steps 10 --warmup 2 --no-secondary > /dev/null 2>&1
 unset VBMC_ELBO_ARM
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_adam -o s -- python $REPO/tools/adam_loop_profile.py > $OUT/adam_loop.txt 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_adam_small -o s -- python $REPO/tools/adam_small_probe.py child > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_rows -o s -- python $REPO/tools/bench_rows.py > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_rows_mfma -o p -- python $REPO/tools/bench_rows.py > /dev/null 2>&1
 # gp.predict at the acquisition batch size (M = 8192, config 3): durations, HBM traffic, matrix-pipe and LDS counters
@@ -56,7 +57,7 @@ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCL
 # the host-driven step's timeline
 bash $REPO/tools/step_timeline.sh $OUT/timeline --no-secondary > $OUT/timeline_stdout.txt 2>&1
 # the same statistics with the launches an armed evaluation cancelled told apart (tools/trace_stats.py)
-for d in stats stats_res stats_c2 stats_c5 stats_c4job stats_c5job stats_adam stats_predict; do
+for d in stats stats_res stats_c2 stats_c5 stats_c4job stats_c5job stats_adam stats_adam_small stats_predict; do
   t=$(find $OUT/$d -name "*_kernel_trace.csv" | head -1)
   [ -n "$t" ] && python $REPO/tools/trace_stats.py "$t" $OUT/$d/completed_stats.csv
 done
@@ -71,7 +72,10 @@ python bench.py --steps 200 --warmup 20 > $OUT/bench_c3_philox.json 2>/dev/null
 python bench.py --config 4 --steps 50 --warmup 5 > $OUT/bench_c4job.json 2>/dev/null
 python bench.py --config 5 --job --steps 50 --warmup 5 > $OUT/bench_c5job.json 2>/dev/null
 python tools/ws_k_probe.py 10 > $OUT/ws_k_probe_d10.txt 2>/dev/null
-python tools/mfma_probe.py > $OUT/mfma_probe.txt 2>/dev/null
+python tools/mfma_probe.py 10 12 16 20 24 32 > $OUT/mfma_probe.txt 2>/dev/null
+VBMC_MFMA_ANY=1 python tools/mfma_c3_probe.py > $OUT/mfma_c3_probe.txt 2>/dev/null
+python tools/adam_small_probe.py > $OUT/adam_small_probe.txt 2>/dev/null
+VBMC_FUSED_TIMES=1 python tools/adam_small_probe.py child 2>&1 | awk '/^fused/ {c[$3]++; if (c[$3] % 4 == 1) {print; getline; print}; next} /phase A of/ {next} {print}' > $OUT/fused_phase_times.txt
 ./tools/ubench_gen2 > $OUT/ubench_gen2.txt 2>/dev/null
 ./tools/ubench_mfma_entropy > $OUT/ubench_mfma_entropy.txt 2>/dev/null
 python bench.py --steps 200 --warmup 20 --rng resident --no-secondary > $OUT/bench_c3_resident.json 2>/dev/null

@@ -23,7 +23,7 @@ out = Path(__file__).resolve().parent.parent / "profiles"
 out.mkdir(exist_ok=True)
 for mode, d in (("philox", "stats"), ("resident", "stats_res"), ("adam_loop", "stats_adam"), ("config2", "stats_c2"),
                 ("config5", "stats_c5"), ("config4_job", "stats_c4job"), ("config5_job", "stats_c5job"),
-                ("predict", "stats_predict")):
+                ("predict", "stats_predict"), ("adam_small", "stats_adam_small")):
     f = src / d / "s_kernel_stats.csv"
     if f.exists():
         shutil.copy(f, out / f"{tag}_kernel_stats_{mode}.csv")
@@ -40,7 +40,7 @@ for p in sorted(src.glob("pmc_*/p_counter_collection.csv")):
     for r in csv.DictReader(open(p)):
         acc[(wl, r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for extra in ("timeline/timeline.txt", "gp_probe.txt", "adam_loop.txt", "rows.json", "ws_k_probe_d10.txt", "mfma_probe.txt",
-              "ubench_gen2.txt", "ubench_mfma_entropy.txt"):
+              "ubench_gen2.txt", "ubench_mfma_entropy.txt", "mfma_c3_probe.txt", "adam_small_probe.txt", "fused_phase_times.txt"):
     f = src / extra
     if f.exists():
         shutil.copy(f, out / f"{tag}_{Path(extra).name}")
