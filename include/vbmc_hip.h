@@ -123,7 +123,7 @@ int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
  *   "adam_fused"   [VBMC_ADAM_FUSED]: 1 = vbmc_adam_run runs a batch of iterations as ONE launch where the shape allows
  *                  (one rank, K <= 64, D <= 16, <= 64 antithetic rows per component, LDS plan fits; default),
  *                  0 = always four launches per iteration; 2 = test hook (the launch also waits for a workgroup
- *                  that does not exist and must end by its 20 ms limit with VBMC_E_HIP)
+ *                  that does not exist, must give up by its 20 ms limit, and the batch is redone as four launches)
  *   "elbo_pregen"  [VBMC_ELBO_PREGEN]: 1 = Philox draws generated ahead of the entropy
  *                  kernel (default), 0 = generated in-line by it; same values either way
  *   "elbo_ahead"   [VBMC_ELBO_AHEAD]: 1 = after a Philox evaluation with seed s the draws of
@@ -388,8 +388,9 @@ int vbmc_neg_elcbo_batch(vbmc_ctx* ctx, const double* thetas_BxN, int B, int n_t
  * vbmc_adam_run: the next n_iters iterations.  y_tab_out[n_iters] = objective values
  *   (minimize_adam's y_tab slice), x_tab_out[n_iters][n_theta] = iterates after each update
  *   (rows; the reference stores them as columns), G_out/H_out[n_iters] the two terms of the
- *   objective.  All nullable.  VBMC_E_NONFINITE if an iterate became non-finite; VBMC_E_HIP if a
- *   workgroup of the one-launch form did not publish its results within 20 ms (the run is over then).
+ *   objective.  All nullable.  VBMC_E_NONFINITE if an iterate became non-finite.  (If a workgroup of the
+ *   one-launch form does not publish its results within 20 ms, the launch gives up with the state of the start
+ *   of the batch intact and this call runs the batch -- and the rest of the run -- as four launches per iteration.)
  * vbmc_adam_end: ends the run; the ctx mixture becomes that of the last iterate (outputs as
  *   in vbmc_theta_to_mixture, nullable; theta_out = last x with its eta tail max-shifted).
  * Between begin and end no other entry point of the same ctx may be called. */

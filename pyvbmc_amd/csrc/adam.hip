@@ -222,6 +222,7 @@ struct AdamState {
   bool eps_started = false;  // the buffer already holds the finish/step slices of the next iteration
   // the fused loop (adam_fused.hip): one launch per batch at the reference's own sample counts
   bool fused = false;
+  int fused_gave_up = 0;  // batches redone as four launches per iteration after a bounded wait ran out
   FusedArgs fz;
   size_t fused_lds = 0;
   double* d_xch = nullptr;
@@ -445,6 +446,7 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
   }
   // the fused loop where its shape applies (adam_fused.hip)
   st->fused = false;
+  st->fused_gave_up = 0;
   if (ctx->opt_adam_fused && ctx->world == 1 && st->row_begin == 0 && st->row_count == n_half) {
     FusedArgs& f = st->fz;
     f = FusedArgs();
@@ -563,7 +565,12 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
   } timing_off(ctx);
   const int i0 = st->iter;
   int rc = 0;
-  // the iteration base every kernel of this call adds its launch-constant offset to
+  int status = 0;
+  std::vector<double> y3(3 * (size_t)n_iters);
+  // (second pass only when the one-launch form gave up waiting: the state in memory is then still that of the start of
+  // the batch -- workgroup 0 writes it back at the very end -- so the batch is simply run again as four launches per
+  // iteration, and the rest of the optimisation too)
+  for (int attempt = 0; attempt < 2; ++attempt) {
   if (st->fused && !multi && n_iters > 0) {
     FusedArgs f = st->fz;
     f.i0 = i0;
@@ -612,9 +619,6 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
   }
   if (rc) return rc;
   HIP_TRY(ctx, hipGetLastError());
-  st->iter = i0 + n_iters;
-  int status = 0;
-  std::vector<double> y3(3 * (size_t)n_iters);
   if (n_iters > 0) {
     HIP_TRY(ctx, hipMemcpyAsync(y3.data(), st->y_tab + 3 * (size_t)i0, sizeof(double) * 3 * n_iters,
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -624,12 +628,18 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
   }
   HIP_TRY(ctx, hipMemcpyAsync(&status, st->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, stream_wait(ctx));
+  if (!(status & 4) || !st->fused) break;
+  st->fused = false;
+  st->fused_gave_up++;
+  HIP_TRY(ctx, hipMemsetAsync(st->d_status, 0, sizeof(int), ctx->stream));
+  }
+  st->iter = i0 + n_iters;
   for (int it = 0; it < n_iters; ++it) {
     if (y_tab_out) y_tab_out[it] = y3[3 * (size_t)it];
     if (G_out) G_out[it] = y3[3 * (size_t)it + 1];
     if (H_out) H_out[it] = y3[3 * (size_t)it + 2];
   }
-  if (status & 4) {
+  if (status & 4) {  // (cannot happen: the second pass does not wait for anybody)
     st->active = false;
     return vbmc_fail(ctx, VBMC_E_HIP, "adam_run: a workgroup of the fused loop did not publish within 20 ms");
   }

@@ -28,7 +28,8 @@
 // memory, no draw buffer and no partial rows.  Workgroup 0 writes the iterate and (y, G, H) rows the
 // host's stopping rule reads, and the state back at the end of the batch.  Every spin is bounded
 // (a workgroup that never arrives -- it cannot happen with <= 192 workgroups on 256 CUs, but a hung
-// GPU is not an acceptable failure mode -- raises status bit 4 and every workgroup leaves).
+// GPU is not an acceptable failure mode -- raises status bit 4 and every workgroup leaves without writing the
+// state back; vbmc_adam_run then redoes the batch as four launches per iteration).
 //
 // Used when the loop runs on one rank, K <= 64, D <= 16, at most 64 antithetic rows per component and
 // the LDS plan fits (adam_fused_plan); everything else keeps the four-launch iteration.  Same draws
