@@ -70,7 +70,7 @@ struct FusedArgs {
   int n_ent = 0, n_gp = 0;        // workgroups: K entropy + n_gp GP-sum workers
   int i0 = 0, n_iters = 0;
   int test_absent = 0;            // test hook (option "adam_fused" = 2): also wait for a workgroup that does not exist
-  int o_pre = 0, o_raw = 0, o_pack = 0, o_ee = 0, o_recs = 0, o_eps = 0, o_part = 0, o_out = 0, o_gp = 0, o_xt = 0,
+  int o_pack = 0, o_ee = 0, o_recs = 0, o_eps = 0, o_part = 0, o_out = 0, o_gp = 0, o_xt = 0,
       o_alpha = 0;                // LDS carve, in doubles (adam_fused_plan)
 };
 size_t adam_fused_plan(FusedArgs& f);

@@ -161,7 +161,6 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
   const int g = blockIdx.x, G = gridDim.x;
   const bool o_mu = a.mask & 1, o_sg = a.mask & 2, o_lm = a.mask & 4, o_w = a.mask & 8;
   const int p_sg = o_mu ? D * K : 0, p_lm = p_sg + (o_sg ? K : 0), p_w = n - K;
-  const int f_w = 1 + D * K + K + D;  // weight block of the raw vector
   const int RE = 2 + 2 * D + K;       // entropy record: slog | raw mu_j (D) | raw sigma_j | lam_j (D) | W_j (K)
   const int RC = 2 * D + 4;           // GP contribution record: gmu (D) | glm (D) | gs | nu | b0 | qbar
   const int n_blocks = S * K;
@@ -172,8 +171,6 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
   double* aux = sh + L.o_aux();
   const double* hyp = sh + L.o_hyp();
   double* work = sh + L.o_raw();  // phase B scratch
-  double* pre = sh + f.o_pre;
-  double* raw = sh + f.o_raw;
   double* pack = sh + f.o_pack;
   double* ee = sh + f.o_ee;
   double* recs = sh + f.o_recs;
@@ -204,12 +201,6 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
   }
   __syncthreads();
 
-  auto raw_index = [&](int i) -> int {
-    if (o_mu && i < D * K) return 1 + i;
-    if (o_sg && i >= p_sg && i < p_sg + K) return 1 + D * K + (i - p_sg);
-    if (o_lm && i >= p_lm && i < p_lm + D) return 1 + D * K + K + (i - p_lm);
-    return f_w + (i - p_w);
-  };
 
   // phase stamps of workgroups 0 (entropy) and n_ent (GP sums), VBMC_FUSED_TIMES=1: a measurement aid
   const int tslot = f.times == nullptr ? -1 : (g == 0 ? 0 : (g == f.n_ent ? 1 : -1));
@@ -489,6 +480,8 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
     const double c1 = 1.0 / (1.0 - fm::exp2_fast(it1 * a.l2_beta1));
     const double c2 = 1.0 / (1.0 - fm::exp2_fast(it1 * a.l2_beta2));
     const double step = a.master_min + (a.master_max - a.master_min) * fm::exp2_fast(-it1 * a.l2e_over_decay);
+    if (o_w)
+      for (int k = tid; k < K; k += NT) ee[k] = fm::exp2_fast(LOG2E * eta[k]);  // softmax terms of the current iterate
     double loss = 0.0;
     if (a.has_bnd) {
       const double* bnd_lb = sh + L.o_blb();
@@ -560,11 +553,12 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
     stamp(t, 4);
     const double* crec = recs + K * RE;  // [S K][2D + 4]: gmu (D) | glm (D) | gs | nu | b0 | qbar
 
-    // ================= phase B (every workgroup): the raw vector [H | mu | sigma | lambda | w] and the
-    // entropy-free part of dF (the sums adam_pre_body's phase 2 makes, over the contribution records) =================
+    // ================= phase B (every workgroup): dF and the update, from the records in LDS =================
+    // stage 1: every wave takes its share of the sums over j (H, lambda_d, w_u); beside that, three independent
+    // jobs, each a chain of LDS round trips, on three groups of waves
     const int n_out = 1 + D + K;
     for (int o = lane; o < n_out; o += 64) {
-      // outputs H, lambda_d, w_u: lane = output, the waves split the components j
+      // lane = output, the waves split the components j
       const int col = o == 0 ? 0 : (o <= D ? 2 + D + (o - 1) : 2 + 2 * D + (o - 1 - D));
       double acc = 0.0;
       for (int j = wave; j < K; j += SW) {
@@ -574,7 +568,6 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
       }
       red2[wave][o] = acc;
     }
-    // the rest of this stage is three independent jobs, each a chain of LDS round trips: one per group of waves
     if (wave == 0) {
       // per component (lane = k; K <= 64): the sums over s, the entropy-free weight gradient, the softmax terms
       double gpart = 0.0, ps = 0.0, pd = 0.0;
@@ -600,8 +593,7 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
         }
         gw[k] = gg;
         if (o_w) {
-          const double e = fm::exp2_fast(LOG2E * eta[k]);
-          ee[k] = e;
+          const double e = ee[k];
           ps = e;
           pd = e * gg;
         }
@@ -630,13 +622,26 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
           bl[d] = accb;
         }
       }
-    } else {
-      // component j's own entries of the raw vector were finished by its workgroup: copies
-      for (int i = tid - 5 * 64; i < K * (D + 1); i += NT - 5 * 64) {
-        const int j = i / (D + 1), c = i - j * (D + 1);
-        if (c < D) raw[1 + j * D + c] = recs[j * RE + 1 + c];
-        else raw[1 + D * K + j] = recs[j * RE + 1 + D];
+    } else if (o_w) {
+      // the softmax Jacobian of the entropy's weight gradient needs sum_k e_k raw_k with raw_k = -(slog_k + sum_j w_j W_jk) / ns:
+      // summed the other way round, sum_j [e_j slog_j + w_j sum_k e_k W_jk], it needs no finished raw_k.  lane = j, the
+      // three waves split the k range
+      const int part = wave - 5, k0 = (K * part) / 3, k1 = (K * (part + 1)) / 3;
+      double term = 0.0;
+      if (lane < K) {
+        const double* rj = recs + (size_t)lane * RE;
+        double d0 = 0.0, d1 = 0.0;
+        int k = k0;
+        for (; k + 1 < k1; k += 2) {
+          d0 = fma(ee[k], rj[2 + 2 * D + k], d0);
+          d1 = fma(ee[k + 1], rj[2 + 2 * D + k + 1], d1);
+        }
+        if (k < k1) d0 = fma(ee[k], rj[2 + 2 * D + k], d0);
+        term = pack[ml.o_w + lane] * (d0 + d1);
+        if (part == 0) term = fma(ee[lane], rj[0], term);
       }
+      term = fm::wave_sum_dpp(term);
+      if (lane == 0) red[6 * SW + part] = term;
     }
     if (a.has_bnd) {
       loss = fm::wave_sum_dpp(loss);
@@ -644,76 +649,24 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
     }
     stamp(t, 5);
     __syncthreads();
-    {
-      double sd = 0.0;
-      const int o = tid;  // n_out <= 81
-      if (o < n_out) {
-        double sum = (red2[0][o] + red2[1][o]) + (red2[2][o] + red2[3][o]);
-        if (SW == 8) sum += (red2[4][o] + red2[5][o]) + (red2[6][o] + red2[7][o]);
-        if (o == 0) {
-          raw[0] = -sum * f.inv_ns;
-        } else if (o <= D) {
-          raw[1 + D * K + K + (o - 1)] = sum * f.inv_ns * pack[ml.o_ilam + (o - 1)];
-        } else {
-          const double rw = -f.inv_ns * (recs[(o - 1 - D) * RE] + sum);
-          raw[f_w + (o - 1 - D)] = rw;
-          if (o_w) sd = ee[o - 1 - D] * rw;  // the softmax Jacobian of the entropy's weight gradient needs sum_k e_k raw_k
-        }
-      }
-      if (wave < 2) {
-        sd = fm::wave_sum_dpp(sd);
-        if (lane == 0) red[6 * SW + wave] = sd;
-      }
-    }
+    stamp(t, 6);
+    // stage 2: per entry of theta, dF = entropy-free part + Jacobian(entropy gradient) (entmc_vbmc.py:114-130) and the
+    // Adam update with the box clamp (minimize_adam.py:89-105)
     {
       const double Gv = red[0], lossv = a.has_bnd ? sumw(red + SW) : 0.0;
-      const double pm_s = o_w ? red[2 * SW] : 1.0;
-      const double pm_dot = o_w ? red[3 * SW] : 0.0;
+      const double sm_s = o_w ? red[2 * SW] : 1.0;       // sum_k e_k
+      const double pm_dot = o_w ? red[3 * SW] : 0.0;     // sum_k e_k gw_k
+      const double sm_dot = o_w ? -f.inv_ns * ((red[6 * SW] + red[6 * SW + 1]) + red[6 * SW + 2]) : 0.0;  // sum_k e_k raw_k
       const int sc0 = o_mu ? D * K : 0;
-      for (int i = tid; i < n; i += NT) {
-        double gg;
-        if (o_mu && i < D * K) {
-          const int k = i / D, d = i - k * D;
-          double gm = 0.0;
-          for (int sidx = 0; sidx < S; ++sidx) gm += crec[(size_t)(sidx * K + k) * RC + d];
-          gg = -gm;
-          if (a.has_bnd) gg += dL[i];
-        } else if (o_sg && i >= p_sg && i < p_sg + K) {
-          const int k = i - p_sg;
-          gg = -gsg[k] * sg[k];
-          if (a.has_bnd) {
-            // the reference reshapes this block C-order (D,K) (:585-587); restated as-is
-            double acc = 0.0;
-            for (int d = 0; d < D; ++d) acc += dL[sc0 + d * K + k];
-            gg += acc;
-          }
-        } else if (o_lm && i >= p_lm && i < p_lm + D) {
-          const int d = i - p_lm;
-          gg = -glm[d] * lm[d];
-          if (a.has_bnd) gg += bl[d];
-        } else {
-          const int k = i - p_w;
-          gg = -ee[k] * pm_dot / (pm_s * pm_s) + ee[k] * gw[k] / pm_s;
-          if (a.has_bnd) gg += dL[a.n_bnd - K + k];
-        }
-        pre[i] = gg;
-      }
-      if (tid == 0) {
-        pre[n] = Gv;
-        pre[n + 1] = lossv;
-      }
-    }
-    __syncthreads();
-    stamp(t, 6);
-
-    // ---- dF, Adam update (minimize_adam.py:89-105), as adam_step_kernel ----
-    {
-      const double sm_s = o_w ? red[2 * SW] : 1.0;                      // sum_k e_k and sum_k e_k raw_k, from the stages above
-      const double sm_dot = o_w ? red[6 * SW] + red[6 * SW + 1] : 0.0;
+      auto out_sum = [&](int o) {
+        double sum = (red2[0][o] + red2[1][o]) + (red2[2][o] + red2[3][o]);
+        if (SW == 8) sum += (red2[4][o] + red2[5][o]) + (red2[6][o] + red2[7][o]);
+        return sum;
+      };
       if (g == 0 && tid == 0) {
-        const double Gv = pre[n], loss = pre[n + 1], H = raw[0];
+        const double H = -out_sum(0) * f.inv_ns;
         double* y_out = a.y_tab + 3 * (size_t)iter;
-        y_out[0] = -Gv - H + loss;
+        y_out[0] = -Gv - H + lossv;
         y_out[1] = Gv;
         y_out[2] = H;
       }
@@ -722,17 +675,37 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
       for (int u = 0; u < U; ++u) {
         const int i = u * NT + tid;
         if (i >= n) continue;
-        const double rr = raw[raw_index(i)], rp = pre[i];
-        double gr;
+        double gr;  // dF_i
         if (o_mu && i < D * K) {
-          gr = rp - rr;
+          const int k = i / D, d = i - k * D;
+          double gm = 0.0;
+          for (int sidx = 0; sidx < S; ++sidx) gm += crec[(size_t)(sidx * K + k) * RC + d];
+          double gg = -gm;
+          if (a.has_bnd) gg += dL[i];
+          gr = gg - recs[k * RE + 1 + d];
         } else if (o_sg && i >= p_sg && i < p_sg + K) {
-          gr = rp - rr * sg[i - p_sg];
+          const int k = i - p_sg;
+          double gg = -gsg[k] * sg[k];
+          if (a.has_bnd) {
+            // the reference reshapes this block C-order (D,K) (:585-587); restated as-is
+            double acc = 0.0;
+            for (int d = 0; d < D; ++d) acc += dL[sc0 + d * K + k];
+            gg += acc;
+          }
+          gr = gg - recs[k * RE + 1 + D] * sg[k];
         } else if (o_lm && i >= p_lm && i < p_lm + D) {
-          gr = rp - rr * lm[i - p_lm];
+          const int d = i - p_lm;
+          double gg = -glm[d] * lm[d];
+          if (a.has_bnd) gg += bl[d];
+          const double rr = out_sum(1 + d) * f.inv_ns * pack[ml.o_ilam + d];
+          gr = gg - rr * lm[d];
         } else {
-          const double e = ee[i - p_w];
-          gr = rp + (e * sm_dot / (sm_s * sm_s) - e * rr / sm_s);
+          const int k = i - p_w;
+          const double e = ee[k];
+          double gg = -e * pm_dot / (sm_s * sm_s) + e * gw[k] / sm_s;
+          if (a.has_bnd) gg += dL[a.n_bnd - K + k];
+          const double rr = -f.inv_ns * (recs[k * RE] + out_sum(1 + D + k));
+          gr = gg + (e * sm_dot / (sm_s * sm_s) - e * rr / sm_s);
         }
         const double m = a.beta1 * r_m[u] + (1.0 - a.beta1) * gr;
         const double v = a.beta2 * r_v[u] + (1.0 - a.beta2) * (gr * gr);
@@ -805,8 +778,6 @@ size_t adam_fused_plan(FusedArgs& f) {
     return (int)at;
   };
   o = (o + 1) & ~(size_t)1;
-  f.o_pre = take((size_t)a.n_theta + 2);
-  f.o_raw = take(raw_len(D, K));
   f.o_pack = take(a.ml.total);
   f.o_ee = take(K);
   f.o_eps = take((size_t)f.rows * D);
