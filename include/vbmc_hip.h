@@ -15,7 +15,7 @@
  *     theta[:D*K] / mu.ravel(order="F") of the reference's (D,K) array
  *     (variational_posterior/variational_posterior.py:653-676).
  *   - return value: 0 = ok, <0 = error (VBMC_E_*); text via vbmc_last_error().  One entry point
- *     has a positive "do it again" code (VBMC_W_GP_CHANGED).
+ *     has a positive "do it again" code (VBMC_W_GP_CHANGED), one a positive "not here" code (VBMC_W_NOT_FUSED).
  *     No C++ exception crosses the boundary.
  *   - a vbmc_ctx owns one device, its HIP streams, device scratch and (optionally)
  *     one RCCL communicator.  A ctx is not thread-safe; distinct ctxs are
@@ -45,9 +45,11 @@ enum {
   VBMC_E_UNSUP = -5,   /* combination the reference raises NotImplemented on */
   VBMC_E_NONFINITE = -6, /* non-finite input where the path needs finite    */
   VBMC_E_NOMEM = -7,    /* host allocation failed (vbmc_mt19937_randn)       */
-  VBMC_W_GP_CHANGED = 1 /* vbmc_neg_elcbo only: the watched GP arrays changed (vbmc_set_gp_watch);
+  VBMC_W_GP_CHANGED = 1, /* vbmc_neg_elcbo only: the watched GP arrays changed (vbmc_set_gp_watch);
                            the outputs were computed on the GP of the last vbmc_set_gp: discard them,
                            upload the GP again and repeat the call                               */
+  VBMC_W_NOT_FUSED = 2   /* vbmc_adam_run_auto only: this run does not have the one-launch form (shape, ranks,
+                           or a launch that gave up waiting); nothing was done: use vbmc_adam_run in batches */
 };
 
 /* GP mean functions understood by the path
@@ -397,6 +399,14 @@ int vbmc_neg_elcbo_batch(vbmc_ctx* ctx, const double* thetas_BxN, int B, int n_t
 int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta, const vbmc_elbo_opts* opts,
                     const double* lb, const double* ub, int max_iter, double master_min,
                     double master_max, double master_decay);
+/* vbmc_adam_run_auto: the rest of the optimisation -- up to max_iters iterations -- in ONE call, where the run has the
+ *   one-launch form (option "adam_fused") and stands at a multiple of 20 iterations: the workgroups apply
+ *   minimize_adam's stopping rule themselves (minimize_adam.py:107-140: every 20 iterations from the 40th on, the
+ *   slope of a straight-line fit through the last 20 objective values against its standard error and tol_fun, and
+ *   the distance between the mean iterates of the last two batches) and *n_done returns how many iterations ran;
+ *   outputs as vbmc_adam_run for those.  Returns VBMC_W_NOT_FUSED (and does nothing) otherwise. */
+int vbmc_adam_run_auto(vbmc_ctx* ctx, int max_iters, double tol_fun, int* n_done, double* y_tab_out,
+                       double* x_tab_out, double* G_out, double* H_out);
 int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, double* x_tab_out,
                   double* G_out, double* H_out);
 int vbmc_adam_end(vbmc_ctx* ctx, double* theta_out, double* mu_KxD, double* sigma_K,

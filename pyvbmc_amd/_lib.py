@@ -17,7 +17,8 @@ LIB_PATH = Path(os.environ.get("VBMC_HIP_LIB", _HERE / "libvbmc_hip.so"))
 EPS_RESIDENT, EPS_PHILOX = 0, 1
 MEAN_ZERO, MEAN_CONST, MEAN_NEGQUAD = 0, 1, 2
 E_ARG, E_HIP, E_RCCL, E_NODEV, E_UNSUP, E_NONFINITE = -1, -2, -3, -4, -5, -6
-W_GP_CHANGED = 1  # vbmc_neg_elcbo: the watched GP arrays changed under it (vbmc_set_gp_watch)
+W_GP_CHANGED = 1
+W_NOT_FUSED = 2  # vbmc_neg_elcbo: the watched GP arrays changed under it (vbmc_set_gp_watch)
 
 
 class VbmcHipError(RuntimeError):
@@ -116,6 +117,7 @@ SIGNATURES = {
         [_vp, _dp, C.c_int, C.POINTER(ElboOpts), _dp, _dp, C.c_int, C.c_double, C.c_double, C.c_double],
     ),
     "vbmc_adam_run": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
+    "vbmc_adam_run_auto": (C.c_int, [_vp, C.c_int, C.c_double, C.POINTER(C.c_int), _dp, _dp, _dp, _dp]),
     "vbmc_adam_end": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
     "vbmc_acq_eval": (
         C.c_int,

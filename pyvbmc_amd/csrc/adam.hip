@@ -390,7 +390,7 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
                        (size_t)max_iter * n_theta + 3 * (size_t)max_iter + 64;
   int rc = ensure_dev(ctx, &st->d_buf, &st->d_cap, total);
   if (rc) return rc;
-  if (!st->d_status) HIP_TRY(ctx, hipMalloc((void**)&st->d_status, 2 * sizeof(int)));  // flag, iteration base
+  if (!st->d_status) HIP_TRY(ctx, hipMalloc((void**)&st->d_status, 4 * sizeof(int)));  // flag, iteration base
   if (!st->d_args) HIP_TRY(ctx, hipMalloc((void**)&st->d_args, sizeof(AdamDev)));
   st->state = st->d_buf;
   st->work = st->state + L.end();
@@ -403,7 +403,7 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
   double* sb = st->state;
   HIP_TRY(ctx, hipMemsetAsync(sb, 0, sizeof(double) * L.end(), sm));  // m = v = 0
   HIP_TRY(ctx, hipMemcpyAsync(sb + L.o_theta(), theta0, sizeof(double) * n_theta, hipMemcpyHostToDevice, sm));
-  HIP_TRY(ctx, hipMemsetAsync(st->d_status, 0, 2 * sizeof(int), sm));
+  HIP_TRY(ctx, hipMemsetAsync(st->d_status, 0, 4 * sizeof(int), sm));
   // attributes of the blocks theta does not carry start from the ctx mixture
   std::vector<double> aux(L.n_aux);
   memcpy(aux.data(), ctx->mu.data(), sizeof(double) * K * D);
@@ -646,6 +646,65 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
   if (status) {
     st->active = false;
     return vbmc_fail(ctx, VBMC_E_NONFINITE, "adam_run: an iterate became non-finite");
+  }
+  return VBMC_OK;
+}
+
+// The whole optimisation in one call where the one-launch form applies: the workgroups apply the reference's stopping
+// rule themselves every 20 iterations (minimize_adam.py:107-140), so the host is not in the loop at all.
+extern "C" int vbmc_adam_run_auto(vbmc_ctx* ctx, int max_iters, double tol_fun, int* n_done, double* y_tab_out,
+                                  double* x_tab_out, double* G_out, double* H_out) {
+  if (!ctx || max_iters < 0 || !n_done) return VBMC_E_ARG;
+  NEED_DEVICE(ctx);
+  AdamState* st = (AdamState*)ctx->adam;
+  if (!st || !st->active) return vbmc_fail(ctx, VBMC_E_ARG, "adam_run_auto: vbmc_adam_begin not called");
+  if (st->iter + max_iters > st->max_iter)
+    return vbmc_fail(ctx, VBMC_E_ARG, "adam_run_auto: %d + %d iterations exceed max_iter %d", st->iter, max_iters, st->max_iter);
+  static const bool force_coll = [] {
+    const char* e = getenv("VBMC_FORCE_COLLECTIVE");
+    return e && e[0] == '1';
+  }();
+  const bool multi = ctx->comm != nullptr && (ctx->world > 1 || force_coll);
+  if (!st->fused || multi || max_iters == 0 || st->iter % 20 != 0) return VBMC_W_NOT_FUSED;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int n = st->n_theta, i0 = st->iter;
+  FusedArgs f = st->fz;
+  f.i0 = i0;
+  f.n_iters = max_iters;
+  f.stop_rule = 1;
+  f.tol_fun = tol_fun;
+  f.n_done = st->d_status + 2;
+  f.test_absent = ctx->opt_adam_fused == 2 ? 1 : 0;
+  HIP_TRY(ctx, hipMemsetAsync(st->d_flags, 0, 256 * sizeof(unsigned long long), ctx->stream));
+  int rc = adam_fused_launch(ctx, ctx->stream, f, st->fused_lds);
+  if (rc) return rc;
+  ctx->last_plan[0] = 4;
+  int word[3] = {0, 0, 0};
+  HIP_TRY(ctx, hipMemcpyAsync(word, st->d_status, 3 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
+  if (word[0] & 4) {  // gave up waiting: nothing was written back, the caller runs its batches (four launches per iteration)
+    st->fused = false;
+    st->fused_gave_up++;
+    HIP_TRY(ctx, hipMemsetAsync(st->d_status, 0, sizeof(int), ctx->stream));
+    return VBMC_W_NOT_FUSED;
+  }
+  const int done = word[2];
+  if (done < 1 || done > max_iters) return vbmc_fail(ctx, VBMC_E_HIP, "adam_run_auto: bad iteration count %d", done);
+  std::vector<double> y3(3 * (size_t)done);
+  HIP_TRY(ctx, hipMemcpyAsync(y3.data(), st->y_tab + 3 * (size_t)i0, sizeof(double) * 3 * done, hipMemcpyDeviceToHost, ctx->stream));
+  if (x_tab_out)
+    HIP_TRY(ctx, hipMemcpyAsync(x_tab_out, st->x_tab + (size_t)i0 * n, sizeof(double) * (size_t)done * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, stream_wait(ctx));
+  st->iter = i0 + done;
+  *n_done = done;
+  for (int it = 0; it < done; ++it) {
+    if (y_tab_out) y_tab_out[it] = y3[3 * (size_t)it];
+    if (G_out) G_out[it] = y3[3 * (size_t)it + 1];
+    if (H_out) H_out[it] = y3[3 * (size_t)it + 2];
+  }
+  if (word[0]) {
+    st->active = false;
+    return vbmc_fail(ctx, VBMC_E_NONFINITE, "adam_run_auto: an iterate became non-finite");
   }
   return VBMC_OK;
 }

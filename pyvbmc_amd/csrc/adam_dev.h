@@ -69,6 +69,9 @@ struct FusedArgs {
   unsigned long long* times = nullptr;   // optional [2][64][16] phase stamps (VBMC_FUSED_TIMES=1)
   int n_ent = 0, n_gp = 0;        // workgroups: K entropy + n_gp GP-sum workers
   int i0 = 0, n_iters = 0;
+  int stop_rule = 0;              // 1: every workgroup applies minimize_adam's stopping rule itself (vbmc_adam_run_auto)
+  double tol_fun = 0.0;
+  int* n_done = nullptr;          // iterations this launch ran (written by workgroup 0)
   int test_absent = 0;            // test hook (option "adam_fused" = 2): also wait for a workgroup that does not exist
   int o_pack = 0, o_ee = 0, o_recs = 0, o_eps = 0, o_part = 0, o_out = 0, o_gp = 0, o_xt = 0,
       o_alpha = 0;                // LDS carve, in doubles (adam_fused_plan)

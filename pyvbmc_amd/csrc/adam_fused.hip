@@ -149,7 +149,7 @@ __device__ void pack_waves(const AdamDev& a, double* theta, double* aux, double*
 template <int DP>
 __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
   extern __shared__ double sh[];
-  __shared__ double red[8 * SW];
+  __shared__ double red[9 * SW];
   __shared__ double red2[SW][128];
   __shared__ int s_ok;
   const AdamDev& a = f.a;
@@ -195,6 +195,14 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
     r_lo[u] = (in && a.has_box) ? a.state[L.o_xlb() + i] : 0.0;
     r_hi[u] = (in && a.has_box) ? a.state[L.o_xub() + i] : 0.0;
   }
+  // minimize_adam's stopping rule (minimize_adam.py:107-140), applied by every workgroup to the same numbers: the sums of
+  // its theta entries over the current and the previous batch of 20 iterations, the batch's objective values
+  constexpr int BATCH = 20;
+  __shared__ double ywin[BATCH];
+  double xs_cur[U], xs_prev[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) xs_cur[u] = xs_prev[u] = 0.0;
+  int n_ran = f.n_iters;
   if (g >= f.n_ent) {
     for (int i = tid; i < D * N; i += NT) sXT[i] = f.XT[i];
     for (int i = tid; i < S * N; i += NT) sAl[i] = f.alpha[i];
@@ -663,12 +671,16 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
         if (SW == 8) sum += (red2[4][o] + red2[5][o]) + (red2[6][o] + red2[7][o]);
         return sum;
       };
-      if (g == 0 && tid == 0) {
+      if (tid == 0) {
         const double H = -out_sum(0) * f.inv_ns;
-        double* y_out = a.y_tab + 3 * (size_t)iter;
-        y_out[0] = -Gv - H + lossv;
-        y_out[1] = Gv;
-        y_out[2] = H;
+        const double y = -Gv - H + lossv;
+        ywin[iter % BATCH] = y;
+        if (g == 0) {
+          double* y_out = a.y_tab + 3 * (size_t)iter;
+          y_out[0] = y;
+          y_out[1] = Gv;
+          y_out[2] = H;
+        }
       }
       double* x_row = a.x_tab + (size_t)iter * n;
 #pragma unroll
@@ -715,9 +727,49 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
         double x = theta[i] - step * m_hat / (sqrt(v_hat) + a.fudge);
         if (a.has_box) x = fmin(r_hi[u], fmax(r_lo[u], x));
         theta[i] = x;
+        xs_cur[u] += x;
         if (g == 0) x_row[i] = x;
       }
       __syncthreads();
+    }
+    bool stop = false;
+    if (f.stop_rule && (iter + 1) % BATCH == 0) {
+      // the slope of a straight-line fit through the batch's objective values against its standard error (np.polyfit's:
+      // residual sum / (n - 2) / sum t^2) and the distance between the mean iterates of the last two batches
+      if (iter + 1 >= 2 * BATCH) {
+        double part = 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const double dm = xs_cur[u] / BATCH - xs_prev[u] / BATCH;  // (entries past n_theta hold zeros)
+          part += dm * dm / BATCH;
+        }
+        part = fm::wave_sum_dpp(part);
+        if (lane == 0) red[7 * SW + wave] = part;
+        __syncthreads();
+        const double dx = sqrt(sumw(red + 7 * SW));
+        double ty = 0.0, ys = 0.0, tt = 0.0;
+        for (int k = 0; k < BATCH; ++k) {
+          const double tk = k - 0.5 * (BATCH - 1);
+          ty = fma(tk, ywin[k], ty);
+          ys += ywin[k];
+          tt = fma(tk, tk, tt);
+        }
+        const double slope = ty / tt, ym = ys / BATCH;
+        double rs = 0.0;
+        for (int k = 0; k < BATCH; ++k) {
+          const double r = ywin[k] - ym - slope * (k - 0.5 * (BATCH - 1));
+          rs = fma(r, r, rs);
+        }
+        const double c00 = rs / (BATCH - 2) / tt;
+        const double tol_max = f.tol_fun * 100.0;
+        const double err = sqrt(c00 + f.tol_fun * f.tol_fun), err_max = sqrt(c00 + tol_max * tol_max);
+        stop = (dx < 0.001 && fabs(slope) < err_max) || (fabs(slope) < err && dx < 0.1);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        xs_prev[u] = xs_cur[u];
+        xs_cur[u] = 0.0;
+      }
     }
 
     // ---- set_parameters + the pack of the next iterate ----
@@ -725,7 +777,12 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
     pack_waves(a, theta, aux, pack);
     __syncthreads();
     stamp(t, 8);
+    if (stop) {
+      n_ran = t + 1;
+      break;
+    }
   }
+  if (g == 0 && tid == 0 && f.n_done) *f.n_done = n_ran;
 
   if (g == 0) {  // the state the next batch (or vbmc_adam_end) starts from
     for (int i = tid; i < L.o_hyp(); i += NT) a.state[i] = sh[i];  // theta | aux

@@ -83,7 +83,7 @@ def minimize_adam(f, x0, lb=None, ub=None, tol_fun=0.001, max_iter=10000, master
 def minimize_adam_elbo(theta0, gp, vp, Ns, theta_bnd=None, beta=0.0, lb=None, ub=None, tol_fun=0.001,
                        max_iter=10000, master_min=0.001, master_max=0.1, master_decay=200,
                        use_early_stopping=True, *, rng=None, seed=None, eps_half=None, ctx=None,
-                       return_parts=False, rows=None):
+                       return_parts=False, rows=None, device_stop=True):
     """``minimize_adam(lambda t: _neg_elcbo(t, gp, vp, beta, Ns, True, theta_bnd=theta_bnd)[:2],
     theta0, lb, ub, ...)`` with the whole inner loop on the device.
 
@@ -93,7 +93,8 @@ def minimize_adam_elbo(theta0, gp, vp, Ns, theta_bnd=None, beta=0.0, lb=None, ub
     have to be uploaded every iteration; ``rng="numpy"`` / ``eps_half`` upload ONE set of
     draws from the NumPy stream that every iteration reuses (common random numbers).  On return ``vp``
     holds the parameters of the last iterate (the reference leaves those of the last
-    *evaluated* iterate; its caller overwrites them right away, :283-300)."""
+    *evaluated* iterate; its caller overwrites them right away, :283-300).  ``device_stop=False`` keeps the
+    stopping rule on the host (batches of 20 iterations) also where the device can apply it itself."""
     if beta != 0 and np.isfinite(beta):
         raise NotImplementedError("Computation of the gradient of ELBO with full variance not supported")
     ctx = ctx_of(vp, ctx)
@@ -141,9 +142,17 @@ def minimize_adam_elbo(theta0, gp, vp, Ns, theta_bnd=None, beta=0.0, lb=None, ub
     x_rows = np.empty((max_iter, n))
     y_tab = np.full((max_iter,), np.nan)
     G_tab, H_tab = np.empty(max_iter), np.empty(max_iter)
-    done = 0
+    done, auto = 0, False
     try:
-        while done < max_iter:
+        if use_early_stopping and device_stop:
+            # where the run has the one-launch form, its workgroups apply the stopping rule themselves: one call
+            nd = C.c_int(0)
+            rc = lib.vbmc_adam_run_auto(h_, int(max_iter), float(tol_fun), C.byref(nd), _lib.ptr(y_tab), _lib.ptr(x_rows),
+                                        _lib.ptr(G_tab), _lib.ptr(H_tab))
+            if rc != _lib.W_NOT_FUSED:  # (else: the batches below)
+                ctx.check(rc)
+                done, auto = nd.value, True
+        while not auto and done < max_iter:
             # without early stopping nothing needs the host until the end
             step = min(b if use_early_stopping else max_iter, max_iter - done)
             ctx.check(lib.vbmc_adam_run(h_, step, _lib.ptr(y_tab[done:]), _lib.ptr(x_rows[done:]),

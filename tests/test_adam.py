@@ -489,3 +489,33 @@ def test_fused_loop_bounded_wait(ctx):
     assert out[2][4] == out[0][4] == out[1][4] == 60
     assert np.array_equal(out[2][2], out[0][2]) and np.array_equal(out[2][3], out[0][3])  # the same four-launch arithmetic
     assert rel_err(out[1][2], out[0][2]) < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tol_fun,step", [(0.05, 0.1), (50.0, 1e-4), (0.5, 1e-4), (0.004, 1e-4)])
+def test_fused_loop_applies_the_stopping_rule_itself(ctx, tol_fun, step):
+    """vbmc_adam_run_auto: the workgroups of the one-launch form apply minimize_adam's stopping rule (minimize_adam.py:107-140)
+    every 20 iterations themselves.  Same number of iterations and the same iterates, bit for bit, as the same kernel run
+    in batches of 20 with the rule on the host (np.polyfit), and the iteration count of oracle Adam."""
+    from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+
+    wl = synthetic.make_workload(3, S=1, D=10, K=50, N=400, Ns_total=50 * 28)
+    wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y, hyp=wl.hyp,
+              s2=np.zeros(0))
+    bnd = synthetic.default_theta_bnd(wl)
+    sched = dict(master_min=step / 100, master_max=step, master_decay=200)  # small steps: iterates nearly at rest
+    kw = dict(tol_fun=tol_fun, max_iter=170, seed=21, rng="philox", **sched)
+    out = {}
+    for dev in (True, False):
+        vp, gp = device_objects(wd, ctx)
+        out[dev] = minimize_adam_elbo(wl.theta.copy(), gp, vp, wl.NsK, bnd, device_stop=dev, **kw)
+        assert ctx.last_entmc_plan()["kernel"] == "adam_fused"
+        out[dev, "vp"] = vp
+    a, b = out[True], out[False]
+    assert a[4] == b[4], (a[4], b[4])
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[0], b[0]) and a[1] == b[1]
+    assert np.array_equal(out[True, "vp"].mu, out[False, "vp"].mu) and np.array_equal(out[True, "vp"].w, out[False, "vp"].w)
+    ref = oracle_philox_run(wl, wd, wl.theta.copy(), bnd, 21, 170, tol_fun=tol_fun, **sched)
+    assert a[4] == ref[4], (a[4], ref[4])
+    assert a[4] % 20 == 0 or a[4] == 170
+    print(f"tol_fun={tol_fun} step={step}: stopped after {a[4]} iterations")
