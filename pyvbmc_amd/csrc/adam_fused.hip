@@ -1,39 +1,44 @@
-// The optimiser loop at the reference's OWN sample counts: one launch per batch of iterations.
+// The optimiser loop at the reference's OWN sample counts: one launch per batch of iterations -- or per optimisation.
 //
 // `optimize_vp` runs minimize_adam (vbmc/minimize_adam.py:84-137) around _neg_elcbo
 // (variational_optimization.py:238-249) with ns_ent = 100 K^(2/3) samples in total
 // (option_configs/advanced_vbmc_options.ini:43): 28 per component at K = 50, 14 antithetic rows.
 // At that size every kernel of the four-launch iteration (adam.hip) sits at its latency floor:
-// 7.5 + 11 + 5 + 7 = 30 us, of which hardly 5 are arithmetic.  Here a batch of iterations is ONE
-// launch of K + min(S K, 128) workgroups that stay resident and meet once per iteration:
+// 7.5 + 11 + 5 + 7 = 30 us, of which hardly 5 are arithmetic.  Here K + min(S K, 128) workgroups of 512
+// threads stay resident and meet once per iteration:
 //
 //   phase A (workgroups side by side, from the mixture pack every workgroup holds in its LDS)
 //     workgroup j < K       Monte-Carlo entropy sums of component j (entropy_small.hip's form: lane =
-//                           component k, the four waves split the rows); its (j,k) table rows and
-//                           its rows' Philox normals are made in place; the entries of the raw
-//                           gradient that only need component j (mu_j, sigma_j) are finished here
-//     workgroup K + q       GP expected-log-joint sums of blocks (s,k) = q, q + n_gp, ... (the
-//                           arithmetic of glj_block.h) with X^T and alpha resident in its LDS
-//   exchange                every workgroup stores its record write-through (sc1), drains the
-//                           stores, counts itself on one monotonic word; everybody polls that word
-//                           and then reads ALL records (sc1 loads) into its own LDS: one all-gather of
-//                           K (2 + 2D + K) + S K (1 + 2D) doubles (37 KB at K = 50, D = 10), no fence,
+//                           component k, the eight waves split the rows); its (j,k) table rows are made in
+//                           place, its rows' Philox normals were made during the previous exchange; the
+//                           2D + 1 per-lane sums go through LDS once and wave c % 8 finishes item c and
+//                           stores the record entry; the entries of the raw gradient that only need
+//                           component j (mu_j, sigma_j) are FINISHED here
+//     workgroup K + q       GP expected-log-joint sums of blocks (s,k) = q, q + n_gp, ... (the arithmetic of
+//                           glj_block.h, X^T and alpha resident in its LDS), then the block's CONTRIBUTIONS
+//                           to the entropy-free part of dF (adam_dev::adam_pre_body is linear in them)
+//   exchange                every workgroup stores its record write-through (sc1), drains the stores and
+//                           sets its own flag to the iteration number; while the flags travel: the next
+//                           normals, the soft bounds, the step size; wave 0 polls the flags, then everybody
+//                           reads ALL records (sc1 loads, ten in flight) into LDS: one all-gather of
+//                           K (2 + 2D + K) + S K (2D + 4) doubles (37 KB at K = 50, D = 10), no fence,
 //                           two buffers alternating between iterations
 //   phase B (every workgroup, redundantly and identically, all operands in LDS / registers)
-//                           the sums over j (H, lambda, w), the entropy-free part of dF
-//                           (adam_dev::adam_pre_body), the Adam update with the moments in registers,
-//                           set_parameters + the pack of the next iterate (adam_dev::pack_from_theta)
+//                           the sums over j and (s,k), dF per entry, the Adam update with the moments in
+//                           registers, set_parameters + the pack of the next iterate (pack_waves), and --
+//                           with f.stop_rule -- minimize_adam's stopping rule every 20 iterations
 //
-// so an iteration has ONE inter-workgroup exchange (~2-3 us) and no launch boundary, no table in
-// memory, no draw buffer and no partial rows.  Workgroup 0 writes the iterate and (y, G, H) rows the
-// host's stopping rule reads, and the state back at the end of the batch.  Every spin is bounded
-// (a workgroup that never arrives -- it cannot happen with <= 192 workgroups on 256 CUs, but a hung
-// GPU is not an acceptable failure mode -- raises status bit 4 and every workgroup leaves without writing the
-// state back; vbmc_adam_run then redoes the batch as four launches per iteration).
+// so an iteration has ONE inter-workgroup exchange and no launch boundary, no table in memory, no draw
+// buffer, no partial rows, and the host is not in the loop.  Workgroup 0 writes the iterate and (y, G, H)
+// rows, and the state back at the end.  Every spin is bounded (a workgroup that never publishes -- it
+// cannot happen with <= 192 workgroups on 256 CUs, but a hung GPU is not an acceptable failure mode --
+// raises status bit 4 and every workgroup leaves without writing the state back; the host then runs
+// four launches per iteration from the same state).
 //
 // Used when the loop runs on one rank, K <= 64, D <= 16, at most 64 antithetic rows per component and
 // the LDS plan fits (adam_fused_plan); everything else keeps the four-launch iteration.  Same draws
 // (Philox(seed + i), philox.h), same formulas: tests/test_adam.py runs both against the oracle loop.
+// Measured steps and the phase times: DESIGN.md section 4.6b.
 #include <cstdlib>
 
 #include "adam_dev.h"

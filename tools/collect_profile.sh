@@ -46,6 +46,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_adam -o s -- 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_adam_small -o s -- python $REPO/tools/adam_small_probe.py child > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_rows -o s -- python $REPO/tools/bench_rows.py > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_rows_mfma -o p -- python $REPO/tools/bench_rows.py > /dev/null 2>&1
+python $REPO/tools/summarize_rows_pmc.py $OUT $TAG --condense
 # gp.predict at the acquisition batch size (M = 8192, config 3): durations, HBM traffic, matrix-pipe and LDS counters
 P="python $REPO/tools/predict_loop.py 3 8192 1 20"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_predict -o s -- $P > /dev/null 2>&1

@@ -15,8 +15,28 @@ src, tag = Path(sys.argv[1]), sys.argv[2]
 out = Path(__file__).resolve().parent.parent / "profiles"
 names = ["SQ_INSTS_VALU", "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES"]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for r in csv.DictReader(open(src / "pmc_rows_mfma" / "p_counter_collection.csv")):
-    acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+raw = src / "pmc_rows_mfma" / "p_counter_collection.csv"
+if len(sys.argv) > 3 and sys.argv[3] == "--condense":
+    # on the GPU box (tools/collect_profile.sh): the per-dispatch file of this pass outgrows what gpurun copies back;
+    # keep per kernel and counter the dispatch count and the sum
+    tot = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(raw)):
+        t = tot[(r["Kernel_Name"], r["Counter_Name"])]
+        t[0] += 1
+        t[1] += float(r["Counter_Value"])
+    with open(src / "rows_mfma_pmc_condensed.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "Counter_Name", "Dispatches", "Sum"])
+        for (k, c), (n, v) in sorted(tot.items()):
+            w.writerow([k, c, n, v])
+    sys.exit(0)
+if raw.exists():
+    for r in csv.DictReader(open(raw)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+else:
+    for r in csv.DictReader(open(src / "rows_mfma_pmc_condensed.csv")):
+        n = int(r["Dispatches"])
+        acc[r["Kernel_Name"]][r["Counter_Name"]] = [float(r["Sum"]) / n] * n
 
 
 def short(k):
