@@ -171,11 +171,11 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
   const int n_blocks = S * K;
   const int RT = K * RE + n_blocks * RC;
 
-  // ---- LDS carve: [state prefix | pre-body scratch] is adam_pre_body's own layout ----
+  // ---- LDS carve: [theta | aux | hyp] as in the state block, then this kernel's own arrays ----
   double* theta = sh + L.o_theta();
   double* aux = sh + L.o_aux();
   const double* hyp = sh + L.o_hyp();
-  double* work = sh + L.o_raw();  // phase B scratch
+  double* work = sh + L.o_res();  // phase B scratch (the LDS image of the state ends with the hyper-parameters)
   double* pack = sh + f.o_pack;
   double* ee = sh + f.o_ee;
   double* recs = sh + f.o_recs;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
   double* sAl = sh + f.o_alpha;
 
   // ---- what persists across the iterations of this launch ----
-  for (int i = tid; i < L.o_raw(); i += NT) sh[i] = a.state[i];
+  for (int i = tid; i < L.o_res(); i += NT) sh[i] = a.state[i];  // theta | aux | hyp
   for (int i = tid; i < ml.total; i += NT) pack[i] = a.mix[i];
   constexpr int U = 1024 / NT;  // n_theta <= 1024 (adam_fused_plan)
   double r_m[U], r_v[U], r_lo[U], r_hi[U];
@@ -497,8 +497,10 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
       for (int k = tid; k < K; k += NT) ee[k] = fm::exp2_fast(LOG2E * eta[k]);  // softmax terms of the current iterate
     double loss = 0.0;
     if (a.has_bnd) {
-      const double* bnd_lb = sh + L.o_blb();
-      const double* bnd_ub = sh + L.o_bub();
+      // (the bounds stay in memory: 2 n_bnd doubles of LDS are what would limit N in adam_fused_plan; requesting them
+      // ahead of the normals, into registers, was measured and cost more in spills than the ~0.3 us it hides)
+      const double* bnd_lb = a.state + L.o_blb();
+      const double* bnd_ub = a.state + L.o_bub();
       const int n_mu = o_mu ? D * K : 0, n_sc = (o_sg || o_lm) ? D * K : 0;
       for (int i = tid; i < a.n_bnd; i += NT) {
         double x;
@@ -833,7 +835,7 @@ size_t adam_fused_plan(FusedArgs& f) {
   const int RE = 2 + 2 * D + K, RG = 1 + 2 * D, RC = 2 * D + 4;
   f.n_ent = K;
   f.n_gp = S * K < 128 ? S * K : 128;
-  size_t o = (size_t)a.lay.o_raw() + (size_t)a.n_bnd + 2 * (size_t)K + 2 * (size_t)D;  // state prefix | phase B scratch
+  size_t o = (size_t)a.lay.o_res() + (size_t)a.n_bnd + 2 * (size_t)K + 2 * (size_t)D;  // theta | aux | hyp | phase B scratch
   auto take = [&](size_t cnt) {
     const size_t at = o;
     o += (cnt + 1) & ~(size_t)1;  // 16-byte granules

@@ -444,7 +444,8 @@ def test_fused_loop_applies_only_to_its_shapes(ctx):
     fit keep the four-launch iteration; a non-finite iterate is reported as before."""
     from pyvbmc_amd.minimize_adam import minimize_adam_elbo
 
-    for kwargs, fused in ((dict(D=10, K=50, N=400, NsK=28), True), (dict(D=10, K=65, N=100, NsK=28), False),
+    for kwargs, fused in ((dict(D=10, K=50, N=400, NsK=28), True), (dict(D=10, K=50, N=800, NsK=28), True),
+                          (dict(D=10, K=65, N=100, NsK=28), False),
                           (dict(D=17, K=10, N=100, NsK=28), False), (dict(D=10, K=20, N=100, NsK=130), False),
                           (dict(D=16, K=40, N=1200, NsK=28), False)):
         wl = synthetic.make_workload(3, S=1, D=kwargs["D"], K=kwargs["K"], N=kwargs["N"], Ns_total=kwargs["NsK"] * kwargs["K"])
