@@ -76,6 +76,8 @@ python tools/ws_k_probe.py 10 > $OUT/ws_k_probe_d10.txt 2>/dev/null
 python tools/mfma_probe.py 10 12 16 20 24 32 > $OUT/mfma_probe.txt 2>/dev/null
 VBMC_MFMA_ANY=1 python tools/mfma_c3_probe.py > $OUT/mfma_c3_probe.txt 2>/dev/null
 python tools/adam_small_probe.py > $OUT/adam_small_probe.txt 2>/dev/null
+python tools/adam_shapes_probe.py > $OUT/adam_shapes_probe.txt 2>/dev/null
+python tools/adam_batch_probe.py > $OUT/adam_batch_probe.txt 2>/dev/null
 VBMC_FUSED_TIMES=1 python tools/adam_small_probe.py child 2>&1 | awk '/^fused/ {c[$3]++; if (c[$3] % 4 == 1) {print; getline; print}; next} /phase A of/ {next} {print}' > $OUT/fused_phase_times.txt
 ./tools/ubench_gen2 > $OUT/ubench_gen2.txt 2>/dev/null
 ./tools/ubench_mfma_entropy > $OUT/ubench_mfma_entropy.txt 2>/dev/null
