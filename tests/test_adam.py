@@ -520,3 +520,78 @@ def test_fused_loop_applies_the_stopping_rule_itself(ctx, tol_fun, step):
     assert a[4] == ref[4], (a[4], ref[4])
     assert a[4] % 20 == 0 or a[4] == 170
     print(f"tol_fun={tol_fun} step={step}: stopped after {a[4]} iterations")
+
+
+@pytest.mark.gpu
+def test_fused_loop_soak_is_deterministic(ctx):
+    """VBMC_FUSED_SOAK_S seconds (default 30) of fused-loop optimisations at three shapes while a second context on
+    another thread keeps the same GPU busy with full-size ELBO evaluations (whose 500-workgroup entropy launches
+    delay, interleave with and take CUs from the loop's resident workgroups).  The loop's workgroups exchange their
+    results through write-through stores, flags and sc1 loads, without fences: a record read before it has landed
+    would change an iterate by an ulp or more -- so every repeat of a run must reproduce the first one bit for bit,
+    whatever the interference (about 2 000 exchanges per run, each of ~100 records read by ~100 workgroups)."""
+    import os
+    import threading
+    import time
+
+    from pyvbmc_amd import _lib
+    from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+    from pyvbmc_amd.variational_optimization import _neg_elcbo
+
+    shapes = [dict(D=10, K=50, N=400, S=1, NsK=28), dict(D=6, K=20, N=150, S=8, NsK=38), dict(D=16, K=7, N=60, S=3, NsK=2)]
+    runs = []
+    for sh in shapes:
+        wl = synthetic.make_workload(3, S=sh["S"], D=sh["D"], K=sh["K"], N=sh["N"], Ns_total=sh["NsK"] * sh["K"])
+        wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y, hyp=wl.hyp,
+                  s2=np.zeros(0))
+        runs.append((wl, wd, synthetic.default_theta_bnd(wl)))
+    stop = threading.Event()
+    other_n = [0]
+    err = []
+
+    def disturb():
+        try:
+            c2 = _lib.Context(0)
+            wl = synthetic.make_workload(3, S=1)
+            wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y, hyp=wl.hyp,
+                      s2=np.zeros(0))
+            vp2, gp2 = device_objects(wd, c2)
+            th = wl.theta.copy()
+            first = None
+            while not stop.is_set():
+                out = _neg_elcbo(th, gp2, vp2, 0.0, wl.NsK, True, False, None, rng="philox", seed=3, ctx=c2)
+                if first is None:
+                    first = (out[0], out[1].copy())
+                elif not (first[0] == out[0] and np.array_equal(first[1], out[1])):
+                    err.append("the disturbing context's own evaluation changed")
+                    break
+                other_n[0] += 1
+            c2.close()
+        except Exception as e:  # noqa: BLE001
+            err.append(repr(e))
+
+    th2 = threading.Thread(target=disturb)
+    th2.start()
+    first, n_runs, n_iter = {}, 0, 0
+    soak_s = float(os.environ.get("VBMC_FUSED_SOAK_S", "30"))
+    t0 = time.time()
+    try:
+        while time.time() - t0 < soak_s and not err:
+            for i, (wl, wd, bnd) in enumerate(runs):
+                vp, gp = device_objects(wd, ctx)
+                out = minimize_adam_elbo(wl.theta.copy(), gp, vp, wl.NsK, bnd, max_iter=200, tol_fun=1e-12, seed=5 + i,
+                                         rng="philox", ctx=ctx)
+                assert ctx.last_entmc_plan()["kernel"] == "adam_fused", ctx.last_entmc_plan()
+                key = (out[2].tobytes(), out[3].tobytes(), np.asarray(vp.mu).tobytes(), np.asarray(vp.w).tobytes())
+                if i not in first:
+                    first[i] = key
+                else:
+                    assert key == first[i], (i, n_runs)
+                n_runs += 1
+                n_iter += out[4]
+    finally:
+        stop.set()
+        th2.join(timeout=60)
+    assert not err, err
+    print(f"{n_runs} runs, {n_iter} iterations, {other_n[0]} full-size evaluations on the other context meanwhile")
+    assert n_runs >= 6 and other_n[0] > 100
