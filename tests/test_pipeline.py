@@ -15,7 +15,10 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "examples"))
 pytestmark = pytest.mark.gpu
 
 
-def test_pipeline_vs_oracle():
+@pytest.mark.parametrize("reference_counts", [False, True], ids=["workload-NsK", "ns_ent-and-ns_ent_fine"])
+def test_pipeline_vs_oracle(reference_counts):
+    """reference_counts: the optimiser at ns_ent = 100 K^(2/3) samples in total (the one-launch loop, csrc/adam_fused.hip)
+    and the report at ns_ent_fine = 2^12 per component, as optimize_vp runs them."""
     from optimize_vp_demo import optimize
 
     from pyvbmc_amd import _lib
@@ -25,7 +28,10 @@ def test_pipeline_vs_oracle():
     try:
         wl = synthetic.make_workload(2, Ns_total=20 * 100)
         n_cand, n_it, seed = 24, 45, 3
-        got = optimize(wl, n_cand, n_it, seed=seed, verbose=False)
+        got = optimize(wl, n_cand, n_it, seed=seed, verbose=False, reference_counts=reference_counts)
+        ns_opt = 2 * int(np.ceil(np.ceil(100.0 * wl.K ** (2.0 / 3.0) / wl.K) / 2.0)) if reference_counts else wl.NsK
+        ns_fine = 2**12 if reference_counts else wl.NsK
+        assert (ctx.last_entmc_plan()["kernel"] is not None)
         # ---- the oracle's run of the same three stages ----
         wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X,
                   y=wl.y, hyp=wl.hyp, s2=np.zeros(0))
@@ -42,16 +48,16 @@ def test_pipeline_vs_oracle():
         it = [0]
 
         def f(t):
-            eps = philox_ref.eps_half(wl.K, wl.NsK // 2, wl.D, seed + 1 + it[0])
+            eps = philox_ref.eps_half(wl.K, ns_opt // 2, wl.D, seed + 1 + it[0])
             it[0] += 1
-            r = elbo_ref.neg_elcbo(t, gp, mix, 0.0, wl.NsK, True, False, bnd, eps_half=eps)
+            r = elbo_ref.neg_elcbo(t, gp, mix, 0.0, ns_opt, True, False, bnd, eps_half=eps)
             return r[0], r[1]
 
         x, y, xt, yt, iters = adam_ref.minimize_adam(f, cands[got["best"]].copy(), tol_fun=0.01, max_iter=n_it)
         assert got["iters"] == iters
         assert rel_err(got["y_tab"], yt) < 1e-7 and rel_err(got["theta"], x) < 1e-7
-        eps = philox_ref.eps_half(wl.K, wl.NsK // 2, wl.D, seed + 2)
-        r = elbo_ref.neg_elcbo(x.copy(), gp, mix, 0.0, wl.NsK, False, True, bnd, True, eps_half=eps)
+        eps = philox_ref.eps_half(wl.K, ns_fine // 2, wl.D, seed + 2)
+        r = elbo_ref.neg_elcbo(x.copy(), gp, mix, 0.0, ns_fine, False, True, bnd, True, eps_half=eps)
         assert abs(got["F"] - r[0]) <= 1e-7 * max(1.0, abs(r[0]))
         assert abs(got["varF"] - np.ravel(r[4])[0]) <= 1e-6 * max(1e-12, abs(np.ravel(r[4])[0]))
         assert rel_err(got["I_sk"], r[9]) < 1e-7
