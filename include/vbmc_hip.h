@@ -366,7 +366,9 @@ int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta, const vbmc_elbo_op
  * candidate (vbmc/variational_optimization.py:775-787): Ns = 0 (lower-bound entropy), no
  * gradient, soft bounds as in `opts`; F_B[b] = -G_b - H_b + bound losses.  opts->ns_per_comp
  * must be 0 and opts->compute_grad 0 (VBMC_E_UNSUP otherwise).  Unlike vbmc_neg_elcbo this
- * neither changes the ctx mixture nor touches the theta rows.  G_B / H_B nullable. */
+ * neither changes the ctx mixture nor touches the theta rows.  G_B / H_B nullable.  Everything per
+ * candidate -- theta -> mixture -> pack, the GP sums, the entropy, G, the bound losses -- runs on the
+ * device (four launches for the whole batch); VBMC_E_NONFINITE names the first non-finite candidate. */
 int vbmc_neg_elcbo_batch(vbmc_ctx* ctx, const double* thetas_BxN, int B, int n_theta,
                          const vbmc_elbo_opts* opts, double* F_B, double* G_B, double* H_B);
 

@@ -3,11 +3,19 @@
 // Reference: vbmc/variational_optimization.py:775-787 (_sieve) calls
 //   _neg_elcbo(theta_b, gp, vp0, 0, ns_ent_K_fast = 0, compute_grad = False, theta_bnd)
 // once per candidate (up to ceil(50 K) of them per VBMC iteration) -- every call tiny and
-// launch-bound.  Here all candidates share ONE upload, ONE GP-sums launch (grid.y = B),
-// ONE lower-bound-entropy launch (a workgroup per candidate) and one read-back.
+// launch-bound.  Here the candidate vectors go up in ONE copy and four launches do everything:
+//   batch_pack_kernel          a workgroup per candidate: set_parameters (variational_posterior.py:680-759) with the
+//                              eta max-shift and the mixture pack (adam_dev::pack_from_theta, the optimiser loop's own)
+//   elbo_prep_kernel           the GP expected-log-joint sums, grid.y = B
+//   entlb_value_batch_kernel   the lower-bound entropy, a workgroup per candidate
+//   batch_finalize_kernel      a workgroup per candidate: G from the sums (api_gp.hip glj_finalize's value part), the
+//                              soft bounds and the weight penalty (:1195-1229), F = -G - H + loss
+// and 3 B doubles come back.  (Rounds 1-2 made the packs and the finalisation on the host, one candidate after the
+// other, and moved 26 MB of packs up and 21 MB of sums down per 2 500 candidates: 11.0 ms, of which the GPU worked 1.8.)
 #include <cmath>
 #include <cstring>
 
+#include "adam_dev.h"
 #include "common.h"
 #include "fastmath.h"
 
@@ -52,6 +60,116 @@ __global__ __launch_bounds__(256) void entlb_value_batch_kernel(const double* __
   if (threadIdx.x == 0) H[blockIdx.x] = (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]);
 }
 
+
+// theta_b -> mixture_b -> pack_b on the device; the attributes (normalised mu | sigma | lambda | w | eta) stay in
+// auxs for the finalisation; theta's eta tail is max-shifted in place (on the device copy)
+__global__ __launch_bounds__(256) void batch_pack_kernel(adam_dev::AdamDev a, double* __restrict__ thetas,
+                                                         double* __restrict__ auxs, const double* __restrict__ base_aux,
+                                                         double* __restrict__ packs, size_t stride, int n_aux,
+                                                         int* __restrict__ bad) {
+  __shared__ double red[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double* th = thetas + (size_t)b * a.n_theta;
+  double* aux = auxs + (size_t)b * n_aux;
+  for (int i = tid; i < n_aux; i += 256) aux[i] = base_aux[i];  // the blocks theta does not carry
+  int nf = 0;
+  for (int i = tid; i < a.n_theta; i += 256) nf |= !isfinite(th[i]);
+  if (nf) atomicMin(bad, b);
+  __syncthreads();
+  adam_dev::pack_from_theta<256>(a, th, aux, red, packs + (size_t)b * stride);
+}
+
+struct BatchFin {
+  int D, K, S, P, mean_kind, mask, n_theta, n_aux, n_bnd;
+  const double *thetas, *auxs, *base_aux, *res, *hyp, *Hd, *blb, *bub;
+  double tol_con, w_thresh, w_pen;
+  double *F, *G, *H;
+};
+
+__global__ __launch_bounds__(256) void batch_finalize_kernel(BatchFin f) {
+  extern __shared__ double sh[];  // iom2 [S][D]
+  __shared__ double red[8];
+  const int D = f.D, K = f.K, S = f.S, b = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const double* th = f.thetas + (size_t)b * f.n_theta;
+  const double* aux = f.auxs + (size_t)b * f.n_aux;
+  const double* mu = aux;
+  const double* sg = mu + K * D;
+  const double* lm = sg + K;
+  const double* w = lm + D;
+  const bool quad = f.mean_kind == VBMC_MEAN_NEGQUAD;
+  const bool o_mu = f.mask & 1, o_sg = f.mask & 2, o_lm = f.mask & 4, o_w = f.mask & 8;
+  const int st1 = 1 + 2 * D;
+  if (quad)
+    for (int i = tid; i < S * D; i += 256) {
+      const int s = i / D, d = i - s * D;
+      sh[i] = exp(-2.0 * f.hyp[(size_t)s * f.P + 2 * D + 3 + d]);
+    }
+  __syncthreads();
+  // ---- G = mean_s sum_k w_k I_sk  (variational_optimization.py:1466-1476) ----
+  double gacc = 0.0;
+  for (int idx = tid; idx < S * K; idx += 256) {
+    const int s = idx / K, k = idx - s * K;
+    const double* h = f.hyp + (size_t)s * f.P;
+    double I = f.res[((size_t)b * S * K + idx) * st1] + (f.mean_kind == VBMC_MEAN_ZERO ? 0.0 : h[D + 2]);
+    if (quad) {
+      double nu = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double m = mu[(size_t)k * D + d], xm = h[D + 3 + d];
+        nu += sh[s * D + d] * (m * m + sg[k] * sg[k] * lm[d] * lm[d] - 2.0 * m * xm + xm * xm);
+      }
+      I += -0.5 * nu;
+    }
+    gacc += w[k] * I;
+  }
+  // ---- soft bounds on (mu, ln sigma + ln lambda, eta) and the weight penalty (:1195-1229) ----
+  double L = 0.0;
+  if (f.n_bnd > 0) {
+    const int n_mu = o_mu ? D * K : 0, n_sc = (o_sg || o_lm) ? D * K : 0;
+    const int p_sg = n_mu, p_lm = p_sg + (o_sg ? K : 0), p_w = f.n_theta - K;
+    const double* bsg = f.base_aux + K * D;
+    const double* blm = bsg + K;
+    for (int q = tid; q < f.n_bnd; q += 256) {
+      double x;
+      if (q < n_mu) {
+        x = th[q];
+      } else if (q < n_mu + n_sc) {
+        const int r = q - n_mu, k = r / D, d = r - k * D;
+        x = (o_lm ? th[p_lm + d] : log(blm[d])) + (o_sg ? th[p_sg + k] : log(bsg[k]));
+      } else {
+        x = th[p_w + (q - n_mu - n_sc)];  // (the tail was max-shifted by the pack kernel)
+      }
+      const double lb = f.blb[q], ub = f.bub[q];
+      const double ell = (ub - lb) * f.tol_con;
+      if (x < lb) L += 0.5 * ((lb - x) / ell) * ((lb - x) / ell);
+      if (x > ub) L += 0.5 * ((x - ub) / ell) * ((x - ub) / ell);
+    }
+    if (o_w)
+      for (int k = tid; k < K; k += 256) L += ((w[k] < f.w_thresh) ? w[k] : f.w_thresh) * f.w_pen;
+  }
+  gacc = wave_sum(gacc);
+  L = wave_sum(L);
+  if (lane == 0) {
+    red[wave] = gacc;
+    red[4 + wave] = L;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double Gv = ((red[0] + red[1]) + (red[2] + red[3])) / S;
+    const double Lv = (red[4] + red[5]) + (red[6] + red[7]);
+    double Hv;
+    if (K > 1) {
+      Hv = f.Hd[b];
+    } else {
+      Hv = 0.5 * D * (1.0 + log(2.0 * M_PI)) + D * log(sg[0]);
+      for (int d = 0; d < D; ++d) Hv += log(lm[d]);
+    }
+    f.F[b] = -Gv - Hv + Lv;
+    f.G[b] = Gv;
+    f.H[b] = Hv;
+  }
+}
+
 }  // namespace
 
 extern "C" int vbmc_neg_elcbo_batch(vbmc_ctx* ctx, const double* thetas_BxN, int B, int n_theta,
@@ -70,43 +188,65 @@ extern "C" int vbmc_neg_elcbo_batch(vbmc_ctx* ctx, const double* thetas_BxN, int
   const int D = ctx->D, K = ctx->K, S = ctx->gp.S;
   const int mask = opts->optimize_mask;
   const bool o_mu = mask & 1, o_sg = mask & 2, o_lm = mask & 4, o_w = mask & 8;
+  const int need = (o_mu ? D * K : 0) + (o_sg ? K : 0) + (o_lm ? D : 0) + (o_w ? K : 0);
+  if (n_theta != need) return vbmc_fail(ctx, VBMC_E_ARG, "neg_elcbo_batch: theta length %d does not match", n_theta);
+  const bool has_bnd = opts->bnd_lb && opts->bnd_ub;
+  const int n_ext = (o_mu ? D * K : 0) + ((o_sg || o_lm) ? D * K : 0) + (o_w ? K : 0);
+  if (has_bnd && n_ext != opts->n_bnd)
+    return vbmc_fail(ctx, VBMC_E_ARG, "neg_elcbo_batch: bounds length %d != %d", opts->n_bnd, n_ext);
+  const int n_bnd = has_bnd ? opts->n_bnd : 0;
   MixLayout ml;
   ml.plan(D, K);
   const size_t stride = (size_t)ml.total;
+  const int n_aux = (int)adam_dev::aux_len(D, K);
 
-  // ---- host: theta_b -> mixture_b -> pack_b -------------------------------------------------
-  std::vector<double> packs(stride * B);
-  std::vector<double> mus((size_t)B * K * D), sgs((size_t)B * K), lms((size_t)B * D), ws((size_t)B * K),
-      etas((size_t)B * K);
-  for (int b = 0; b < B; ++b) {
-    double* mu = mus.data() + (size_t)b * K * D;
-    double* sg = sgs.data() + (size_t)b * K;
-    double* lm = lms.data() + (size_t)b * D;
-    double* w = ws.data() + (size_t)b * K;
-    double* eta = etas.data() + (size_t)b * K;
-    memcpy(mu, ctx->mu.data(), sizeof(double) * K * D);
-    memcpy(sg, ctx->sigma.data(), sizeof(double) * K);
-    memcpy(lm, ctx->lambd.data(), sizeof(double) * D);
-    memcpy(w, ctx->w.data(), sizeof(double) * K);
-    memcpy(eta, ctx->eta.data(), sizeof(double) * K);
-    const int st = theta_to_arrays(D, K, thetas_BxN + (size_t)b * n_theta, n_theta, mask, mu, sg, lm, w, eta);
-    if (st == -1) return vbmc_fail(ctx, VBMC_E_ARG, "neg_elcbo_batch: theta length %d does not match", n_theta);
-    if (st == -2) return vbmc_fail(ctx, VBMC_E_NONFINITE, "neg_elcbo_batch: candidate %d is not finite", b);
-    write_mixture_pack(ml, mu, sg, lm, w, packs.data() + stride * b);
-  }
-
-  // ---- device ------------------------------------------------------------------------------
-  const size_t n_res = (size_t)B * S * K;  // value only: one sum per (b, s, k)
-  const size_t n_H = (K > 1) ? (size_t)B : 0;
-  int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, stride * B + n_res * (1 + 2 * D) + n_H);
+  // ---- device memory: thetas | attributes | packs | sums | H | F G H | base attributes | bounds | flags ----
+  const size_t n_res = (size_t)B * S * K * (1 + 2 * D);
+  const size_t total = (size_t)B * n_theta + (size_t)B * n_aux + stride * B + n_res + 4 * (size_t)B + n_aux + 2 * (size_t)n_bnd + 4;
+  int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, total);
   if (rc) return rc;
-  rc = ensure_pinned(ctx, n_res * (1 + 2 * D) + n_H);
+  rc = ensure_pinned(ctx, 3 * (size_t)B + n_aux + 2 * (size_t)n_bnd + 2);
   if (rc) return rc;
-  double* d_packs = ctx->d_scratch;
+  double* d_th = ctx->d_scratch;
+  double* d_aux = d_th + (size_t)B * n_theta;
+  double* d_packs = d_aux + (size_t)B * n_aux;
   double* d_res = d_packs + stride * B;
-  double* d_H = d_res + n_res * (1 + 2 * D);
-  HIP_TRY(ctx, hipMemcpyAsync(d_packs, packs.data(), sizeof(double) * stride * B, hipMemcpyHostToDevice,
-                              ctx->stream));
+  double* d_H = d_res + n_res;
+  double* d_out = d_H + B;  // F | G | H
+  double* d_base = d_out + 3 * (size_t)B;
+  double* d_bnd = d_base + n_aux;
+  int* d_flags = (int*)(d_bnd + 2 * (size_t)n_bnd);  // [0] non-finite status of the pack, [1] first bad candidate
+  hipStream_t sm = ctx->stream;
+  // the small host-side inputs through the pinned buffer: the ctx mixture's attributes, the bounds
+  double* hp = ctx->h_pinned + 3 * (size_t)B;
+  memcpy(hp, ctx->mu.data(), sizeof(double) * K * D);
+  memcpy(hp + K * D, ctx->sigma.data(), sizeof(double) * K);
+  memcpy(hp + K * D + K, ctx->lambd.data(), sizeof(double) * D);
+  memcpy(hp + K * D + K + D, ctx->w.data(), sizeof(double) * K);
+  memcpy(hp + K * D + 2 * K + D, ctx->eta.data(), sizeof(double) * K);
+  if (has_bnd) {
+    memcpy(hp + n_aux, opts->bnd_lb, sizeof(double) * n_bnd);
+    memcpy(hp + n_aux + n_bnd, opts->bnd_ub, sizeof(double) * n_bnd);
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(d_base, hp, sizeof(double) * (n_aux + 2 * (size_t)n_bnd), hipMemcpyHostToDevice, sm));
+  HIP_TRY(ctx, hipMemcpyAsync(d_th, thetas_BxN, sizeof(double) * (size_t)B * n_theta, hipMemcpyHostToDevice, sm));
+  const int flags0[2] = {0, 0x7fffffff};
+  HIP_TRY(ctx, hipMemcpyAsync(d_flags, flags0, sizeof(flags0), hipMemcpyHostToDevice, sm));
+
+  adam_dev::AdamDev a;
+  memset(&a, 0, sizeof(a));
+  a.ml = ml;
+  a.D = D;
+  a.K = K;
+  a.S = S;
+  a.mask = mask;
+  a.n_theta = n_theta;
+  a.c_norm = 1.0 / std::pow(2.0 * M_PI, 0.5 * D);
+  a.status = d_flags;
+  hipLaunchKernelGGL(batch_pack_kernel, dim3(B), dim3(256), 0, sm, a, d_th, d_aux, (const double*)d_base, d_packs, stride, n_aux,
+                     d_flags + 1);
+  HIP_TRY(ctx, hipGetLastError());
+
   PrepArgs pa;
   glj_fill_prep(ctx, 0, d_res, nullptr, pa);
   pa.mix = d_packs;
@@ -117,98 +257,26 @@ extern "C" int vbmc_neg_elcbo_batch(vbmc_ctx* ctx, const double* thetas_BxN, int
   rc = launch_prep(ctx, pa);
   if (rc) return rc;
   if (K > 1) {
-    hipLaunchKernelGGL(entlb_value_batch_kernel, dim3(B), dim3(256), 0, ctx->stream,
-                       (const double*)d_packs, ml, stride, d_H);
+    hipLaunchKernelGGL(entlb_value_batch_kernel, dim3(B), dim3(256), 0, sm, (const double*)d_packs, ml, stride, d_H);
     HIP_TRY(ctx, hipGetLastError());
   }
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, d_res, sizeof(double) * (n_res * (1 + 2 * D) + n_H),
-                              hipMemcpyDeviceToHost, ctx->stream));
+  BatchFin f;
+  f.D = D; f.K = K; f.S = S; f.P = ctx->gp.P; f.mean_kind = ctx->gp.mean_kind; f.mask = mask;
+  f.n_theta = n_theta; f.n_aux = n_aux; f.n_bnd = n_bnd;
+  f.thetas = d_th; f.auxs = d_aux; f.base_aux = d_base; f.res = d_res; f.hyp = ctx->gp.d_hyp; f.Hd = d_H;
+  f.blb = d_bnd; f.bub = d_bnd + n_bnd;
+  f.tol_con = opts->tol_con; f.w_thresh = opts->weight_threshold; f.w_pen = opts->weight_penalty;
+  f.F = d_out; f.G = d_out + B; f.H = d_out + 2 * (size_t)B;
+  hipLaunchKernelGGL(batch_finalize_kernel, dim3(B), dim3(256), sizeof(double) * ((size_t)S * D + 1), sm, f);
+  HIP_TRY(ctx, hipGetLastError());
+  int flags[2] = {0, 0};
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, d_out, sizeof(double) * 3 * (size_t)B, hipMemcpyDeviceToHost, sm));
+  HIP_TRY(ctx, hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, sm));
   HIP_TRY(ctx, stream_wait(ctx));
-
-  // ---- host finalisation per candidate (glj_finalize's value part + bound losses) ---------------
-  const GpState& g = ctx->gp;
-  const double* res = ctx->h_pinned;
-  const double* Hd = ctx->h_pinned + n_res * (1 + 2 * D);
-  const int st1 = 1 + 2 * D;
-  std::vector<double> iom2(D), xm(D);
-  for (int b = 0; b < B; ++b) {
-    const double* mu = mus.data() + (size_t)b * K * D;
-    const double* sg = sgs.data() + (size_t)b * K;
-    const double* lm = lms.data() + (size_t)b * D;
-    const double* w = ws.data() + (size_t)b * K;
-    double Gv = 0.0;
-    for (int s = 0; s < S; ++s) {
-      const double* h = g.hyp.data() + (size_t)s * g.P;
-      const bool quad = g.mean_kind == VBMC_MEAN_NEGQUAD;
-      const double m0 = g.mean_kind == VBMC_MEAN_ZERO ? 0.0 : h[D + 2];
-      if (quad)
-        for (int d = 0; d < D; ++d) {
-          xm[d] = h[D + 3 + d];
-          iom2[d] = std::exp(-2.0 * h[2 * D + 3 + d]);
-        }
-      for (int k = 0; k < K; ++k) {
-        double I_k = res[((size_t)b * S * K + (size_t)s * K + k) * st1] + m0;
-        if (quad) {
-          double nu = 0.0;
-          for (int d = 0; d < D; ++d) {
-            const double m = mu[(size_t)k * D + d];
-            nu += iom2[d] * (m * m + sg[k] * sg[k] * lm[d] * lm[d] - 2.0 * m * xm[d] + xm[d] * xm[d]);
-          }
-          I_k += -0.5 * nu;
-        }
-        Gv += w[k] * I_k;
-      }
-    }
-    Gv /= S;
-    double Hv;
-    if (K > 1) {
-      Hv = Hd[b];
-    } else {
-      Hv = 0.5 * D * (1.0 + std::log(2.0 * M_PI)) + D * std::log(sg[0]);
-      for (int d = 0; d < D; ++d) Hv += std::log(lm[d]);
-    }
-    double Fv = -Gv - Hv;
-    if (opts->bnd_lb && opts->bnd_ub) {
-      // soft bounds on (mu, ln sigma + ln lambda, eta) with the max-shifted eta tail, as
-      // _neg_elcbo sees them (:1082-1085, :1195-1229)
-      const double* th = thetas_BxN + (size_t)b * n_theta;
-      int pos = 0, q = 0;
-      double L = 0.0;
-      auto pen = [&](double x, int i) {
-        const double lb = opts->bnd_lb[i], ub = opts->bnd_ub[i];
-        const double ell = (ub - lb) * opts->tol_con;
-        if (x < lb) L += 0.5 * ((lb - x) / ell) * ((lb - x) / ell);
-        if (x > ub) L += 0.5 * ((x - ub) / ell) * ((x - ub) / ell);
-      };
-      const int n_ext = (o_mu ? D * K : 0) + ((o_sg || o_lm) ? D * K : 0) + (o_w ? K : 0);
-      if (n_ext != opts->n_bnd)
-        return vbmc_fail(ctx, VBMC_E_ARG, "neg_elcbo_batch: bounds length %d != %d", opts->n_bnd, n_ext);
-      if (o_mu) {
-        for (int i = 0; i < D * K; ++i) pen(th[i], q++);
-        pos = D * K;
-      }
-      if (o_sg || o_lm) {
-        const double* ls = o_sg ? th + pos : nullptr;
-        if (o_sg) pos += K;
-        const double* ll = o_lm ? th + pos : nullptr;
-        for (int k = 0; k < K; ++k)
-          for (int d = 0; d < D; ++d)
-            pen((ll ? ll[d] : std::log(ctx->lambd[d])) + (ls ? ls[k] : std::log(ctx->sigma[k])), q++);
-      }
-      if (o_w) {
-        const double* e = th + (n_theta - K);
-        double mx = e[0];
-        for (int k = 1; k < K; ++k) mx = e[k] > mx ? e[k] : mx;
-        for (int k = 0; k < K; ++k) pen(e[k] - mx, q++);
-        double a = 0.0;
-        for (int k = 0; k < K; ++k) a += (w[k] < opts->weight_threshold) ? w[k] : opts->weight_threshold;
-        L += a * opts->weight_penalty;
-      }
-      Fv += L;
-    }
-    F_B[b] = Fv;
-    if (G_B) G_B[b] = Gv;
-    if (H_B) H_B[b] = Hv;
-  }
+  if (flags[1] != 0x7fffffff || flags[0])
+    return vbmc_fail(ctx, VBMC_E_NONFINITE, "neg_elcbo_batch: candidate %d is not finite", flags[1] != 0x7fffffff ? flags[1] : -1);
+  memcpy(F_B, ctx->h_pinned, sizeof(double) * B);
+  if (G_B) memcpy(G_B, ctx->h_pinned + B, sizeof(double) * B);
+  if (H_B) memcpy(H_B, ctx->h_pinned + 2 * (size_t)B, sizeof(double) * B);
   return VBMC_OK;
 }
