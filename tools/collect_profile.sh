@@ -75,6 +75,7 @@ python bench.py --config 5 --job --steps 50 --warmup 5 > $OUT/bench_c5job.json 2
 python tools/ws_k_probe.py 10 > $OUT/ws_k_probe_d10.txt 2>/dev/null
 python tools/mfma_probe.py 10 12 16 20 24 32 > $OUT/mfma_probe.txt 2>/dev/null
 VBMC_MFMA_ANY=1 python tools/mfma_c3_probe.py > $OUT/mfma_c3_probe.txt 2>/dev/null
+python tools/sieve_probe.py > $OUT/sieve_probe.txt 2>/dev/null
 python tools/adam_small_probe.py > $OUT/adam_small_probe.txt 2>/dev/null
 python tools/adam_shapes_probe.py > $OUT/adam_shapes_probe.txt 2>/dev/null
 python tools/adam_batch_probe.py > $OUT/adam_batch_probe.txt 2>/dev/null

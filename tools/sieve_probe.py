@@ -1,3 +1,5 @@
+"""The sieve's batch of candidate evaluations (reference _sieve, vbmc/variational_optimization.py:775-787) at
+BASELINE config 3's shape: milliseconds per batch of 256 and of 2 500 (= 50 K) candidates."""
 import sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np

@@ -40,7 +40,7 @@ for p in sorted(src.glob("pmc_*/p_counter_collection.csv")):
     for r in csv.DictReader(open(p)):
         acc[(wl, r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for extra in ("timeline/timeline.txt", "gp_probe.txt", "adam_loop.txt", "rows.json", "ws_k_probe_d10.txt", "mfma_probe.txt",
-              "ubench_gen2.txt", "ubench_mfma_entropy.txt", "mfma_c3_probe.txt", "adam_small_probe.txt", "adam_shapes_probe.txt", "adam_batch_probe.txt", "fused_phase_times.txt"):
+              "ubench_gen2.txt", "ubench_mfma_entropy.txt", "mfma_c3_probe.txt", "sieve_probe.txt", "adam_small_probe.txt", "adam_shapes_probe.txt", "adam_batch_probe.txt", "fused_phase_times.txt"):
     f = src / extra
     if f.exists():
         shutil.copy(f, out / f"{tag}_{Path(extra).name}")
