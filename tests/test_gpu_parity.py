@@ -528,3 +528,72 @@ def test_batched_sieve_matches_per_candidate_calls(ctx, golden, name):
         o.ns_per_comp, o.compute_grad, o.optimize_mask = 10, 0, 15
         Fb = np.empty(B)
         ctx.check(ctx._lib.vbmc_neg_elcbo_batch(ctx._h, _lib.ptr(keep), B, keep.shape[1], C.byref(o), _lib.ptr(Fb), None, None))
+
+
+@pytest.mark.parametrize("flags", [(True, True, True, False), (True, True, False, True), (False, True, True, True),
+                                   (True, False, True, True)],
+                         ids=["no-weights", "no-lambda", "no-mu", "no-sigma"])
+def test_batched_sieve_partial_masks_vs_oracle(ctx, flags):
+    """The batch with blocks that are NOT optimised (their values, and the logarithms the soft bounds take of them, come
+    from the vp) -- pack, G, bounds and F are made on the device (csrc/api_batch.hip) -- against the oracle per candidate."""
+    from pyvbmc_amd.variational_optimization import _neg_elcbo_batch
+
+    wl = synthetic.make_workload(3, S=3, D=5, K=7, N=60, Ns_total=7 * 20)
+    g = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y, hyp=wl.hyp,
+             s2=np.zeros(0))
+    gp, ogp = make_gp(g, ctx), oracle_gp(g)
+    mix = oracle_mix(g)
+    mix.optimize_mu, mix.optimize_sigma, mix.optimize_lambd, mix.optimize_weights = flags
+    theta0 = mixture_ref.get_parameters(mix)
+    full = synthetic.default_theta_bnd(wl)
+    DK, K = wl.D * wl.K, wl.K
+    keep = np.concatenate([np.full(DK, flags[0]), np.full(DK, flags[1] or flags[2]), np.full(K, flags[3])])
+    bnd = dict(full)
+    bnd["lb"], bnd["ub"] = full["lb"][keep], full["ub"][keep]
+    rng = np.random.default_rng(7)
+    B = 33
+    thetas = theta0[None, :] + 0.4 * rng.standard_normal((B, theta0.size))
+    thetas[2, 0] += 30.0  # far outside a bound
+    vp = make_vp(g, ctx)
+    vp.optimize_mu, vp.optimize_sigma, vp.optimize_lambd, vp.optimize_weights = flags
+    F, G, H = _neg_elcbo_batch(thetas, gp, vp, bnd, return_parts=True)
+    for b in range(B):
+        m = oracle_mix(g)
+        m.optimize_mu, m.optimize_sigma, m.optimize_lambd, m.optimize_weights = flags
+        Fo, _, Go, Ho, _ = elbo_ref.neg_elcbo(thetas[b].copy(), ogp, m, 0.0, 0, False, False, bnd, False)
+        assert abs(F[b] - Fo) <= 1e-10 * abs(Fo), (flags, b, F[b], Fo)
+        assert abs(G[b] - Go) <= 1e-10 * abs(Go) and abs(H[b] - Ho) <= 1e-10 * abs(Ho)
+
+
+def test_batched_sieve_large_batch_single_component_and_bad_candidate(ctx):
+    """2 500 candidates (50 K, what _sieve evaluates per VBMC iteration) give what the same rows give in batches of 100; K = 1
+    takes the closed-form entropy; a non-finite candidate is reported by its index and the context stays usable."""
+    from pyvbmc_amd import _lib
+    from pyvbmc_amd.variational_optimization import _neg_elcbo_batch
+
+    wl = synthetic.make_workload(3, S=2, D=10, K=50, N=120, Ns_total=50 * 20)
+    g = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y, hyp=wl.hyp,
+             s2=np.zeros(0))
+    gp, vp = make_gp(g, ctx), make_vp(g, ctx)
+    bnd = synthetic.default_theta_bnd(wl)
+    rng = np.random.default_rng(1)
+    thetas = wl.theta[None, :] + 0.3 * rng.standard_normal((2500, wl.theta.size))
+    F = _neg_elcbo_batch(thetas, gp, vp, bnd)
+    assert np.all(np.isfinite(F))
+    for lo in (0, 700, 2400):
+        assert np.array_equal(F[lo:lo + 100], _neg_elcbo_batch(thetas[lo:lo + 100], gp, vp, bnd))
+    bad = thetas[:40].copy()
+    bad[17, 5] = np.nan
+    with pytest.raises(_lib.VbmcHipError, match="candidate 17"):
+        _neg_elcbo_batch(bad, gp, vp, bnd)
+    assert np.array_equal(F[:40], _neg_elcbo_batch(thetas[:40], gp, vp, bnd))
+    # K = 1
+    wl1 = synthetic.make_workload(3, S=1, D=4, K=1, N=30, Ns_total=20)
+    g1 = dict(D=wl1.D, K=wl1.K, mu=wl1.mu, sigma=wl1.sigma, lambd=wl1.lambd, w=wl1.w, eta=wl1.eta, X=wl1.X, y=wl1.y,
+              hyp=wl1.hyp, s2=np.zeros(0))
+    gp1, vp1, ogp1 = make_gp(g1, ctx), make_vp(g1, ctx), oracle_gp(g1)
+    th1 = wl1.theta[None, :] + 0.2 * rng.standard_normal((5, wl1.theta.size))
+    F1, G1, H1 = _neg_elcbo_batch(th1, gp1, vp1, None, return_parts=True)
+    for b in range(5):
+        Fo, _, Go, Ho, _ = elbo_ref.neg_elcbo(th1[b].copy(), ogp1, oracle_mix(g1), 0.0, 0, False, False, None, False)
+        assert abs(F1[b] - Fo) <= 1e-10 * abs(Fo) and abs(H1[b] - Ho) <= 1e-10 * abs(Ho)
