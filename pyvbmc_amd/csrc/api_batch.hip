@@ -6,7 +6,7 @@
 // launch-bound.  Here the candidate vectors go up in ONE copy and four launches do everything:
 //   batch_pack_kernel          a workgroup per candidate: set_parameters (variational_posterior.py:680-759) with the
 //                              eta max-shift and the mixture pack (adam_dev::pack_from_theta, the optimiser loop's own)
-//   elbo_prep_kernel           the GP expected-log-joint sums, grid.y = B
+//   glj_value_batch_kernel     the GP expected-log-joint values: lane = (candidate, component), points through scalar loads
 //   entlb_value_batch_kernel   the lower-bound entropy, a workgroup per candidate
 //   batch_finalize_kernel      a workgroup per candidate: G from the sums (api_gp.hip glj_finalize's value part), the
 //                              soft bounds and the weight penalty (:1195-1229), F = -G - H + loss
@@ -77,6 +77,80 @@ __global__ __launch_bounds__(256) void batch_pack_kernel(adam_dev::AdamDev a, do
   if (nf) atomicMin(bad, b);
   __syncthreads();
   adam_dev::pack_from_theta<256>(a, th, aux, red, packs + (size_t)b * stride);
+}
+
+// The GP expected-log-joint VALUES of a batch (variational_optimization.py:1400-1406,1466: I_sk = sum_n z_n alpha_n with
+// z_n = exp(lnnf - 1/2 sum_d ((mu_dk - X_nd) / tau_dk)^2)): lane = one (candidate b, component k) pair, grid.y = GP sample s.
+// Everything indexed by the point n -- X_n, alpha_n -- is then wave-uniform and arrives through SCALAR loads as SGPR
+// operands, as the table rows of the entropy kernel do; the lane keeps mu_dk and 1/tau_dk in registers and runs over the
+// N points with no memory instruction of its own: 2 D + ~20 float64 instructions per (pair, point).  (The block kernel,
+// glj_block.h, is built for ONE mixture and its gradient: a workgroup per (s,k) re-reads X for every candidate --
+// 125 000 workgroups and 4 GB of L2 reads per 2 500 candidates, 0.83 ms.)
+template <int DP>
+__global__ __launch_bounds__(256) void glj_value_batch_kernel(const double* __restrict__ packs, MixLayout ml, size_t stride,
+                                                              int n_pairs, const double* __restrict__ X,
+                                                              const double* __restrict__ alpha, const double* __restrict__ hyp,
+                                                              int N, int P, int S, double* __restrict__ res) {
+  const int D = ml.D, K = ml.K;
+  const int s = blockIdx.y;
+  const int pair = blockIdx.x * 256 + threadIdx.x;
+  const bool live = pair < n_pairs;
+  const int pc = live ? pair : n_pairs - 1;
+  const int b = pc / K, k = pc - b * K;
+  const double* mix = packs + (size_t)b * stride;
+  const double* h = hyp + (size_t)s * P;
+  const double sigk = mix[ml.o_sig + k];
+  double mu[DP], itau[DP], term = 0.0;
+#pragma unroll
+  for (int d = 0; d < DP; ++d) {
+    if (d < D) {
+      const double ell = fm::exp2_fast(0x1.71547652b82fep+0 * h[d]);  // exp(h_d)
+      const double lam = mix[ml.o_lam + d];
+      const double tau2 = sigk * sigk * lam * lam + ell * ell;
+      itau[d] = fm::rsqrt_fast(tau2);
+      mu[d] = mix[ml.o_mu + k * D + d] * itau[d];  // mu_dk / tau_dk: (mu - x) / tau is then one FMA per dimension
+      term += h[d] - 0.5 * fm::log_fast(tau2);
+    } else {
+      itau[d] = 0.0;
+      mu[d] = 0.0;
+    }
+  }
+  const double lnnf = 2.0 * h[D] + term;
+  const double* al = alpha + (size_t)s * N;
+  // four points per step: their scalar loads are issued together, ahead of the arithmetic (one point per step left every
+  // iteration waiting for its own operands: 0.30 ms per 2 500 candidates instead of 0.1x)
+  double acc = 0.0;
+  constexpr int PU = 4;
+  for (int n0 = 0; n0 < N; n0 += PU) {
+    double d2[PU], a_n[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int n = n0 + u < N ? n0 + u : N - 1;
+      const double* x = X + (size_t)n * D;  // wave-uniform: scalar loads
+      a_n[u] = n0 + u < N ? al[n] : 0.0;
+      double q = 0.0;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        const double dl = fma(-x[d < D ? d : 0], itau[d], mu[d]);
+        q = fma(dl, dl, q);
+      }
+      d2[u] = q;
+    }
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const double z = fm::exp2_fast(0x1.71547652b82fep+0 * (lnnf - 0.5 * d2[u]));
+      acc = fma(z, a_n[u], acc);
+    }
+  }
+  if (live) res[((size_t)b * S * K + (size_t)s * K + k) * (1 + 2 * D)] = acc;
+}
+
+template <int DP>
+static void launch_glj_value_batch(hipStream_t st, const double* packs, const MixLayout& ml, size_t stride, int B, const GpState& g,
+                                   double* res) {
+  const int n_pairs = B * ml.K;
+  hipLaunchKernelGGL((glj_value_batch_kernel<DP>), dim3((n_pairs + 255) / 256, g.S), dim3(256), 0, st, packs, ml, stride, n_pairs,
+                     (const double*)g.d_X, (const double*)g.d_alpha, (const double*)g.d_hyp, g.N, g.P, g.S, res);
 }
 
 struct BatchFin {
@@ -247,15 +321,26 @@ extern "C" int vbmc_neg_elcbo_batch(vbmc_ctx* ctx, const double* thetas_BxN, int
                      d_flags + 1);
   HIP_TRY(ctx, hipGetLastError());
 
-  PrepArgs pa;
-  glj_fill_prep(ctx, 0, d_res, nullptr, pa);
-  pa.mix = d_packs;
-  pa.ml = ml;
-  pa.batch = B;
-  pa.mix_stride = stride;
-  pa.res_stride = (size_t)S * K * (1 + 2 * D);
-  rc = launch_prep(ctx, pa);
-  if (rc) return rc;
+  if (D <= 32 && (int64_t)B * K < ((int64_t)1 << 31)) {
+    const GpState& g = ctx->gp;
+    if (D <= 4) launch_glj_value_batch<4>(sm, d_packs, ml, stride, B, g, d_res);
+    else if (D <= 8) launch_glj_value_batch<8>(sm, d_packs, ml, stride, B, g, d_res);
+    else if (D <= 12) launch_glj_value_batch<12>(sm, d_packs, ml, stride, B, g, d_res);
+    else if (D <= 16) launch_glj_value_batch<16>(sm, d_packs, ml, stride, B, g, d_res);
+    else if (D <= 24) launch_glj_value_batch<24>(sm, d_packs, ml, stride, B, g, d_res);
+    else launch_glj_value_batch<32>(sm, d_packs, ml, stride, B, g, d_res);
+    HIP_TRY(ctx, hipGetLastError());
+  } else {  // more dimensions than the lane-per-pair kernel keeps in registers: the block kernel, grid.y = candidate
+    PrepArgs pa;
+    glj_fill_prep(ctx, 0, d_res, nullptr, pa);
+    pa.mix = d_packs;
+    pa.ml = ml;
+    pa.batch = B;
+    pa.mix_stride = stride;
+    pa.res_stride = (size_t)S * K * (1 + 2 * D);
+    rc = launch_prep(ctx, pa);
+    if (rc) return rc;
+  }
   if (K > 1) {
     hipLaunchKernelGGL(entlb_value_batch_kernel, dim3(B), dim3(256), 0, sm, (const double*)d_packs, ml, stride, d_H);
     HIP_TRY(ctx, hipGetLastError());
