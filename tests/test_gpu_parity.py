@@ -597,3 +597,21 @@ def test_batched_sieve_large_batch_single_component_and_bad_candidate(ctx):
     for b in range(5):
         Fo, _, Go, Ho, _ = elbo_ref.neg_elcbo(th1[b].copy(), ogp1, oracle_mix(g1), 0.0, 0, False, False, None, False)
         assert abs(F1[b] - Fo) <= 1e-10 * abs(Fo) and abs(H1[b] - Ho) <= 1e-10 * abs(Ho)
+
+
+def test_batched_sieve_more_than_32_dimensions(ctx):
+    """D > 32: the batch's lane-per-pair GP kernel does not hold a component in registers any more and the block kernel
+    (grid.y = candidate) takes over; same answers."""
+    from pyvbmc_amd.variational_optimization import _neg_elcbo_batch
+
+    wl = synthetic.make_workload(3, S=2, D=35, K=4, N=40, Ns_total=4 * 20)
+    g = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y, hyp=wl.hyp,
+             s2=np.zeros(0))
+    gp, vp, ogp = make_gp(g, ctx), make_vp(g, ctx), oracle_gp(g)
+    bnd = synthetic.default_theta_bnd(wl)
+    rng = np.random.default_rng(3)
+    thetas = wl.theta[None, :] + 0.2 * rng.standard_normal((9, wl.theta.size))
+    F, G, H = _neg_elcbo_batch(thetas, gp, vp, bnd, return_parts=True)
+    for b in range(9):
+        Fo, _, Go, Ho, _ = elbo_ref.neg_elcbo(thetas[b].copy(), ogp, oracle_mix(g), 0.0, 0, False, False, bnd, False)
+        assert abs(F[b] - Fo) <= 1e-10 * abs(Fo) and abs(G[b] - Go) <= 1e-10 * abs(Go) and abs(H[b] - Ho) <= 1e-10 * abs(Ho)
