@@ -181,7 +181,7 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
   double* recs = sh + f.o_recs;
   double* sE = sh + f.o_eps;
   double* part = sh + f.o_part;   // entropy workgroups' reduction scratch, laid over recs | gsc | sXT | sAl (dead / unused there)
-  double* out = sh + f.o_out;
+  double* out = sh + f.o_out;      // [1 + 2D] a GP block's sums
   double* gsc = sh + f.o_gp;
   double* sXT = sh + f.o_xt;
   double* sAl = sh + f.o_alpha;
@@ -845,7 +845,7 @@ size_t adam_fused_plan(FusedArgs& f) {
   f.o_pack = take(a.ml.total);
   f.o_ee = take(K);
   f.o_eps = take((size_t)f.rows * D);
-  f.o_out = take(RE > RG ? RE : RG);
+  f.o_out = take(RG);  // a GP block's sums (the entropy workgroups store their record entries straight from registers)
   // the entropy workgroups' reduction scratch lies over what they do not use in phase A: the gathered
   // records (dead until the gather) and the GP workgroups' arrays
   f.o_recs = take((size_t)K * RE + (size_t)S * K * RC);
