@@ -175,6 +175,7 @@ def main():
     tseq, Fs = med(seq, reps=3, warm=1)
     nb = 20
     tc, Fo = once(lambda: [elbo_ref.neg_elcbo(thetas[b].copy(), ogp, mix.copy(), 0.0, 0, False, False, bnd, False)[0] for b in range(nb)])
+    tc_sieve_per_cand = tc / nb
     emit("8f-1 sieve batch: _neg_elcbo x B (Ns=0, no grad)", "vbmc/variational_optimization.py:775-787", f"B={B} K={K} N={N}",
          t, tc * B / nb, f"oracle on {nb} candidates, scaled", rel(Fb[:nb], Fo),
          {"per_candidate_device_calls_ms": 1e3 * tseq * B / nseq, "batch_vs_sequential_device": tseq * B / nseq / t})
@@ -210,6 +211,21 @@ def main():
          f"NsK={nsk_ref} K={K} N={N} iters=400", per[1][0], tc_entmc_grad * nsk_ref / wl1.NsK,
          "oracle entropy value+grad of one evaluation, scaled to this NsK", rel(per[1][1][3], per[0][1][3]),
          {"four_launch_iteration_ms": 1e3 * per[0][0], "fused_vs_four_launches": per[0][0] / per[1][0], "kernels": [per[0][2], per[1][2]]})
+    # ---- the three stages of optimize_vp together, at the counts it uses (examples/optimize_vp_demo.py) ----
+    nc = 50 * K
+    cands = thetas  # the sieve row's candidates
+    kw3 = dict(max_iter=1000, master_min=0.001, master_max=0.1, master_decay=200, tol_fun=1e-12)
+    def vp_opt():
+        vv = mkvp(wl1)
+        Fs = _neg_elcbo_batch(cands, g, vv, bnd)
+        out = minimize_adam_elbo(cands[int(np.argmin(Fs))], g, vv, nsk_ref, bnd, seed=3, rng="philox", **kw3)
+        rr = _neg_elcbo(out[0].copy(), g, vv, 0.0, 4096, False, True, bnd, 0.0, True, rng="philox", seed=4)
+        return Fs, out, rr
+    t3, (Fs3, out3, rr3) = med(vp_opt, reps=5, warm=1)
+    emit("optimize_vp's accelerated stages: sieve of 50 K candidates + Adam at ns_ent until the reference's stopping rule ends it (at most 1000 iterations) + full ELBO at ns_ent_fine",
+         "vbmc/variational_optimization.py:90-391,428-500,660-810", f"K={K} N={N} candidates={nc} NsK={nsk_ref}/4096", t3,
+         tc_sieve_per_cand * nc + int(out3[4]) * tc_entmc_grad * nsk_ref / wl1.NsK, "oracle: sieve scaled from 20 candidates + iterations x (entropy value+grad at ns_ent, scaled)",
+         0.0, {"iterations": int(out3[4]), "F_report": float(rr3[0])})
     # ---- 8f row 3: acquisition evaluation on the cached search batch (2^13 points) ------------
     from types import SimpleNamespace
     from oracle import acq_ref
