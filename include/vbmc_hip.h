@@ -122,6 +122,8 @@ int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
  *   "entmc_mfma"   1 = shapes the FP64 matrix tile pads little and the wave-split kernel runs one wave per SIMD on
  *                  (D > 10 or K > 80, K within 12 below a multiple of 16: BASELINE config 5) take the matrix-pipe form
  *                  of the entropy kernel (default), 0 = the wave-split kernel everywhere
+ *   "acq_poll"     [VBMC_ACQ_POLL]: 1 = vbmc_acq_eval with at most 256 points has the CPU write the points into host-writable
+ *                  device memory and polls a completion word for the results (default), 0 = copies + stream wait
  *   "adam_fused"   [VBMC_ADAM_FUSED]: 1 = vbmc_adam_run runs a batch of iterations as ONE launch where the shape allows
  *                  (one rank, K <= 64, D <= 16, <= 64 antithetic rows per component, LDS plan fits; default),
  *                  0 = always four launches per iteration; 2 = test hook (the launch also waits for a workgroup

@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstring>
 
+#include <chrono>
+
 #include "common.h"
 
 namespace {
@@ -22,21 +24,28 @@ __global__ __launch_bounds__(256) void acq_combine_kernel(
     const double* __restrict__ fmu, const double* __restrict__ fs2, const double* __restrict__ dens,
     const double* __restrict__ sn2, int S, int64_t M, int64_t ld, int kind, double y_max,
     double tol_var, double* __restrict__ acq, double* __restrict__ f_bar_out,
-    double* __restrict__ var_tot_out) {
+    double* __restrict__ var_tot_out, uint64_t* done_flag, uint64_t done_seq) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
+  // done_flag (small batches, ONE workgroup): acq / f_bar / var_tot are pinned host memory; every result goes out as a
+  // write-through store, the stores are drained, the workgroup meets, and thread 0 publishes the sequence number the
+  // host polls -- no copy, no stream synchronisation (the recipe of the ELBO step's completion word, entropy.hip)
+  // (with it every thread of the workgroup goes through the same single barrier, so threads past the end compute
+  // the last point again and store nothing)
+  const bool active = m < M;
+  if (!active && !done_flag) return;
+  const int64_t mm = active ? m : M - 1;
   // abstract_acq_fcn.py:82-97
   double fsum = 0.0, vsum = 0.0;
   for (int s = 0; s < S; ++s) {
-    fsum += fmu[(size_t)s * ld + m];
-    vsum += fs2[(size_t)s * ld + m];
+    fsum += fmu[(size_t)s * ld + mm];
+    vsum += fs2[(size_t)s * ld + mm];
   }
   const double f_bar = fsum / S, var_bar = vsum / S;
   double var_f = 0.0;
   if (S > 1) {
     double q = 0.0;
     for (int s = 0; s < S; ++s) {
-      const double t = fmu[(size_t)s * ld + m] - f_bar;
+      const double t = fmu[(size_t)s * ld + mm] - f_bar;
       q += t * t;
     }
     var_f = q / (S - 1);
@@ -46,24 +55,24 @@ __global__ __launch_bounds__(256) void acq_combine_kernel(
   bool log_flag = false;
   switch (kind) {
     case VBMC_ACQ_LOG: {  // acq_fcn_log.py:43-52
-      const double log_p = fmax(dens[m], kLogRealMin);
+      const double log_p = fmax(dens[mm], kLogRealMin);
       a = -(log(var_tot) + f_bar - y_max + log_p);
       log_flag = true;
       break;
     }
     case VBMC_ACQ_VANILLA: {  // acq_fcn_vanilla.py:38-42
-      const double p = fmax(dens[m], kRealMin);
+      const double p = fmax(dens[mm], kRealMin);
       a = -var_tot * (p * p);
       break;
     }
     case VBMC_ACQ_NOISY: {  // acq_fcn_noisy.py:33-41
-      const double p = fmax(dens[m], kRealMin);
-      const double sn = sn2[m];
+      const double p = fmax(dens[mm], kRealMin);
+      const double sn = sn2[mm];
       a = -var_tot * (1.0 - sn / (var_tot + sn)) * exp(f_bar - y_max) * p;
       break;
     }
     default: {  // VBMC_ACQ_STD, acq_fcn.py:38-45
-      const double p = fmax(dens[m], kRealMin);
+      const double p = fmax(dens[mm], kRealMin);
       a = -var_tot * exp(f_bar - y_max) * p;
       break;
     }
@@ -76,9 +85,21 @@ __global__ __launch_bounds__(256) void acq_combine_kernel(
     else
       a *= exp(-pen);
   }
-  acq[m] = fmax(a, -kRealMax);  // :130-131
-  if (f_bar_out) f_bar_out[m] = f_bar;
-  if (var_tot_out) var_tot_out[m] = var_tot;
+  const double av = fmax(a, -kRealMax);  // :130-131
+  if (!done_flag) {
+    acq[m] = av;
+    if (f_bar_out) f_bar_out[m] = f_bar;
+    if (var_tot_out) var_tot_out[m] = var_tot;
+    return;
+  }
+  if (active) {
+    __hip_atomic_store(acq + m, av, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (f_bar_out) __hip_atomic_store(f_bar_out + m, f_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (var_tot_out) __hip_atomic_store(var_tot_out + m, var_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace
@@ -119,6 +140,58 @@ extern "C" int vbmc_acq_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int
   double* d_dens = d_fs2 + (size_t)S * mb;
   double* d_sn2 = d_dens + mb;
   double* d_acq = d_sn2 + mb;  // acq | f_bar | var_tot, contiguous
+  // ---- small batches (a CMA-ES population, a single point): the CPU writes the points straight into host-writable
+  // device memory, the last kernel writes the results into pinned host memory and publishes a completion word that the
+  // CPU polls: no copy calls and no stream synchronisation around ~30 us of kernels ----
+  if (M <= 256 && ctx->opt_acq_poll && !ctx->acq_fg_failed) {
+    if (!ctx->d_acq_fg) {
+      int large_bar = 0;
+      if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) != hipSuccess || !large_bar ||
+          hipExtMallocWithFlags((void**)&ctx->d_acq_fg, sizeof(double) * 256 * 33, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->d_acq_fg = nullptr;
+        ctx->acq_fg_failed = true;
+      }
+    }
+  }
+  if (M <= 256 && ctx->opt_acq_poll && ctx->d_acq_fg) {
+    if (ctx->spec.armed) spec_disarm(ctx);  // (launches waiting for a theta would sit in front of these)
+    const int64_t m = M;
+    memcpy(ctx->d_acq_fg, xs_MxD, sizeof(double) * m * D);
+    if (kind == VBMC_ACQ_NOISY) memcpy(ctx->d_acq_fg + 256 * 32, sn2_M, sizeof(double) * m);
+    __builtin_ia32_sfence();  // write-combined stores drained before the doorbell of the launches
+    const double* x_dev = ctx->d_acq_fg;
+    rc = launch_gp_predict_all(ctx, m, x_dev, d_Ks, d_part, 0, d_fmu, d_fs2, mb);
+    if (rc) return rc;
+    rc = launch_mixture_pdf(ctx, m, x_dev, kind == VBMC_ACQ_LOG, 0, INFINITY, d_dens, nullptr);
+    if (rc) return rc;
+    const uint64_t seq = ++ctx->acq_seq;
+    volatile uint64_t* flag = ctx->h_done + 7;
+    hipLaunchKernelGGL(acq_combine_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)d_fmu, (const double*)d_fs2,
+                       (const double*)d_dens, (const double*)(ctx->d_acq_fg + 256 * 32), S, m, mb, kind, y_max, tol_gp_var,
+                       ctx->hp_dev, f_bar_M ? ctx->hp_dev + mb : (double*)nullptr, var_tot_M ? ctx->hp_dev + 2 * mb : (double*)nullptr,
+                       ctx->hd_done + 7, seq);
+    HIP_TRY(ctx, hipGetLastError());
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (long spin = 0;; ++spin) {
+      if (*flag == seq) {
+        seen = true;
+        break;
+      }
+      if ((spin & 1023) == 1023 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0)
+        break;  // (a stuck queue: the stream wait below reports what happened)
+      __builtin_ia32_pause();
+    }
+    if (!seen) HIP_TRY(ctx, stream_wait(ctx));
+    if (!seen && *flag != seq) return vbmc_fail(ctx, VBMC_E_HIP, "acq_eval: the completion word did not arrive");
+    ctx->pack_in_flight = false;  // (everything queued before the last kernel has run)
+    memcpy(acq_M, ctx->h_pinned, sizeof(double) * m);
+    if (f_bar_M) memcpy(f_bar_M, ctx->h_pinned + mb, sizeof(double) * m);
+    if (var_tot_M) memcpy(var_tot_M, ctx->h_pinned + 2 * mb, sizeof(double) * m);
+    return VBMC_OK;
+  }
   for (int64_t o = 0; o < M; o += mb) {
     const int64_t m = (M - o) < mb ? (M - o) : mb;
     HIP_TRY(ctx, hipMemcpyAsync(d_xs, xs_MxD + o * D, sizeof(double) * m * D, hipMemcpyHostToDevice,
@@ -132,7 +205,7 @@ extern "C" int vbmc_acq_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int
     hipLaunchKernelGGL(acq_combine_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const double*)d_fmu, (const double*)d_fs2, (const double*)d_dens,
                        (const double*)d_sn2, S, m, mb, kind, y_max, tol_gp_var, d_acq, d_acq + mb,
-                       d_acq + 2 * mb);
+                       d_acq + 2 * mb, (uint64_t*)nullptr, (uint64_t)0);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, d_acq, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
     if (f_bar_M)

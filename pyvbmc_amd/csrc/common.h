@@ -123,6 +123,9 @@ struct vbmc_ctx {
   double* d_stage = nullptr;   // device staging of the results the polled step hands to the host (DoneSignal)
   size_t d_stage_cap = 0;
   double* d_mix_fg = nullptr;  // host-writable (fine-grained) device memory: the host-driven step writes the pack here itself
+  double* d_acq_fg = nullptr;  // the same kind of memory for a small acquisition batch's points (api_acq.hip); 256 x 33 doubles
+  bool acq_fg_failed = false;
+  uint64_t acq_seq = 0;        // sequence number of the acquisition completion word (h_done[7])
   size_t d_mix_fg_cap = 0;
   bool mix_fg_failed = false;
   size_t d_mix_cap = 0;
@@ -187,6 +190,7 @@ struct vbmc_ctx {
   int opt_ahead_mode = 2;   // speculative draws: 2 = spare workgroups of the finish launch, 0 = a launch of their own behind it, 1 = on their own stream (measured: slower)
   int opt_ahead_pct = 100;  // armed evaluations: percent of the next draws generated in the finish launch (the rest in the armed prep launch, which runs them while it waits for theta)
   int opt_arm_late_test = 0;  // test hook: n > 0 = the n-th use of an armed evaluation from now takes the late-go recovery path
+  int opt_acq_poll = 1;       // small acquisition batches: points written by the CPU, results polled (api_acq.hip)
   int opt_adam_fused = 1;     // the optimiser loop as one launch per batch where its shape applies (adam_fused.hip)
   int opt_gen_pt = 1;         // speculative draws in the finish launch: Philox blocks per thread
   int opt_ident_test = 0;     // test hook: n > 0 = the n-th identity check from now fails (the recovery path runs)

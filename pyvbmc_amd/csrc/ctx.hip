@@ -66,6 +66,8 @@ static void options_from_env(vbmc_ctx* c) {
   if (e) c->opt_ahead_pct = atoi(e);
   e = getenv("VBMC_ELBO_ARM");
   c->opt_elbo_arm = !(e && e[0] == '0');
+  e = getenv("VBMC_ACQ_POLL");
+  c->opt_acq_poll = !(e && e[0] == '0');
   e = getenv("VBMC_ADAM_FUSED");
   c->opt_adam_fused = !(e && e[0] == '0');
   e = getenv("VBMC_WS_PAIR");
@@ -163,7 +165,7 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   vbmc_comm_destroy(ctx);
   adam_free(ctx);
   acq_is_free(ctx);
-  double* bufs[] = {ctx->d_mix, ctx->d_mix_fg, ctx->d_stage, ctx->d_eps, ctx->d_scratch, ctx->d_out, ctx->gp.d_X, ctx->gp.d_XT,
+  double* bufs[] = {ctx->d_mix, ctx->d_mix_fg, ctx->d_acq_fg, ctx->d_stage, ctx->d_eps, ctx->d_scratch, ctx->d_out, ctx->gp.d_X, ctx->gp.d_XT,
                     ctx->gp.d_alpha, ctx->gp.d_L, ctx->gp.d_Linv, ctx->gp.d_LinvP, ctx->gp.d_sW, ctx->gp.d_hyp,
                     ctx->gp.d_xc, ctx->gp.d_smeta};
   for (double* b : bufs)
@@ -229,6 +231,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "ws_pair")) ctx->opt_ws_pair = value != 0;
   else if (!strcmp(key, "elbo_arm")) ctx->opt_elbo_arm = value != 0;
   else if (!strcmp(key, "ahead_pct")) ctx->opt_ahead_pct = value;
+  else if (!strcmp(key, "acq_poll")) ctx->opt_acq_poll = value != 0;
   else if (!strcmp(key, "adam_fused")) ctx->opt_adam_fused = value;  // 2: test hook, see FusedArgs::test_absent
   else if (!strcmp(key, "gen_pt")) ctx->opt_gen_pt = value < 1 ? 1 : value > 16 ? 16 : value;
   else if (!strcmp(key, "ahead_mode")) {

@@ -343,3 +343,37 @@ def test_device_quantile_acq_vs_oracle_larger():
     finally:
         _lib.set_default_context(None)
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_small_batches_polled_completion_equals_copy_path(ctx):
+    """Batches of up to 256 points (a CMA-ES population, a single point) go up by CPU stores into host-writable device
+    memory and come back through pinned memory and a polled completion word (csrc/api_acq.hip); the results are those of
+    the copy-and-synchronise path bit for bit -- at every batch size around the wave and workgroup boundaries, for every
+    acquisition kind, and when such calls alternate with other entry points."""
+    from pyvbmc_amd import acquisition
+
+    wl = synthetic.make_workload(3, S=3, N=100)
+    wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y, hyp=wl.hyp,
+              s2=np.zeros(0))
+    from test_gpu_parity import make_gp, make_vp
+
+    vp, gp = make_vp(wd, ctx), make_gp(wd, ctx)
+    rng = np.random.default_rng(0)
+    state = dict(integer_vars=None, lb_eps_orig=wl.X.min(0) - 20.0, ub_eps_orig=wl.X.max(0) + 20.0,
+                 gp_length_scale=np.exp(wl.hyp[0, : wl.D]), variance_regularized_acq_fcn=True, tol_gp_var=1e-4)
+    flog = SimpleNamespace(y_max=float(np.max(wl.y)))
+    fns = [acquisition.AcqFcn(), acquisition.AcqFcnLog(), acquisition.AcqFcnVanilla()]
+    for M in (1, 2, 15, 16, 63, 64, 65, 127, 129, 200, 255, 256, 257):
+        comp = rng.integers(0, wl.K, size=M)
+        Xs = wl.mu.T[comp] + 1.5 * wl.lambd * wl.sigma[comp, None] * rng.standard_normal((M, wl.D))
+        for fn in fns:
+            ctx.set_option("acq_poll", 1)
+            a = fn(Xs, gp, vp, flog, state)
+            if M % 3 == 0:
+                vp.pdf(Xs[:2])  # another entry point in between
+            a2 = fn(Xs, gp, vp, flog, state)
+            ctx.set_option("acq_poll", 0)
+            b = fn(Xs, gp, vp, flog, state)
+            assert np.array_equal(a, b) and np.array_equal(a2, b), (M, type(fn).__name__)
+    ctx.set_option("acq_poll", 1)
