@@ -213,6 +213,12 @@ int vbmc_set_mixture(vbmc_ctx* ctx, int D, int K, const double* mu_KxD,
                      const double* sigma_K, const double* lambd_D, const double* w_K,
                      const double* eta_K);
 
+/* The same with the means in the reference's own layout, mu (D,K) row-major -- the array a VariationalPosterior
+ * holds -- so that a caller in front of every pdf / acquisition call passes its attribute arrays as they are. */
+int vbmc_set_mixture_dk(vbmc_ctx* ctx, int D, int K, const double* mu_DxK,
+                        const double* sigma_K, const double* lambd_D, const double* w_K,
+                        const double* eta_K);
+
 /* Host-side restatement of VariationalPosterior.set_parameters (raw_flag=True)
  * (variational_posterior.py:680-759) for the fused objective: theta ->
  * (mu, sigma, lambd, w) with exp, softmax (max-shifted), lambda renormalised to

@@ -21,12 +21,39 @@ def ctx_of(obj, ctx=None):
     return own if own is not None else _lib.default_context()
 
 
+class _VpArgs:
+    """The ctypes argument tuple of vbmc_set_mixture_dk for one set of attribute ARRAYS (held, so their ids stay
+    theirs): built when an attribute is rebound, reused while the same arrays are edited in place or left alone --
+    the library compares their contents with what the device holds."""
+
+    __slots__ = ("ids", "held", "args", "D", "K")
+
+
+def _f64c(a):
+    return isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+
+
 def upload_vp(vp, ctx):
     """Push the mixture attributes of ``vp`` to the device context (a no-op inside the
     library when they are the values the device already holds)."""
-    D, K = int(vp.D), int(vp.K)
-    ctx.set_mixture(np.asarray(vp.mu, dtype=np.float64).reshape(D, K), vp.sigma, vp.lambd, vp.w,
-                    getattr(vp, "eta", None))
+    mu, sg, lm, w = vp.mu, vp.sigma, vp.lambd, vp.w
+    eta = getattr(vp, "eta", None)
+    ids = (id(mu), id(sg), id(lm), id(w), id(eta))
+    st = ctx.__dict__.get("_vp_args")
+    if st is None or st.ids != ids or st.D != vp.D or st.K != vp.K:
+        D, K = int(vp.D), int(vp.K)
+        if not (_f64c(mu) and _f64c(sg) and _f64c(lm) and _f64c(w) and mu.shape == (D, K) and sg.size == K
+                and lm.size == D and w.size == K and (eta is None or (_f64c(eta) and eta.size == K))):
+            # anything else (lists, other dtypes, views): through NumPy conversions, every call
+            ctx.__dict__["_vp_args"] = None
+            ctx.set_mixture(np.asarray(mu, dtype=np.float64).reshape(D, K), sg, lm, w, eta)
+            return ctx
+        st = _VpArgs()
+        st.ids, st.held, st.D, st.K = ids, (mu, sg, lm, w, eta), D, K
+        st.args = (ctx._h, D, K, _lib.ptr(mu), _lib.ptr(sg), _lib.ptr(lm), _lib.ptr(w), _lib.ptr(eta))
+        ctx.__dict__["_vp_args"] = st
+    ctx.check(ctx._lib.vbmc_set_mixture_dk(*st.args))
+    ctx.D, ctx.K = st.D, st.K
     return ctx
 
 

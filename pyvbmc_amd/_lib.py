@@ -75,6 +75,7 @@ SIGNATURES = {
     "vbmc_last_kernel_ms": (C.c_int, [_vp, C.c_int, _dp]),
     "vbmc_last_host_us": (C.c_int, [_vp, _dp]),
     "vbmc_set_mixture": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "vbmc_set_mixture_dk": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "vbmc_theta_to_mixture": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "vbmc_mixture_pdf": (C.c_int, [_vp, C.c_int64, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp]),
     "vbmc_set_eps": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, _dp, C.c_int64, C.c_int64]),

@@ -74,7 +74,7 @@ class AbstractAcqFcn:
 
     @staticmethod
     def _real2int(X, parameter_transformer, integer_vars):
-        if np.any(integer_vars):
+        if integer_vars is not None and np.any(integer_vars):
             X_temp = parameter_transformer.inverse(X)
             X_temp[:, integer_vars] = np.around(X_temp[:, integer_vars])
             X_temp = parameter_transformer(X_temp)
@@ -111,9 +111,9 @@ class AbstractAcqFcn:
                                          _lib.ptr(sn2), _lib.ptr(acq), None, None))
         # hard bounds in original space (abstract_acq_fcn.py:133-139)
         X_orig = vp.parameter_transformer.inverse(Xs)
-        out = np.logical_or(np.any(X_orig < optim_state.get("lb_eps_orig"), axis=1),
-                            np.any(X_orig > optim_state.get("ub_eps_orig"), axis=1))
-        acq[out] = np.inf
+        out = ((X_orig < optim_state.get("lb_eps_orig")) | (X_orig > optim_state.get("ub_eps_orig"))).any(axis=1)
+        if out.any():
+            acq[out] = np.inf
         return acq
 
 
@@ -225,9 +225,9 @@ class _QuantileAcq(AbstractAcqFcn):
             acq[low] += tol_var / var_tot[low] - 1  # log_flag is set for both classes
         acq = np.maximum(acq, -np.finfo(np.float64).max)
         X_orig = vp.parameter_transformer.inverse(Xs)
-        out = np.logical_or(np.any(X_orig < optim_state.get("lb_eps_orig"), axis=1),
-                            np.any(X_orig > optim_state.get("ub_eps_orig"), axis=1))
-        acq[out] = np.inf
+        out = ((X_orig < optim_state.get("lb_eps_orig")) | (X_orig > optim_state.get("ub_eps_orig"))).any(axis=1)
+        if out.any():
+            acq[out] = np.inf
         return acq
 
 

@@ -12,6 +12,7 @@
 #include <chrono>
 
 #include "common.h"
+#include "fastmath.h"
 
 namespace {
 
@@ -19,60 +20,30 @@ constexpr double kRealMin = 2.2250738585072014e-308;   // sys.float_info.min
 constexpr double kRealMax = 1.7976931348623157e+308;   // sys.float_info.max
 constexpr double kLogRealMin = -708.3964185322641;     // np.log(sys.float_info.min)
 
-// fmu, fs2: [S][M] per-sample predictive moments; dens: pdf (or log pdf for VBMC_ACQ_LOG).
-__global__ __launch_bounds__(256) void acq_combine_kernel(
-    const double* __restrict__ fmu, const double* __restrict__ fs2, const double* __restrict__ dens,
-    const double* __restrict__ sn2, int S, int64_t M, int64_t ld, int kind, double y_max,
-    double tol_var, double* __restrict__ acq, double* __restrict__ f_bar_out,
-    double* __restrict__ var_tot_out, uint64_t* done_flag, uint64_t done_seq) {
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // done_flag (small batches, ONE workgroup): acq / f_bar / var_tot are pinned host memory; every result goes out as a
-  // write-through store, the stores are drained, the workgroup meets, and thread 0 publishes the sequence number the
-  // host polls -- no copy, no stream synchronisation (the recipe of the ELBO step's completion word, entropy.hip)
-  // (with it every thread of the workgroup goes through the same single barrier, so threads past the end compute
-  // the last point again and store nothing)
-  const bool active = m < M;
-  if (!active && !done_flag) return;
-  const int64_t mm = active ? m : M - 1;
-  // abstract_acq_fcn.py:82-97
-  double fsum = 0.0, vsum = 0.0;
-  for (int s = 0; s < S; ++s) {
-    fsum += fmu[(size_t)s * ld + mm];
-    vsum += fs2[(size_t)s * ld + mm];
-  }
-  const double f_bar = fsum / S, var_bar = vsum / S;
-  double var_f = 0.0;
-  if (S > 1) {
-    double q = 0.0;
-    for (int s = 0; s < S; ++s) {
-      const double t = fmu[(size_t)s * ld + mm] - f_bar;
-      q += t * t;
-    }
-    var_f = q / (S - 1);
-  }
-  const double var_tot = var_f + var_bar;
+// the acquisition value of one point from its mean prediction, total variance and (log) density
+__device__ __forceinline__ double acq_value(int kind, double f_bar, double var_tot, double dens, double sn, double y_max,
+                                            double tol_var) {
   double a;
   bool log_flag = false;
   switch (kind) {
     case VBMC_ACQ_LOG: {  // acq_fcn_log.py:43-52
-      const double log_p = fmax(dens[mm], kLogRealMin);
+      const double log_p = fmax(dens, kLogRealMin);
       a = -(log(var_tot) + f_bar - y_max + log_p);
       log_flag = true;
       break;
     }
     case VBMC_ACQ_VANILLA: {  // acq_fcn_vanilla.py:38-42
-      const double p = fmax(dens[mm], kRealMin);
+      const double p = fmax(dens, kRealMin);
       a = -var_tot * (p * p);
       break;
     }
     case VBMC_ACQ_NOISY: {  // acq_fcn_noisy.py:33-41
-      const double p = fmax(dens[mm], kRealMin);
-      const double sn = sn2[mm];
+      const double p = fmax(dens, kRealMin);
       a = -var_tot * (1.0 - sn / (var_tot + sn)) * exp(f_bar - y_max) * p;
       break;
     }
     default: {  // VBMC_ACQ_STD, acq_fcn.py:38-45
-      const double p = fmax(dens[mm], kRealMin);
+      const double p = fmax(dens, kRealMin);
       a = -var_tot * exp(f_bar - y_max) * p;
       break;
     }
@@ -85,21 +56,134 @@ __global__ __launch_bounds__(256) void acq_combine_kernel(
     else
       a *= exp(-pen);
   }
-  const double av = fmax(a, -kRealMax);  // :130-131
-  if (!done_flag) {
-    acq[m] = av;
-    if (f_bar_out) f_bar_out[m] = f_bar;
-    if (var_tot_out) var_tot_out[m] = var_tot;
-    return;
+  return fmax(a, -kRealMax);  // :130-131
+}
+
+// fmu, fs2: [S][M] per-sample predictive moments; dens: pdf (or log pdf for VBMC_ACQ_LOG).
+__global__ __launch_bounds__(256) void acq_combine_kernel(
+    const double* __restrict__ fmu, const double* __restrict__ fs2, const double* __restrict__ dens,
+    const double* __restrict__ sn2, int S, int64_t M, int64_t ld, int kind, double y_max,
+    double tol_var, double* __restrict__ acq, double* __restrict__ f_bar_out,
+    double* __restrict__ var_tot_out) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  // abstract_acq_fcn.py:82-97
+  double fsum = 0.0, vsum = 0.0;
+  for (int s = 0; s < S; ++s) {
+    fsum += fmu[(size_t)s * ld + m];
+    vsum += fs2[(size_t)s * ld + m];
   }
-  if (active) {
-    __hip_atomic_store(acq + m, av, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (f_bar_out) __hip_atomic_store(f_bar_out + m, f_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (var_tot_out) __hip_atomic_store(var_tot_out + m, var_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const double f_bar = fsum / S, var_bar = vsum / S;
+  double var_f = 0.0;
+  if (S > 1) {
+    double q = 0.0;
+    for (int s = 0; s < S; ++s) {
+      const double t = fmu[(size_t)s * ld + m] - f_bar;
+      q += t * t;
+    }
+    var_f = q / (S - 1);
   }
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): acknowledged
+  const double var_tot = var_f + var_bar;
+  acq[m] = acq_value(kind, f_bar, var_tot, dens[m], kind == VBMC_ACQ_NOISY ? sn2[m] : 0.0, y_max, tol_var);
+  if (f_bar_out) f_bar_out[m] = f_bar;
+  if (var_tot_out) var_tot_out[m] = var_tot;
+}
+
+// Small batches (at most 256 points: a CMA-ES population, a single point): what follows the two predict products as ONE
+// launch, wave = point -- predict's finish (gp.hip predict_finish_kernel: partial sums -> f_mu, f_s2
+// per GP sample, mean function), the mixture density at the point (mixture.hip's wave-per-point form), the
+// formula -- with the results stored write-through into pinned host memory, drained, counted, and a completion word published for
+// the host to poll (the recipe of the ELBO step's completion word, entropy.hip): three launches, no copy call and no
+// stream synchronisation per batch instead of five launches, two copies and a wait.
+struct AcqTail {
+  const double* part;  // predict partials [S][2][ntiles][M]
+  int64_t pstride;
+  int ntiles, M, D, P, S, mean_kind, kind, log_dens;
+  const double *hyp, *smeta, *xs, *mix, *sn2;
+  MixLayout ml;
+  double y_max, tol_var;
+  double *acq, *f_bar, *var_tot;  // pinned host memory (device addresses); f_bar / var_tot nullable
+  uint64_t* flag;
+  uint64_t seq;
+  int* cnt;  // zero between launches: workgroups that have stored their results
+};
+
+__global__ __launch_bounds__(256) void acq_tail_small_kernel(AcqTail a) {
+  // wave = point: lanes over the GP samples for predict's finish, lanes over the components for the density
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * 4 + wave, M = a.M, D = a.D, S = a.S;
+  if (m < M) {
+    // ---- predict's finish (gp.hip predict_finish_kernel), lane = GP sample ----
+    double fmu = 0.0, fs2 = 0.0;
+    if (lane < S) {
+      const int smp = lane;
+      const double* part = a.part + (size_t)smp * a.pstride;
+      const double* fpart = part + (size_t)a.ntiles * M;
+      const double* hyp = a.hyp + (size_t)smp * a.P;
+      const bool chol = a.smeta[3 * smp] != 0.0;
+      const double sf2 = exp(2.0 * hyp[D]);
+      double sv = 0.0, f = 0.0;
+      for (int t = 0; t < a.ntiles; ++t) {
+        sv += part[(size_t)t * M + m];
+        f += fpart[(size_t)t * M + m];
+      }
+      fs2 = fmax(chol ? sf2 - sv : sf2 + sv, 0.0);
+      double mean = 0.0;
+      const double* hm = hyp + D + 2;
+      if (a.mean_kind == VBMC_MEAN_CONST) mean = hm[0];
+      if (a.mean_kind == VBMC_MEAN_NEGQUAD) {
+        mean = hm[0];
+        for (int d = 0; d < D; ++d) {
+          const double t = (a.xs[m * D + d] - hm[1 + d]) * exp(-hm[1 + D + d]);
+          mean -= 0.5 * t * t;
+        }
+      }
+      fmu = mean + f;
+    }
+    // ---- abstract_acq_fcn.py:82-97 ----
+    const double f_bar = fm::wave_sum_dpp(fmu) / S, var_bar = fm::wave_sum_dpp(fs2) / S;
+    double var_f = 0.0;
+    if (S > 1) {
+      const double t = lane < S ? fmu - f_bar : 0.0;
+      var_f = fm::wave_sum_dpp(t * t) / (S - 1);
+    }
+    const double var_tot = var_f + var_bar;
+    // ---- the mixture density at the point (variational_posterior.py:450-463), lane = component ----
+    const int K = a.ml.K;
+    const double* mup = a.mix + a.ml.o_mup;
+    const double* is2 = a.mix + a.ml.o_is2;
+    const double* wc = a.mix + a.ml.o_wc;
+    const double* ilam = a.mix + a.ml.o_ilam;
+    double y = 0.0;
+    for (int k = lane; k < K; k += 64) {
+      const double* mk = mup + k * D;
+      double d2 = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double u = a.xs[m * D + d] * ilam[d] - mk[d];
+        d2 = fma(u, u, d2);
+      }
+      y += wc[k] * fm::exp2_fast((-0.5 * 0x1.71547652b82fep+0 * is2[k]) * d2);
+    }
+    y = fm::wave_sum_dpp(y);
+    if (lane == 0) {
+      const double dens = a.log_dens ? ((y == 0.0) ? -INFINITY : log(y)) : y;
+      const double av = acq_value(a.kind, f_bar, var_tot, dens, a.kind == VBMC_ACQ_NOISY ? a.sn2[m] : 0.0, a.y_max, a.tol_var);
+      __hip_atomic_store(a.acq + m, av, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (a.f_bar) __hip_atomic_store(a.f_bar + m, f_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (a.var_tot) __hip_atomic_store(a.var_tot + m, var_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  // every workgroup: results acknowledged, then ONE count; the last workgroup to count publishes the sequence number
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(a.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {
+    __hip_atomic_store(a.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 }  // namespace
@@ -143,7 +227,7 @@ extern "C" int vbmc_acq_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int
   // ---- small batches (a CMA-ES population, a single point): the CPU writes the points straight into host-writable
   // device memory, the last kernel writes the results into pinned host memory and publishes a completion word that the
   // CPU polls: no copy calls and no stream synchronisation around ~30 us of kernels ----
-  if (M <= 256 && ctx->opt_acq_poll && !ctx->acq_fg_failed) {
+  if (M <= 256 && S <= 64 && ctx->opt_acq_poll && !ctx->acq_fg_failed) {
     if (!ctx->d_acq_fg) {
       int large_bar = 0;
       if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) != hipSuccess || !large_bar ||
@@ -154,23 +238,43 @@ extern "C" int vbmc_acq_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int
       }
     }
   }
-  if (M <= 256 && ctx->opt_acq_poll && ctx->d_acq_fg) {
+  if (M <= 256 && S <= 64 && ctx->opt_acq_poll && ctx->d_acq_fg) {
     if (ctx->spec.armed) spec_disarm(ctx);  // (launches waiting for a theta would sit in front of these)
     const int64_t m = M;
     memcpy(ctx->d_acq_fg, xs_MxD, sizeof(double) * m * D);
     if (kind == VBMC_ACQ_NOISY) memcpy(ctx->d_acq_fg + 256 * 32, sn2_M, sizeof(double) * m);
     __builtin_ia32_sfence();  // write-combined stores drained before the doorbell of the launches
     const double* x_dev = ctx->d_acq_fg;
-    rc = launch_gp_predict_all(ctx, m, x_dev, d_Ks, d_part, 0, d_fmu, d_fs2, mb);
-    if (rc) return rc;
-    rc = launch_mixture_pdf(ctx, m, x_dev, kind == VBMC_ACQ_LOG, 0, INFINITY, d_dens, nullptr);
+    rc = launch_gp_predict_products(ctx, m, x_dev, d_Ks, d_part);  // K*, the variance product: their partial sums
     if (rc) return rc;
     const uint64_t seq = ++ctx->acq_seq;
     volatile uint64_t* flag = ctx->h_done + 7;
-    hipLaunchKernelGGL(acq_combine_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)d_fmu, (const double*)d_fs2,
-                       (const double*)d_dens, (const double*)(ctx->d_acq_fg + 256 * 32), S, m, mb, kind, y_max, tol_gp_var,
-                       ctx->hp_dev, f_bar_M ? ctx->hp_dev + mb : (double*)nullptr, var_tot_M ? ctx->hp_dev + 2 * mb : (double*)nullptr,
-                       ctx->hd_done + 7, seq);
+    AcqTail t;
+    t.part = d_part;
+    t.ntiles = ntiles;
+    t.pstride = 2 * (int64_t)ntiles * m;
+    t.M = (int)m;
+    t.D = D;
+    t.P = g.P;
+    t.S = S;
+    t.mean_kind = g.mean_kind;
+    t.kind = kind;
+    t.log_dens = kind == VBMC_ACQ_LOG;
+    t.hyp = g.d_hyp;
+    t.smeta = g.d_smeta;
+    t.xs = x_dev;
+    t.mix = ctx->d_mix;
+    t.sn2 = ctx->d_acq_fg + 256 * 32;
+    t.ml = ctx->ml;
+    t.y_max = y_max;
+    t.tol_var = tol_gp_var;
+    t.acq = ctx->hp_dev;
+    t.f_bar = f_bar_M ? ctx->hp_dev + mb : nullptr;
+    t.var_tot = var_tot_M ? ctx->hp_dev + 2 * mb : nullptr;
+    t.flag = ctx->hd_done + 7;
+    t.seq = seq;
+    t.cnt = ctx->d_done_cnt + 4;
+    hipLaunchKernelGGL(acq_tail_small_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->stream, t);
     HIP_TRY(ctx, hipGetLastError());
     const auto t0 = std::chrono::steady_clock::now();
     bool seen = false;
@@ -205,7 +309,7 @@ extern "C" int vbmc_acq_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int
     hipLaunchKernelGGL(acq_combine_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const double*)d_fmu, (const double*)d_fs2, (const double*)d_dens,
                        (const double*)d_sn2, S, m, mb, kind, y_max, tol_gp_var, d_acq, d_acq + mb,
-                       d_acq + 2 * mb, (uint64_t*)nullptr, (uint64_t)0);
+                       d_acq + 2 * mb);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, d_acq, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
     if (f_bar_M)

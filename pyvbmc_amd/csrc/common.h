@@ -123,6 +123,7 @@ struct vbmc_ctx {
   double* d_stage = nullptr;   // device staging of the results the polled step hands to the host (DoneSignal)
   size_t d_stage_cap = 0;
   double* d_mix_fg = nullptr;  // host-writable (fine-grained) device memory: the host-driven step writes the pack here itself
+  std::vector<double> mu_scratch;  // vbmc_set_mixture_dk's transposed means
   double* d_acq_fg = nullptr;  // the same kind of memory for a small acquisition batch's points (api_acq.hip); 256 x 33 doubles
   bool acq_fg_failed = false;
   uint64_t acq_seq = 0;        // sequence number of the acquisition completion word (h_done[7])
@@ -465,6 +466,7 @@ inline int predict_ld(int N) { return (N + 63) / 64 * 64; }
 inline size_t predict_ks_elems(int S, int64_t mb, int N) {
   return (size_t)S * (size_t)((mb + 63) / 64 * 64) * (size_t)predict_ld(N);
 }
+int launch_gp_predict_products(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* d_Ks, double* d_part);
 int launch_gp_predict_all(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* d_Ks, double* d_part,
                           int add_noise, double* d_fmu, double* d_fs2, int64_t ld);
 // c[n][m] = |a_n - b_m|^2 (centred expansion, cross term on the FP64 matrix cores), optional

@@ -523,6 +523,18 @@ int vbmc_set_mixture(vbmc_ctx* ctx, int D, int K, const double* mu_KxD, const do
   return set_mixture_host(ctx, D, K, mu_KxD, sigma_K, lambd_D, w_K, eta_K, true);
 }
 
+int vbmc_set_mixture_dk(vbmc_ctx* ctx, int D, int K, const double* mu_DxK, const double* sigma_K,
+                        const double* lambd_D, const double* w_K, const double* eta_K) {
+  if (!ctx || !mu_DxK || !sigma_K || !lambd_D || !w_K || D < 1 || K < 1) return VBMC_E_ARG;
+  if (ctx->device >= 0) HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // (D, K) -> K rows of D: the transposition the Python mirror used to make with NumPy on every pdf / acquisition call
+  std::vector<double>& t = ctx->mu_scratch;
+  t.resize((size_t)D * K);
+  for (int d = 0; d < D; ++d)
+    for (int k = 0; k < K; ++k) t[(size_t)k * D + d] = mu_DxK[(size_t)d * K + k];
+  return set_mixture_host(ctx, D, K, t.data(), sigma_K, lambd_D, w_K, eta_K, true);
+}
+
 int vbmc_theta_to_mixture(vbmc_ctx* ctx, const double* theta, int n_theta, int optimize_mask,
                           double* mu_KxD, double* sigma_K, double* lambd_D, double* w_K,
                           double* eta_K) {

@@ -1124,8 +1124,8 @@ int launch_trinv(vbmc_ctx* ctx) {
 // All S GP samples, one batch of M points already on the device: three launches in total
 // (grid.z / grid.y = sample).  d_Ks: S * M * N doubles; d_part: S * 2 * ntiles * M doubles;
 // d_fmu / d_fs2: [S][ld].
-int launch_gp_predict_all(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* d_Ks, double* d_part,
-                          int add_noise, double* d_fmu, double* d_fs2, int64_t ld) {
+// predict, stages 1 and 2 for all GP samples: K* (+ the partial means) and the variance product's partial row sums
+int launch_gp_predict_products(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* d_Ks, double* d_part) {
   const GpState& g = ctx->gp;
   const int N = g.N, D = g.D, S = g.S;
   const int ntiles = (N + TS - 1) / TS;
@@ -1173,6 +1173,18 @@ int launch_gp_predict_all(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* 
     HIP_TRY(ctx, hipEventRecord(ctx->ev[11], ctx->stream));
     ctx->ev_valid[5] = true;
   }
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_gp_predict_all(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* d_Ks, double* d_part,
+                          int add_noise, double* d_fmu, double* d_fs2, int64_t ld) {
+  const GpState& g = ctx->gp;
+  const int N = g.N, D = g.D, S = g.S;
+  const int ntiles = (N + TS - 1) / TS;
+  const int64_t pstride = 2 * (int64_t)ntiles * M;
+  const int rc = launch_gp_predict_products(ctx, M, d_xs, d_Ks, d_part);
+  if (rc) return rc;
   hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((M + 255) / 256), S), dim3(256), 0, ctx->stream,
                      (const double*)d_part, pstride, ntiles, M, D, g.P, g.mean_kind, (const double*)g.d_hyp,
                      (const double*)g.d_smeta, d_xs, add_noise, d_fmu, d_fs2, ld);

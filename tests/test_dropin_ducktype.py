@@ -311,3 +311,46 @@ def test_theta_bnd_edited_in_place_is_seen(ctx, golden):
     F2 = both(bnd)
     assert len({F0, F1, F2}) == 3
     assert both(None) != F2
+
+
+@pytest.mark.gpu
+def test_vp_attributes_edited_in_place_rebound_or_odd_typed_are_seen(ctx, golden):
+    """upload_vp keeps the ctypes pointers of the attribute ARRAYS of the last vp (pyvbmc_amd/_duck.py) and lets the library
+    compare their contents with what the device holds: an interior in-place edit, a rebound attribute, another vp object,
+    a float32 / non-contiguous attribute and a vp of another shape must each reach the device."""
+    g = golden("c2s")
+    D = int(g["D"])
+    xs = np.random.default_rng(2).standard_normal((23, D)) * 0.5 + g["mu"].mean(axis=1)
+    from oracle import mixture_ref
+
+    def check(vp, mix):
+        y = vp.pdf(xs, orig_flag=False)
+        yo = mixture_ref.pdf(mix, xs)
+        assert rel_err(np.ravel(y), np.ravel(yo)) < 1e-10
+
+    from test_gpu_parity import make_vp
+
+    vp = make_vp(g, ctx)
+    mix = oracle_mix(g)
+    check(vp, mix)
+    check(vp, mix)  # same arrays, same contents: the cached pointers
+    vp.mu[1, 2] += 0.37  # interior, in place
+    mix.mu[1, 2] += 0.37
+    check(vp, mix)
+    vp.sigma = vp.sigma * 1.3  # rebound
+    mix.sigma = mix.sigma * 1.3
+    check(vp, mix)
+    vp.w = (vp.w[::-1] if vp.w.ndim == 1 else vp.w[:, ::-1])  # a non-contiguous view
+    mix.w = np.ascontiguousarray(mix.w[:, ::-1] if mix.w.ndim == 2 else mix.w[::-1])
+    check(vp, mix)
+    vp.lambd = vp.lambd.astype(np.float32).astype(np.float64) * 1.0 + 0.0
+    mix.lambd = vp.lambd.copy()
+    check(vp, mix)
+    vp2 = make_vp(g, ctx)  # another object holding other arrays with the golden values
+    check(vp2, oracle_mix(g))
+    check(vp, mix)
+    g1 = golden("c1")  # another (D, K) through the same context
+    xs1 = np.random.default_rng(3).standard_normal((9, int(g1["D"])))
+    vp1 = make_vp(g1, ctx)
+    assert rel_err(np.ravel(vp1.pdf(xs1, orig_flag=False)), np.ravel(mixture_ref.pdf(oracle_mix(g1), xs1))) < 1e-10
+    check(vp, mix)

@@ -25,3 +25,15 @@ for M in (1, 16, 64, 8192):
     for _ in range(200 if M < 1000 else 20):
         t0 = time.perf_counter(); a = fn(Xs, g, vp, flog, state); ts.append(time.perf_counter() - t0)
     print(f"M={M}: {np.median(ts)*1e6:.1f} us per call")
+# the C entry point alone (points already float64, no Python wrapper work)
+import ctypes as C
+for M in (1, 16, 64):
+    comp = rng.integers(0, K, size=M)
+    Xs = np.ascontiguousarray(wl.mu.T[comp] + 1.5 * wl.lambd * wl.sigma[comp, None] * rng.standard_normal((M, D)))
+    acq = np.empty(M)
+    args = (ctx._h, M, _lib.ptr(Xs), 1, float(flog.y_max), 1e-4, None, _lib.ptr(acq), None, None)
+    for _ in range(5): ctx._lib.vbmc_acq_eval(*args)
+    ts = []
+    for _ in range(300):
+        t0 = time.perf_counter(); ctx._lib.vbmc_acq_eval(*args); ts.append(time.perf_counter() - t0)
+    print(f"M={M}: vbmc_acq_eval alone {np.median(ts)*1e6:.1f} us per call")
