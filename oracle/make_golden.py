@@ -483,6 +483,295 @@ def vpmc():
     print("wrote vpmc:", len(out), "keys")
 
 
+MEAN_CLASSES = {"zero": "ZeroMean", "const": "ConstantMean", "negquad": "NegativeQuadratic"}
+
+
+def _mean_hyp(wl, kind, hyp):
+    """Columns of the synthetic hyper-parameter rows a GP with this mean function carries:
+    [cov (D+1) | noise (1) | mean (0 / 1 / 1+2D)] (variational_optimization.py:1383-1392)."""
+    n_mean = {"zero": 0, "const": 1, "negquad": 1 + 2 * wl.D}[kind]
+    return np.ascontiguousarray(hyp[:, : wl.D + 2 + n_mean])
+
+
+def ref_gp_kind(wl, kind, hyp):
+    gp = gpr.GP(
+        D=wl.D,
+        covariance=gpr.covariance_functions.SquaredExponential(),
+        mean=getattr(gpr.mean_functions, MEAN_CLASSES[kind])(),
+        noise=gpr.noise_functions.GaussianNoise(constant_add=True, user_provided_add=wl.s2 is not None),
+    )
+    gp.update(X_new=wl.X, y_new=wl.y, s2_new=wl.s2, hyp=_mean_hyp(wl, kind, hyp))
+    return gp
+
+
+def variants():
+    """The branches the reference takes outside "all blocks optimised, NegativeQuadratic mean",
+    run by the REFERENCE on a D=6, K=20, N=200 workload (config 2's shape, S = 3 hyper-samples):
+
+    * GP mean kinds zero / const / negquad (gaussian_process_train.py:219-224; vbmc.py:1064-1078
+      switches to "const" temporarily): ``_gp_log_joint`` with avg_flag x jacobian_flag, variance +
+      separate_K, ``_neg_elcbo`` (lower-bound and Monte-Carlo entropy), the closed-form acquisition
+      classes and a ``minimize_adam`` trajectory per kind;
+    * the partial optimise masks the reference can produce -- weights off (every warm-up iteration,
+      variational_optimization.py:142-143), means off (options variable_means, vbmc.py:249), both --
+      through ``_neg_elcbo`` with the reduced ``theta_bnd`` of the reference's own
+      ``vp.get_bounds`` (variational_posterior.py:140-239);
+    * ``pdf`` / ``log_pdf`` with ``orig_flag=True`` on a bounded ``ParameterTransformer`` (finite and
+      infinite bounds mixed, plausible bounds => centring), rows inside, ON and outside the bounds
+      (variational_posterior.py:429-439, 543-559), with the transformer's own outputs stored so
+      that oracle/transform_ref.py is pinned as well.
+    """
+    from types import SimpleNamespace
+
+    from pyvbmc.acquisition_functions import AcqFcn, AcqFcnLog
+    from pyvbmc.parameter_transformer import ParameterTransformer
+
+    out = {}
+    S = 3
+    wl = synthetic.make_workload(2, S=S, Ns_total=20 * 200)
+    D, K, NsK = wl.D, wl.K, wl.NsK
+    seed = 21
+    out.update(D=D, K=K, N=wl.N, NsK=NsK, seed=seed, S=S, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w,
+               eta=wl.eta, X=wl.X, y=wl.y, hyp=wl.hyp, theta=wl.theta, s2=np.zeros(0))
+    opts = {"tol_length": 1e-6, "tol_weight": 1e-2, "tol_con_loss": 0.01, "weight_penalty": 0.1}
+    rng = np.random.default_rng(909)
+    Xs = wl.mu.T[rng.integers(0, K, size=40)] + 1.2 * rng.standard_normal((40, D))
+    Xs[:4] = wl.X[:4] + 1e-3 * rng.standard_normal((4, D))
+    out["Xs"] = Xs
+
+    # ---- GP mean kinds -----------------------------------------------------------------------
+    for kind in MEAN_CLASSES:
+        for tag, hyp in (("S1", wl.hyp[:1]), ("SM", wl.hyp)):
+            gp = ref_gp_kind(wl, kind, hyp)
+            for avg in (True, False):
+                for jac in (True, False):
+                    G, dG, _, _, _ = _gp_log_joint(ref_vp(wl), gp, True, avg, jac, False, False)
+                    k = f"glj_{kind}_{tag}_a{int(avg)}_j{int(jac)}"
+                    out[k + "_G"], out[k + "_dG"] = np.asarray(G), np.asarray(dG)
+                G, _, varG, _, var_ss, I_sk, J_sjk = _gp_log_joint(ref_vp(wl), gp, False, avg, True, True, True)
+                k = f"glj_{kind}_{tag}_a{int(avg)}_var"
+                out[k + "_G"], out[k + "_varG"], out[k + "_var_ss"] = np.asarray(G), np.asarray(varG), var_ss
+                out[k + "_I_sk"], out[k + "_J_sjk"] = I_sk, J_sjk
+        gp = ref_gp_kind(wl, kind, wl.hyp[:1])
+        gpM = ref_gp_kind(wl, kind, wl.hyp)
+        vp = ref_vp(wl)
+        bnd = vp.get_bounds(wl.X, opts)
+        if kind == "zero":
+            out["bnd_full_lb"], out["bnd_full_ub"] = bnd["lb"], bnd["ub"]
+            out["bnd_tol_con"], out["bnd_weight_threshold"] = bnd["tol_con"], bnd["weight_threshold"]
+            out["bnd_weight_penalty"] = bnd["weight_penalty"]
+        for g_, gtag in ((gp, "S1"), (gpM, "SM")):
+            for ns_tag, Ns in (("mc", NsK), ("lb", 0)):
+                vp = ref_vp(wl)
+                np.random.seed(seed)
+                th = wl.theta.copy()
+                F, dF, G, H, _ = _neg_elcbo(th, g_, vp, 0.0, Ns, True, False, bnd, 0.0, False)
+                k = f"elbo_{kind}_{gtag}_{ns_tag}"
+                out[k + "_F"], out[k + "_dF"], out[k + "_G"], out[k + "_H"] = F, dF, G, H
+        # the acquisition classes through AbstractAcqFcn.__call__ (predict by the gpyreg stand-in)
+        length = np.exp(wl.hyp[0, :D])
+        gpM.temporary_data["X_rescaled"] = wl.X / length
+        flog = SimpleNamespace(y_max=float(np.max(wl.y)))
+        st = dict(integer_vars=None, lb_eps_orig=wl.X.min(0) - 2.0, ub_eps_orig=wl.X.max(0) + 2.0,
+                  gp_length_scale=length, variance_regularized_acq_fcn=False)
+        for cls in (AcqFcn, AcqFcnLog):
+            with np.errstate(all="ignore"):
+                out[f"acq_{kind}_{cls.__name__}"] = cls()(Xs.copy(), gpM, ref_vp(wl), flog, dict(st))
+        # what the gpyreg stand-in's predict returned for those calls (restated third-party arithmetic)
+        fmu, fs2 = gpM.predict(Xs, separate_samples=True)
+        out[f"pred_{kind}_fmu"], out[f"pred_{kind}_fs2"] = fmu, fs2
+        # a short optimiser trajectory per kind: the reference's minimize_adam around its _neg_elcbo
+        vp = ref_vp(wl)
+        theta0 = wl.theta.copy()
+        theta0[0] = bnd["ub"][0] + 0.1
+
+        def f(t, gp=gp, vp=vp, bnd=bnd):
+            r = _neg_elcbo(t, gp, vp, 0.0, 40, True, False, bnd)
+            return r[0], r[1]
+
+        np.random.seed(70)
+        x, y, xt, yt, it = minimize_adam(f, theta0.copy(), tol_fun=0.05, max_iter=30, master_min=0.001,
+                                         master_max=0.1, master_decay=200)
+        out[f"adam_{kind}_theta0"] = theta0
+        out[f"adam_{kind}_x"], out[f"adam_{kind}_y"] = x, y
+        out[f"adam_{kind}_x_tab"], out[f"adam_{kind}_y_tab"], out[f"adam_{kind}_iters"] = xt, yt, it
+        print(f"variants {kind}: adam {it} iterations, y {yt[0]:.4f} -> {yt[-1]:.4f}")
+
+    # ---- partial optimise masks -----------------------------------------------------------------
+    gp = ref_gp_kind(wl, "negquad", wl.hyp[:1])
+    gpc = ref_gp_kind(wl, "const", wl.hyp)
+    for mname, flags in (("mask1110", (1, 1, 1, 0)), ("mask0111", (0, 1, 1, 1)), ("mask0110", (0, 1, 1, 0))):
+        def masked_vp():
+            vp = ref_vp(wl)
+            vp.optimize_mu, vp.optimize_sigma, vp.optimize_lambd, vp.optimize_weights = map(bool, flags)
+            return vp
+
+        vp = masked_vp()
+        bnd = vp.get_bounds(wl.X, opts)
+        theta = vp.get_parameters()
+        theta = theta + 0.05 * np.random.default_rng(31).standard_normal(theta.size)
+        if flags[0]:
+            theta[0] = bnd["ub"][0] + 0.3  # outside a soft bound
+        out[f"{mname}_theta"], out[f"{mname}_lb"], out[f"{mname}_ub"] = theta, bnd["lb"], bnd["ub"]
+        out[f"{mname}_has_weight_keys"] = int("weight_threshold" in bnd)
+        for g_, gtag in ((gp, "nq1"), (gpc, "constM")):
+            for ns_tag, Ns in (("mc", NsK), ("lb", 0)):
+                vp = masked_vp()
+                np.random.seed(seed)
+                th = theta.copy()
+                F, dF, G, H, _ = _neg_elcbo(th, g_, vp, 0.0, Ns, True, False, bnd, 0.0, False)
+                k = f"{mname}_{gtag}_{ns_tag}"
+                out[k + "_F"], out[k + "_dF"], out[k + "_G"], out[k + "_H"] = F, dF, G, H
+                out[k + "_theta_after"] = th
+                out[k + "_mu"], out[k + "_sigma"], out[k + "_lambd"] = vp.mu, vp.sigma.ravel(), vp.lambd.ravel()
+                out[k + "_w"], out[k + "_eta"] = vp.w.ravel(), vp.eta.ravel()
+            # value only, no bounds: what _sieve's candidates see when theta_bnd is None
+            vp = masked_vp()
+            th = theta.copy()
+            out[f"{mname}_{gtag}_lb_F_nograd"] = _neg_elcbo(th, g_, vp, 0.0, 0, False, False, bnd, 0.0, False)[0]
+        # the entropy estimators with exactly these blocks (disabled blocks omitted, entmc_vbmc.py:48-51)
+        gf = tuple(map(bool, flags))
+        vp = ref_vp(wl)  # (the constructor consumes np.random: build first, seed after)
+        np.random.seed(seed)
+        out[f"{mname}_entmc_H"], out[f"{mname}_entmc_dH"] = entmc_vbmc(vp, NsK, gf, True)
+        out[f"{mname}_entlb_H"], out[f"{mname}_entlb_dH"] = entlb_vbmc(ref_vp(wl), gf, True)
+
+    # ---- orig-space density with a bounded transformer ----------------------------------------------
+    lb = np.array([[-3.0, -np.inf, 0.0, -2.0, -np.inf, -5.0]])
+    ub = np.array([[3.0, np.inf, 4.0, 6.0, np.inf, 5.0]])
+    plb = np.array([[-2.0, -1.5, 0.5, -1.0, -2.0, -4.0]])
+    pub = np.array([[2.5, 1.5, 3.0, 4.0, 2.0, 4.5]])
+    pt = ParameterTransformer(D, lb, ub, plb, pub)
+    out.update(pt_lb=lb, pt_ub=ub, pt_plb=plb, pt_pub=pub, pt_mu=pt.mu, pt_delta=pt.delta, pt_type=pt.type)
+    vp = ref_vp(wl)
+    vp.parameter_transformer = pt
+    rngp = np.random.default_rng(444)
+    comp = rngp.integers(0, K, size=40)
+    u = wl.mu.T[comp] + wl.lambd * wl.sigma[comp, None] * rngp.standard_normal((40, D))
+    x_in = pt.inverse(u)
+    x_edge = pt.inverse(wl.mu.T[:6].copy())
+    x_edge[0, 0] = lb[0, 0]            # ON the lower bound
+    x_edge[1, 2] = ub[0, 2]            # ON the upper bound
+    x_edge[2, 3] = lb[0, 3] - 1e-3     # just outside
+    x_edge[3, 5] = ub[0, 5] + 2.0      # far outside
+    x_edge[4, 0] = np.nextafter(lb[0, 0], np.inf)   # the closest inside value
+    x_edge[5, 2] = np.nextafter(ub[0, 2], -np.inf)
+    xo = np.vstack([x_in, x_edge])
+    out["pdfo_x"] = xo
+    mask = np.logical_and(np.all(xo > lb, axis=1), np.all(xo < ub, axis=1))
+    out["pdfo_mask"] = mask
+    out["pdfo_u"] = pt(xo[mask])
+    out["pdfo_ladj"] = pt.log_abs_det_jacobian(out["pdfo_u"])
+    out["pdfo_inv"] = pt.inverse(out["pdfo_u"])
+    with np.errstate(all="ignore"):
+        out["pdfo_y"] = vp.pdf(xo, orig_flag=True)
+        out["pdfo_logy"] = vp.pdf(xo, orig_flag=True, log_flag=True)
+        out["pdfo_logy_method"] = vp.log_pdf(xo, orig_flag=True)
+        yy, dy = vp.pdf(xo, orig_flag=True, grad_flag=True)
+        out["pdfo_y_g"], out["pdfo_dy"] = yy, dy
+        for df in (7.0, -3.0):
+            out[f"pdfo_y_df{df}"] = vp.pdf(xo, orig_flag=True, df=df)
+            out[f"pdfo_logy_df{df}"] = vp.pdf(xo, orig_flag=True, log_flag=True, df=df)
+        out["pdfo_1d"] = vp.pdf(xo[3], orig_flag=True)
+        # the reference's own edge test (test_variational_posterior.py:304-332): D = 2, lb = -3, ub = 3
+        lb2, ub2 = -3.0 * np.ones((1, 2)), 3.0 * np.ones((1, 2))
+        pt2 = ParameterTransformer(2, lb2, ub2)
+        vp2 = VariationalPosterior(2, 2, np.array([[2.0, 2.0], [-2.0, -2.0]]), pt2)
+        vp2.sigma = np.ones((1, 2))
+        pts = np.vstack([lb2, lb2 - 1e-3, ub2, ub2 + 1e-3, lb2 + 0.5, ub2 - 0.5])
+        out["pdfo2_mu"], out["pdfo2_x"] = vp2.mu, pts
+        out["pdfo2_y"] = vp2.pdf(pts, orig_flag=True)
+        out["pdfo2_logy"] = vp2.log_pdf(pts, orig_flag=True)
+    np.random.seed(12)
+    xs_o, _ = vp.sample(300, orig_flag=True, balance_flag=True)
+    out["pdfo_sample_x"] = xs_o  # (inverse transform of the reference's NumPy-stream samples)
+    np.savez_compressed(OUT / "variants.npz", **out)
+    print("wrote variants:", len(out), "keys")
+
+
+def is_known():
+    """What the reference's ``fess`` and ``active_sample_proposal_pdf`` return on the inputs of its own
+    MATLAB known-answer tests (testing/vbmc/test_active_importance_sampling.py:113-250), together with
+    the values of ``gp.predict`` and ``vp.pdf`` those two functions consumed on the way -- recorded by
+    wrapping the two methods while the reference runs.  The tests hold the device's predict / pdf to
+    the recorded values; no restatement of the two functions travels."""
+    import scipy.stats as sps
+
+    from pyvbmc.acquisition_functions import AcqFcnIMIQR, AcqFcnVIQR
+    from pyvbmc.vbmc.active_importance_sampling import active_sample_proposal_pdf, fess
+
+    out = {}
+    D, K = 3, 2
+    X = np.arange(-7, 8).reshape((5, 3), order="F").astype(float)
+    y = np.array([sps.multivariate_normal.logpdf(x, mean=np.zeros(D)) for x in X]).reshape((-1, 1))
+    hyp = np.array([-2.0, -3.0, -4.0, 1.0, 0.0, -(D / 2) * np.log(2 * np.pi), 0.0, 0.25, 0.5, -0.5, 0.0, 0.5])
+    hyp = np.vstack([hyp, 2 * hyp])
+    wl = SimpleNamespaceWL(D=D, X=X, y=y, s2=None)
+    Xa = 2 * np.arange(-4, 5).reshape((3, 3), order="F") / np.pi
+    out.update(X=X, y=y, hyp=hyp, Xa=Xa)
+
+    def recording(gp, vp, log):
+        p0, d0 = gp.predict, vp.pdf
+
+        def predict(x, *a, **k):
+            r = p0(x, *a, **k)
+            log.append(("predict", np.array(x), bool(k.get("separate_samples", False)), r))
+            return r
+
+        def pdf(x, *a, **k):
+            r = d0(x, *a, **k)
+            log.append(("pdf", np.array(x), dict(k), r))
+            return r
+
+        gp.predict, vp.pdf = predict, pdf
+
+    # fess (test_fess)
+    vp = VariationalPosterior(D=D, K=K)
+    vp.mu = np.array([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]).T
+    vp.w = np.array([[0.7, 0.3]])
+    vp.lambd = np.ones(vp.lambd.shape)
+    out.update(fess_mu=vp.mu, fess_sigma=vp.sigma.ravel(), fess_w=vp.w.ravel())
+    gp = ref_gp(wl, hyp)
+    gp_means = np.arange(-5, 5).reshape((5, 2), order="F") * np.pi
+    log = []
+    recording(gp, vp, log)
+    out["fess_means"] = fess(vp, gp_means, X)
+    out["fess_means_logpdf"] = log[-1][3]   # vp.pdf(X, log) consumed by the call above
+    log.clear()
+    out["fess_gp"] = fess(vp, gp, Xa)
+    (k1, x1, sep1, r1), (k2, x2, kw2, r2) = log
+    assert k1 == "predict" and k2 == "pdf" and not sep1 and np.array_equal(x1, Xa) and np.array_equal(x2, Xa)
+    out["fess_gp_fbar"], out["fess_gp_fs2"], out["fess_gp_logpdf"] = r1[0], r1[1], r2
+    # active_sample_proposal_pdf (test_active_sample_proposal_pdf)
+    vp = VariationalPosterior(D=D, K=K)
+    vp.mu = np.array([[-1.0, -2.0, -3.0], [3.0, 2.0, 1.0]]).T
+    vp.w = np.array([[0.7, 0.3]])
+    vp.sigma = np.ones(vp.sigma.shape)
+    vp.lambd = np.ones(vp.lambd.shape)
+    out["aspp_mu"] = vp.mu
+    gp = ref_gp(wl, hyp)
+    rect_delta = 2 * np.std(gp.X, ddof=1, axis=0)
+    for name, acq in (("viqr", AcqFcnVIQR()), ("imiqr", AcqFcnIMIQR())):
+        log = []
+        g2, v2 = ref_gp(wl, hyp), vp
+        p_keep = v2.pdf
+        recording(g2, v2, log)
+        lw, fs2 = active_sample_proposal_pdf(Xa, g2, v2, 0.5, rect_delta, acq)
+        v2.pdf = p_keep
+        out[f"aspp_{name}_ln_weights"], out[f"aspp_{name}_f_s2"] = lw, fs2
+        pred = [e for e in log if e[0] == "predict"][0]
+        dens = [e for e in log if e[0] == "pdf"][0]
+        assert pred[2] and np.array_equal(pred[1], Xa)
+        out[f"aspp_{name}_fmu"], out[f"aspp_{name}_pred_fs2"], out[f"aspp_{name}_logpdf"] = pred[3][0], pred[3][1], dens[3]
+    np.savez_compressed(OUT / "is_known.npz", **out)
+    print("wrote is_known:", sorted(out))
+
+
+class SimpleNamespaceWL:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
 if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
     jobs = {
@@ -500,6 +789,8 @@ if __name__ == "__main__":
         "adam": adam,
         "acq": acq,
         "vpmc": vpmc,
+        "variants": variants,
+        "is_known": is_known,
     }
     for name in sys.argv[1:] or list(jobs):  # no argument: rewrite everything
         jobs[name]()

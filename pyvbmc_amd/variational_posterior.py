@@ -235,9 +235,11 @@ class VariationalPosterior:
         y = np.empty(n)
         dy = np.empty((n, D)) if grad_flag else None
         xin = np.ascontiguousarray(x)
-        if not np.all(mask):
-            xin = xin.copy()
-            xin[~mask] = 0.0  # masked rows are overwritten below; keep them finite
+        if not np.all(mask) and not np.all(np.isfinite(xin)):
+            # rows outside the bounds stay in original coordinates and go through the density like
+            # the reference's (their value is overwritten below, their gradient rows are returned
+            # as computed, :464-469); only non-finite coordinates are kept off the device
+            xin = np.where(np.isfinite(xin), xin, 0.0)
         ctx.check(
             ctx._lib.vbmc_mixture_pdf(
                 ctx._h, n, _lib.ptr(xin), int(bool(log_flag)), int(bool(grad_flag)), float(df),

@@ -328,57 +328,10 @@ def matlab_gp_and_points(ctx):
     return D, X, gp, Xa
 
 
-@pytest.mark.gpu
-def test_fess(ctx, golden):
-    """vbmc/test_active_importance_sampling.py:113: MATLAB's fractional effective sample sizes."""
-    from is_helpers import fess
-
-    m = golden("matlab_known")
-    D, X, gp, Xa = matlab_gp_and_points(ctx)
-    vp = new_vp(D, 2, ctx)
-    vp.mu = np.array([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]).T
-    vp.w = np.array([[0.7, 0.3]])
-    vp.lambd = np.ones(vp.lambd.shape)
-    gp_means = np.arange(-5, 5).reshape((5, 2), order="F") * np.pi
-    fess_means, fess_gp = fess(vp, gp_means, X), fess(vp, gp, Xa)
-    assert np.isscalar(fess_means) and np.isscalar(fess_gp)
-    assert np.isclose(fess_means, m["fess_fess_means"]) and np.isclose(fess_gp, m["fess_fess_gp"])
-    with pytest.raises(ValueError):
-        fess(vp, gp_means[:3], X)
-    assert 0.0 < fess(vp, gp, 200) <= 1.0  # the sampling form (the reference's own crashes on its tuple)
-
-
-@pytest.mark.gpu
-def test_active_sample_proposal_pdf(ctx, golden):
-    """vbmc/test_active_importance_sampling.py:178: MATLAB's log importance weights, VIQR and IMIQR."""
-    from is_helpers import active_sample_proposal_pdf
-    from pyvbmc_amd.acquisition import AcqFcnIMIQR, AcqFcnVIQR
-
-    m = golden("matlab_known")
-    D, X, gp, Xa = matlab_gp_and_points(ctx)
-    vp = new_vp(D, 2, ctx)
-    vp.mu = np.array([[-1.0, -2.0, -3.0], [3.0, 2.0, 1.0]]).T
-    vp.w = np.array([[0.7, 0.3]])
-    vp.sigma = np.ones(vp.sigma.shape)
-    vp.lambd = np.ones(vp.lambd.shape)
-    rect_delta = 2 * np.std(gp.X, ddof=1, axis=0)
-    lw_v, s2_v = active_sample_proposal_pdf(Xa, gp, vp, 0.5, rect_delta, AcqFcnVIQR())
-    lw_i, s2_i = active_sample_proposal_pdf(Xa, gp, vp, 0.5, rect_delta, AcqFcnIMIQR())
-    assert lw_v.shape == lw_i.shape == (D, 2) and s2_v.shape == s2_i.shape == (D, 2)
-    assert np.allclose(lw_v, m["activesample_proposalpdf_ln_weights_viqr"])
-    assert np.allclose(s2_v, m["activesample_proposalpdf_f_s2_viqr"])
-    assert np.allclose(lw_i, m["activesample_proposalpdf_ln_weights_imiqr"])
-    assert np.allclose(s2_i, m["activesample_proposalpdf_f_s2_imiqr"])
-    # pure-VP proposal (w_vp = 1) has a single mixture column
-    lw1, _ = active_sample_proposal_pdf(Xa, gp, vp, 1.0, rect_delta, AcqFcnVIQR())
-    assert lw1.shape == (D, 2) and np.all(np.isfinite(lw1))
-
-
 def test_is_log_densities_and_weights():
-    """acq_fcn_viqr.py:159-247 / acq_fcn_imiqr.py:173-260 log densities; renormalize_weights :481."""
+    """acq_fcn_viqr.py:159-247 / acq_fcn_imiqr.py:173-260 log densities."""
     from scipy.stats import norm
 
-    from is_helpers import get_mcmc_opts, renormalize_weights
     from pyvbmc_amd.acquisition import AcqFcnIMIQR, AcqFcnVIQR
 
     v, i = AcqFcnVIQR(), AcqFcnIMIQR(quantile=0.9)
@@ -391,7 +344,3 @@ def test_is_log_densities_and_weights():
     assert np.array_equal(v.is_log_base(None, f_mu=f_mu, f_s2=f_s2), np.zeros((1, 2)))
     with pytest.raises(ValueError):
         v.is_log_full(np.zeros(3))
-    w = renormalize_weights(np.array([0.0, 1.0, 2.0]))
-    assert np.isclose(np.sum(np.exp(w)), 1.0)
-    assert get_mcmc_opts(100) == ({"display": "off", "diagnostics": False}, 1, 50)
-    assert get_mcmc_opts(10, thin=3)[2] == 15
