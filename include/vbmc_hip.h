@@ -160,15 +160,33 @@ int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
  *                  default 1)
  *   "ws_pair"      [VBMC_WS_PAIR]: 1 = the wave-split entropy kernel hands its (component, chunk)
  *                  items out so that the two workgroups of a CU read the same table row (default)
- * The results of an evaluation do not depend on any of these.  Unknown key -> VBMC_E_ARG. */
+ *   "ws_span"      [VBMC_WS_SPAN]: 1 = the wave-split entropy kernel in span mode (default): every CU's
+ *                  first-dispatched workgroup takes "ws_front" per mille of the CU's batches, the second one
+ *                  the rest, parts crossing component boundaries, so that all workgroups end together
+ *                  (csrc/entropy_args.h WsSpan); 0 = equal chunks per component
+ *   "ws_front"     [VBMC_WS_FRONT]: that share (0 = built-in per instantiation); "ws_pad" [VBMC_WS_PAD]:
+ *                  batches a component's end is priced at when the parts are cut (-1 = built-in)
+ * The results of an evaluation do not depend on any of these -- except that "ws_span" / "ws_front" /
+ * "ws_pad" change how the Monte-Carlo rows are grouped into partial sums, i.e. the last bits of the
+ * entropy (<= 1e-15 relative); for given values every evaluation is bit-reproducible.
+ * Unknown key -> VBMC_E_ARG. */
 int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value);
 
 /* Launch geometry of the most recent Monte-Carlo entropy of this ctx (vbmc_entmc,
- * vbmc_neg_elcbo, the optimiser loop): out[0] = kernel (0 generic, 1 wave-split, 2 small-
- * sample, 3 matrix-pipe form, 4 the fused optimiser loop: no entropy launch of its own), out[1] = 64-row batches per workgroup (the wave-split kernel's batch loop count),
- * out[2] = workgroups per component, out[3] = 1 if the draws were read from HBM, 0 if
- * generated in-line.  Lets the parity tests assert which code path they exercised. */
+ * vbmc_neg_elcbo, the optimiser loop): out[0] = kernel (0 generic, 1 wave-split on equal chunks, 2 small-
+ * sample, 3 matrix-pipe form, 4 the fused optimiser loop: no entropy launch of its own, 5 wave-split in span
+ * mode), out[1] = 64-row batches per workgroup (the wave-split kernel's batch loop count; span mode: the
+ * longest part), out[2] = partial rows (workgroups) per component, out[3] = 1 if the draws were read from
+ * HBM, 0 if generated in-line.  Lets the parity tests assert which code path they exercised. */
 int vbmc_last_entmc_plan(const vbmc_ctx* ctx, int out[4]);
+
+/* Host utility (no device, no ctx): the span-mode partition of the wave-split entropy kernel for cus CUs of
+ * which pb have a filler part, front share `front` (per mille), nb batches per component, `pad` slots priced
+ * per component end, K components -- part_lo[cus + pb + 1] = first slot of every part of the padded list
+ * (part_lo[last] = K (nb + pad)), first_part[K] = the part that holds each component's first batch,
+ * *rows_per_component = partial rows per component.  The CPU suite checks the partition's invariants. */
+int vbmc_ws_span_layout(int cus, int pb, int front, int nb, int pad, int K, int64_t* part_lo, int* first_part,
+                        int* rows_per_component);
 
 /* Host utility (no device, no ctx): a 64-bit checksum over n blocks of doubles,
  * sum_a (sum_i bits(v_ai) * odd_i + len_a) * odd_a mod 2^64 -- any change of a single element changes
@@ -410,7 +428,8 @@ int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta, const vbmc
                     const double* lb, const double* ub, int max_iter, double master_min,
                     double master_max, double master_decay);
 /* vbmc_adam_run_auto: the rest of the optimisation -- up to max_iters iterations -- in ONE call, where the run has the
- *   one-launch form (option "adam_fused") and stands at a multiple of 20 iterations: the workgroups apply
+ *   one-launch form (option "adam_fused") and has not run an iteration yet (the kernel's stopping rule needs the
+ *   mean iterate of the previous batch, which it collects itself from iteration 0 on): the workgroups apply
  *   minimize_adam's stopping rule themselves (minimize_adam.py:107-140: every 20 iterations from the 40th on, the
  *   slope of a straight-line fit through the last 20 objective values against its standard error and tol_fun, and
  *   the distance between the mean iterates of the last two batches) and *n_done returns how many iterations ran;

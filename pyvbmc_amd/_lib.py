@@ -67,6 +67,8 @@ SIGNATURES = {
     "vbmc_synchronize": (C.c_int, [_vp]),
     "vbmc_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "vbmc_last_entmc_plan": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "vbmc_ws_span_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vbmc_last_elbo_raw": (C.c_int, [_vp, _dp, C.c_int]),
     "vbmc_armed_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "vbmc_set_gp_watch": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_uint64]),
@@ -248,11 +250,13 @@ class Context:
 
     def last_entmc_plan(self):
         """Launch geometry of the most recent Monte-Carlo entropy: which kernel ran, how many
-        64-row batches each workgroup looped over, workgroups per component, draw source."""
+        64-row batches each workgroup looped over (span mode: the longest part), partial rows per
+        component, draw source; ``span``: the wave-split kernel ran in span mode (front / filler parts
+        sized to end together, csrc/entropy_args.h) rather than on equal chunks."""
         out = (C.c_int * 4)()
         self.check(self._lib.vbmc_last_entmc_plan(self._h, out))
-        return {"kernel": ("valu", "ws", "small", "mfma", "adam_fused")[out[0]] if out[0] >= 0 else None, "rg": out[1],
-                "chunks": out[2], "resident_draws": bool(out[3])}
+        return {"kernel": ("valu", "ws", "small", "mfma", "adam_fused", "ws")[out[0]] if out[0] >= 0 else None, "rg": out[1],
+                "chunks": out[2], "resident_draws": bool(out[3]), "span": out[0] == 5}
 
     def philox_normals(self, K, n_half, D, seed, row_begin=0, row_count=None):
         """[K][row_count][D] draws of the device generator (vbmc_philox_normals)."""

@@ -71,7 +71,7 @@ def _launcher_start_time():
         btime = next(int(l.split()[1]) for l in Path("/proc/stat").read_text().splitlines() if l.startswith("btime"))
         return btime + ticks / os.sysconf("SC_CLK_TCK")
     except (OSError, ValueError, IndexError, StopIteration):
-        return time.time() - 5.0
+        return None
 
 
 def _own_start_time():
@@ -87,7 +87,10 @@ def _launch_nonce():
     """What tells this launch from an earlier one that reused the same key: VBMC_LAUNCH_NONCE when the
     launcher sets one (bench.py's own spawner and the test harness do: random per launch), and the
     launcher's pid and start time (every launch under torchrun has its own agent process)."""
-    return f"{os.environ.get('VBMC_LAUNCH_NONCE', '')}|{os.getppid()}|{_launcher_start_time():.2f}".encode()
+    t = _launcher_start_time()
+    # (an unreadable /proc leaves the start time out: a per-rank fallback value would never match across ranks)
+    stamp = "" if t is None else f"{t:.2f}"
+    return f"{os.environ.get('VBMC_LAUNCH_NONCE', '')}|{os.getppid()}|{stamp}".encode()
 
 
 def exchange_unique_id(rank, world, make_id, timeout=300.0):
@@ -99,7 +102,8 @@ def exchange_unique_id(rank, world, make_id, timeout=300.0):
     path = _rendezvous_path()
     t0 = time.time()
     nonce = _launch_nonce()
-    not_before = max(_launcher_start_time() - 1.0, _own_start_time() - 60.0)
+    t_launcher = _launcher_start_time()
+    not_before = max((time.time() - 5.0 if t_launcher is None else t_launcher) - 1.0, _own_start_time() - 60.0)
     if rank == 0:
         uid = make_id()
         tmp = path.with_suffix(".tmp%d" % os.getpid())

@@ -230,6 +230,23 @@ struct AdamState {
   unsigned long long* d_flags = nullptr;  // [256]
 };
 
+static size_t fused_backup_len(const AdamDev& a) { return (size_t)a.lay.o_hyp() + 2 * (size_t)a.n_theta + (size_t)a.ml.total; }
+
+// A fused launch that gave up waiting may have got as far as its write-back in workgroup 0 (the others can run out of
+// time during the very last iteration): put back the state it started from -- workgroup 0 saved it behind the exchange
+// records before its first iteration -- so that the batch can be redone from the same point.
+static int fused_restore(vbmc_ctx* ctx, AdamState* st) {
+  const AdamDev& a = st->fz.a;
+  const AdamLayout& L = a.lay;
+  const double* b = st->fz.backup;
+  const size_t nh = (size_t)L.o_hyp(), n = (size_t)a.n_theta;
+  HIP_TRY(ctx, hipMemcpyAsync(a.state, b, sizeof(double) * nh, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(a.state + L.o_m(), b + nh, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(a.state + L.o_v(), b + nh + n, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(a.mix, b + nh + 2 * n, sizeof(double) * (size_t)a.ml.total, hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
+}
+
 static AdamState* adam_of(vbmc_ctx* ctx) {
   if (!ctx->adam) ctx->adam = new AdamState();
   return (AdamState*)ctx->adam;
@@ -456,7 +473,8 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
     const size_t lds = st->row_count <= 64 ? adam_fused_plan(f) : 0;
     if (lds) {
       const size_t rt = (size_t)K * (2 + 2 * D + K) + (size_t)S * K * (2 * D + 4);
-      rc = ensure_dev(ctx, &st->d_xch, &st->xch_cap, 2 * rt);
+      // (behind the records: the copy of the state a launch starts from, restored if it gives up waiting)
+      rc = ensure_dev(ctx, &st->d_xch, &st->xch_cap, 2 * rt + fused_backup_len(a));
       if (rc) return rc;
       if (!st->d_flags) HIP_TRY(ctx, hipMalloc((void**)&st->d_flags, 256 * sizeof(unsigned long long)));
       f.XT = ctx->gp.d_XT;
@@ -469,6 +487,7 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
       f.seed = st->seed;
       f.inv_ns = 1.0 / (double)st->ns;
       f.xch = st->d_xch;
+      f.backup = st->d_xch + 2 * rt;
       f.flags = st->d_flags;
       st->fused_lds = lds;
       st->fused = true;
@@ -499,7 +518,7 @@ static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool
     glj_fill_prep(ctx, 1, st->state + st->lay.o_res(), nullptr, pa);
     EntPlan plan;
     int rc = entmc_plan(ctx, st->ns, use_gen ? VBMC_EPS_RESIDENT : st->eps_mode, st->seed + (uint64_t)(i0 + it),
-                        st->row_begin, st->row_count, 1, plan);
+                        st->row_begin, st->row_count, 1, plan, 0, /*allow_span=*/false);  // (the pre row is a grid row of the chunk grid)
     if (rc) return rc;
     if (use_gen) {
       plan.a.eps = st->d_eps1;
@@ -631,6 +650,8 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
   if (!(status & 4) || !st->fused) break;
   st->fused = false;
   st->fused_gave_up++;
+  rc = fused_restore(ctx, st);
+  if (rc) return rc;
   HIP_TRY(ctx, hipMemsetAsync(st->d_status, 0, sizeof(int), ctx->stream));
   }
   st->iter = i0 + n_iters;
@@ -665,7 +686,9 @@ extern "C" int vbmc_adam_run_auto(vbmc_ctx* ctx, int max_iters, double tol_fun, 
     return e && e[0] == '1';
   }();
   const bool multi = ctx->comm != nullptr && (ctx->world > 1 || force_coll);
-  if (!st->fused || multi || max_iters == 0 || st->iter % 20 != 0) return VBMC_W_NOT_FUSED;
+  // the kernel's stopping rule compares the mean iterate of a batch with the previous batch's, which it accumulates
+  // itself from iteration 0 on: a run resumed after vbmc_adam_run iterations has no previous-batch mean to compare with
+  if (!st->fused || multi || max_iters == 0 || st->iter != 0) return VBMC_W_NOT_FUSED;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int n = st->n_theta, i0 = st->iter;
   FusedArgs f = st->fz;
@@ -685,6 +708,8 @@ extern "C" int vbmc_adam_run_auto(vbmc_ctx* ctx, int max_iters, double tol_fun, 
   if (word[0] & 4) {  // gave up waiting: nothing was written back, the caller runs its batches (four launches per iteration)
     st->fused = false;
     st->fused_gave_up++;
+    rc = fused_restore(ctx, st);
+    if (rc) return rc;
     HIP_TRY(ctx, hipMemsetAsync(st->d_status, 0, sizeof(int), ctx->stream));
     return VBMC_W_NOT_FUSED;
   }

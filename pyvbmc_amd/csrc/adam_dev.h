@@ -64,6 +64,7 @@ struct FusedArgs {
   unsigned long long seed = 0;
   double inv_ns = 0.0;
   double* xch = nullptr;                 // [2][K (2 + 2D + K) + S K (2D + 4)] exchange records
+  double* backup = nullptr;              // [o_hyp + 2 n_theta + pack]: theta | aux, m, v and the pack as this launch found them
   unsigned long long* flags = nullptr;   // [n_ent + n_gp], zeroed before the launch: the iteration a workgroup has published
   unsigned long long timeout = 2000000;  // wall-clock ticks (100 MHz) a workgroup waits for the others: 20 ms
   unsigned long long* times = nullptr;   // optional [2][64][16] phase stamps (VBMC_FUSED_TIMES=1)

@@ -208,6 +208,21 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
 #pragma unroll
   for (int u = 0; u < U; ++u) xs_cur[u] = xs_prev[u] = 0.0;
   int n_ran = f.n_iters;
+  if (g == 0 && f.backup) {  // what a launch that gives up is rolled back to (adam.hip fused_restore)
+    double* b = f.backup;
+    for (int i = tid; i < L.o_hyp(); i += NT) b[i] = a.state[i];
+    b += L.o_hyp();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = u * NT + tid;
+      if (i < n) {
+        b[i] = r_m[u];
+        b[n + i] = r_v[u];
+      }
+    }
+    b += 2 * n;
+    for (int i = tid; i < ml.total; i += NT) b[i] = a.mix[i];
+  }
   if (g >= f.n_ent) {
     for (int i = tid; i < D * N; i += NT) sXT[i] = f.XT[i];
     for (int i = tid; i < S * N; i += NT) sAl[i] = f.alpha[i];
@@ -791,7 +806,9 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
   }
   if (g == 0 && tid == 0 && f.n_done) *f.n_done = n_ran;
 
-  if (g == 0) {  // the state the next batch (or vbmc_adam_end) starts from
+  // the state the next batch (or vbmc_adam_end) starts from -- not if another workgroup has given up meanwhile (the host
+  // redoes the batch from the state this launch started with, and restores it in case the flag is raised after this test)
+  if (g == 0 && !(__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4)) {
     for (int i = tid; i < L.o_hyp(); i += NT) a.state[i] = sh[i];  // theta | aux
     for (int i = tid; i < ml.total; i += NT) a.mix[i] = pack[i];
 #pragma unroll

@@ -227,7 +227,7 @@ extern "C" int vbmc_acq_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int
   // ---- small batches (a CMA-ES population, a single point): the CPU writes the points straight into host-writable
   // device memory, the last kernel writes the results into pinned host memory and publishes a completion word that the
   // CPU polls: no copy calls and no stream synchronisation around ~30 us of kernels ----
-  if (M <= 256 && S <= 64 && ctx->opt_acq_poll && !ctx->acq_fg_failed) {
+  if (M <= 256 && M <= mb && S <= 64 && ctx->opt_acq_poll && !ctx->acq_fg_failed) {
     if (!ctx->d_acq_fg) {
       int large_bar = 0;
       if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) != hipSuccess || !large_bar ||
@@ -238,7 +238,8 @@ extern "C" int vbmc_acq_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int
       }
     }
   }
-  if (M <= 256 && S <= 64 && ctx->opt_acq_poll && ctx->d_acq_fg) {
+  // (M <= mb: the scratch and the pinned result rows are laid out for batches of mb points, which S * N can push below M)
+  if (M <= 256 && M <= mb && S <= 64 && ctx->opt_acq_poll && ctx->d_acq_fg) {
     if (ctx->spec.armed) spec_disarm(ctx);  // (launches waiting for a theta would sit in front of these)
     const int64_t m = M;
     memcpy(ctx->d_acq_fg, xs_MxD, sizeof(double) * m * D);
@@ -290,6 +291,7 @@ extern "C" int vbmc_acq_eval(vbmc_ctx* ctx, int64_t M, const double* xs_MxD, int
     }
     if (!seen) HIP_TRY(ctx, stream_wait(ctx));
     if (!seen && *flag != seq) return vbmc_fail(ctx, VBMC_E_HIP, "acq_eval: the completion word did not arrive");
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);  // the results were written before the word: read them after it
     ctx->pack_in_flight = false;  // (everything queued before the last kernel has run)
     memcpy(acq_M, ctx->h_pinned, sizeof(double) * m);
     if (f_bar_M) memcpy(f_bar_M, ctx->h_pinned + mb, sizeof(double) * m);

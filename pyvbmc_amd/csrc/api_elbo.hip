@@ -221,7 +221,10 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     glj_fill_prep(ctx, grad_flags != 0, res_out, nullptr, pa);
     EntPlan plan;
     if (mc) {
-      rc2 = entmc_plan(ctx, opts->ns_per_comp, opts->eps_mode, seed, row_begin, row_count, grad_flags != 0, plan);
+      // (the GP sums may ride in this launch's spare workgroup slots: only in the polled single-GPU step, see below)
+      const bool gp_rides = can_poll && ctx->opt_mix_bar && ctx->opt_gp_tail == 2 && ctx->d_mix_fg != nullptr;
+      rc2 = entmc_plan(ctx, opts->ns_per_comp, opts->eps_mode, seed, row_begin, row_count, grad_flags != 0, plan,
+                       gp_rides ? pa.n_glj : 0);
       if (rc2) return rc2;
       entmc_fill_prep(ctx, plan, pa);
       rc2 = entmc_pregen(ctx, plan, pa);  // Philox draws generated by extra blocks of the prep launch
@@ -257,11 +260,16 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
       // `chunks` workgroup slots free (one round: K * chunks <= CUs * resident workgroups per CU) --
       // else they stay in the prep launch (measured at config 5, whose grid is two rounds: prep
       // placement 215 us, finish placement 225 us); 1: the finish launch; 0: the prep launch.
+      // (Few slots carry them: beyond ~6 items per slot they would outlast the entropy kernel -- S = 4 hyper-parameter
+      // samples took 186 us per step against 114 with the prep placement -- so larger S keeps the prep launch.)
       bool in_ws = false;
-      if (ctx->opt_gp_tail == 2 && pa.n_glj > 0 && plan.ws && !entmc_small_applies(plan.a, plan.DP)) {
+      if (plan.a.sp.cus > 0) {
+        in_ws = plan.gp_in_ws && pa.n_glj > 0;  // span mode: the plan reserved the slots
+      } else if (ctx->opt_gp_tail == 2 && pa.n_glj > 0 && plan.ws && !entmc_small_applies(plan.a, plan.DP)) {
         const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
         const int slots = cus * ws_min_waves(plan.DP, ws_ktmax_for(K), grad_flags != 0);
-        in_ws = slots - K * plan.a.chunks >= plan.a.chunks;
+        const int free_slots = slots - K * plan.a.chunks;
+        in_ws = free_slots >= plan.a.chunks && pa.n_glj <= 6 * plan.a.chunks;
       }
       if (pa.n_glj > 0 && (in_ws || ctx->opt_gp_tail == 1)) {
         gp_tail = pa;

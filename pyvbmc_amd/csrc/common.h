@@ -198,6 +198,9 @@ struct vbmc_ctx {
   bool ident_retry = false;   // inside the re-evaluation after a failed identity check
   int opt_elbo_arm = 1;     // queue the next host-driven evaluation's launches ahead of its theta (armed evaluation)
   int opt_ws_pair = 1;      // entropy kernel: co-resident workgroups take the same table row (scalar-cache locality)
+  int opt_ws_span = 1;      // entropy kernel: span mode (entropy_args.h WsSpan: front / filler parts sized to end together); 0 = equal chunks
+  int opt_ws_front = 0;     // span mode: the front workgroup's share of a CU's batches, per mille (0 = the built-in value)
+  int opt_ws_pad = -1;      // span mode: padding slots behind every component (-1 = the built-in value)
   int opt_gp_tail = 2;      // with mix_bar: GP sums in a last row of the entropy launch (2; needs free workgroup slots, else 1), in the finish launch (1), in the prep launch (0)
   int opt_mix_bar = 1;      // host-driven step: pack written by the CPU into device memory (no upload launch), GP sums in the finish launch
   int opt_mix_kernel = 1;   // the mixture pack goes up through a copy kernel of our own instead of hipMemcpyAsync
@@ -421,8 +424,10 @@ int launch_prep_on(vbmc_ctx* ctx, hipStream_t stream, const PrepArgs& a);
 
 // staged launch of the Monte-Carlo entropy (entropy.hip)
 struct EntPlan;
+// gp_items: GP expected-log-joint items the caller would like this launch to carry in spare workgroup slots (the plan
+// says whether it does: EntPlan::gp_in_ws); allow_span = false keeps the chunk grid (the Adam loop's extra row)
 int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, int64_t row_begin,
-               int64_t row_count, int want_grad, EntPlan& p);
+               int64_t row_count, int want_grad, EntPlan& p, int gp_items = 0, bool allow_span = true);
 void entmc_fill_prep(const vbmc_ctx* ctx, const EntPlan& p, PrepArgs& a);
 int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& a);
 

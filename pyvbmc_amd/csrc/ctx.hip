@@ -72,6 +72,12 @@ static void options_from_env(vbmc_ctx* c) {
   c->opt_adam_fused = !(e && e[0] == '0');
   e = getenv("VBMC_WS_PAIR");
   c->opt_ws_pair = !(e && e[0] == '0');
+  e = getenv("VBMC_WS_SPAN");
+  c->opt_ws_span = !(e && e[0] == '0');
+  e = getenv("VBMC_WS_FRONT");
+  if (e) c->opt_ws_front = atoi(e);
+  e = getenv("VBMC_WS_PAD");
+  if (e) c->opt_ws_pad = atoi(e);
   e = getenv("VBMC_GP_TAIL");
   c->opt_gp_tail = e ? atoi(e) : 2;
   e = getenv("VBMC_MIX_BAR");
@@ -229,6 +235,9 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "mix_bar")) ctx->opt_mix_bar = value != 0;
   else if (!strcmp(key, "gp_tail")) ctx->opt_gp_tail = value;
   else if (!strcmp(key, "ws_pair")) ctx->opt_ws_pair = value != 0;
+  else if (!strcmp(key, "ws_span")) ctx->opt_ws_span = value != 0;
+  else if (!strcmp(key, "ws_pad")) ctx->opt_ws_pad = value > 8 ? 8 : value;
+  else if (!strcmp(key, "ws_front")) ctx->opt_ws_front = value < 0 ? 0 : value > 990 ? 990 : value;
   else if (!strcmp(key, "elbo_arm")) ctx->opt_elbo_arm = value != 0;
   else if (!strcmp(key, "ahead_pct")) ctx->opt_ahead_pct = value;
   else if (!strcmp(key, "acq_poll")) ctx->opt_acq_poll = value != 0;

@@ -525,9 +525,21 @@ static int padded_d(int D) {
   return -1;
 }
 
+// Span mode: the front workgroup's share of a CU's batches, per mille (entropy_args.h WsSpan) -- the fraction of the
+// issue slots one wave per SIMD of this instantiation uses when it runs alone.  Read off tools/ws_front_probe.py
+// (kernel time over the share, every padded D x register-array size of the 2-waves/SIMD builds, value and value +
+// gradient): padded D <= 12: 620-700 is the flat optimum everywhere (3-15 % under the equal chunks); padded D = 16 (the
+// rows' loads weigh more against the arithmetic of a batch, the waves already alternate): 540-580, and with at most 8
+// components per wave the equal chunks stay ahead by 1-4 % -- 0 = keep them.
+static int ws_front_default(int DP, int KT) {
+  if (DP <= 12) return 660;
+  if (DP == 16) return KT <= 8 ? 0 : 570;
+  return 660;  // (one wave per SIMD: no filler parts, the value is not used)
+}
+
 // Decide the launch geometry and carve the scratch buffer.
 int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, int64_t row_begin,
-               int64_t row_count, int want_grad, EntPlan& p) {
+               int64_t row_count, int want_grad, EntPlan& p, int gp_items, bool allow_span) {
   const int D = ctx->D, K = ctx->K;
   p.DP = padded_d(D);
   if (p.DP < 0) return vbmc_fail(ctx, VBMC_E_UNSUP, "entmc: D=%d > 32 not supported", D);
@@ -586,6 +598,59 @@ int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
     if (ws_min_waves(p.DP, ws_ktmax_for(K), want_grad != 0) == 2 && total > cus && total <= 2 * (int64_t)cus)
       a.pair_cus = cus;
   }
+  // Span mode (entropy_args.h WsSpan): every CU gets a front part, all but the GP row's a filler part, sized so that
+  // they end together.  Used when the launch is the plain wave-split kernel (not its matrix-pipe or small-count forms)
+  // and a part is at least a few batches long.
+  a.sp = WsSpan();
+  a.gp_wgs = 0;
+  p.gp_in_ws = false;
+  EntArgs at_launch = a;  // (Philox draws generated ahead of the kernel reach it as resident draws: entmc_pregen)
+  {
+    const size_t n_eps = (size_t)K * (size_t)row_count * D;
+    if (eps_mode == VBMC_EPS_PHILOX && ctx->opt_elbo_pregen && n_eps > 0 && n_eps <= ((size_t)1 << 28)) {
+      at_launch.eps_mode = VBMC_EPS_RESIDENT;
+      at_launch.eps = ctx->d_scratch ? ctx->d_scratch : (const double*)ctx;  // any non-null address: only tested
+    }
+  }
+  if (p.ws && allow_span && ctx->opt_ws_span && !entmc_small_applies(at_launch, p.DP) &&
+      !(ctx->opt_entmc_mfma && entmc_mfma_applies(at_launch, p.DP))) {
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    const int waves = ws_min_waves(p.DP, ws_ktmax_for(K), want_grad != 0);
+    WsSpan sp;
+    sp.cus = cus;
+    sp.nb = (int)((row_count + 63) >> 6);
+    sp.pad = ctx->opt_ws_pad >= 0 ? ctx->opt_ws_pad : 2;
+    sp.T = (int64_t)K * sp.nbv();
+    sp.front = ctx->opt_ws_front > 0 ? ctx->opt_ws_front : ws_front_default(p.DP, ws_ktmax_for(K));
+    // The GP sums of the host-driven step ride in this launch when they fit WS_GP_SLOTS workgroups of at most six
+    // items each (they are then done inside the first half of the kernel).  The slots are left free whether or not
+    // anything rides in them: how the batches are cut -- hence the order of every sum -- depends on the job alone,
+    // never on where the GP sums run or on any option (the step's launch plans stay bit-identical).
+    constexpr int WS_GP_SLOTS = 10;
+    const int gp_wgs = gp_items > 0 ? std::min(WS_GP_SLOTS, (gp_items + 4) / 5) : 0;
+    const bool gp_here = waves == 2 && gp_wgs > 0 && gp_items <= 6 * WS_GP_SLOTS;
+    sp.pb = waves == 2 ? cus - WS_GP_SLOTS : 0;
+    if (sp.pb == 0) sp.front = 1000;
+    const int64_t min_part = sp.front > 0 ? (sp.pb > 0 ? 1000 - sp.front : sp.front) * sp.T / sp.W() : 0;
+    if (min_part >= 3 && sp.T < ((int64_t)1 << 40)) {
+      int R = 1;
+      int longest = 0;
+      for (int j = 0; j < K; ++j) {
+        const int n = sp.part_of((int64_t)j * sp.nbv() + sp.nb - 1) - sp.part_of((int64_t)j * sp.nbv()) + 1;
+        R = n > R ? n : R;
+      }
+      for (int u = 0; u < sp.n_parts(); ++u) longest = std::max(longest, (int)(sp.lo(u + 1) - sp.lo(u)));
+      sp.R = R;
+      a.sp = sp;
+      a.chunks = R;
+      a.rg = longest;
+      a.pair_cus = 0;
+      if (gp_here) {
+        a.gp_wgs = gp_wgs;
+        p.gp_in_ws = true;
+      }
+    }
+  }
   a.stride = 2 + 2 * D + K;
   const size_t n_part = (size_t)K * a.chunks * a.stride;
   int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, n_part + n_table);
@@ -593,6 +658,29 @@ int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
   a.partial = ctx->d_scratch;
   p.table = p.ws ? ctx->d_scratch + n_part : nullptr;
   return 0;
+}
+
+// Host-only view of the span arithmetic (the CPU suite checks its invariants; the kernels use the same struct).
+extern "C" int vbmc_ws_span_layout(int cus, int pb, int front, int nb, int pad, int K, int64_t* part_lo, int* first_part,
+                                   int* rows_per_component) {
+  if (cus <= 0 || pb < 0 || pb > cus || front <= 0 || front >= 1000 + (pb == 0) || nb <= 0 || pad < 0 || K <= 0 || !part_lo ||
+      !first_part || !rows_per_component)
+    return VBMC_E_ARG;
+  WsSpan sp;
+  sp.cus = cus;
+  sp.pb = pb;
+  sp.front = front;
+  sp.nb = nb;
+  sp.pad = pad;
+  sp.T = (int64_t)K * sp.nbv();
+  for (int u = 0; u <= sp.n_parts(); ++u) part_lo[u] = sp.lo(u);
+  int R = 1;
+  for (int j = 0; j < K; ++j) {
+    first_part[j] = sp.part_of((int64_t)j * sp.nbv());
+    R = std::max(R, sp.part_of((int64_t)j * sp.nbv() + nb - 1) - first_part[j] + 1);
+  }
+  *rows_per_component = R;
+  return VBMC_OK;
 }
 
 void entmc_fill_prep(const vbmc_ctx* ctx, const EntPlan& p, PrepArgs& a) {
@@ -702,9 +790,9 @@ int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p) {
   // timing: the wave-split launch carries the event pair on its own dispatch packet; the generic
   // kernel is bracketed by two records (each a barrier packet, ~6 us between dependent kernels)
   hipEvent_t e0 = ctx->timing ? ctx->ev[0] : nullptr, e1 = ctx->timing ? ctx->ev[1] : nullptr;
-  const bool small = p.ws && entmc_small_applies(a, p.DP);
-  const bool mfma = p.ws && !small && ctx->opt_entmc_mfma && entmc_mfma_applies(a, p.DP);
-  ctx->last_plan[0] = small ? 2 : mfma ? 3 : (p.ws ? 1 : 0);
+  const bool small = p.ws && a.sp.cus == 0 && entmc_small_applies(a, p.DP);  // (a span-mode plan is the wave-split kernel's)
+  const bool mfma = p.ws && a.sp.cus == 0 && !small && ctx->opt_entmc_mfma && entmc_mfma_applies(a, p.DP);
+  ctx->last_plan[0] = small ? 2 : mfma ? 3 : (p.ws ? (a.sp.cus > 0 ? 5 : 1) : 0);  // (5: the wave-split kernel in span mode)
   ctx->last_plan[1] = a.rg;
   ctx->last_plan[2] = a.chunks;
   ctx->last_plan[3] = a.eps_mode == VBMC_EPS_RESIDENT ? 1 : 0;

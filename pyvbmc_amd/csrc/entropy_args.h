@@ -2,6 +2,56 @@
 #pragma once
 #include "common.h"
 
+// Span mode of the wave-split kernel: which 64-row batches a workgroup works through.
+//
+// The SIMD issues the OLDER of two ready waves first.  With two workgroups resident per CU (the 2-waves/SIMD builds)
+// the first-dispatched one therefore runs as if it had the CU to itself and the other only fills the issue slots it
+// leaves: given equal shares the first ends after 2/3 of the kernel and the second finishes alone at the one-wave
+// cadence (tools/ws_times.py: 52 against 79 us at BASELINE config 3).  So the shares are made unequal on purpose: the
+// `front` workgroup of a CU (block p < cus, dispatched in the first round) takes `front` per mille of the CU's batches,
+// the `filler` (block cus + p, which the dispatcher places beside it) the rest, and both end together.  Batches are
+// numbered g over components j and cut into cus + pb consecutive parts
+//     A_0 B_0 A_1 B_1 ... A_pb-1 B_pb-1 A_pb ... A_cus-1        (units p >= pb have no filler: their second slot is left
+// to the GP-sum workgroups of the host-driven step) whose lengths are proportional to the weights front / 1000 - front,
+// so every CU ends at the same time whatever K and the row count are.  A part that crosses a component boundary is
+// worked through as two stretches with a partial row each; component j's rows are those of the parts that overlap it,
+// in part order (slot = part - first part of j), R per component, the unused ones zeroed by the part that ends j.
+// Ending a component costs its part a second end-of-workgroup reduction (~3 us, about one batch of the front
+// workgroup): the list that is cut is therefore the VIRTUAL one in which every component is followed by `pad` slots
+// of no work -- the part that ends a component gets that much less of everything else.
+// Everything is static arithmetic on (T, nb, cus, pb, front): results are bit-reproducible.
+struct WsSpan {
+  int cus = 0;      // > 0: span mode
+  int pb = 0;       // units that have a filler part
+  int front = 0;    // weight of a front part, per mille of a full unit
+  int nb = 0;       // batches per component
+  int pad = 0;      // virtual slots behind every component (the price of ending it)
+  int R = 0;        // partial rows per component
+  int64_t T = 0;    // K * (nb + pad): slots of the virtual list; component j's batches are [j (nb + pad), j (nb + pad) + nb)
+  __host__ __device__ int nbv() const { return nb + pad; }
+  __host__ __device__ int n_parts() const { return cus + pb; }
+  __host__ __device__ int64_t W() const { return (int64_t)pb * 1000 + (int64_t)(cus - pb) * front; }
+  // cumulative weight in front of part u; cw(n_parts()) = W()
+  __host__ __device__ int64_t cw(int u) const {
+    return u < 2 * pb ? (int64_t)(u >> 1) * 1000 + (int64_t)(u & 1) * front : (int64_t)pb * 1000 + (int64_t)(u - 2 * pb) * front;
+  }
+  __host__ __device__ int64_t lo(int u) const { return cw(u) * T / W(); }  // first slot of part u; lo(n_parts()) = T
+  // the part that holds slot g: the largest u with lo(u) <= g, i.e. cw(u) T < (g + 1) W
+  __host__ __device__ int part_of(int64_t g) const {
+    const int64_t c = ((g + 1) * W() - 1) / T;
+    int u;
+    if (c < (int64_t)pb * 1000) {
+      const int p = (int)(c / 1000);
+      u = 2 * p + ((c - (int64_t)p * 1000) >= front ? 1 : 0);
+    } else {
+      u = 2 * pb + (int)((c - (int64_t)pb * 1000) / front);
+    }
+    return u < n_parts() ? u : n_parts() - 1;
+  }
+  // block -> part: blocks [0, cus) are the front parts of units 0 .. cus-1, blocks [cus, cus + pb) the fillers
+  __host__ __device__ int part_of_block(int b) const { return b < cus ? (b < pb ? 2 * b : 2 * pb + (b - pb)) : 2 * (b - cus) + 1; }
+};
+
 struct EntArgs {
   const double* mix;
   MixLayout ml;
@@ -32,6 +82,8 @@ struct EntArgs {
   // that the two workgroups of a CU read the same table row (entropy_ws.hip).  Set by entmc_plan for
   // one-round grids of the 2-waves/SIMD builds.
   int pair_cus = 0;
+  WsSpan sp;          // wave-split kernel: span mode (above); then chunks = sp.R and rg = the longest part
+  int gp_wgs = 0;     // span mode: workgroups of the GP row (blocks behind the entropy parts)
   // armed evaluation (common.h ArmedEval): every workgroup returns at once when *cancel == ~0
   const uint64_t* cancel = nullptr;
 };
@@ -59,6 +111,7 @@ constexpr int ws_min_waves(int dp, int ktmax, bool grad) {
 
 struct EntPlan {
   EntArgs a;
+  bool gp_in_ws = false;    // span mode: the plan left workgroup slots for the GP sums (a.gp_wgs of them)
   bool pregen_hit = false;  // the draws come from a speculative generation (entmc_pregen)
   bool ws = false;
   int DP = 0;

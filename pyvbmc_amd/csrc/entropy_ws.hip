@@ -127,8 +127,9 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   // Adam loop (adam.hip): grid row 0 is not an entropy row -- its first workgroup computes the
   // entropy-free part of the iteration's gradient beside the entropy workgroups (adam_dev.h)
   constexpr bool EXTRA_ROW = GRAD && !PHILOX;
+  const bool span = a.sp.cus > 0;  // (span mode: a one-dimensional grid, entropy_args.h WsSpan)
   if constexpr (EXTRA_ROW) {
-    if (a.extra != nullptr && blockIdx.y == 0) {
+    if (a.extra != nullptr && !span && blockIdx.y == 0) {
       if (blockIdx.x == 0) {
         const adam_dev::AdamDev& pa = *(const adam_dev::AdamDev*)a.extra;
         if (a.extra_lds > 0) adam_dev::adam_pre_body<true>(pa, dyn, &sRed[0][0], pa.pre);
@@ -139,10 +140,11 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   }
   // armed evaluation that the host cancelled (common.h ArmedEval): nothing to do
   if (a.cancel != nullptr && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ~(uint64_t)0) return;
-  // Host-driven step (api_elbo.hip): the LAST grid row works through the GP expected-log-joint
-  // items in the workgroup slots this launch's entropy rows leave free (entropy_args.h)
-  if (a.gp_items > 0 && blockIdx.y == gridDim.y - 1) {
-    for (int it = blockIdx.x; it < a.gp_items; it += gridDim.x) {
+  // Host-driven step (api_elbo.hip): the LAST workgroups of the grid work through the GP expected-log-joint
+  // items in the workgroup slots this launch's entropy parts leave free (entropy_args.h)
+  if (a.gp_items > 0 && (span ? (int)blockIdx.x >= a.sp.n_parts() : blockIdx.y == gridDim.y - 1)) {
+    const int first = span ? (int)blockIdx.x - a.sp.n_parts() : (int)blockIdx.x, step = span ? a.gp_wgs : (int)gridDim.x;
+    for (int it = first; it < a.gp_items; it += step) {
       glj_block(a.gp, it, dyn);
       __syncthreads();
     }
@@ -150,30 +152,45 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   }
   const int D = a.ml.D;
   constexpr int KT = KTMAX, K4 = KT * 4;
-  int j = (EXTRA_ROW && a.extra != nullptr) ? blockIdx.y - 1 : blockIdx.y, chunk = blockIdx.x;
-  // Scalar-cache locality.  With two workgroups resident per CU and a grid of one round, workgroups
-  // b and b + CUs of a launch share a CU (tools/probes/placement.hip); in grid order they would read
-  // table rows j and j + CUs / chunks -- every CU (and the neighbour it shares its 16 KB scalar cache
-  // with) then sweeps distinct 6.6 KB rows 32 times each and the rows evict each other.  Hand the
-  // (j, chunk) items out so that co-resident workgroups take neighbouring items, i.e. the same j.
-  if (a.pair_cus > 0) {
-    const int total = a.ml.K * a.chunks, b = j * a.chunks + chunk;
-    const int paired = total - a.pair_cus;  // workgroups of the second round = pairs (b, b + pair_cus)
-    if (paired > 0 && b < 2 * a.pair_cus) {
-      const int m = b < a.pair_cus ? b : b - a.pair_cus;
-      const int item = m < paired ? 2 * m + (b >= a.pair_cus ? 1 : 0) : paired + m;
-      j = item / a.chunks;
-      chunk = item - j * a.chunks;
+  // ---- this workgroup's batches: [g_lo, g_hi) of the component-major batch list, cut into stretches inside one
+  // component.  Chunk mode: one stretch (component j = blockIdx.y, batches [chunk rg, chunk rg + rg) of its nb). ----
+  int64_t g_lo, g_hi;
+  int nb, part = 0, chunk_slot = 0, j_chunk = 0;
+  int nbv;  // slots per component in the list that is cut: its batches, then (span mode) the padding slots
+  if (span) {
+    nb = a.sp.nb;
+    nbv = a.sp.nbv();
+    part = a.sp.part_of_block((int)blockIdx.x);
+    g_lo = a.sp.lo(part);
+    g_hi = a.sp.lo(part + 1);
+  } else {
+    int j = (EXTRA_ROW && a.extra != nullptr) ? blockIdx.y - 1 : blockIdx.y, chunk = blockIdx.x;
+    // Scalar-cache locality.  With two workgroups resident per CU and a grid of one round, workgroups
+    // b and b + CUs of a launch share a CU (tools/probes/placement.hip); in grid order they would read
+    // table rows j and j + CUs / chunks -- every CU (and the neighbour it shares its 16 KB scalar cache
+    // with) then sweeps distinct 6.6 KB rows 32 times each and the rows evict each other.  Hand the
+    // (j, chunk) items out so that co-resident workgroups take neighbouring items, i.e. the same j.
+    if (a.pair_cus > 0) {
+      const int total = a.ml.K * a.chunks, b = j * a.chunks + chunk;
+      const int paired = total - a.pair_cus;  // workgroups of the second round = pairs (b, b + pair_cus)
+      if (paired > 0 && b < 2 * a.pair_cus) {
+        const int m = b < a.pair_cus ? b : b - a.pair_cus;
+        const int item = m < paired ? 2 * m + (b >= a.pair_cus ? 1 : 0) : paired + m;
+        j = item / a.chunks;
+        chunk = item - j * a.chunks;
+      }
     }
+    nb = (int)((a.row_count + 63) >> 6);
+    nbv = nb;
+    chunk_slot = chunk;
+    j_chunk = j;
+    const int64_t i0 = (int64_t)chunk * a.rg;
+    g_lo = (int64_t)j * nb + (i0 < nb ? i0 : nb);
+    g_hi = (int64_t)j * nb + (i0 + a.rg < nb ? i0 + a.rg : nb);
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   WS_STAMP(0);
-
-  const double sig_j = a.mix[a.ml.o_sig + j];
-  const double sj2 = sig_j * sig_j;
-  const double two_sj = 2.0 * sig_j;
-  const double* Tj = T + (size_t)j * K4 * TS;
 
   double ec[10];
   {
@@ -182,6 +199,22 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
 #pragma unroll
     for (int i = 0; i < 10; ++i) ec[i] = kExp2C[i + vz];
   }
+  WS_STAMP(1);
+  bool first_stretch = true;
+  for (int64_t g = g_lo; g < g_hi || (first_stretch && !span);) {  // (chunk mode: an empty chunk still writes its zero row)
+  first_stretch = false;
+  const int j = span ? (int)(g / nbv) : j_chunk;
+  const int ib0 = (int)(g - (int64_t)j * nbv);  // first batch of the stretch within component j (or a padding slot >= nb)
+  if (ib0 >= nb) {                               // padding behind component j: no work
+    g = (int64_t)(j + 1) * nbv;
+    continue;
+  }
+  const int n_it = g < g_hi ? (int)((g_hi - g < nb - ib0) ? g_hi - g : nb - ib0) : 0;  // its batches
+  const int slot = span ? part - a.sp.part_of((int64_t)j * nbv) : chunk_slot;    // its partial row among component j's
+  const double sig_j = a.mix[a.ml.o_sig + j];
+  const double sj2 = sig_j * sig_j;
+  const double two_sj = 2.0 * sig_j;
+  const double* Tj = T + (size_t)j * K4 * TS;
   double slog_acc = 0.0;
   double mu_acc[DP], lam_acc[DP], Wacc[KTMAX];
 #pragma unroll
@@ -189,10 +222,8 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
 #pragma unroll
   for (int kk = 0; kk < KTMAX; ++kk) Wacc[kk] = 0.0;
 
-  const int rows_per_wg = a.rg * 64;
-  WS_STAMP(1);
-  for (int it = 0; it < a.rg; ++it) {
-    const int64_t i_loc = (int64_t)chunk * rows_per_wg + it * 64 + lane;
+  for (int it = 0; it < n_it; ++it) {
+    const int64_t i_loc = ((int64_t)(ib0 + it) << 6) + lane;
     const bool valid = i_loc < a.row_count;
 
     // ---- this row's D standard normals ----
@@ -214,11 +245,11 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
       constexpr int NP = DP / 2;
       const int nbk = (D + 3) / 4;  // blocks actually needed
       if ((it % GB) == 0) {
-        const int nb = min(GB, a.rg - it);
+        const int nb = min(GB, n_it - it);
         __syncthreads();  // readers of the previous round are done with sE
         for (int q = wave; q < nb * nbk; q += WAVES) {
           const int bq = q / nbk, blk = q - bq * nbk;
-          const int64_t il = (int64_t)chunk * rows_per_wg + (it + bq) * 64 + lane;
+          const int64_t il = ((int64_t)(ib0 + it + bq) << 6) + lane;
           const uint64_t grow = (uint64_t)j * (uint64_t)a.n_half + (uint64_t)(a.row_begin + il);
           double z[4];
           philox_normal_quad(grow, (uint32_t)blk, a.seed, z);
@@ -423,7 +454,7 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   }
 
   WS_STAMP(3);
-  double* out = a.partial + ((int64_t)j * a.chunks + chunk) * a.stride;
+  double* out = a.partial + ((int64_t)j * a.chunks + slot) * a.stride;
   for (int t = tid; t < a.stride; t += WG) {
     double v = 0.0;
     if (t == 0) {
@@ -443,6 +474,15 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
     }
     out[t] = v;
   }
+  if (span) {
+    // the part that ends component j zeroes the rows of j that no part writes (the finish kernel sums R of them)
+    if (ib0 + n_it == nb)
+      for (int t = tid; t < (a.chunks - 1 - slot) * a.stride; t += WG) out[a.stride + t] = 0.0;
+    __syncthreads();  // sRed / sW are free again
+  }
+  g += n_it;
+  if (!span) break;
+  }
 }
 
 template <int DP, int KTMAX>
@@ -452,7 +492,9 @@ void launch_one(hipStream_t st, const EntArgs& a, const double* d_table, hipEven
   size_t lds = sizeof(double) * ((size_t)K4 + ws_epi_doubles(DP, KTMAX, a.want_grad != 0));
   const bool philox = a.eps_mode == VBMC_EPS_PHILOX;
   const bool extra_row = a.extra != nullptr && a.want_grad && !philox;  // see EXTRA_ROW in the kernel
-  const dim3 grid(a.chunks, K + (extra_row ? 1 : 0) + (a.gp_items > 0 ? 1 : 0)), block(WG);
+  const dim3 grid = a.sp.cus > 0 ? dim3(a.sp.n_parts() + (a.gp_items > 0 ? a.gp_wgs : 0))
+                                 : dim3(a.chunks, K + (extra_row ? 1 : 0) + (a.gp_items > 0 ? 1 : 0));
+  const dim3 block(WG);
   if (extra_row && sizeof(double) * (size_t)a.extra_lds > lds) lds = sizeof(double) * (size_t)a.extra_lds;
   if (a.gp_items > 0 && glj_block_lds(a.ml.D, a.gp.N) > lds) lds = glj_block_lds(a.ml.D, a.gp.N);
   int dev = 0;

@@ -178,3 +178,56 @@ def test_workload_generator_is_stable(golden):
         assert np.array_equal(wl.hyp, g["hyp"]) and wl.NsK == int(g["NsK"])
     assert synthetic.ns_per_component(1_000_000, 50) == 20000
     assert synthetic.ns_per_component(1000, 3) == 334
+
+
+@pytest.mark.parametrize("cus,pb,front,nb,pad,K", [(256, 246, 660, 157, 2, 50), (256, 246, 570, 1250, 2, 50), (256, 0, 1000, 40, 2, 100),
+                                                    (256, 246, 660, 3, 0, 128), (304, 294, 700, 79, 1, 7), (64, 54, 620, 500, 3, 1)])
+def test_span_mode_partition_invariants(cus, pb, front, nb, pad, K):
+    """The wave-split entropy kernel's span mode (csrc/entropy_args.h WsSpan) cuts the padded batch list into
+    cus + pb consecutive parts whose lengths follow the front / filler weights: the parts tile the list, their
+    lengths are within one slot of the weights' shares, every component's batches are covered exactly once, in
+    part order, by at most rows_per_component parts, and part_of inverts the boundaries."""
+    import ctypes as C
+
+    from pyvbmc_amd import _lib
+
+    lib = _lib.load()
+    n = cus + pb
+    lo = (C.c_int64 * (n + 1))()
+    first = (C.c_int * K)()
+    R = C.c_int()
+    assert lib.vbmc_ws_span_layout(cus, pb, front, nb, pad, K, lo, first, C.byref(R)) == 0
+    lo = np.array(lo[:], dtype=np.int64)
+    first = np.array(first[:])
+    nbv = nb + pad
+    T = K * nbv
+    assert lo[0] == 0 and lo[-1] == T and np.all(np.diff(lo) >= 0)
+    W = pb * 1000 + (cus - pb) * front
+    w = np.array([front if (u % 2 == 0 or u >= 2 * pb) else 1000 - front for u in range(n)], dtype=np.float64)
+    if pb == 0:
+        w[:] = front
+    assert np.all(np.abs(np.diff(lo) - w * T / W) < 1.0 + 1e-9)  # every part within one slot of its share
+    covered = np.zeros((K, nb), dtype=np.int32)
+    rows = np.zeros(K, dtype=np.int32)
+    written = [set() for _ in range(K)]
+    for u in range(n):
+        g = lo[u]
+        while g < lo[u + 1]:
+            j, i = divmod(int(g), nbv)
+            if i >= nb:  # padding slot
+                g = (j + 1) * nbv
+                continue
+            cnt = min(int(lo[u + 1] - g), nb - i)
+            covered[j, i : i + cnt] += 1
+            slot = u - first[j]
+            assert 0 <= slot < R.value, (u, j, slot, R.value)
+            assert slot not in written[j]
+            written[j].add(slot)
+            rows[j] = max(rows[j], slot + 1)
+            g += cnt
+    assert np.all(covered == 1)
+    assert rows.max() == R.value
+    for j in range(K):  # the rows of a component are a dense prefix: the finish kernel sums R of them, the rest zeroed
+        assert written[j] == set(range(rows[j]))
+    # a part's stretches within one component are contiguous, so slots are distinct per (part, component)
+    assert lib.vbmc_ws_span_layout(cus, cus + 1, front, nb, pad, K, lo.ctypes.data_as(C.POINTER(C.c_int64)), first.ctypes.data_as(C.POINTER(C.c_int)), C.byref(R)) != 0
