@@ -181,7 +181,7 @@ def test_workload_generator_is_stable(golden):
 
 
 @pytest.mark.parametrize("cus,pb,front,nb,pad,K", [(256, 246, 660, 157, 2, 50), (256, 246, 570, 1250, 2, 50), (256, 0, 1000, 40, 2, 100),
-                                                    (256, 246, 660, 3, 0, 128), (304, 294, 700, 79, 1, 7), (64, 54, 620, 500, 3, 1)])
+                                                    (256, 246, 660, 30, 0, 128), (304, 294, 700, 790, 1, 7), (64, 54, 620, 500, 3, 1)])
 def test_span_mode_partition_invariants(cus, pb, front, nb, pad, K):
     """The wave-split entropy kernel's span mode (csrc/entropy_args.h WsSpan) cuts the padded batch list into
     cus + pb consecutive parts whose lengths follow the front / filler weights: the parts tile the list, their
@@ -199,6 +199,7 @@ def test_span_mode_partition_invariants(cus, pb, front, nb, pad, K):
     assert lib.vbmc_ws_span_layout(cus, pb, front, nb, pad, K, lo, first, C.byref(R)) == 0
     lo = np.array(lo[:], dtype=np.int64)
     first = np.array(first[:])
+    assert np.min(np.diff(lo)) >= 3  # (what entmc_plan requires before it uses span mode: no part shorter than three slots)
     nbv = nb + pad
     T = K * nbv
     assert lo[0] == 0 and lo[-1] == T and np.all(np.diff(lo) >= 0)
