@@ -518,7 +518,7 @@ static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool
     glj_fill_prep(ctx, 1, st->state + st->lay.o_res(), nullptr, pa);
     EntPlan plan;
     int rc = entmc_plan(ctx, st->ns, use_gen ? VBMC_EPS_RESIDENT : st->eps_mode, st->seed + (uint64_t)(i0 + it),
-                        st->row_begin, st->row_count, 1, plan, 0, /*allow_span=*/false);  // (the pre row is a grid row of the chunk grid)
+                        st->row_begin, st->row_count, 1, plan);
     if (rc) return rc;
     if (use_gen) {
       plan.a.eps = st->d_eps1;

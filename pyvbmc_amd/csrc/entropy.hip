@@ -609,8 +609,10 @@ int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
     const size_t n_eps = (size_t)K * (size_t)row_count * D;
     if (eps_mode == VBMC_EPS_PHILOX && ctx->opt_elbo_pregen && n_eps > 0 && n_eps <= ((size_t)1 << 28)) {
       at_launch.eps_mode = VBMC_EPS_RESIDENT;
-      at_launch.eps = ctx->d_scratch ? ctx->d_scratch : (const double*)ctx;  // any non-null address: only tested
+      at_launch.eps = (const double*)ctx;  // any non-null address: only tested
     }
+    // (resident draws whose buffer the caller fills in after planning: the optimiser loop's own)
+    if (at_launch.eps_mode == VBMC_EPS_RESIDENT && at_launch.eps == nullptr) at_launch.eps = (const double*)ctx;
   }
   if (p.ws && allow_span && ctx->opt_ws_span && !entmc_small_applies(at_launch, p.DP) &&
       !(ctx->opt_entmc_mfma && entmc_mfma_applies(at_launch, p.DP))) {

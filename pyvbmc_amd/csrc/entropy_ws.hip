@@ -129,8 +129,10 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   constexpr bool EXTRA_ROW = GRAD && !PHILOX;
   const bool span = a.sp.cus > 0;  // (span mode: a one-dimensional grid, entropy_args.h WsSpan)
   if constexpr (EXTRA_ROW) {
-    if (a.extra != nullptr && !span && blockIdx.y == 0) {
-      if (blockIdx.x == 0) {
+    // (span mode: the one workgroup behind the entropy parts and the GP row -- it finds a free slot at once, the
+    // plan leaves some: entropy_args.h)
+    if (a.extra != nullptr && (span ? (int)blockIdx.x == a.sp.n_parts() + (a.gp_items > 0 ? a.gp_wgs : 0) : blockIdx.y == 0)) {
+      if (span || blockIdx.x == 0) {
         const adam_dev::AdamDev& pa = *(const adam_dev::AdamDev*)a.extra;
         if (a.extra_lds > 0) adam_dev::adam_pre_body<true>(pa, dyn, &sRed[0][0], pa.pre);
         else adam_dev::adam_pre_body<false>(pa, nullptr, &sRed[0][0], pa.pre);
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   if (a.cancel != nullptr && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ~(uint64_t)0) return;
   // Host-driven step (api_elbo.hip): the LAST workgroups of the grid work through the GP expected-log-joint
   // items in the workgroup slots this launch's entropy parts leave free (entropy_args.h)
-  if (a.gp_items > 0 && (span ? (int)blockIdx.x >= a.sp.n_parts() : blockIdx.y == gridDim.y - 1)) {
+  if (a.gp_items > 0 && (span ? (int)blockIdx.x >= a.sp.n_parts() && (int)blockIdx.x < a.sp.n_parts() + a.gp_wgs : blockIdx.y == gridDim.y - 1)) {
     const int first = span ? (int)blockIdx.x - a.sp.n_parts() : (int)blockIdx.x, step = span ? a.gp_wgs : (int)gridDim.x;
     for (int it = first; it < a.gp_items; it += step) {
       glj_block(a.gp, it, dyn);
@@ -492,7 +494,7 @@ void launch_one(hipStream_t st, const EntArgs& a, const double* d_table, hipEven
   size_t lds = sizeof(double) * ((size_t)K4 + ws_epi_doubles(DP, KTMAX, a.want_grad != 0));
   const bool philox = a.eps_mode == VBMC_EPS_PHILOX;
   const bool extra_row = a.extra != nullptr && a.want_grad && !philox;  // see EXTRA_ROW in the kernel
-  const dim3 grid = a.sp.cus > 0 ? dim3(a.sp.n_parts() + (a.gp_items > 0 ? a.gp_wgs : 0))
+  const dim3 grid = a.sp.cus > 0 ? dim3(a.sp.n_parts() + (a.gp_items > 0 ? a.gp_wgs : 0) + (extra_row ? 1 : 0))
                                  : dim3(a.chunks, K + (extra_row ? 1 : 0) + (a.gp_items > 0 ? 1 : 0));
   const dim3 block(WG);
   if (extra_row && sizeof(double) * (size_t)a.extra_lds > lds) lds = sizeof(double) * (size_t)a.extra_lds;
