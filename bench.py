@@ -55,6 +55,10 @@ def parse():
     p.add_argument("--config", type=int, default=3, choices=sorted(PER_GPU_NS),
                    help="BASELINE config whose per-GPU shape is run (3 = the headline metric's; 4 = config 4's "
                         "job, Ns = 8e6, split over the ranks)")
+    p.add_argument("--S", type=int, default=1,
+                   help="GP hyper-parameter samples of the measured workload (1 = the headline; the reference's default is "
+                        "about 80 / sqrt(N), gaussian_process_train.py:455-472: 4 at N = 400; S = 4 and 8 are also "
+                        "reported as secondary figures of the default run)")
     p.add_argument("--rng", choices=["philox", "resident"], default="philox",
                    help="philox: fresh in-kernel draws every eval; resident: HBM-resident eps reused")
     p.add_argument("--job", action="store_true",
@@ -176,7 +180,7 @@ def main():
     # process, where a coarse activity sampler can see them
     cpu_res = None
     ns_gpu = (JOB_NS[a.config] // world) if job_mode else PER_GPU_NS[a.config]
-    wl = synthetic.make_workload(a.config, Ns_total=ns_gpu)
+    wl = synthetic.make_workload(a.config, Ns_total=ns_gpu, S=a.S)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         # ~10-30 s of host work: the whole workload at configs 2 and 3, a bounded part of it otherwise
         div = {2: 1, 3: 1, 4: 8, 5: 5 if not job_mode else 40}[a.config]
@@ -307,7 +311,7 @@ def main():
 
     nsk_job = nsk_of[scaling]
     ns_job = nsk_job * K
-    headline = a.config == 3 and not job_mode
+    headline = a.config == 3 and not job_mode and a.S == 1
     min_timed = a.min_timed_s if a.min_timed_s is not None else (MIN_TIMED_S if headline else MIN_TIMED_SECONDARY_S)
 
     predict_roofline = adam_loop = reference_stream = None
@@ -384,6 +388,62 @@ def main():
                         "the host generator",
             }
 
+    gp_samples = full_elcbo = None
+    if not a.no_secondary and world == 1 and not job_mode and a.rng == "philox":
+        # Secondary figures ("S = 1 (also S = 8)"): the same step with S = 4 (the reference's default at
+        # N = 400) and S = 8 GP hyper-parameter samples -- step time, where the GP sums ran and when their word and
+        # the entropy's reached the host (vbmc_last_step_marks: the GP word must arrive first, or the sums are
+        # on the critical path)
+        gp_samples = {}
+        for S2 in (4, 8):
+            if S2 == a.S:
+                continue
+            wl2 = synthetic.make_workload(a.config, Ns_total=ns_gpu, S=S2)
+            gp2 = gpm.GP(D, gpm.SquaredExponential(), gpm.NegativeQuadratic(),
+                         gpm.GaussianNoise(constant_add=True, user_provided_add=wl2.s2 is not None))
+            gp2.update(X_new=wl2.X, y_new=wl2.y, s2_new=wl2.s2, hyp=wl2.hyp)
+            th2 = wl2.theta.copy()
+
+            def step2(i):
+                return _neg_elcbo(th2 + 1e-9 * (i % 7), gp2, vp, 0.0, nsk_job, True, False, bnd, rng="philox", seed=50_000 + i)
+
+            for i in range(30):
+                step2(i)
+            ctx.synchronize()
+            n2 = max(200, int(0.4 / max(1e-6, 1.2e-4)))
+            marks = []
+            t1 = time.perf_counter()
+            for i in range(n2):
+                out2 = step2(30 + i)
+                if i % 64 == 63:
+                    marks.append(ctx.last_step_marks())
+            ctx.synchronize()
+            dt2 = (time.perf_counter() - t1) / n2
+            gp_samples[f"S{S2}"] = {
+                "ms_per_step": 1e3 * dt2, "evals_per_s": 1.0 / dt2, "steps": n2, "F": float(out2[0]),
+                "gp_sums_in": marks[-1]["gp_sums_in"],
+                "gp_word_us": float(np.median([m_["gp_word_us"] for m_ in marks])),
+                "entropy_word_us": float(np.median([m_["entropy_word_us"] for m_ in marks])),
+            }
+        _neg_elcbo(theta.copy(), gp, vp, 0.0, nsk_job, True, False, bnd, rng="philox", seed=1)  # (the headline GP back on the device)
+        # SURVEY 8d's secondary unit of work: `_eval_full_elcbo` (variational_optimization.py:428-500) -- value,
+        # variance and the per-component terms (compute_var, separate_K) at ns_ent_fine = 2^12 per component
+        nsk_full = 4096
+        fe = lambda i: _neg_elcbo(theta.copy(), gp, vp, 0.0, nsk_full, False, True, None, 0.0, True, rng="philox", seed=90_000 + i)
+        for i in range(5):
+            r_full = fe(i)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        n_full = 100
+        for i in range(n_full):
+            r_full = fe(5 + i)
+        ctx.synchronize()
+        dt_full = (time.perf_counter() - t1) / n_full
+        full_elcbo = {"ms_per_eval": 1e3 * dt_full, "evals_per_s": 1.0 / dt_full, "NsK": nsk_full, "evals": n_full,
+                      "F": float(r_full[0]), "varF": float(np.ravel(r_full[4])[0]),
+                      "what": "_neg_elcbo(theta, gp, vp, 0, NsK=4096, compute_grad=False, compute_var=True, separate_K=True): "
+                              "value + variance + per-component I_sk / J_sjk, the call _eval_full_elcbo makes"}
+
     # the other reading of "N GPUs" first (a short region), then the line's own
     other = None
     if world > 1 and not job_mode and a.rng == "philox":
@@ -424,6 +484,8 @@ def main():
         pass
     if headline:
         metric = "ELBO+entropy evals/sec at D=10, K=50, N=400, Ns=1e6 (1e6-sample-equivalent evals/s)"
+    elif a.config == 3 and not job_mode:
+        metric = f"ELBO+entropy evals/sec at D=10, K=50, N=400, Ns=1e6 with S={a.S} GP hyper-parameter samples (secondary line)"
     elif job_mode:
         metric = (f"ELBO+entropy evals/sec at D={D}, K={K}, N={wl.N}, Ns={JOB_NS[a.config]:.0e} (BASELINE config "
                   f"{a.config}'s whole job per evaluation, split over {world} GPU{'s' if world > 1 else ''}; secondary line)")
@@ -447,7 +509,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"BASELINE config {a.config}{' job' if job_mode else ' per GPU'}: D={D} K={K} N={wl.N} S=1, "
+            "workload": f"BASELINE config {a.config}{' job' if job_mode else ' per GPU'}: D={D} K={K} N={wl.N} S={a.S}, "
                         f"Ns={wl.Ns_total if not job_mode else ns_job // world} MC samples per GPU (job Ns={ns_job}), "
                         f"value+grad _neg_elcbo with soft bounds, eps={a.rng}",
             "evals_per_s_job": evals_per_s,
@@ -486,6 +548,8 @@ def main():
         "predict_roofline": predict_roofline,
         "device_resident_adam_loop": adam_loop,
         "reference_stream": reference_stream,
+        "gp_samples": gp_samples,
+        "full_elcbo": full_elcbo,
         "F": F,
         "host_us_per_step": dict(zip(["pack_upload", "launch", "wait_device", "finalize", "c_total"],
                                      np.asarray(host_us).round(2).tolist())),

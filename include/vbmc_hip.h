@@ -114,6 +114,12 @@ int vbmc_last_kernel_ms(vbmc_ctx* ctx, int which, double* ms_out);
  * out[2] wait for the device, out[3] host finalisation, out[4] total.
  * Profiling aid for bench.py / DESIGN.md; no reference counterpart. */
 int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
+/* Where the two result blocks of the most recent vbmc_neg_elcbo arrived on the host's clock, microseconds from
+ * the call's entry: out[0] the GP sums' completion word (the host finalises G / dG behind it, while the entropy
+ * kernel still runs), out[1] the entropy's completion word (or the end of the stream wait); out[2] where the
+ * GP sums ran: 0 the prep launch, 1 the finish launch, 2 spare workgroup slots of the entropy launch; out[3]
+ * reserved (0).  Profiling aid for bench.py (S > 1 hyper-parameter samples). */
+int vbmc_last_step_marks(const vbmc_ctx* ctx, double out[4]);
 
 /* Per-context switches for tests and measurements (no reference counterpart).  Each starts
  * from the environment variable in brackets, read when the context is created.

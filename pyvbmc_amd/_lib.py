@@ -76,6 +76,7 @@ SIGNATURES = {
     "vbmc_set_timing": (C.c_int, [_vp, C.c_int]),
     "vbmc_last_kernel_ms": (C.c_int, [_vp, C.c_int, _dp]),
     "vbmc_last_host_us": (C.c_int, [_vp, _dp]),
+    "vbmc_last_step_marks": (C.c_int, [_vp, _dp]),
     "vbmc_set_mixture": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "vbmc_set_mixture_dk": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "vbmc_theta_to_mixture": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
@@ -289,6 +290,14 @@ class Context:
         out = np.zeros(5)
         self.check(self._lib.vbmc_last_host_us(self._h, ptr(out)))
         return out
+
+    def last_step_marks(self):
+        """us from the last fused evaluation's entry to its GP word / its entropy word, and where the GP
+        sums ran (vbmc_last_step_marks)."""
+        out = np.zeros(4)
+        self.check(self._lib.vbmc_last_step_marks(self._h, ptr(out)))
+        return {"gp_word_us": out[0], "entropy_word_us": out[1],
+                "gp_sums_in": ("prep launch", "finish launch", "entropy launch")[int(out[2])]}
 
     def set_mixture(self, mu_DK, sigma, lambd, w, eta):
         mu_DK = np.asarray(mu_DK, dtype=np.float64)

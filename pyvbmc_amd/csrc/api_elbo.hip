@@ -246,6 +246,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     }
     seq_out = ctx->done_seq;
     ident_out_flag = false;
+    ctx->gp_where = 0;
     // Polled step: the CPU writes the pack into device memory itself (no upload launch; the prep
     // launch copies it on for the later kernels).
     PrepArgs gp_tail;
@@ -280,8 +281,10 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
         if (in_ws) {
           plan.a.gp = gp_tail;
           plan.a.gp_items = gp_tail.n_glj;
+          ctx->gp_where = 2;
         } else {
           gp_in_tail = true;
+          ctx->gp_where = 1;
         }
       }
       pa.mix = fg;
@@ -430,6 +433,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     if (rc) return rc;
     check_ident = polled && ident_out_flag;
   }
+  ctx->step_marks[2] = (double)ctx->gp_where;  // (of THIS evaluation's launches: issued just now, or armed by the previous call)
   // Arm the next evaluation (seed + 1, same shapes): its launches go into the queue now, behind this
   // one's, and wait for the next call's theta.
   if (polled && arm_next && ctx->d_ctl && ctx->d_mix_fg) {
@@ -637,6 +641,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   if (polled) {
     int st_w = spin_on(ctx->h_done + 4, cur_seq);
     HSTAMP(3);
+    ctx->step_marks[0] = us_since(t_begin);
     if (st_w == 0) {
       rc = finalize_gp();  // overlaps the entropy kernel
       if (rc) return rc;
@@ -663,6 +668,8 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     HIP_TRY(ctx, stream_wait(ctx));
   }
   ctx->pack_in_flight = false;  // the pack upload precedes everything waited for
+  ctx->step_marks[1] = us_since(t_begin);
+  if (!polled) ctx->step_marks[0] = ctx->step_marks[1];
   ctx->host_us[2] = us_since(t_wait);
   HSTAMP(4);
   const auto t_fin = clk::now();
@@ -720,6 +727,12 @@ extern "C" int vbmc_armed_stats(const vbmc_ctx* ctx, uint64_t out[6]) {
 extern "C" int vbmc_last_elbo_raw(const vbmc_ctx* ctx, double* out, int n) {
   if (!ctx || !out || ctx->last_raw_n <= 0 || n != ctx->last_raw_n || !ctx->h_pinned) return VBMC_E_ARG;
   memcpy(out, ctx->h_pinned + ctx->last_raw_off, sizeof(double) * (size_t)n);
+  return VBMC_OK;
+}
+
+extern "C" int vbmc_last_step_marks(const vbmc_ctx* ctx, double out[4]) {
+  if (!ctx || !out) return VBMC_E_ARG;
+  for (int i = 0; i < 4; ++i) out[i] = ctx->step_marks[i];
   return VBMC_OK;
 }
 

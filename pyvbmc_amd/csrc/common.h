@@ -182,6 +182,8 @@ struct vbmc_ctx {
   double* hp_dev = nullptr;    // device-side address of h_pinned (cached: the query is an API call)
   bool timing = false;         // record the HIP event pair around the dominant kernel (vbmc_set_timing)
   double host_us[5] = {0, 0, 0, 0, 0};  // see vbmc_last_host_us
+  double step_marks[4] = {0, 0, 0, 0};  // see vbmc_last_step_marks
+  int gp_where = 0;  // where the GP sums of the launches issued last run: 0 prep launch, 1 finish launch, 2 entropy launch
   // vbmc_set_option switches (defaults from the environment at context creation)
   int opt_entmc_valu = 0;   // 1: always the generic entropy kernel
   int opt_entmc_mfma = 1;   // the matrix-pipe form of the entropy kernel where its shape applies (entropy_mfma.hip)

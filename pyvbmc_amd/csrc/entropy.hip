@@ -621,7 +621,7 @@ int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
     WsSpan sp;
     sp.cus = cus;
     sp.nb = (int)((row_count + 63) >> 6);
-    sp.pad = ctx->opt_ws_pad >= 0 ? ctx->opt_ws_pad : 2;
+    sp.pad = ctx->opt_ws_pad >= 0 ? ctx->opt_ws_pad : 3;
     sp.T = (int64_t)K * sp.nbv();
     sp.front = ctx->opt_ws_front > 0 ? ctx->opt_ws_front : ws_front_default(p.DP, ws_ktmax_for(K));
     // The GP sums of the host-driven step ride in this launch when they fit WS_GP_SLOTS workgroups of at most six

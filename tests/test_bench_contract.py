@@ -6,6 +6,7 @@ import pathlib
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = pathlib.Path(__file__).resolve().parents[1]
@@ -66,8 +67,34 @@ def test_bench_job_size_lines(cfg, extra):
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.strip()][0])
     K = 50 if cfg == 4 else 100
-    assert d["config"]["entropy_launch"]["chunks"] * K > 512 and d["scaling"] == "strong"
+    el = d["config"]["entropy_launch"]
+    assert (el["span"] and el["rg"] > 16 or el["chunks"] * K > 512) and d["scaling"] == "strong"  # many batches per workgroup / several grid rounds
     assert f"Ns={'8e+06' if cfg == 4 else '4e+06'}" in d["metric"] and 0.3 < d["roofline"]["frac"] < 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [("--spawn", "--scaling", "strong"), ("--spawn", "--config", "4"), ("--spawn",)],
+                         ids=["strong", "config4-job", "weak"])
+def test_bench_lines_through_the_collective_branch(args):
+    """What the driver's multi-GPU runs execute, on the one GPU there is: the ranks started by bench.py itself, a real
+    RCCL communicator of one rank and -- VBMC_FORCE_COLLECTIVE=1 -- the multi-rank step (finish -> all-reduce ->
+    publish, never armed) for the weak line, the strong line and config 4's job: each must print ONE schema-valid
+    JSON line, not a traceback."""
+    import os
+
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", *args, "--steps", "6", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-secondary", "--min-timed-s", "0.3"], capture_output=True, text=True,
+                       timeout=900, cwd=str(ROOT), env=dict(os.environ, VBMC_FORCE_COLLECTIVE="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["comm_world"] == 1 and d["value"] > 0 and np.isfinite(d["F"])
+    assert d["scaling"] == ("strong" if "--config" in args else "weak")  # (one rank: the two readings coincide)
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] in ("hbm", "mfma")
 
 
 def test_bench_more_gpus_than_visible_fails_cleanly():
