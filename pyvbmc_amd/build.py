@@ -55,10 +55,13 @@ def _sources():
     return [CSRC / s for s in SOURCES if (CSRC / s).exists()]
 
 
+SOURCE_FLAGS = {}  # per-source extra flags (file name -> list)
+
+
 def _jobs(bdir):
     """(source, object, extra flags) for every translation unit; the wave-split entropy
     kernel is compiled once per padded D so the instantiations build in parallel."""
-    jobs = [(src, bdir / (src.stem + ".o"), list(ALL_EXTRA)) for src in _sources()]
+    jobs = [(src, bdir / (src.stem + ".o"), list(ALL_EXTRA) + SOURCE_FLAGS.get(src.name, [])) for src in _sources()]
     for dp in WS_DPS:
         jobs.append((CSRC / "entropy_ws.hip", bdir / f"entropy_ws_dp{dp}.o", [f"-DVBMC_DP={dp}"] + WS_EXTRA))
     for dp in MFMA_DPS:
