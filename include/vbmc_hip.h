@@ -137,19 +137,12 @@ int vbmc_last_step_marks(const vbmc_ctx* ctx, double out[4]);
  *   "elbo_pregen"  [VBMC_ELBO_PREGEN]: 1 = Philox draws generated ahead of the entropy
  *                  kernel (default), 0 = generated in-line by it; same values either way
  *   "elbo_ahead"   [VBMC_ELBO_AHEAD]: 1 = after a Philox evaluation with seed s the draws of
- *                  seed s+1 are generated speculatively while the host finalises (default),
- *                  0 = never
- *   "ahead_mode"   [VBMC_AHEAD_MODE]: where that speculative generation runs: 2 = spare
- *                  workgroups of the finish launch (default; 3 = the same), 0 = a launch of its
- *                  own behind the finish kernel, 1 = a stream of its own (measured slower; kept as
- *                  the record)
+ *                  seed s+1 are generated speculatively, by spare workgroups of the finish launch,
+ *                  while the host finalises (default), 0 = never
  *   "mix_bar"      [VBMC_MIX_BAR]: 1 = in the polled host-driven step the CPU writes the mixture
- *                  pack straight into (fine-grained) device memory (default), 0 = upload kernel,
+ *                  pack straight into (fine-grained) device memory and the GP sums ride in spare
+ *                  workgroup slots of the entropy launch when they fit (default), 0 = upload kernel,
  *                  GP sums in the prep launch
- *   "gp_tail"      [VBMC_GP_TAIL]: with mix_bar, where the GP expected-log-joint sums run: 2 = in
- *                  the free workgroup slots of the entropy launch when its grid leaves enough
- *                  (default; else 1), 1 = in the finish launch, 0 = in the prep launch
- *   "mix_kernel"   [VBMC_MIX_KERNEL]: 1 = that upload is a copy kernel (default), 0 = hipMemcpyAsync
  *   "predict_dma"  [VBMC_PREDICT_DMA]: 1 = gp_predict's variance product for batches of > 32
  *                  points on Cholesky samples runs in the LDS-direct kernel (default), 0 = the
  *                  plain 64 x 64-tile kernel (cross-check)
@@ -160,12 +153,6 @@ int vbmc_last_step_marks(const vbmc_ctx* ctx, double out[4]);
  *   "arm_late_test" / "ident_test": test hooks -- the n-th use of an armed evaluation from now takes
  *                  the late-go recovery path / the n-th identity check of a result block from now
  *                  fails (the evaluation is repeated unarmed); see vbmc_armed_stats
- *   "ahead_pct"    [VBMC_AHEAD_PCT]: with elbo_arm, percent of the speculative draws generated in the
- *                  finish launch (rest: the armed prep launch); default 100
- *   "gen_pt"       Philox blocks per thread of the speculative generation in the finish launch (1..16;
- *                  default 1)
- *   "ws_pair"      [VBMC_WS_PAIR]: 1 = the wave-split entropy kernel hands its (component, chunk)
- *                  items out so that the two workgroups of a CU read the same table row (default)
  *   "ws_span"      [VBMC_WS_SPAN]: 1 = the wave-split entropy kernel in span mode (default): every CU's
  *                  first-dispatched workgroup takes "ws_front" per mille of the CU's batches, the second one
  *                  the rest, parts crossing component boundaries, so that all workgroups end together

@@ -389,8 +389,7 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
   const size_t n_work = work_len(D, K, S, st->n_bnd);
   {
     // LDS plan: each kernel keeps its working set in LDS when it fits
-    const char* no_lds = getenv("VBMC_ADAM_NO_LDS");  // test hook: force the global-memory path
-    const size_t cap = (no_lds && no_lds[0] == '1') ? 0 : 150 * 1024 / sizeof(double);
+    const size_t cap = 150 * 1024 / sizeof(double);  // (beyond it the kernels work from global memory: config 5's shape)
     const size_t n_pre = (size_t)L.o_raw() + n_work, n_step = (size_t)L.o_hyp() + K;
     st->pre_lds = n_pre <= cap;
     st->step_lds = n_step <= cap;
@@ -448,10 +447,8 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
   HIP_TRY(ctx, hipGetLastError());
   // draws generated ahead by spare workgroups (Philox mode, unless switched off or > 32 GiB)
   {
-    const char* off = getenv("VBMC_ADAM_PREGEN");
     st->n_eps = (size_t)K * (size_t)st->row_count * D;
-    st->pregen = st->eps_mode == VBMC_EPS_PHILOX && !(off && off[0] == '0') && st->n_eps > 0 &&
-                 st->n_eps <= ((size_t)1 << 32);
+    st->pregen = st->eps_mode == VBMC_EPS_PHILOX && st->n_eps > 0 && st->n_eps <= ((size_t)1 << 32);
     st->eps_started = false;
     if (st->pregen && st->eps_cap < st->n_eps) {
       if (st->d_eps1) HIP_TRY(ctx, hipFree(st->d_eps1));
@@ -532,11 +529,7 @@ static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool
     if (rc) return rc;
     // the entropy-free part of dF: an extra row of the entropy launch when that kernel has one
     // (wave-split, draws from memory), otherwise a launch of its own in front of it
-    static const bool pre_row_on = [] {
-      const char* e = getenv("VBMC_ADAM_PREROW");  // test hook: 0 = always the stand-alone launch
-      return !(e && e[0] == '0');
-    }();
-    const bool pre_row = pre_row_on && plan.ws && plan.a.eps_mode != VBMC_EPS_PHILOX;
+    const bool pre_row = plan.ws && plan.a.eps_mode != VBMC_EPS_PHILOX;
     if (pre_row) {
       plan.a.extra = st->d_args;
       // its working set in LDS when two entropy workgroups per CU still fit beside it

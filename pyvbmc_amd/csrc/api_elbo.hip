@@ -195,7 +195,6 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     stage = ctx->d_stage;
   }
   vbmc_ctx::ArmedEval& sp = ctx->spec;
-  // (whether the next evaluation will be armed decides how the next draws are split, see ahead_pct)
   // Not for long evaluations: what arming saves is ~10 us of launch latency, under 1 % of a step of a
   // millisecond, while a queued prep kernel that nobody releases keeps the device busy until its
   // time-out -- which every device-wide wait elsewhere in the process (another library's hipFree,
@@ -203,8 +202,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   // ARM_MAX_EVAL_US, and the wait is capped whatever the evaluation took.
   constexpr double ARM_MAX_EVAL_US = 1000.0, ARM_MAX_LIMIT_MS = 2.5;
   const bool arm_next = can_poll && !multi && ctx->opt_elbo_arm && ctx->opt_mix_bar && !ctx->timing &&
-                        opts->eps_mode == VBMC_EPS_PHILOX && ctx->opt_ahead_pct > 0 && ctx->opt_ahead_pct <= 100 &&
-                        (ctx->opt_ahead_mode == 2 || ctx->opt_ahead_mode == 3) && ctx->host_us[4] <= ARM_MAX_EVAL_US;
+                        opts->eps_mode == VBMC_EPS_PHILOX && ctx->host_us[4] <= ARM_MAX_EVAL_US;
   // an armed evaluation is used within max(1 ms, 2.5 x the last evaluation's duration) -- at most
   // ARM_MAX_LIMIT_MS -- of its arming; its prep kernel waits twice that before it gives up by itself
   const double arm_limit_ms = std::min(ARM_MAX_LIMIT_MS, std::max(1.0, 2.5e-3 * ctx->host_us[4]));
@@ -222,7 +220,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     EntPlan plan;
     if (mc) {
       // (the GP sums may ride in this launch's spare workgroup slots: only in the polled single-GPU step, see below)
-      const bool gp_rides = can_poll && ctx->opt_mix_bar && ctx->opt_gp_tail == 2 && ctx->d_mix_fg != nullptr;
+      const bool gp_rides = can_poll && ctx->opt_mix_bar && ctx->d_mix_fg != nullptr;
       rc2 = entmc_plan(ctx, opts->ns_per_comp, opts->eps_mode, seed, row_begin, row_count, grad_flags != 0, plan,
                        gp_rides ? pa.n_glj : 0);
       if (rc2) return rc2;
@@ -250,42 +248,36 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     // Polled step: the CPU writes the pack into device memory itself (no upload launch; the prep
     // launch copies it on for the later kernels).
     PrepArgs gp_tail;
-    bool gp_in_tail = false;
     double* fg = nullptr;
     if (can_poll && ctx->opt_mix_bar) fg = spin ? ctx->d_mix_fg : write_pack_to_device(ctx);
     if (spin && !fg) return -1000;
     const bool ident = fg != nullptr && mc;  // self-identifying results (DoneSignal): the copy block exists
     if (ident) pa.ident_out = (uint64_t*)(ctx->d_done_cnt + 12);
     if (fg) {
-      // Where the GP sums run.  2: a last row of the entropy launch, if that grid leaves at least
-      // `chunks` workgroup slots free (one round: K * chunks <= CUs * resident workgroups per CU) --
-      // else they stay in the prep launch (measured at config 5, whose grid is two rounds: prep
-      // placement 215 us, finish placement 225 us); 1: the finish launch; 0: the prep launch.
+      // Where the GP sums run: in spare workgroup slots of the entropy launch when it has them (their 7 us
+      // latency chain then runs beside the entropy kernel and the host finalises G / dG meanwhile), else in the
+      // prep launch (measured at config 5, whose chunk grid is two rounds: prep placement 215 us, finish
+      // placement 225 us -- the finish placement was dropped in round 4).
       // (Few slots carry them: beyond ~6 items per slot they would outlast the entropy kernel -- S = 4 hyper-parameter
       // samples took 186 us per step against 114 with the prep placement -- so larger S keeps the prep launch.)
       bool in_ws = false;
       if (plan.a.sp.cus > 0) {
         in_ws = plan.gp_in_ws && pa.n_glj > 0;  // span mode: the plan reserved the slots
-      } else if (ctx->opt_gp_tail == 2 && pa.n_glj > 0 && plan.ws && !entmc_small_applies(plan.a, plan.DP)) {
+      } else if (pa.n_glj > 0 && plan.ws && !entmc_small_applies(plan.a, plan.DP)) {
         const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
         const int slots = cus * ws_min_waves(plan.DP, ws_ktmax_for(K), grad_flags != 0);
         const int free_slots = slots - K * plan.a.chunks;
         in_ws = free_slots >= plan.a.chunks && pa.n_glj <= 6 * plan.a.chunks;
       }
-      if (pa.n_glj > 0 && (in_ws || ctx->opt_gp_tail == 1)) {
+      if (pa.n_glj > 0 && in_ws) {
         gp_tail = pa;
         gp_tail.n_table = 0;
         gp_tail.gen = GenSlice();
         gp_tail.mix = ctx->d_mix;
         pa.n_glj = 0;
-        if (in_ws) {
-          plan.a.gp = gp_tail;
-          plan.a.gp_items = gp_tail.n_glj;
-          ctx->gp_where = 2;
-        } else {
-          gp_in_tail = true;
-          ctx->gp_where = 1;
-        }
+        plan.a.gp = gp_tail;
+        plan.a.gp_items = gp_tail.n_glj;
+        ctx->gp_where = 2;
       }
       pa.mix = fg;
       pa.mix_copy = ctx->d_mix;
@@ -319,7 +311,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
       GenSlice ahead_gen;
       DoneSignal done;
       if (can_poll) {
-        if (ahead_ok) ahead_gen = entmc_ahead_slice(ctx, plan, arm_next ? 0.01 * ctx->opt_ahead_pct : 1.0);
+        if (ahead_ok) ahead_gen = entmc_ahead_slice(ctx, plan);
         done.cnt = ctx->d_done_cnt;
         done.flag = ctx->hd_done;
         done.seq = seq_out;
@@ -334,38 +326,21 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
         polled_out = true;
         ident_out_flag = ident;
       }
-      // where the speculative generation goes: (2) spare workgroups of the finish launch itself,
-      // (1) its own stream, queued before the finish launch, (0) a launch of its own behind the
-      // finish kernel on the main stream
-      int gen_mode = ahead_gen.n_blocks > 0 ? ctx->opt_ahead_mode : -1;
-      if (spin && gen_mode != 2 && gen_mode != 3 && gen_mode != -1) gen_mode = 2;  // armed launches keep everything in three kernels
-      const bool defer = gen_mode == 2;  // (3 = the same placement with the generator's plain one-pair-per-thread form)
-      if (gen_mode == 3) gen_mode = 2;
-      if (defer && ctx->opt_gen_pt > 1) {  // several items per thread (philox.h; "gen_pt")
-        ahead_gen.per_thread = ctx->opt_gen_pt;
-        ahead_gen.n_blocks = (int)((ahead_gen.item_count + 256 * (int64_t)ctx->opt_gen_pt - 1) / (256 * (int64_t)ctx->opt_gen_pt));
-      }
-      if (gen_mode == 1) {
-        rc2 = entmc_launch_ahead(ctx, ahead_gen);
-        if (rc2) return rc2;
-      }
+      // the speculative generation runs in spare workgroups of the finish launch itself (a launch of its own behind
+      // it: +1.5-3 us per step; a stream of its own: +8-12 us -- both measured in round 2 and dropped in round 4)
+      const GenSlice* gen_here = ahead_gen.n_blocks > 0 ? &ahead_gen : nullptr;
       if (!multi) {
-        rc2 = entmc_launch_finish(ctx, plan, polled_out ? stage + n_res : raw_out, gen_mode == 2 ? &ahead_gen : nullptr,
-                                  polled_out ? &done : nullptr, gp_in_tail ? &gp_tail : nullptr);
+        rc2 = entmc_launch_finish(ctx, plan, polled_out ? stage + n_res : raw_out, gen_here, polled_out ? &done : nullptr);
         if (rc2) return rc2;
-        if (gen_mode == 0) {
-          rc2 = launch_eps_gen(ctx, ctx->stream, ahead_gen);
-          if (rc2) return rc2;
-        }
       } else {
         // finish (this rank's rows) -> all-reduce -> publish (+ the next draws): raw_out is device memory
-        rc2 = entmc_launch_finish(ctx, plan, raw_out, nullptr, nullptr, gp_in_tail ? &gp_tail : nullptr);
+        rc2 = entmc_launch_finish(ctx, plan, raw_out, nullptr, nullptr);
         if (rc2) return rc2;
         rc2 = comm_allreduce_sum(ctx, raw_out, n_raw);
         if (rc2) return rc2;
         if (polled_out) {
           done.host_out = raw_host;
-          rc2 = entmc_launch_publish(ctx, raw_out, done, (gen_mode == 2 || gen_mode == 0) ? &ahead_gen : nullptr);
+          rc2 = entmc_launch_publish(ctx, raw_out, done, gen_here);
           if (rc2) return rc2;
         } else {
           HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned + n_res, raw_out, sizeof(double) * n_raw,

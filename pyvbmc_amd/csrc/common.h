@@ -137,13 +137,6 @@ struct vbmc_ctx {
   double* d_epsgen[2] = {nullptr, nullptr};
   size_t d_epsgen_cap[2] = {0, 0};
   int gen_cur = 0;  // buffer the current evaluation reads
-  // the speculative generation runs on a stream of its own (it then fills the CUs the entropy
-  // kernel's workgroups leave and overlaps the finish launch and the host's turnaround instead of
-  // standing in front of the next evaluation's first launch); gen_ev is recorded behind it and
-  // queried before the entropy kernel that reads the draws is launched
-  hipStream_t gen_stream = nullptr;
-  hipEvent_t gen_ev = nullptr;
-  bool gen_pending = false;
   struct AheadDraws {
     bool valid = false;
     uint64_t seed = 0;
@@ -190,22 +183,16 @@ struct vbmc_ctx {
   int opt_elbo_pregen = 1;  // Philox draws generated ahead of the entropy kernel
   int opt_elbo_ahead = 1;   // ... and those of seed+1 speculatively behind the finish kernel
   int opt_predict_dma = 1;  // predict's variance product through the LDS-direct kernel (batches on Cholesky samples)
-  int opt_ahead_mode = 2;   // speculative draws: 2 = spare workgroups of the finish launch, 0 = a launch of their own behind it, 1 = on their own stream (measured: slower)
-  int opt_ahead_pct = 100;  // armed evaluations: percent of the next draws generated in the finish launch (the rest in the armed prep launch, which runs them while it waits for theta)
   int opt_arm_late_test = 0;  // test hook: n > 0 = the n-th use of an armed evaluation from now takes the late-go recovery path
   int opt_acq_poll = 1;       // small acquisition batches: points written by the CPU, results polled (api_acq.hip)
   int opt_adam_fused = 1;     // the optimiser loop as one launch per batch where its shape applies (adam_fused.hip)
-  int opt_gen_pt = 1;         // speculative draws in the finish launch: Philox blocks per thread
   int opt_ident_test = 0;     // test hook: n > 0 = the n-th identity check from now fails (the recovery path runs)
   bool ident_retry = false;   // inside the re-evaluation after a failed identity check
   int opt_elbo_arm = 1;     // queue the next host-driven evaluation's launches ahead of its theta (armed evaluation)
-  int opt_ws_pair = 1;      // entropy kernel: co-resident workgroups take the same table row (scalar-cache locality)
   int opt_ws_span = 1;      // entropy kernel: span mode (entropy_args.h WsSpan: front / filler parts sized to end together); 0 = equal chunks
   int opt_ws_front = 0;     // span mode: the front workgroup's share of a CU's batches, per mille (0 = the built-in value)
   int opt_ws_pad = -1;      // span mode: padding slots behind every component (-1 = the built-in value)
-  int opt_gp_tail = 2;      // with mix_bar: GP sums in a last row of the entropy launch (2; needs free workgroup slots, else 1), in the finish launch (1), in the prep launch (0)
   int opt_mix_bar = 1;      // host-driven step: pack written by the CPU into device memory (no upload launch), GP sums in the finish launch
-  int opt_mix_kernel = 1;   // the mixture pack goes up through a copy kernel of our own instead of hipMemcpyAsync
   double* h_pack_dev = nullptr;     // device-side address of h_pack ...
   double* h_pack_dev_of = nullptr;  // ... valid for this h_pack
   // exp(eta) and its sum, shared by the three softmax Jacobians of an evaluation
@@ -281,7 +268,7 @@ static inline int raw_len(int D, int K) { return 1 + D * K + 2 * K + D; }
 // and/or the GP expected-log-joint sums
 // A slice of the draw buffer eps[K][rows][D] for other kernels' spare workgroups to fill: the
 // (row, block) items [item_begin, item_begin + item_count) of the K * rows * ceil(D/4) items -- one
-// Philox block = up to four normals of a row (philox.h) -- 256 * per_thread per workgroup.  The values
+// Philox block = up to four normals of a row (philox.h) -- 256 per workgroup.  The values
 // depend on (seed, row, block) only, so any kernel may generate any slice.
 // completion signalling of entmc_finish_kernel (all null/0: none)
 struct DoneSignal {
@@ -365,8 +352,7 @@ struct GenSlice {
   uint64_t seed = 0;
   const int* seed_add = nullptr;  // optional device-side addend (the Adam loop's iteration base)
   int64_t item_begin = 0, item_count = 0;
-  int n_blocks = 0;        // ceil(item_count / (256 * per_thread))
-  int per_thread = 1;      // items per thread, 256 apart
+  int n_blocks = 0;        // ceil(item_count / 256)
 };
 
 struct PrepArgs {
@@ -412,11 +398,6 @@ GenSlice make_gen_slice(double* eps, int K, int D, int64_t rows, int64_t n_half,
 // wait for everything queued on the ctx stream (also: the pinned mixture pack is free again)
 inline hipError_t stream_wait(vbmc_ctx* ctx) {
   if (ctx->spec.armed) spec_disarm(ctx);  // (launches waiting for a theta would make this wait last their time-out)
-  if (ctx->gen_pending) {  // the speculative draws on their own stream
-    const hipError_t eg = hipStreamSynchronize(ctx->gen_stream);
-    if (eg != hipSuccess) return eg;
-    ctx->gen_pending = false;
-  }
   const hipError_t e = hipStreamSynchronize(ctx->stream);
   if (e == hipSuccess) ctx->pack_in_flight = false;
   return e;
@@ -435,17 +416,13 @@ int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& a);
 
 int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p);
 // `gen`: optional slice of draws for spare workgroups of the finish launch to generate
-// gp: optional GP blocks (glj_block.h) appended to the finish launch's grid
 int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out, const GenSlice* gen = nullptr,
-                        const DoneSignal* done = nullptr, const PrepArgs* gp = nullptr);
+                        const DoneSignal* done = nullptr);
 // multi-GPU step: hand the all-reduced raw vector (device memory) to the host and publish done.seq;
 // spare workgroups generate `gen` (entropy.hip)
 int entmc_launch_publish(vbmc_ctx* ctx, const double* d_raw, const DoneSignal& done, const GenSlice* gen);
 // the slice of seed+1's draws the finish launch's spare workgroups should generate (n_blocks == 0: none)
-GenSlice entmc_ahead_slice(vbmc_ctx* ctx, const EntPlan& p, double frac_end = 1.0);
-// launch the speculative slice (on gen_stream when enabled) / wait until a pending one has completed
-int entmc_launch_ahead(vbmc_ctx* ctx, const GenSlice& g);
-int entmc_ahead_wait(vbmc_ctx* ctx);
+GenSlice entmc_ahead_slice(vbmc_ctx* ctx, const EntPlan& p);
 void glj_fill_prep(const vbmc_ctx* ctx, int want_grad, double* res, double* Z, PrepArgs& a);
 
 // kernels' host launchers (one per .hip file) -------------------------------

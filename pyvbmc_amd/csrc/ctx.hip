@@ -58,28 +58,18 @@ static void options_from_env(vbmc_ctx* c) {
   c->opt_elbo_pregen = !(e && e[0] == '0');
   e = getenv("VBMC_ELBO_AHEAD");
   c->opt_elbo_ahead = !(e && e[0] == '0');
-  e = getenv("VBMC_MIX_KERNEL");
-  c->opt_mix_kernel = !(e && e[0] == '0');
-  e = getenv("VBMC_AHEAD_MODE");
-  c->opt_ahead_mode = e ? atoi(e) : 2;
-  e = getenv("VBMC_AHEAD_PCT");
-  if (e) c->opt_ahead_pct = atoi(e);
   e = getenv("VBMC_ELBO_ARM");
   c->opt_elbo_arm = !(e && e[0] == '0');
   e = getenv("VBMC_ACQ_POLL");
   c->opt_acq_poll = !(e && e[0] == '0');
   e = getenv("VBMC_ADAM_FUSED");
   c->opt_adam_fused = !(e && e[0] == '0');
-  e = getenv("VBMC_WS_PAIR");
-  c->opt_ws_pair = !(e && e[0] == '0');
   e = getenv("VBMC_WS_SPAN");
   c->opt_ws_span = !(e && e[0] == '0');
   e = getenv("VBMC_WS_FRONT");
   if (e) c->opt_ws_front = atoi(e);
   e = getenv("VBMC_WS_PAD");
   if (e) c->opt_ws_pad = atoi(e);
-  e = getenv("VBMC_GP_TAIL");
-  c->opt_gp_tail = e ? atoi(e) : 2;
   e = getenv("VBMC_MIX_BAR");
   c->opt_mix_bar = !(e && e[0] == '0');
   e = getenv("VBMC_PREDICT_DMA");
@@ -163,11 +153,6 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   if (getenv("VBMC_DEBUG_ARM")) fprintf(stderr, "[vbmc] armed evaluations: %llu used, %llu cancelled\n", (unsigned long long)ctx->spec.hits, (unsigned long long)ctx->spec.cancels);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->d_ctl) (void)hipFree(ctx->d_ctl);
-  if (ctx->gen_stream) {
-    (void)hipStreamSynchronize(ctx->gen_stream);
-    (void)hipStreamDestroy(ctx->gen_stream);
-  }
-  if (ctx->gen_ev) (void)hipEventDestroy(ctx->gen_ev);
   vbmc_comm_destroy(ctx);
   adam_free(ctx);
   acq_is_free(ctx);
@@ -230,23 +215,14 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "entmc_mfma")) ctx->opt_entmc_mfma = value != 0;
   else if (!strcmp(key, "elbo_pregen")) ctx->opt_elbo_pregen = value != 0;
   else if (!strcmp(key, "elbo_ahead")) ctx->opt_elbo_ahead = value != 0;
-  else if (!strcmp(key, "mix_kernel")) ctx->opt_mix_kernel = value != 0;
   else if (!strcmp(key, "predict_dma")) ctx->opt_predict_dma = value != 0;
   else if (!strcmp(key, "mix_bar")) ctx->opt_mix_bar = value != 0;
-  else if (!strcmp(key, "gp_tail")) ctx->opt_gp_tail = value;
-  else if (!strcmp(key, "ws_pair")) ctx->opt_ws_pair = value != 0;
   else if (!strcmp(key, "ws_span")) ctx->opt_ws_span = value != 0;
   else if (!strcmp(key, "ws_pad")) ctx->opt_ws_pad = value > 8 ? 8 : value;
   else if (!strcmp(key, "ws_front")) ctx->opt_ws_front = value < 0 ? 0 : value > 990 ? 990 : value;
   else if (!strcmp(key, "elbo_arm")) ctx->opt_elbo_arm = value != 0;
-  else if (!strcmp(key, "ahead_pct")) ctx->opt_ahead_pct = value;
   else if (!strcmp(key, "acq_poll")) ctx->opt_acq_poll = value != 0;
   else if (!strcmp(key, "adam_fused")) ctx->opt_adam_fused = value;  // 2: test hook, see FusedArgs::test_absent
-  else if (!strcmp(key, "gen_pt")) ctx->opt_gen_pt = value < 1 ? 1 : value > 16 ? 16 : value;
-  else if (!strcmp(key, "ahead_mode")) {
-    (void)entmc_ahead_wait(ctx);
-    ctx->opt_ahead_mode = value;
-  }
   else return vbmc_fail(ctx, VBMC_E_ARG, "vbmc_set_option: unknown key '%s'", key);
   return VBMC_OK;
 }
@@ -462,7 +438,8 @@ double* write_pack_to_device(vbmc_ctx* ctx) {
 int upload_packed_mixture(vbmc_ctx* ctx) {
   if (ctx->device < 0) return 0;
   if (ctx->spec.armed) spec_disarm(ctx);  // (queued behind launches that wait for a theta it would wait with them)
-  if (ctx->opt_mix_kernel) {
+  {
+    // (a copy kernel of our own: hipMemcpyAsync from pinned memory measured slower on this stack)
     double* src = nullptr;
     if (ctx->h_pack_dev_of != ctx->h_pack) {
       HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ctx->h_pack_dev, ctx->h_pack, 0));
@@ -473,9 +450,7 @@ int upload_packed_mixture(vbmc_ctx* ctx) {
     hipLaunchKernelGGL(mix_upload_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const double*)src,
                        ctx->d_mix, n);
     HIP_TRY(ctx, hipGetLastError());
-  } else
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mix, ctx->h_pack, sizeof(double) * ctx->ml.total, hipMemcpyHostToDevice,
-                              ctx->stream));
+  }
   ctx->pack_in_flight = true;
   ctx->pack_valid = true;
   return 0;

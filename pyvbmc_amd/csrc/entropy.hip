@@ -211,8 +211,7 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
                                                            MixLayout ml, double inv_ns,
                                                            int want_grad, int mu_from_w,
                                                            double* __restrict__ raw, GenSlice gen,
-                                                           DoneSignal done, PrepArgs gp) {
-  extern __shared__ double fin_lds[];
+                                                           DoneSignal done) {
   if (done.cancel != nullptr && __hip_atomic_load(done.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ~(uint64_t)0)
     return;  // armed evaluation that was cancelled (common.h ArmedEval)
   const int D = ml.D, K = ml.K;
@@ -223,16 +222,10 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
   // running end maximum are copied there by the last-numbered block, which is dispatched last
 #endif
   {
-    // spare workgroups after the reduction's own: the GP expected-log-joint blocks of the
-    // host-driven step (glj_block.h) -- independent of the entropy, their latency chain runs
-    // beside this short reduction -- then a slice of the next draws (Adam loop)
+    // spare workgroups after the reduction's own: a slice of the next draws (host-driven step, Adam loop)
     const int n_main = (1 + D * K + 2 * K + D + 3) / 4;
-    if ((int)blockIdx.x >= n_main + gp.n_glj) {
-      gen_slice_block(gen, blockIdx.x - n_main - gp.n_glj, threadIdx.x);
-      return;
-    }
     if ((int)blockIdx.x >= n_main) {
-      glj_block(gp, blockIdx.x - n_main, fin_lds);
+      gen_slice_block(gen, blockIdx.x - n_main, threadIdx.x);
       return;
     }
   }
@@ -591,7 +584,7 @@ int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
     }
   }
   a.pair_cus = 0;
-  if (p.ws && ctx->opt_ws_pair) {
+  if (p.ws) {
     // one round of the 2-waves/SIMD build: workgroups b and b + CUs share a CU (entropy_ws.hip)
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     const int64_t total = (int64_t)K * a.chunks;
@@ -709,7 +702,7 @@ int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& pa) {
   int cur;
   if (ah.valid && ah.seed == p.a.seed && ah.K == K && ah.D == D && ah.rows == p.a.row_count &&
       ah.n_half == p.a.n_half && ah.row_begin == p.a.row_begin) {
-    // the previous evaluation already queued exactly these draws (entmc_launch_ahead) -- or the
+    // the previous evaluation already queued exactly these draws (spare workgroups of its finish launch) -- or the
     // first part of them: the rest is generated by this evaluation's prep launch
     cur = ah.buf;
     p.pregen_hit = true;
@@ -717,9 +710,7 @@ int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& pa) {
       pa.gen = make_gen_slice(ctx->d_epsgen[cur], K, D, p.a.row_count, p.a.n_half, p.a.row_begin, p.a.seed, nullptr, ah.frac, 1.0);
   } else {
     cur = ah.valid ? 1 - ah.buf : 0;  // keep clear of a speculative buffer that is not the one wanted
-    int rc = entmc_ahead_wait(ctx);  // (a generation still running on the other stream)
-    if (rc) return rc;
-    rc = ensure_dev(ctx, &ctx->d_epsgen[cur], &ctx->d_epsgen_cap[cur], n_eps);
+    int rc = ensure_dev(ctx, &ctx->d_epsgen[cur], &ctx->d_epsgen_cap[cur], n_eps);
     if (rc) return rc;
     pa.gen = make_gen_slice(ctx->d_epsgen[cur], K, D, p.a.row_count, p.a.n_half, p.a.row_begin, p.a.seed, nullptr, 0.0, 1.0);
   }
@@ -731,7 +722,8 @@ int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& pa) {
   return 0;
 }
 
-GenSlice entmc_ahead_slice(vbmc_ctx* ctx, const EntPlan& p, double frac_end) {
+GenSlice entmc_ahead_slice(vbmc_ctx* ctx, const EntPlan& p) {
+  const double frac_end = 1.0;
   const EntArgs& a = p.a;
   GenSlice none;
   if (!ctx->opt_elbo_ahead || a.eps == nullptr || a.eps != ctx->d_epsgen[ctx->gen_cur]) return none;
@@ -756,38 +748,7 @@ GenSlice entmc_ahead_slice(vbmc_ctx* ctx, const EntPlan& p, double frac_end) {
   return make_gen_slice(ctx->d_epsgen[other], K, D, a.row_count, a.n_half, a.row_begin, ah.seed, nullptr, 0.0, frac_end);
 }
 
-int entmc_launch_ahead(vbmc_ctx* ctx, const GenSlice& g) {
-  if (g.n_blocks <= 0) return 0;
-  if (ctx->opt_ahead_mode != 1) return launch_eps_gen(ctx, ctx->stream, g);
-  if (!ctx->gen_stream) {
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->gen_stream, hipStreamNonBlocking));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->gen_ev, hipEventDisableTiming));
-  }
-  int rc = entmc_ahead_wait(ctx);  // (one generation in flight at a time)
-  if (rc) return rc;
-  rc = launch_eps_gen(ctx, ctx->gen_stream, g);
-  if (rc) return rc;
-  HIP_TRY(ctx, hipEventRecord(ctx->gen_ev, ctx->gen_stream));
-  ctx->gen_pending = true;
-  return 0;
-}
-
-// The draws generated on gen_stream are complete (kernel finished and its writes released) once
-// the event behind it has fired; normally long before the next evaluation asks.
-int entmc_ahead_wait(vbmc_ctx* ctx) {
-  if (!ctx->gen_pending) return 0;
-  hipError_t e;
-  while ((e = hipEventQuery(ctx->gen_ev)) == hipErrorNotReady) __builtin_ia32_pause();
-  if (e != hipSuccess) HIP_TRY(ctx, e);
-  ctx->gen_pending = false;
-  return 0;
-}
-
 int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p) {
-  {  // draws of a generation on the other stream: complete before anything reads (or rewrites) them
-    const int rc = entmc_ahead_wait(ctx);
-    if (rc) return rc;
-  }
   const EntArgs& a = p.a;
   // timing: the wave-split launch carries the event pair on its own dispatch packet; the generic
   // kernel is bracketed by two records (each a barrier packet, ~6 us between dependent kernels)
@@ -893,26 +854,15 @@ int launch_eps_gen(vbmc_ctx* ctx, hipStream_t st, const GenSlice& g) {
 }
 
 int entmc_launch_finish(vbmc_ctx* ctx, const EntPlan& p, double* raw_out, const GenSlice* gen,
-                        const DoneSignal* done, const PrepArgs* gp) {
+                        const DoneSignal* done) {
   const int n_out = raw_len(ctx->D, ctx->K);
   if ((uint64_t)ctx->K * (uint64_t)p.a.chunks * (uint64_t)p.a.stride >= ((uint64_t)1 << 31))
     return vbmc_fail(ctx, VBMC_E_UNSUP, "entropy: partial block of %d x %d rows too large", ctx->K, p.a.chunks);
   const GenSlice g = gen ? *gen : GenSlice();
   const DoneSignal ds = done ? *done : DoneSignal();
-  PrepArgs ga;
-  size_t lds = 0;
-  if (gp && gp->n_glj > 0) {
-    ga = *gp;
-    lds = glj_block_lds(ctx->D, ga.N);
-    if (lds > 150 * 1024) return vbmc_fail(ctx, VBMC_E_UNSUP, "gp_log_joint: N=%d too large", ga.N);
-    if (lds > 64 * 1024)
-      HIP_TRY(ctx, hipFuncSetAttribute((const void*)entmc_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  } else {
-    ga.n_glj = 0;
-  }
-  hipLaunchKernelGGL(entmc_finish_kernel, dim3((n_out + 3) / 4 + g.n_blocks + ga.n_glj), dim3(256), lds, ctx->stream,
+  hipLaunchKernelGGL(entmc_finish_kernel, dim3((n_out + 3) / 4 + g.n_blocks), dim3(256), 0, ctx->stream,
                      p.a.partial, p.a.chunks, p.a.stride, ctx->d_mix, ctx->ml, p.inv_ns,
-                     p.a.want_grad, p.ws ? 1 : 0, raw_out, g, ds, ga);
+                     p.a.want_grad, p.ws ? 1 : 0, raw_out, g, ds);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }

@@ -159,34 +159,9 @@ __device__ __forceinline__ void gen_item(const GenSlice& g, int64_t t, uint64_t 
   }
 }
 
-// workgroup `block` (0-based among the slice's n_blocks) of a 256-thread launch; a thread takes
-// per_thread items, 256 apart (every store instruction of a wave writes one contiguous span)
+// workgroup `block` (0-based among the slice's n_blocks) of a 256-thread launch: one item per thread
 __device__ inline void gen_slice_block(const GenSlice& g, int block, int tid) {
   const uint64_t seed = g.seed + (g.seed_add ? (uint64_t)g.seed_add[0] : 0);
-  const bool fits32 = gen_fits32(g);
-  const int pt = g.per_thread > 1 ? g.per_thread : 1;
-  const int64_t base = (int64_t)block * (256 * (int64_t)pt) + tid;
-  for (int u = 0; u < pt; ++u) {
-    const int64_t local = base + (int64_t)u * 256;
-    if (local >= g.item_count) break;
-    gen_item(g, g.item_begin + local, seed, fits32);
-  }
-}
-
-// The generator of rounds 1-2 (one block and 53-bit uniforms per pair, <= 1 ulp elementary
-// functions); no kernel of the library uses it any more -- kept for tools/ubench_gen*.hip, which
-// time the old form beside the new one.
-__device__ inline void philox_normal_pair(uint64_t row, uint32_t pair, uint64_t seed,
-                                          double& z0, double& z1) {
-  Philox4 r = philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), pair, 0u, (uint32_t)seed,
-                            (uint32_t)(seed >> 32));
-  uint64_t a = (((uint64_t)r.x[0] << 32) | r.x[1]) >> 11;
-  uint64_t b = (((uint64_t)r.x[2] << 32) | r.x[3]) >> 11;
-  double u1 = (double)(a + 1) * 0x1.0p-53;
-  double u2 = (double)b * 0x1.0p-53;
-  double rad = sqrt(-2.0 * fm::log_fast(u1));
-  double s, c;
-  fm::sincospi_fast(2.0 * u2, s, c);
-  z0 = rad * c;
-  z1 = rad * s;
+  const int64_t local = (int64_t)block * 256 + tid;
+  if (local < g.item_count) gen_item(g, g.item_begin + local, seed, gen_fits32(g));
 }

@@ -308,13 +308,15 @@ def test_config5_share_on_one_gpu(ctx, ws_mode):
 
 
 @pytest.mark.parametrize("S", [1, 3])
-def test_step_pipeline_variants_bit_identical(ctx, S):
-    """The host-driven step has several launch plans (include/vbmc_hip.h, vbmc_set_option): the pack
-    written by the CPU into device memory with the GP sums in the finish launch or an upload kernel
-    with the GP sums in the prep launch (`mix_bar`), and three places for the speculative
-    generation of the next seed's draws (`ahead_mode`).  They run the same kernels' code on the
-    same inputs: consecutive-seed evaluations (so that the speculation hits from the second one
-    on) must return bit-identical F, dF, G, H under every plan -- and the oracle's values."""
+def test_step_option_combinations_bit_identical(ctx, S):
+    """The host-driven step's launch plan depends on a handful of switches (include/vbmc_hip.h, vbmc_set_option:
+    one fallback per mechanism): the armed evaluation (`elbo_arm`), the CPU-written pack with the GP sums in
+    the entropy launch's spare slots or an upload kernel with the GP sums in the prep launch (`mix_bar`), the
+    speculative generation of the next seed's draws (`elbo_ahead`), draws generated ahead of the entropy
+    kernel or in-line by it (`elbo_pregen`).  They run the same kernels' code on the same inputs: four
+    consecutive-seed evaluations (so that arming and the speculation hit from the second one on) must return
+    bit-identical F, dF, G, H under EVERY combination -- all sixteen are run, in a seeded random order with the
+    options changed between evaluations too -- and the oracle's values."""
     from pyvbmc_amd.variational_optimization import _neg_elcbo
 
     wl = synthetic.make_workload(3, S=S, N=120)
@@ -323,43 +325,39 @@ def test_step_pipeline_variants_bit_identical(ctx, S):
              s2=wl.s2 if wl.s2 is not None else np.zeros(0))
     gp = make_gp(g, ctx, wl.hyp)
     rng = np.random.default_rng(5)
-    thetas = []
     vp0 = make_vp(g, ctx)
     th0 = vp0.get_parameters()
-    for i in range(4):
-        thetas.append(th0 + 0.05 * rng.standard_normal(th0.size))
+    thetas = [th0 + 0.05 * rng.standard_normal(th0.size) for _ in range(4)]
     NsK = 2 * 64 * 9  # per component; rows = 576
+    KEYS = ("elbo_arm", "mix_bar", "elbo_ahead", "elbo_pregen")
 
-    def run(mix_bar, ahead_mode):
-        # (ahead_mode + 10 * k: GP sums in the finish launch (k = 1) / the prep launch (k = 0) instead of
-        # the entropy launch's last row)
-        arm = 1
-        if ahead_mode >= 100:  # 100 + m: without the armed evaluation
-            arm, ahead_mode = 0, ahead_mode - 100
-        gp_tail, ahead_mode = (ahead_mode // 10 - 1, ahead_mode % 10) if ahead_mode >= 10 else (2, ahead_mode)
-        ctx.set_option("elbo_arm", arm)
-        ctx.set_option("mix_bar", mix_bar)
-        ctx.set_option("gp_tail", gp_tail)
-        ctx.set_option("ahead_mode", ahead_mode)
+    def run(combo_of_eval):
         out = []
         try:
             vp = make_vp(g, ctx)
             for i, th in enumerate(thetas):
+                for key, val in zip(KEYS, combo_of_eval(i)):
+                    ctx.set_option(key, val)
                 F, dF, G, H, _ = _neg_elcbo(th.copy(), gp, vp, 0.0, NsK, True, False, None, 0.0, False,
                                             rng="philox", seed=900 + i)
                 out.append((F, dF.copy(), G, H))
         finally:
-            ctx.set_option("mix_bar", 1)
-            ctx.set_option("gp_tail", 2)
-            ctx.set_option("ahead_mode", 2)
-            ctx.set_option("elbo_arm", 1)
+            for key in KEYS:
+                ctx.set_option(key, 1)
         return out
 
-    base = run(1, 2)
-    for plan in [(1, 0), (1, 1), (1, 3), (0, 2), (0, 0), (0, 1), (1, 22), (1, 12), (1, 102), (1, 103)]:
-        got = run(*plan)
+    base = run(lambda i: (1, 1, 1, 1))
+    combos = [tuple((c >> b) & 1 for b in range(4)) for c in range(16)]
+    order = np.random.default_rng(2024 + S).permutation(16)
+    for c in order:
+        got = run(lambda i, c=c: combos[c])
         for (F, dF, G, H), (F0, dF0, G0, H0) in zip(got, base):
-            assert F == F0 and G == G0 and H == H0 and np.array_equal(dF, dF0), plan
+            assert F == F0 and G == G0 and H == H0 and np.array_equal(dF, dF0), combos[c]
+    for trial in range(6):  # the options changing from one evaluation to the next
+        pick = np.random.default_rng(77 + 10 * S + trial).integers(0, 16, size=len(thetas))
+        got = run(lambda i: combos[pick[i]])
+        for (F, dF, G, H), (F0, dF0, G0, H0) in zip(got, base):
+            assert F == F0 and G == G0 and H == H0 and np.array_equal(dF, dF0), [combos[q] for q in pick]
     # and the values themselves: the oracle on the restated generator's draws (last evaluation)
     vp = make_vp(g, ctx)
     vp.set_parameters(thetas[-1].copy())
@@ -408,8 +406,8 @@ def test_armed_evaluation_cancel_paths(ctx):
                     elif i == 4:
                         gp.update(X_new=wl.X, y_new=wl.y, s2_new=wl.s2, hyp=wl.hyp)  # same GP, new upload
                     elif i == 5:
-                        ctx.set_option("ws_pair", 0)
-                        ctx.set_option("ws_pair", 1)
+                        ctx.set_option("predict_dma", 0)      # (any option change cancels an armed evaluation)
+                        ctx.set_option("predict_dma", 1)
                     elif i == 8:
                         time.sleep(0.05)                       # longer than the armed launches wait
                     elif i == 9:

@@ -253,7 +253,7 @@ int main() {
   };
   const int nbq = (g.items + 255) / 256;
   GenSlice o8 = o;
-  o8.per_thread = 8;
+  // (the eight-items-per-thread form was dropped from the library in round 4)
   o8.n_blocks = (int)((o.item_count + 2047) / 2048);
   time("old, 1 pair/thread", [&] { hipLaunchKernelGGL(k_old, dim3(o.n_blocks), dim3(256), 0, 0, o); });
   time("old, 8 pairs/thread deferred", [&] { hipLaunchKernelGGL(k_old, dim3(o8.n_blocks), dim3(256), 0, 0, o8); });
