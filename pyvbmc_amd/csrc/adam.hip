@@ -588,6 +588,7 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
     f.i0 = i0;
     f.n_iters = n_iters;
     f.test_absent = ctx->opt_adam_fused == 2 ? 1 : 0;
+    f.rel_acq = ctx->opt_adam_fused == 3 ? 1 : 0;
     HIP_TRY(ctx, hipMemsetAsync(st->d_flags, 0, 256 * sizeof(unsigned long long), ctx->stream));
     static const bool want_times = [] {
       const char* e = getenv("VBMC_FUSED_TIMES");  // measurement aid: phase stamps of two workgroups to stderr
@@ -691,6 +692,7 @@ extern "C" int vbmc_adam_run_auto(vbmc_ctx* ctx, int max_iters, double tol_fun, 
   f.tol_fun = tol_fun;
   f.n_done = st->d_status + 2;
   f.test_absent = ctx->opt_adam_fused == 2 ? 1 : 0;
+  f.rel_acq = ctx->opt_adam_fused == 3 ? 1 : 0;
   HIP_TRY(ctx, hipMemsetAsync(st->d_flags, 0, 256 * sizeof(unsigned long long), ctx->stream));
   int rc = adam_fused_launch(ctx, ctx->stream, f, st->fused_lds);
   if (rc) return rc;

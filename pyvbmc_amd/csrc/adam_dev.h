@@ -73,9 +73,10 @@ struct FusedArgs {
   int stop_rule = 0;              // 1: every workgroup applies minimize_adam's stopping rule itself (vbmc_adam_run_auto)
   double tol_fun = 0.0;
   int* n_done = nullptr;          // iterations this launch ran (written by workgroup 0)
+  int rel_acq = 0;                // option "adam_fused" = 3: the flags as release stores / acquire fences (adam_fused.hip, exchange)
   int test_absent = 0;            // test hook (option "adam_fused" = 2): also wait for a workgroup that does not exist
   int o_pack = 0, o_ee = 0, o_recs = 0, o_eps = 0, o_part = 0, o_out = 0, o_gp = 0, o_xt = 0,
-      o_alpha = 0;                // LDS carve, in doubles (adam_fused_plan)
+      o_alpha = 0;  // LDS carve, in doubles (adam_fused_plan)
 };
 size_t adam_fused_plan(FusedArgs& f);
 int adam_fused_launch(vbmc_ctx* ctx, hipStream_t st, const FusedArgs& f, size_t lds_bytes);

@@ -59,6 +59,11 @@ __device__ __forceinline__ void st_wt(double* p, double v) { __hip_atomic_store(
 __device__ __forceinline__ double ld_wt(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0)
 
+// a wave-uniform double moved to scalar registers (an LDS read lands in vector registers)
+__device__ __forceinline__ double to_sgpr(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 // the SW per-wave partials r[0 .. SW) in a fixed order
 __device__ __forceinline__ double sumw(const double* r) {
   double v = (r[0] + r[1]) + (r[2] + r[3]);
@@ -71,8 +76,8 @@ __device__ __forceinline__ double sumw(const double* r) {
 // per-component and per-dimension quantities itself (lane = k, lane = d) and so owns the four wave-wide
 // reductions: one barrier (before theta's eta tail is shifted in place) instead of five.  The waves share the
 // stores.  theta, aux and p are LDS arrays.
-__device__ void pack_waves(const AdamDev& a, double* theta, double* aux, double* p) {
-  const int D = a.D, K = a.K, tid = threadIdx.x, n = a.n_theta;
+__device__ void pack_waves(const AdamDev& a, double* theta, double* aux, double* p, int tid) {
+  const int D = a.D, K = a.K, n = a.n_theta;
   const int lane = tid & 63, wave = tid >> 6;
   const bool o_mu = a.mask & 1, o_sg = a.mask & 2, o_lm = a.mask & 4, o_w = a.mask & 8;
   const int p_sg = o_mu ? D * K : 0, p_lm = p_sg + (o_sg ? K : 0), p_w = n - K;
@@ -189,31 +194,37 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
   // ---- what persists across the iterations of this launch ----
   for (int i = tid; i < L.o_res(); i += NT) sh[i] = a.state[i];  // theta | aux | hyp
   for (int i = tid; i < ml.total; i += NT) pack[i] = a.mix[i];
-  constexpr int U = 1024 / NT;  // n_theta <= 1024 (adam_fused_plan)
-  double r_m[U], r_v[U], r_lo[U], r_hi[U];
+  // Adam's moments of this thread's entries of theta (n_theta <= 2 NT, adam_fused_plan)
+  double r_m[2], r_v[2];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
+  for (int u = 0; u < 2; ++u) {
     const int i = u * NT + tid;
-    const bool in = i < n;
-    r_m[u] = in ? a.state[L.o_m() + i] : 0.0;
-    r_v[u] = in ? a.state[L.o_v() + i] : 0.0;
-    r_lo[u] = (in && a.has_box) ? a.state[L.o_xlb() + i] : 0.0;
-    r_hi[u] = (in && a.has_box) ? a.state[L.o_xub() + i] : 0.0;
+    r_m[u] = i < n ? a.state[L.o_m() + i] : 0.0;
+    r_v[u] = i < n ? a.state[L.o_v() + i] : 0.0;
   }
   // minimize_adam's stopping rule (minimize_adam.py:107-140), applied by every workgroup to the same numbers: the sums of
   // its theta entries over the current and the previous batch of 20 iterations, the batch's objective values
   constexpr int BATCH = 20;
   __shared__ double ywin[BATCH];
-  double xs_cur[U], xs_prev[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) xs_cur[u] = xs_prev[u] = 0.0;
+  // loop-invariant doubles of phase B: read from LDS where they are used (as values hoisted out of the iteration loop
+  // they sat in vector registers across phase A, or in scratch)
+  __shared__ double cst[6];
+  if (tid == 0) {
+    cst[0] = 1.0 - a.beta1;
+    cst[1] = 1.0 - a.beta2;
+    cst[2] = 1.0 / S;
+    const double tol_max = f.tol_fun * 100.0;
+    cst[3] = f.tol_fun * f.tol_fun;
+    cst[4] = tol_max * tol_max;
+    cst[5] = a.master_max - a.master_min;
+  }
   int n_ran = f.n_iters;
   if (g == 0 && f.backup) {  // what a launch that gives up is rolled back to (adam.hip fused_restore)
     double* b = f.backup;
     for (int i = tid; i < L.o_hyp(); i += NT) b[i] = a.state[i];
     b += L.o_hyp();
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < 2; ++u) {
       const int i = u * NT + tid;
       if (i < n) {
         b[i] = r_m[u];
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
   };
 
   // the normals of component g's rows at iteration `it` (philox.h: row j n_half + row_begin + i, block d / 4)
-  auto make_draws = [&](int it) {
+  auto make_draws = [&](int it, int tid) {
     const int rows = f.rows;
     if (f.eps_mode == VBMC_EPS_PHILOX) {
       const int nb = (D + 3) >> 2;
@@ -258,15 +269,15 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
       for (int i = tid; i < rows * D; i += NT) sE[i] = src[i];
     }
   };
-  if (g < f.n_ent) make_draws(f.i0);
+  if (g < f.n_ent) make_draws(f.i0, tid);
 
   const int tid_launch = tid;
   for (int t = 0; t < f.n_iters; ++t) {
-    // (an opaque zero ties everything derived from the thread index to the iteration: hoisted out of this long loop,
+    // (an opaque copy of the thread index ties everything derived from it to the iteration: hoisted out of this long loop,
     // the address arithmetic of its ~40 inner loops was worth 75 spilled registers)
-    int zoff;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(zoff));
-    const int tid = tid_launch + zoff, lane = tid & 63;
+    int tid;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(tid) : "v"(tid_launch));
+    const int lane = tid & 63;
     const int iter = f.i0 + t;
     double* xb = f.xch + (size_t)(t & 1) * RT;
     stamp(t, 0);
@@ -278,8 +289,12 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
       const int rows = f.rows;
       // the lane's table row (prep.hip's table block, from the pack in LDS)
       const double* mup = pack + ml.o_mup;
-      const double sig_j = pack[ml.o_sig + j];
-      const double sj2 = sig_j * sig_j, two_sj = 2.0 * sig_j;
+      double sj2, two_sj;
+      {
+        const double sig_j = pack[ml.o_sig + j];
+        sj2 = to_sgpr(sig_j * sig_j);
+        two_sj = to_sgpr(2.0 * sig_j);
+      }
       double dl[DP], d2s = 0.0;
 #pragma unroll
       for (int d = 0; d < DP; ++d) {
@@ -315,7 +330,7 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
         const double sp = fma(two_sj, c, bq), sm = fma(-two_sj, c, bq);
         const double r1 = fm::exp2_fast(fma(ak, sp, c0)), r2 = fm::exp2_fast(fma(ak, sm, c0));
         const double qp = fm::wave_sum_dpp(wk * r1), qm = fm::wave_sum_dpp(wk * r2);
-        slog += fm::log_fast(qp) + fm::log_fast(qm);
+        slog = to_sgpr(slog + (fm::log_fast(qp) + fm::log_fast(qm)));  // (the same value in every lane)
         const double t1 = r1 * fm::rcp_fast(qp), t2 = r2 * fm::rcp_fast(qm);
         const double ts = t1 + t2, td = t1 - t2;
         W += ts;
@@ -332,6 +347,8 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
       // every wave lays its 2D per-lane values down in LDS, then wave c % SW sums item c over the waves and its lanes
       stamp(t, 10);
       const int NI = 2 * D + 1;
+      asm volatile("" ::: "memory");  // (sigma_j is read again rather than held across the row loop: the <16> build's last spill)
+      const double sig_j = pack[ml.o_sig + j];
       double* pc = part;                      // [SW][2D + 1][K]
       double* pW = pc + (size_t)SW * NI * K;  // [SW][64]
       double* pS = pW + SW * 64;              // [SW] slog
@@ -444,7 +461,7 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
           double r0 = (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]);
           if (SW == 8) r0 += (sPart[4] + sPart[5]) + (sPart[6] + sPart[7]);
           const bool quad = a.mean_kind == VBMC_MEAN_NEGQUAD;
-          const double inv_S = 1.0 / S;
+          const double inv_S = cst[2];
           const double wk = pack[ml.o_w + k];
           double c_gs = 0.0, c_nu = 0.0, c_qb = 0.0;
           double* rec = xb + (size_t)K * RE + (size_t)b * RC;
@@ -485,14 +502,31 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
 
     // ================= exchange: drained write-through records, one flag per workgroup, all-gather =================
     stamp(t, 1);
+    // Default: every record entry is a write-through store (st_wt: past the XCD's L2, which the other XCDs do not
+    // snoop) and every gathered one a load that bypasses the caches (ld_wt), so the flag itself needs no fence -- the
+    // wave's stores have left (vmcnt(0)) before the workgroup's barrier, the flag is stored after it.  rel_acq = 1 is
+    // the same exchange written with the memory model's own words: the flag is an agent-scope RELEASE store (the
+    // compiler adds the write-back of the L2's dirty lines, buffer_wbl2 sc1), the reader runs an agent-scope ACQUIRE
+    // fence behind the spin (buffer_inv sc1: its L2 and L1 drop what they hold).  Measured at K = 50, NsK = 28:
+    // DESIGN.md section 4.6b; the default stays the relaxed form, the fenced one is the documented fallback
+    // (option "adam_fused" = 3) and tests/test_adam.py runs both.
     drain();
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(f.flags + g, (unsigned long long)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      if (f.rel_acq) __hip_atomic_store(f.flags + g, (unsigned long long)(t + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_store(f.flags + g, (unsigned long long)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     stamp(t, 2);
 
+    // (a second opaque copy: what phase B derives from the thread index is not computed ahead of phase A and carried
+    // across its register-hungry loop -- with one zero per iteration that was 100 B of scratch per thread at D = 16)
+    int tid_b;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(tid_b) : "v"(tid_launch));
+    {
+    const int tid = tid_b, lane = tid & 63;
     // ---- while the flags travel: the next iteration's normals, and the soft bounds (_vp_bound_loss :537-606),
     // which need theta only ----
-    if (g < f.n_ent && t + 1 < f.n_iters) make_draws(iter + 1);
+    if (g < f.n_ent && t + 1 < f.n_iters) make_draws(iter + 1, tid);
     double* dL = work;              // [n_bnd]
     double* gsg = dL + a.n_bnd;     // [K]
     double* gw = gsg + K;           // [K]
@@ -507,7 +541,7 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
     const double it1 = (double)(iter + 1);
     const double c1 = 1.0 / (1.0 - fm::exp2_fast(it1 * a.l2_beta1));
     const double c2 = 1.0 / (1.0 - fm::exp2_fast(it1 * a.l2_beta2));
-    const double step = a.master_min + (a.master_max - a.master_min) * fm::exp2_fast(-it1 * a.l2e_over_decay);
+    const double step = a.master_min + cst[5] * fm::exp2_fast(-it1 * a.l2e_over_decay);
     if (o_w)
       for (int k = tid; k < K; k += NT) ee[k] = fm::exp2_fast(LOG2E * eta[k]);  // softmax terms of the current iterate
     double loss = 0.0;
@@ -555,7 +589,9 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
         for (int q = lane; q < G + f.test_absent; q += 64)
           all = all && __hip_atomic_load(f.flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
         if (__all(all)) break;
-        if (__builtin_amdgcn_readfirstlane((int)((wall_clock64() - t0) > f.timeout))) {
+        // (the first exchange also waits for every workgroup to be DISPATCHED: beside another queue's launches that
+        // keep the CUs' LDS taken -- tests/test_adam.py's soak -- that has been seen to take longer than 20 ms; 10x)
+        if (__builtin_amdgcn_readfirstlane((int)((wall_clock64() - t0) > (t == 0 ? 10 * f.timeout : f.timeout)))) {
           ok = 0;
           break;
         }
@@ -568,6 +604,7 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
     }
     __syncthreads();  // (also: dL complete)
     if (!s_ok) return;
+    if (f.rel_acq) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     stamp(t, 3);
     for (int base = 0; base < RT; base += NT * 10) {
       double v[10];
@@ -706,7 +743,7 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
       }
       double* x_row = a.x_tab + (size_t)iter * n;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < 2; ++u) {
         const int i = u * NT + tid;
         if (i >= n) continue;
         double gr;  // dF_i
@@ -741,16 +778,18 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
           const double rr = -f.inv_ns * (recs[k * RE] + out_sum(1 + D + k));
           gr = gg + (e * sm_dot / (sm_s * sm_s) - e * rr / sm_s);
         }
-        const double m = a.beta1 * r_m[u] + (1.0 - a.beta1) * gr;
-        const double v = a.beta2 * r_v[u] + (1.0 - a.beta2) * (gr * gr);
+        const double m = a.beta1 * r_m[u] + cst[0] * gr;
+        const double v = a.beta2 * r_v[u] + cst[1] * (gr * gr);
         r_m[u] = m;
         r_v[u] = v;
         const double m_hat = m * c1, v_hat = v * c2;
         double x = theta[i] - step * m_hat / (sqrt(v_hat) + a.fudge);
-        if (a.has_box) x = fmin(r_hi[u], fmax(r_lo[u], x));
+        if (a.has_box) x = fmin(a.state[L.o_xub() + i], fmax(a.state[L.o_xlb() + i], x));  // (minimize_adam's lb / ub: not optimize_vp's path)
         theta[i] = x;
-        xs_cur[u] += x;
-        if (g == 0) x_row[i] = x;
+        if (g == 0) {
+          if (f.stop_rule) st_wt(x_row + i, x);  // read back by every workgroup at the end of the batch (below)
+          else x_row[i] = x;
+        }
       }
       __syncthreads();
     }
@@ -760,9 +799,16 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
       // residual sum / (n - 2) / sum t^2) and the distance between the mean iterates of the last two batches
       if (iter + 1 >= 2 * BATCH) {
         double part = 0.0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const double dm = xs_cur[u] / BATCH - xs_prev[u] / BATCH;  // (entries past n_theta hold zeros)
+        // the sums of the last two batches' iterates, added up in iteration order from the rows workgroup 0 has written
+        // (complete before the flag of the iteration after them, i.e. before this iteration's gather; the last row is
+        // this iteration's own update, the same bits in every workgroup)
+        for (int i = tid; i < n; i += NT) {
+          const double* col = a.x_tab + i;
+          double xp = 0.0, xc = 0.0;
+          for (int q = iter + 1 - 2 * BATCH; q <= iter - BATCH; ++q) xp += ld_wt(col + (size_t)q * n);
+          for (int q = iter + 1 - BATCH; q < iter; ++q) xc += ld_wt(col + (size_t)q * n);
+          xc += theta[i];
+          const double dm = xc / BATCH - xp / BATCH;
           part += dm * dm / BATCH;
         }
         part = fm::wave_sum_dpp(part);
@@ -783,27 +829,26 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
           rs = fma(r, r, rs);
         }
         const double c00 = rs / (BATCH - 2) / tt;
-        const double tol_max = f.tol_fun * 100.0;
-        const double err = sqrt(c00 + f.tol_fun * f.tol_fun), err_max = sqrt(c00 + tol_max * tol_max);
+        const double err = sqrt(c00 + cst[3]), err_max = sqrt(c00 + cst[4]);
         stop = (dx < 0.001 && fabs(slope) < err_max) || (fabs(slope) < err && dx < 0.1);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        xs_prev[u] = xs_cur[u];
-        xs_cur[u] = 0.0;
       }
     }
 
     // ---- set_parameters + the pack of the next iterate ----
     stamp(t, 7);
-    pack_waves(a, theta, aux, pack);
+    pack_waves(a, theta, aux, pack, tid);
     __syncthreads();
     stamp(t, 8);
     if (stop) {
       n_ran = t + 1;
       break;
     }
+    }
   }
+  int tid_e;  // (a last opaque copy: the write-back's addresses are not the start-up copies' carried across the loop)
+  asm volatile("v_mov_b32 %0, %1" : "=v"(tid_e) : "v"(tid_launch));
+  {
+  const int tid = tid_e;
   if (g == 0 && tid == 0 && f.n_done) *f.n_done = n_ran;
 
   // the state the next batch (or vbmc_adam_end) starts from -- not if another workgroup has given up meanwhile (the host
@@ -812,13 +857,14 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
     for (int i = tid; i < L.o_hyp(); i += NT) a.state[i] = sh[i];  // theta | aux
     for (int i = tid; i < ml.total; i += NT) a.mix[i] = pack[i];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < 2; ++u) {
       const int i = u * NT + tid;
       if (i < n) {
         a.state[L.o_m() + i] = r_m[u];
         a.state[L.o_v() + i] = r_v[u];
       }
     }
+  }
   }
 }
 

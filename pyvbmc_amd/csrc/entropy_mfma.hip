@@ -42,17 +42,16 @@ namespace {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int WG = 256, WAVES = 4;
 
-// 2^x, degree 10 (4.1e-16): the entropy kernels' exp2 (entropy_ws.hip kExp2C), coefficients as literals
+// 2^x: the entropy kernels' polynomial (fastmath.h VBMC_ENT_EXP2_COEFFS), coefficients as literals
 __device__ __forceinline__ void exp2_pair(double x1, double x2, double& r1, double& r2) {
   const double t1 = __builtin_rint(x1), t2 = __builtin_rint(x2);
   const double f1 = x1 - t1, f2 = x2 - t2;
   const int n1 = (int)t1, n2 = (int)t2;
-  constexpr double c[10] = {0x1.62e42fefa3a19p-1, 0x1.ebfbdff82c598p-3, 0x1.c6b08d703ce49p-5, 0x1.3b2ab6fba1ddap-7,
-                            0x1.5d87fe9d7a584p-10, 0x1.430913096fd9fp-13, 0x1.ffcb54062e698p-17, 0x1.62bfd47773353p-20,
-                            0x1.b675bca4eeebbp-24, 0x1.e6063f7217bc6p-28};
-  double p1 = c[9], p2 = c[9];
+  constexpr int EN = VBMC_ENT_EXP2_N;
+  constexpr double c[EN] = VBMC_ENT_EXP2_COEFFS;
+  double p1 = c[EN - 1], p2 = c[EN - 1];
 #pragma unroll
-  for (int i = 8; i >= 0; --i) {
+  for (int i = EN - 2; i >= 0; --i) {
     p1 = fma(p1, f1, c[i]);
     p2 = fma(p2, f2, c[i]);
   }

@@ -36,29 +36,32 @@
 #include "fastmath.h"
 #include "glj_block.h"
 
-// exp2 with its polynomial coefficients held in VGPRs (frees 20 SGPRs for table rows).  Degree
-// 10 here (fastmath.h uses 11): max relative error 4.1e-16 instead of 1.6e-16 in float64 Horner
-// evaluation (tools/fit_polys.py), one FMA less per density -- the entropy averages ~10^6 of them.
-__device__ __forceinline__ double exp2_vc(double x, const double (&c)[10]) {
+// exp2 with its polynomial coefficients held in VGPRs (frees SGPRs for table rows); the polynomial: fastmath.h,
+// VBMC_ENT_EXP2_COEFFS (degree 8, 1.07e-12 -- the accuracy argument is there).
+#ifndef WS_EXP2_N
+#define WS_EXP2_N VBMC_ENT_EXP2_N
+#endif
+constexpr int EN = WS_EXP2_N;  // coefficients beside the constant 1: the polynomial's degree
+__device__ __forceinline__ double exp2_vc(double x, const double (&c)[EN]) {
   const double t = __builtin_rint(x);
   const double f = x - t;
   const int n = (int)t;
-  double p = c[9];
+  double p = c[EN - 1];
 #pragma unroll
-  for (int i = 8; i >= 0; --i) p = fma(p, f, c[i]);
+  for (int i = EN - 2; i >= 0; --i) p = fma(p, f, c[i]);
   p = fma(p, f, 1.0);
   return __builtin_amdgcn_ldexp(p, n);
 }
 // two independent exp2 evaluations with their Horner chains interleaved step by step
 // (a dependent v_fma_f64 chain alone leaves the FP64 pipe half idle)
-__device__ __forceinline__ void exp2_vc2(double x1, double x2, const double (&c)[10], double& r1,
+__device__ __forceinline__ void exp2_vc2(double x1, double x2, const double (&c)[EN], double& r1,
                                          double& r2) {
   const double t1 = __builtin_rint(x1), t2 = __builtin_rint(x2);
   const double f1 = x1 - t1, f2 = x2 - t2;
   const int n1 = (int)t1, n2 = (int)t2;
-  double p1 = c[9], p2 = c[9];
+  double p1 = c[EN - 1], p2 = c[EN - 1];
 #pragma unroll
-  for (int i = 8; i >= 0; --i) {
+  for (int i = EN - 2; i >= 0; --i) {
     p1 = fma(p1, f1, c[i]);
     p2 = fma(p2, f2, c[i]);
   }
@@ -67,7 +70,13 @@ __device__ __forceinline__ void exp2_vc2(double x1, double x2, const double (&c)
   r1 = __builtin_amdgcn_ldexp(p1, n1);
   r2 = __builtin_amdgcn_ldexp(p2, n2);
 }
+#if WS_EXP2_N == VBMC_ENT_EXP2_N
+__device__ const double kExp2C[EN] = VBMC_ENT_EXP2_COEFFS;
+#elif WS_EXP2_N == 10  // rounds 1-3 (4.1e-16); kept for the A/B in profiles/r04_exp2_degree.md
 __device__ const double kExp2C[10] = {0x1.62e42fefa3a19p-1, 0x1.ebfbdff82c598p-3, 0x1.c6b08d703ce49p-5, 0x1.3b2ab6fba1ddap-7, 0x1.5d87fe9d7a584p-10, 0x1.430913096fd9fp-13, 0x1.ffcb54062e698p-17, 0x1.62bfd47773353p-20, 0x1.b675bca4eeebbp-24, 0x1.e6063f7217bc6p-28};
+#elif WS_EXP2_N == 9  // 3.8e-14
+__device__ const double kExp2C[9] = {0x1.62e42fefa39f7p-1, 0x1.ebfbdff8149f2p-3, 0x1.c6b08d7044119p-5, 0x1.3b2ab72b175eep-7, 0x1.5d87fe908f88ap-10, 0x1.43088e257f341p-13, 0x1.ffcb76789860fp-17, 0x1.63ef969a64d3cp-20, 0x1.b6571de2f2351p-24};
+#endif
 
 #include "philox.h"
 
@@ -194,12 +203,12 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   WS_STAMP(0);
 
-  double ec[10];
+  double ec[EN];
   {
     int vz;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vz));  // opaque per-lane zero: keeps the loads vector loads
 #pragma unroll
-    for (int i = 0; i < 10; ++i) ec[i] = kExp2C[i + vz];
+    for (int i = 0; i < EN; ++i) ec[i] = kExp2C[i + vz];
   }
   WS_STAMP(1);
   bool first_stretch = true;

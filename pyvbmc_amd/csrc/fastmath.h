@@ -33,6 +33,19 @@ __device__ __forceinline__ double exp2_fast(double x) {
   return __builtin_amdgcn_ldexp(p, n);
 }
 
+// The entropy kernels' own 2^f on |f| <= 1/2 (entropy_ws.hip, entropy_mfma.hip): 1 + f (c0 + f (c1 + ...)), degree 8,
+// max relative error 1.07e-12 in float64 Horner evaluation (tools/fit_polys.py).  Their densities do not need
+// exp2_fast's 1.6e-16: the Monte-Carlo entropy is an average of log sum_k w_k N_k over 10^5 .. 10^7 draws, compared
+// with the reference at 1e-10 (tests; BASELINE's bar is 1e-6) -- a relative error e in every density moves log q by at
+// most e, H by at most 1.1e-12 absolute, its gradients by 2e times their terms' cancellation; measured against the
+// float64 oracle at BASELINE config 3: H 1.2e-15, gradients 1.6e-15 relative, against 7.0e-16 / 1.5e-15 with degree
+// 10 (the interpolation error equi-oscillates around zero in f and averages out over the draws).  Rounds 1-3 used degree 10 (4.1e-16); each degree is one FMA of the ~70 instructions per evaluated
+// (pair, component): 73.7 -> 70.2 us per launch at config 3 (profiles/r04_exp2_degree.md).
+#define VBMC_ENT_EXP2_N 8
+#define VBMC_ENT_EXP2_COEFFS                                                                                        \
+  {0x1.62e42fef84cf0p-1, 0x1.ebfbdff823cedp-3, 0x1.c6b08dd6fd234p-5, 0x1.3b2ab7181b755p-7, 0x1.5d8745a728441p-10, \
+   0x1.4308ac85aa947p-13, 0x1.00dc4a532fb8ep-16, 0x1.63d136366db24p-20}
+
 // 1/x to ~1 ulp: v_rcp_f64 + two Newton steps.
 __device__ __forceinline__ double rcp_fast(double x) {
   double r = __builtin_amdgcn_rcp(x);

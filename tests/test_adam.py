@@ -336,7 +336,11 @@ def test_device_loop_random_shapes(ctx):
 
 FUSED_SHAPES = [dict(cfg=3, D=10, K=50, N=400, S=1, NsK=28), dict(cfg=5, D=16, K=12, N=60, S=3, NsK=40),
                 dict(cfg=2, D=4, K=20, N=200, S=2, NsK=22), dict(cfg=3, D=7, K=64, N=90, S=1, NsK=2),
-                dict(cfg=5, D=11, K=1, N=50, S=1, NsK=128), dict(cfg=3, D=6, K=20, N=60, S=8, NsK=28)]
+                dict(cfg=5, D=11, K=1, N=50, S=1, NsK=128), dict(cfg=3, D=6, K=20, N=60, S=8, NsK=28),
+                # the widest builds at full register pressure (<12>, <16>: 0 B of scratch since round 4), theta near
+                # its 1 024-entry limit, and the largest training set whose LDS plan fits at D = 10
+                dict(cfg=3, D=12, K=40, N=300, S=2, NsK=28), dict(cfg=3, D=16, K=30, N=100, S=1, NsK=6),
+                dict(cfg=3, D=10, K=50, N=800, S=1, NsK=28)]
 
 
 @pytest.mark.gpu
@@ -438,6 +442,36 @@ def test_fused_loop_applies_only_to_its_shapes(ctx):
     vp, gp = device_objects(wd, ctx)
     minimize_adam_elbo(wl.theta.copy(), gp, vp, wl.NsK, synthetic.default_theta_bnd(wl), max_iter=20, seed=1, rows=(0, 7))
     assert ctx.last_entmc_plan()["kernel"] != "adam_fused"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [FUSED_SHAPES[0], FUSED_SHAPES[1], FUSED_SHAPES[5]],
+                         ids=lambda s: "D%d-K%d-S%d" % (s["D"], s["K"], s["S"]))
+def test_fused_loop_release_acquire_exchange(ctx, shape):
+    """Option adam_fused = 3: the flags of the loop's exchange as agent-scope release stores and acquire fences
+    (csrc/adam_fused.hip, exchange) instead of write-through stores + relaxed flags.  The fallback form computes the
+    same numbers from the same records: iterates, objective values and the stopping decision, bit for bit."""
+    from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+
+    wl = synthetic.make_workload(shape["cfg"], S=shape["S"], D=shape["D"], K=shape["K"], N=shape["N"],
+                                 Ns_total=shape["NsK"] * shape["K"])
+    wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,
+              hyp=wl.hyp, s2=np.zeros(0) if wl.s2 is None else wl.s2)
+    bnd = synthetic.default_theta_bnd(wl)
+    out = {}
+    try:
+        for mode in (1, 3):
+            ctx.set_option("adam_fused", mode)
+            for dev in (False, True):
+                vp, gp = device_objects(wd, ctx)
+                out[mode, dev] = minimize_adam_elbo(wl.theta.copy(), gp, vp, wl.NsK, bnd, max_iter=90, seed=9, rng="philox",
+                                                    tol_fun=0.05, device_stop=dev)
+                assert ctx.last_entmc_plan()["kernel"] == "adam_fused"
+    finally:
+        ctx.set_option("adam_fused", 1)
+    for dev in (False, True):
+        a, b = out[1, dev], out[3, dev]
+        assert a[4] == b[4] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[0], b[0])
 
 
 @pytest.mark.gpu
@@ -548,7 +582,7 @@ def test_fused_loop_soak_is_deterministic(ctx):
 
     th2 = threading.Thread(target=disturb)
     th2.start()
-    first, n_runs, n_iter = {}, 0, 0
+    first, n_runs, n_iter, n_fallback = {}, 0, 0, 0
     soak_s = float(os.environ.get("VBMC_FUSED_SOAK_S", "30"))
     t0 = time.time()
     try:
@@ -557,17 +591,22 @@ def test_fused_loop_soak_is_deterministic(ctx):
                 vp, gp = device_objects(wd, ctx)
                 out = minimize_adam_elbo(wl.theta.copy(), gp, vp, wl.NsK, bnd, max_iter=200, tol_fun=1e-12, seed=5 + i,
                                          rng="philox", ctx=ctx)
-                assert ctx.last_entmc_plan()["kernel"] == "adam_fused", ctx.last_entmc_plan()
+                # (a launch whose workgroups are not all dispatched within its bound -- the other context's launches can
+                # keep the CUs' LDS taken -- gives up and the run continues as four launches per iteration: the same
+                # numbers to ~1e-10, in another summation order.  Such a run is compared with its own kind.)
+                kern = ctx.last_entmc_plan()["kernel"]
+                n_fallback += kern != "adam_fused"
                 key = (out[2].tobytes(), out[3].tobytes(), np.asarray(vp.mu).tobytes(), np.asarray(vp.w).tobytes())
-                if i not in first:
-                    first[i] = key
+                if (i, kern) not in first:
+                    first[i, kern] = key
                 else:
-                    assert key == first[i], (i, n_runs)
+                    assert key == first[i, kern], (i, kern, n_runs)
                 n_runs += 1
                 n_iter += out[4]
     finally:
         stop.set()
         th2.join(timeout=60)
     assert not err, err
-    print(f"{n_runs} runs, {n_iter} iterations, {other_n[0]} full-size evaluations on the other context meanwhile")
-    assert n_runs >= 6 and other_n[0] > 100
+    print(f"{n_runs} runs ({n_fallback} of them gave the one-launch form up), {n_iter} iterations, {other_n[0]} full-size "
+          f"evaluations on the other context meanwhile")
+    assert n_runs >= 6 and other_n[0] > 100 and n_fallback <= n_runs // 4

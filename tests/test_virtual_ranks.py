@@ -102,7 +102,7 @@ def test_entmc_virtual_ranks(ctx, cfg, W, inline):
     err = additive_err(r["raw"], r["parts"], D, K)
     Ho, dHo = oracle_entropy(cfg, SEED + cfg, grad=(cfg == 3))
     print(f"cfg {cfg} W={W} {'inline' if inline else 'pregen'}: plan {plan}; |sum_r raw_r - raw| {err:.2e}; "
-          f"H rel {abs(r['H'] - Ho) / abs(Ho):.2e}")
+          f"H rel {abs(r['H'] - Ho) / abs(Ho):.2e}" + ("" if dHo is None else f"; dH rel {rel_err(r['dH'], dHo):.2e}"))
     assert err <= 1e-12
     assert abs(r["H"] - Ho) <= 1e-10 * abs(Ho)
     # the summed slices, finalised like the job's vector

@@ -38,7 +38,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
               f"|x| {np.linalg.norm(out[0]):.12f}  plan {ctx.last_entmc_plan()}")
 else:
     for tag, env in (("four launches per iteration (VBMC_ADAM_FUSED=0)", {"VBMC_ADAM_FUSED": "0"}),
-                     ("one launch per batch of 20 iterations (adam_fused.hip)", {})):
+                     ("one launch per batch of 20 iterations (adam_fused.hip)", {}),
+                     ("the same with release / acquire flags (VBMC_ADAM_FUSED=3)", {"VBMC_ADAM_FUSED": "3"})):
         print(tag)
         sys.stdout.flush()
         subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, **env))
