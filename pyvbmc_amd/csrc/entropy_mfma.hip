@@ -216,8 +216,8 @@ __global__ __launch_bounds__(WG, 1) void entmc_mfma_kernel(EntArgs a, const doub
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double t1 = rp[kt][r] * ip, t2 = rm[kt][r] * im;
-        const double ts = t1 + t2, td = t1 - t2;
+        const double t2 = rm[kt][r] * im;
+        const double ts = fma(rp[kt][r], ip, t2), td = fma(rp[kt][r], ip, -t2);  // (entropy_ws.hip pass 2)
         Wacc[kt][r] += ts;
         sgs = fma(ts, w2c[r], sgs);
         const double gd = td * w2c[r];

@@ -376,8 +376,9 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
             n2[DP + 3] = tn[DP + 3];
           }
           __builtin_amdgcn_sched_barrier(0);
-          const double t1 = rp_[kk] * ip, t2 = rm_[kk] * im;  // norm_j1 / q
-          const double ts = t1 + t2, td = t1 - t2;
+          // norm_j1 / q of the two samples, their sum and difference: three instructions (t1 is never rounded on its own)
+          const double t2 = rm_[kk] * im;
+          const double ts = fma(rp_[kk], ip, t2), td = fma(rp_[kk], ip, -t2);
           Wacc[kk] += ts;
           sgs = fma(ts, c2[DP + 3], sgs);  // sum_k (gp + gm),  g = w_k / sigma_k^2 * norm_j1 / q
           const double gd = td * c2[DP + 3];
