@@ -437,7 +437,9 @@ __global__ __launch_bounds__(256, 2) void predict_var_dma_kernel(const double* _
   // to the XCDs (block b runs on XCD b % 8), so that every workgroup of a group finds the
   // group's A rows in the same L2.  The grid is padded to 8 * ceil(ngroups / 8) * (nct + 1).
   // (M = 8192, N = 400: 512 workgroups of 13 or 14 panels, two per CU.)
-  int it_c[2], it_g[2], nitem = 0;  // up to two (row tile, column tile) items
+  // up to two (row tile, column tile) items (four scalars, selected by ?: -- as arrays indexed at run time they
+  // lived in 20 bytes of scratch)
+  int it_c0 = 0, it_c1 = 0, it_g0 = 0, it_g1 = 0, nitem = 0;
   {
     const int x = blockIdx.x & 7, o = blockIdx.x >> 3;
     const int ngr = (G + 1) / 2;
@@ -448,16 +450,16 @@ __global__ __launch_bounds__(256, 2) void predict_var_dma_kernel(const double* _
     if (w < 2 * per_row) {
       const int g = 2 * grp + w / per_row, j = w % per_row;
       if (g < G) {
-        it_g[0] = it_g[1] = g;
-        it_c[0] = j == 0 ? nct - 1 : nct - 1 - j;
-        it_c[1] = j - 1;
+        it_g0 = it_g1 = g;
+        it_c0 = j == 0 ? nct - 1 : nct - 1 - j;
+        it_c1 = j - 1;
         nitem = j == 0 ? 1 : 2;
       }
     } else {  // nct even: the two middle tiles of the group
-      it_c[0] = it_c[1] = nct / 2 - 1;
-      it_g[0] = 2 * grp;
-      it_g[1] = 2 * grp + 1;
-      nitem = it_g[1] < G ? 2 : 1;
+      it_c0 = it_c1 = nct / 2 - 1;
+      it_g0 = 2 * grp;
+      it_g1 = 2 * grp + 1;
+      nitem = it_g1 < G ? 2 : 1;
     }
     if (nitem == 0) return;
   }
@@ -472,13 +474,14 @@ __global__ __launch_bounds__(256, 2) void predict_var_dma_kernel(const double* _
   const int wm = wave >> 1, wc = wave & 1;
   const int li = lane & 15, lk = lane >> 4;
   // panels of an item: n < min(N, 64 c + 64) (upper-triangular B: n <= c)
-  const int P1 = (min(N, it_c[0] * TS + TS) + DK - 1) / DK;
-  const int P = P1 + (nitem > 1 ? (min(N, it_c[1] * TS + TS) + DK - 1) / DK : 0);
+  const int P1 = (min(N, it_c0 * TS + TS) + DK - 1) / DK;
+  const int P = P1 + (nitem > 1 ? (min(N, it_c1 * TS + TS) + DK - 1) / DK : 0);
   const char* Arow[2];
   const char* Bcol[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const int g = it_g[nitem > 1 ? q : 0], c = it_c[nitem > 1 ? q : 0];
+    const bool second = nitem > 1 && q == 1;
+    const int g = second ? it_g1 : it_g0, c = second ? it_c1 : it_c0;
     const int z = g / nrt;
     const int64_t m0 = (int64_t)(g - z * nrt) * TS;
     Arow[q] = uniform_ptr(A + (size_t)z * a_stride + (size_t)m0 * ld);
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void predict_var_dma_kernel(const double* _
   // row sums of T^2 over an item's 64 columns (the padding columns of B are zero)
   double* sRow = (double*)(dsm + 2 * DMA_STAGE);  // [64][2]
   auto finish_item = [&](int q) {
-    const int g = it_g[q], c = it_c[q];
+    const int g = q ? it_g1 : it_g0, c = q ? it_c1 : it_c0;
     const int z = g / nrt;
     const int64_t m0 = (int64_t)(g - z * nrt) * TS;
 #pragma unroll
