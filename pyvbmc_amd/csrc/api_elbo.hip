@@ -355,7 +355,8 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   };
 
   // What the result block must identify as (DoneSignal): the pack this call writes and its seed.
-  const uint64_t want_ck = (mc && can_poll && ctx->opt_mix_bar) ? pack_checksum(ctx->h_pack, (size_t)ctx->ml.total) : 0;
+  // (taken further down, once the pack and the go word have left: it is compared when the results are back)
+  uint64_t want_ck = 0;
   bool check_ident = false;
   // An armed evaluation planned for exactly this call?  Then its launches are already queued: write
   // the pack and the go word.  Otherwise cancel it (if any) and launch as usual.
@@ -408,6 +409,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     if (rc) return rc;
     check_ident = polled && ident_out_flag;
   }
+  if (mc && can_poll && ctx->opt_mix_bar) want_ck = pack_checksum(ctx->h_pack, (size_t)ctx->ml.total);
   ctx->step_marks[2] = (double)ctx->gp_where;  // (of THIS evaluation's launches: issued just now, or armed by the previous call)
   // Arm the next evaluation (seed + 1, same shapes): its launches go into the queue now, behind this
   // one's, and wait for the next call's theta.

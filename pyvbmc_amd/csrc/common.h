@@ -123,7 +123,8 @@ struct vbmc_ctx {
   double* d_stage = nullptr;   // device staging of the results the polled step hands to the host (DoneSignal)
   size_t d_stage_cap = 0;
   double* d_mix_fg = nullptr;  // host-writable (fine-grained) device memory: the host-driven step writes the pack here itself
-  std::vector<double> mu_scratch;  // vbmc_set_mixture_dk's transposed means
+  std::vector<double> mu_scratch;
+  std::vector<double> t2m_mu, t2m_sg, t2m_lm, t2m_w, t2m_eta;  // vbmc_theta_to_mixture's working copies  // vbmc_set_mixture_dk's transposed means
   double* d_acq_fg = nullptr;  // the same kind of memory for a small acquisition batch's points (api_acq.hip); 256 x 33 doubles
   bool acq_fg_failed = false;
   uint64_t acq_seq = 0;        // sequence number of the acquisition completion word (h_done[7])

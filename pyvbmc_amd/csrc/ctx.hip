@@ -526,7 +526,13 @@ int vbmc_theta_to_mixture(vbmc_ctx* ctx, const double* theta, int n_theta, int o
   if (!ctx->mix_set) return vbmc_fail(ctx, VBMC_E_ARG, "theta_to_mixture: mixture (D,K) not set");
   if (ctx->device >= 0) HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int D = ctx->D, K = ctx->K;
-  std::vector<double> mu = ctx->mu, sg = ctx->sigma, lm = ctx->lambd, w = ctx->w, eta = ctx->eta;
+  // (scratch that lives with the context: this runs between two evaluations of the optimiser, with the device idle)
+  std::vector<double>&mu = ctx->t2m_mu, &sg = ctx->t2m_sg, &lm = ctx->t2m_lm, &w = ctx->t2m_w, &eta = ctx->t2m_eta;
+  mu = ctx->mu;
+  sg = ctx->sigma;
+  lm = ctx->lambd;
+  w = ctx->w;
+  eta = ctx->eta;
   const int st = theta_to_arrays(D, K, theta, n_theta, optimize_mask, mu.data(), sg.data(), lm.data(),
                                  w.data(), eta.data());
   if (st == -1)
