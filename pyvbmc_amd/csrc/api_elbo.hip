@@ -220,9 +220,10 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
     EntPlan plan;
     if (mc) {
       // (the GP sums may ride in this launch's spare workgroup slots: only in the polled single-GPU step, see below)
-      const bool gp_rides = can_poll && ctx->opt_mix_bar && ctx->d_mix_fg != nullptr;
+      // (the plan reserves the slots by the step's GP item count whether or not they ride -- only in the polled
+      // single-GPU step with a CPU-written pack, below: the partition of the batches must not depend on that)
       rc2 = entmc_plan(ctx, opts->ns_per_comp, opts->eps_mode, seed, row_begin, row_count, grad_flags != 0, plan,
-                       gp_rides ? pa.n_glj : 0);
+                       pa.n_glj);
       if (rc2) return rc2;
       entmc_fill_prep(ctx, plan, pa);
       rc2 = entmc_pregen(ctx, plan, pa);  // Philox draws generated by extra blocks of the prep launch

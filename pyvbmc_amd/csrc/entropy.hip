@@ -621,7 +621,19 @@ int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
     // items each (they are then done inside the first half of the kernel).  The slots are left free whether or not
     // anything rides in them: how the batches are cut -- hence the order of every sum -- depends on the job alone,
     // never on where the GP sums run or on any option (the step's launch plans stay bit-identical).
-    constexpr int WS_GP_SLOTS = 10;
+    // How many: five (s, k) blocks per slot are done well inside the kernel (six is the measured limit), so a
+    // step with S hyper-parameter samples reserves ceil(S K / 5) slots -- ten at S = 1, K = 50, never fewer than ten
+    // (other launches' jobs keep the round-4 partition) nor more than 100; each costs the kernel the filler part of one
+    // CU (about a third of a CU's throughput), which is less than the 7-12 us the sums' latency chain costs in front of the
+    // kernel.  Beyond 100 slots' worth the sums stay in the prep launch and ten slots are left, as without GP items.
+    static const int slots_env = [] {
+      const char* e = getenv("VBMC_WS_GP_SLOTS");  // measurement aid: a fixed slot count
+      return e ? atoi(e) : 0;
+    }();
+    int WS_GP_SLOTS = 10;
+    if (slots_env > 0) WS_GP_SLOTS = slots_env;
+    else if (gp_items > 50 && gp_items <= 500) WS_GP_SLOTS = (gp_items + 4) / 5;
+    if (WS_GP_SLOTS > cus / 2) WS_GP_SLOTS = cus / 2;
     const int gp_wgs = gp_items > 0 ? std::min(WS_GP_SLOTS, (gp_items + 4) / 5) : 0;
     const bool gp_here = waves == 2 && gp_wgs > 0 && gp_items <= 6 * WS_GP_SLOTS;
     sp.pb = waves == 2 ? cus - WS_GP_SLOTS : 0;

@@ -12,7 +12,7 @@
 // the `filler` (block cus + p, which the dispatcher places beside it) the rest, and both end together.  Batches are
 // numbered g over components j and cut into cus + pb consecutive parts
 //     A_0 B_0 A_1 B_1 ... A_pb-1 B_pb-1 A_pb ... A_cus-1        (units p >= pb have no filler: their second slot is left
-// to the GP-sum workgroups of the host-driven step) whose lengths are proportional to the weights front / 1000 - front,
+// to the GP-sum workgroups of the host-driven step; cus - pb = ceil(S K / 5) of them, at least ten: entmc_plan) whose lengths are proportional to the weights front / 1000 - front,
 // so every CU ends at the same time whatever K and the row count are.  A part that crosses a component boundary is
 // worked through as two stretches with a partial row each; component j's rows are those of the parts that overlap it,
 // in part order (slot = part - first part of j), R per component, the unused ones zeroed by the part that ends j.
