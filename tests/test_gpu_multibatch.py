@@ -585,6 +585,61 @@ def test_full_size_fused_step_vs_oracle(ctx):
         assert dF.size == 610 and err < 1e-9
 
 
+def test_full_size_fused_step_several_gp_samples(ctx):
+    """Config 3's size with S = 4 GP hyper-parameter samples: 200 (s, k) blocks of GP sums ride in 40 free workgroup
+    slots of the span-mode entropy launch (ceil(S K / 5)).  F, G, H and all gradient entries against the
+    oracle on the restated draws; and the same evaluations with the sums in the prep launch (`mix_bar` = 0), with and
+    without arming: bit-identical -- the partition of the batches follows the job, not where the sums run."""
+    from pyvbmc_amd.variational_optimization import _neg_elcbo
+
+    from oracle import elbo_ref, gp_ref
+
+    S = 4
+    wl = synthetic.make_workload(3, S=S)
+    D, K, NsK = wl.D, wl.K, wl.NsK
+    g = dict(D=D, K=K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,
+             s2=wl.s2 if wl.s2 is not None else np.zeros(0), hyp=wl.hyp)
+    gp = make_gp(g, ctx, wl.hyp)
+    ogp = gp_ref.make_gp(g["X"], g["y"], wl.hyp, gp_ref.MEAN_NEGQUAD)
+    bnd = synthetic.default_theta_bnd(wl)
+    rng = np.random.default_rng(8)
+    th0 = make_vp(g, ctx).get_parameters()
+    thetas = [th0 + 0.02 * rng.standard_normal(th0.size) for _ in range(3)]
+
+    def run(mix_bar, arm):
+        out = []
+        try:
+            ctx.set_option("mix_bar", mix_bar)
+            ctx.set_option("elbo_arm", arm)
+            vp = make_vp(g, ctx)
+            for i, theta in enumerate(thetas):
+                F, dF, G, H, _ = _neg_elcbo(theta.copy(), gp, vp, 0.0, NsK, True, False, bnd, 0.0, False,
+                                            rng="philox", seed=515100 + i)
+                out.append((F, dF.copy(), G, H))
+                plan = ctx.last_entmc_plan()
+                assert plan["kernel"] == "ws", plan
+                if plan["span"]:  # (equal chunks: 500 workgroups leave 12 slots, too few for 200 blocks)
+                    where = ctx.last_step_marks()["gp_sums_in"]
+                    assert where == ("entropy launch" if mix_bar else "prep launch"), (where, mix_bar)
+        finally:
+            ctx.set_option("mix_bar", 1)
+            ctx.set_option("elbo_arm", 1)
+        return out
+
+    base = run(1, 1)
+    for mb, arm in ((0, 1), (1, 0), (0, 0)):
+        for (F, dF, G, H), (F0, dF0, G0, H0) in zip(run(mb, arm), base):
+            assert F == F0 and G == G0 and H == H0 and np.array_equal(dF, dF0), (mb, arm)
+    theta, (F, dF, G, H) = thetas[-1], base[-1]
+    mix = oracle_mix(g)
+    eps = philox_ref.eps_half(K, NsK // 2, D, 515100 + len(thetas) - 1)
+    Fo, dFo, Go, Ho, _ = elbo_ref.neg_elcbo(theta.copy(), ogp, mix, 0.0, NsK, True, False, bnd, False, eps_half=eps)
+    err = rel_err(dF, dFo)
+    print(f"S = {S}: F rel {abs(F - Fo) / abs(Fo):.2e}  dF rel {err:.2e}  G rel {abs(G - Go) / abs(Go):.2e}  H rel {abs(H - Ho) / abs(Ho):.2e}")
+    assert abs(F - Fo) <= 1e-10 * abs(Fo) and abs(G - Go) <= 1e-10 * abs(Go) and abs(H - Ho) <= 1e-10 * abs(Ho)
+    assert err < 1e-9
+
+
 def test_armed_evaluation_problem_switches(ctx):
     """Four problems of different (D, K, N, Ns) evaluated in turns on one context, switching at random
     (every switch re-uploads the GP and the mixture shape and cancels an armed evaluation): every
