@@ -134,6 +134,9 @@ int vbmc_last_step_marks(const vbmc_ctx* ctx, double out[4]);
  *                  (one rank, K <= 64, D <= 16, <= 64 antithetic rows per component, LDS plan fits; default),
  *                  0 = always four launches per iteration; 2 = test hook (the launch also waits for a workgroup
  *                  that does not exist, must give up by its 20 ms limit, and the batch is redone as four launches)
+ *                  3 = the one-launch form with its exchange written as agent-scope release stores / acquire fences
+ *                  instead of write-through records and relaxed flags (the documented fallback: the same results bit
+ *                  for bit, +5 us per iteration)
  *   "elbo_pregen"  [VBMC_ELBO_PREGEN]: 1 = Philox draws generated ahead of the entropy
  *                  kernel (default), 0 = generated in-line by it; same values either way
  *   "elbo_ahead"   [VBMC_ELBO_AHEAD]: 1 = after a Philox evaluation with seed s the draws of
