@@ -242,11 +242,15 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
   // leaves v unchanged): a wave's 8 steps at K * chunks = 500 cost two memory latencies instead of
   // eight, and this reduction is on the path between the entropy kernel and the completion word
   // (32-bit element offsets: the launcher refuses a partial block of 2^31 elements or more)
+#ifndef FIN_FOLD_U
+#define FIN_FOLD_U 10
+#endif
+  constexpr int FOLD_U = FIN_FOLD_U;
   auto fold = [&](double acc, int total, auto&& coef, auto&& at, auto&& step) {
-    for (int b = 0; b < total; b += 4 * 64) {
-      double c[4], x[4];
+    for (int b = 0; b < total; b += FOLD_U * 64) {
+      double c[FOLD_U], x[FOLD_U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < FOLD_U; ++u) {
         const int i = b + 64 * u + lane;
         const int ic = min(i, total - 1);
         x[u] = partial[at(ic)];
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
         if (i >= total) c[u] = 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc = step(acc, c[u], x[u]);
+      for (int u = 0; u < FOLD_U; ++u) acc = step(acc, c[u], x[u]);
     }
     return acc;
   };
