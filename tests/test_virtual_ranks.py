@@ -116,6 +116,9 @@ def test_entmc_virtual_ranks(ctx, cfg, W, inline):
     assert rel_err(dHs, r["dH"]) <= 1e-11
     if dHo is not None:
         assert rel_err(r["dH"], dHo) < 1e-9 and rel_err(dHs, dHo) < 1e-9
+        # the entropy kernels' exp2 is a degree-8 polynomial (1.07e-12 pointwise, csrc/fastmath.h): its error averages
+        # out over the 5e7 densities of an evaluation -- far inside the parity bar (measured: H 1.2e-15, dH 1.6e-15)
+        assert abs(r["H"] - Ho) <= 1e-12 * abs(Ho) and rel_err(r["dH"], dHo) < 1e-11
 
 
 def test_draw_forms_agree_bitwise(ctx):
