@@ -43,7 +43,7 @@ def show(name, coef):
 
 if __name__ == "__main__":
     half = mp.mpf(1) / 2
-    for n in (11, 12):
+    for n in (8, 9, 10, 11, 12):  # 8: the entropy kernels' (fastmath.h VBMC_ENT_EXP2_COEFFS, c0 = 1); 11: exp2_fast
         c = cheb_fit(lambda x: mp.mpf(2) ** x, -half, half, n)
         f = np.linspace(-0.5, 0.5, 400001)
         err = np.max(np.abs(horner64(c, f) / np.exp2(f) - 1))
