@@ -120,6 +120,12 @@ int vbmc_last_host_us(const vbmc_ctx* ctx, double out[5]);
  * GP sums ran: 0 the prep launch, 1 the finish launch, 2 spare workgroup slots of the entropy launch; out[3]
  * reserved (0).  Profiling aid for bench.py (S > 1 hyper-parameter samples). */
 int vbmc_last_step_marks(const vbmc_ctx* ctx, double out[4]);
+/* A function the library calls from inside vbmc_neg_elcbo once the evaluation's launches are released (the pack and
+ * the go word written, or the launches queued) and before it starts waiting for the device: the caller's own
+ * bookkeeping that depends on theta alone -- the reference's vp.set_parameters side effects, which the Python mirror
+ * applies from the mu / sigma / lambda / w / eta outputs, already filled at that point -- then runs while the device
+ * works instead of between two evaluations.  fn = NULL clears it.  No reference counterpart. */
+int vbmc_set_release_callback(vbmc_ctx* ctx, void (*fn)(void*), void* user);
 
 /* Per-context switches for tests and measurements (no reference counterpart).  Each starts
  * from the environment variable in brackets, read when the context is created.

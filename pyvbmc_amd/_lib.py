@@ -77,6 +77,7 @@ SIGNATURES = {
     "vbmc_last_kernel_ms": (C.c_int, [_vp, C.c_int, _dp]),
     "vbmc_last_host_us": (C.c_int, [_vp, _dp]),
     "vbmc_last_step_marks": (C.c_int, [_vp, _dp]),
+    "vbmc_set_release_callback": (C.c_int, [_vp, C.c_void_p, C.c_void_p]),
     "vbmc_set_mixture": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "vbmc_set_mixture_dk": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "vbmc_theta_to_mixture": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),

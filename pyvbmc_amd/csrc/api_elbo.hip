@@ -456,6 +456,8 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
       return rc2;
     }
   }
+  // the caller's theta-only bookkeeping (vbmc_set_release_callback): the device is at work from here on
+  if (ctx->release_cb && !ctx->ident_retry) ctx->release_cb(ctx->release_cb_user);
   // ---- soft bounds and weight penalty (:1195-1229, _vp_bound_loss :537-606) ----
   // They depend on theta and the new mixture only: evaluated here, while the device works.
   ElboScratch& sc = ctx->elbo;  // reused vectors: the hot call does not allocate
@@ -705,6 +707,13 @@ extern "C" int vbmc_armed_stats(const vbmc_ctx* ctx, uint64_t out[6]) {
 extern "C" int vbmc_last_elbo_raw(const vbmc_ctx* ctx, double* out, int n) {
   if (!ctx || !out || ctx->last_raw_n <= 0 || n != ctx->last_raw_n || !ctx->h_pinned) return VBMC_E_ARG;
   memcpy(out, ctx->h_pinned + ctx->last_raw_off, sizeof(double) * (size_t)n);
+  return VBMC_OK;
+}
+
+extern "C" int vbmc_set_release_callback(vbmc_ctx* ctx, void (*fn)(void*), void* user) {
+  if (!ctx) return VBMC_E_ARG;
+  ctx->release_cb = fn;
+  ctx->release_cb_user = user;
   return VBMC_OK;
 }
 

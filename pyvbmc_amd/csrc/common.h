@@ -186,6 +186,8 @@ struct vbmc_ctx {
   int opt_predict_dma = 1;  // predict's variance product through the LDS-direct kernel (batches on Cholesky samples)
   int opt_arm_late_test = 0;  // test hook: n > 0 = the n-th use of an armed evaluation from now takes the late-go recovery path
   int opt_acq_poll = 1;       // small acquisition batches: points written by the CPU, results polled (api_acq.hip)
+  void (*release_cb)(void*) = nullptr;  // vbmc_set_release_callback
+  void* release_cb_user = nullptr;
   int opt_adam_fused = 1;     // the optimiser loop as one launch per batch where its shape applies (adam_fused.hip)
   int opt_ident_test = 0;     // test hook: n > 0 = the n-th identity check from now fails (the recovery path runs)
   bool ident_retry = false;   // inside the re-evaluation after a failed identity check

@@ -14,6 +14,7 @@ device round trip.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -199,23 +200,23 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
         fc.shape = shape
     if ns > 0:
         opts.seed = seed
-    rc = fc.fn(*fc.args)
-    if rc != 0:
-        if rc == _lib.W_GP_CHANGED:
-            # a GP array was edited in place since the upload: what came back was computed on the old GP
-            upload_gp(gp, ctx)
-            rc = fc.fn(*fc.args)  # (theta's tail is already shifted: shifting it again changes nothing)
+    # The reference's side effects on vp and on the caller's theta depend on theta alone: the library calls
+    # fc.released() once its launches are out and the device is at work (vbmc_set_release_callback), so they cost
+    # nothing between two evaluations; whatever path did not get there applies them after the call.
+    fc.side = (vp, theta, mask, K)
+    try:
+        rc = fc.fn(*fc.args)
         if rc != 0:
-            ctx.check(rc)
-    # mirror the reference's side effects on vp and on the caller's theta
-    # (store_mixture() through views shaped once: this sits between two evaluations of the optimiser)
-    vp.mu, vp.sigma, vp.lambd, vp.w = fc.mu_T.copy(), fc.sg_row.copy(), fc.lm_col.copy(), fc.w_row.copy()
-    if mask & 8:
-        vp.eta = fc.eta_row.copy()
-        if type(theta) is np.ndarray and theta.dtype == fc.th.dtype:
-            theta[-K:] = fc.th[-K:]
-    if hasattr(vp, "_mode"):
-        vp._mode = None  # set_parameters drops the cached mode (variational_posterior.py:759)
+            if rc == _lib.W_GP_CHANGED:
+                # a GP array was edited in place since the upload: what came back was computed on the old GP
+                upload_gp(gp, ctx)
+                rc = fc.fn(*fc.args)  # (theta's tail is already shifted: shifting it again changes nothing)
+            if rc != 0:
+                ctx.check(rc)
+        if fc.side is not None:
+            fc.apply_side_effects()
+    finally:
+        fc.side = None
     return fc.F.value, (fc.dF.copy() if compute_grad else None), fc.G.value, fc.H.value, 0
 
 
@@ -249,6 +250,9 @@ def _neg_elcbo_batch(thetas, gp, vp, theta_bnd=None, *, ctx=None, return_parts=F
     return (F, G, H) if return_parts else F
 
 
+_RELEASE_CB = os.environ.get("VBMC_RELEASE_CB", "1") != "0"  # measurement aid: 0 = side effects after the call
+
+
 class _FusedCall:
     """Pre-built argument block of vbmc_neg_elcbo for one (ctx, D, K, n_theta): the ctypes
     pointers of the persistent buffers are created once, not per evaluation.  The soft
@@ -269,11 +273,31 @@ class _FusedCall:
         self.shape = None  # (ns, compute_grad, mask, eps mode, rows) the option block currently holds
         self.lb_src = self.ub_src = self.lb = self.ub = None
         self.fn = ctx._lib.vbmc_neg_elcbo
+        self.side = None  # (vp, theta, mask, K) of the call in flight whose side effects are still to be applied
+        self._cb = C.CFUNCTYPE(None, C.c_void_p)(self._released)  # held: the library keeps the raw pointer
         self.args = (
             ctx._h, _lib.ptr(self.th), n_theta, C.byref(o), C.byref(self.F), _lib.ptr(self.dF),
             C.byref(self.G), C.byref(self.H), _lib.ptr(self.mu), _lib.ptr(self.sg), _lib.ptr(self.lm),
             _lib.ptr(self.w), _lib.ptr(self.eta),
         )
+
+    def apply_side_effects(self):
+        """vp.set_parameters(theta)'s effects from the arrays the library filled (store_mixture() through views shaped
+        once), and the max-shifted eta tail of the caller's theta (variational_optimization.py:1082-1085)."""
+        vp, theta, mask, K = self.side
+        self.side = None
+        vp.mu, vp.sigma, vp.lambd, vp.w = self.mu_T.copy(), self.sg_row.copy(), self.lm_col.copy(), self.w_row.copy()
+        if mask & 8:
+            vp.eta = self.eta_row.copy()
+            if type(theta) is np.ndarray and theta.dtype == self.th.dtype:
+                theta[-K:] = self.th[-K:]
+        if hasattr(vp, "_mode"):
+            vp._mode = None  # set_parameters drops the cached mode (variational_posterior.py:759)
+
+    def _released(self, _user):
+        # called by the library from inside vbmc_neg_elcbo, launches released, device at work
+        if self.side is not None:
+            self.apply_side_effects()
 
     def bind_bounds(self, theta_bnd):
         o = self.opts
@@ -301,6 +325,7 @@ def _fused_call(ctx, D, K, n_theta, theta_bnd):
         fc = last[3]
         fc.bind_bounds(theta_bnd)
         return fc
+    # (another argument block takes over: the library's release callback follows it)
     cache = ctx.__dict__.setdefault("_fused_cache", {})
     key = (D, K, n_theta)
     fc = cache.get(key)
@@ -309,6 +334,7 @@ def _fused_call(ctx, D, K, n_theta, theta_bnd):
             cache.clear()
         fc = cache[key] = _FusedCall(ctx, D, K, n_theta)
     ctx.__dict__["_fused_last"] = (D, K, n_theta, fc)
+    ctx.check(ctx._lib.vbmc_set_release_callback(ctx._h, C.cast(fc._cb, C.c_void_p) if _RELEASE_CB else None, None))
     fc.bind_bounds(theta_bnd)
     return fc
 

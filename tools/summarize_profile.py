@@ -21,7 +21,7 @@ from pathlib import Path
 src, tag = Path(sys.argv[1]), sys.argv[2]
 out = Path(__file__).resolve().parent.parent / "profiles"
 out.mkdir(exist_ok=True)
-for mode, d in (("philox", "stats"), ("resident", "stats_res"), ("adam_loop", "stats_adam"), ("config2", "stats_c2"),
+for mode, d in (("philox", "stats"), ("philox_secondary", "stats_sec"), ("resident", "stats_res"), ("adam_loop", "stats_adam"), ("config2", "stats_c2"),
                 ("config5", "stats_c5"), ("config4_job", "stats_c4job"), ("config5_job", "stats_c5job"),
                 ("predict", "stats_predict"), ("adam_small", "stats_adam_small")):
     f = src / d / "s_kernel_stats.csv"
