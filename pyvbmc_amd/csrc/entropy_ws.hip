@@ -121,13 +121,16 @@ __device__ unsigned long long g_ws_times[1024 * 4];  // per workgroup: start, ba
 #else
 #define WS_STAMP(i) (void)0
 #endif
-template <int DP, int KTMAX, bool GRAD, bool PHILOX>
+// EXACT (resident draws only): D == D_p and the draws are 16-byte aligned -- every even D; the host checks (launch_one)
+template <int DP, int KTMAX, bool GRAD, bool PHILOX, bool EXACT = false>
 __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_kernel(
     EntArgs a, const double* __restrict__ T) {
   constexpr int TS = DP + 6;
   __shared__ double sQ[2][WAVES][2][64];          // q partials, double-buffered by batch parity
   constexpr int GB = 4;                           // Philox mode: batches generated per round
-  __shared__ double sE[PHILOX ? GB : 1][DP][64];  // their normals
+  // Philox mode: their normals [batch][d][row].  Resident draws: the rows of this batch and of the next one as they
+  // lie in memory ([2][64 rows][DP]), filled one batch ahead by LDS-direct loads (ws_fill below)
+  __shared__ __attribute__((aligned(16))) double sE[PHILOX ? GB : 2][DP][64];
   __shared__ double sRed[WAVES][2 * DP + 1];
   extern __shared__ double dyn[];                 // [epilogue transpose buffer | sW[K4]]
   constexpr int EPI = ws_epi_doubles(DP, KTMAX, GRAD);
@@ -202,6 +205,7 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   WS_STAMP(0);
+  constexpr bool eps_exact = !PHILOX && EXACT;
 
   double ec[EN];
   {
@@ -233,6 +237,35 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
 #pragma unroll
   for (int kk = 0; kk < KTMAX; ++kk) Wacc[kk] = 0.0;
 
+  // LDS-direct copy of batch ib's rows into sE[buf]: D_p / 2 instructions of 1 KB, dealt over the waves.  The compiler
+  // does not count these loads: the wave drains them (vmcnt) in front of the batch's barrier, one batch after issue.
+  auto ws_fill = [&](int ib, int buf) {
+    if constexpr (!PHILOX) {
+      const char* base = (const char*)(a.eps + ((int64_t)j * a.eps_rows + ((int64_t)ib << 6)) * DP);
+      const int64_t left = (a.row_count - ((int64_t)ib << 6)) * (DP * 8) - 16;  // last 16 bytes of the slice, relative
+      const unsigned last = (unsigned)(left < 64 * DP * 8 - 16 ? left : 64 * DP * 8 - 16);
+#pragma unroll
+      for (int c = 0; c < DP / 2; ++c) {
+        if ((c & 3) != wave) continue;
+        unsigned voff = (unsigned)(c * 1024 + lane * 16);
+        voff = voff < last ? voff : last;
+        const unsigned dst = (unsigned)(uintptr_t)&sE[buf][0][0] + (unsigned)(c * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(dst) : "memory");
+      }
+    }
+  };
+  (void)ws_fill;
+  if (eps_exact && n_it > 0) {
+    ws_fill(ib0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // log q of a row is taken once per LOGB batches: the mantissas of the q are multiplied up and their exponents
+  // added (six instructions per batch instead of the ~30 of a logarithm on the two waves that carry it)
+  constexpr int LOGB = 8;
+  double lmant = 1.0;
+  int lexp = 0;
+
   for (int it = 0; it < n_it; ++it) {
     const int64_t i_loc = ((int64_t)(ib0 + it) << 6) + lane;
     const bool valid = i_loc < a.row_count;
@@ -242,7 +275,20 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
 #pragma unroll
     for (int d = 0; d < DP; ++d) e[d] = 0.0;
     if (!PHILOX) {
-      if (valid) {
+      if constexpr (eps_exact) {
+        // D == D_p (every even D): the batch's 64 rows are one contiguous block of 512 D_p bytes that the four waves
+        // copied into LDS while the previous batch was computed (no per-dimension guards, the load latency off the
+        // wave's path, every row fetched once per workgroup instead of once per wave); rows beyond the slice hold
+        // copies of its last 16 bytes -- they only have to be finite, every sum they enter is masked (valid) below
+        if (it + 1 < n_it) ws_fill(ib0 + it + 1, (it + 1) & 1);
+        const double2* rp = (const double2*)&sE[it & 1][0][0] + lane * (DP / 2);
+#pragma unroll
+        for (int d = 0; d < DP / 2; ++d) {
+          const double2 v = rp[d];
+          e[2 * d] = v.x;
+          e[2 * d + 1] = v.y;
+        }
+      } else if (valid) {
         const double* rp = a.eps + ((int64_t)j * a.eps_rows + i_loc) * D;
 #pragma unroll
         for (int d = 0; d < DP; ++d)
@@ -330,14 +376,21 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
     const int buf = it & 1;
     sQ[buf][wave][0][lane] = qp;
     sQ[buf][wave][1][lane] = qm;
+    if constexpr (eps_exact) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next batch's rows
     __syncthreads();
     qp = (sQ[buf][0][0][lane] + sQ[buf][1][0][lane]) + (sQ[buf][2][0][lane] + sQ[buf][3][0][lane]);
     qm = (sQ[buf][0][1][lane] + sQ[buf][1][1][lane]) + (sQ[buf][2][1][lane] + sQ[buf][3][1][lane]);
 
     // log q: wave 0 takes the + samples, wave 1 the - samples
     if (wave < 2) {
-      const double lq = fm::log_fast(wave == 0 ? qp : qm);
-      slog_acc += valid ? lq : 0.0;
+      const double qv = valid ? (wave == 0 ? qp : qm) : 1.0;
+      lmant *= __builtin_amdgcn_frexp_mant(qv);  // [1/2, 1) each: eight of them stay far from underflow; q = 0 -> 0 -> -inf
+      lexp += __builtin_amdgcn_frexp_exp(qv);
+      if ((it & (LOGB - 1)) == LOGB - 1 || it + 1 == n_it) {
+        slog_acc += fma((double)lexp, 0x1.62e42fefa39efp-1, fm::log_fast(lmant));
+        lmant = 1.0;
+        lexp = 0;
+      }
     }
     if (GRAD) {
       // ---- pass 2: with 1/q known, every gradient sum is accumulated already normalised.
@@ -512,9 +565,9 @@ void launch_one(hipStream_t st, const EntArgs& a, const double* d_table, hipEven
   int dev = 0;
   if (lds > 32 * 1024) (void)hipGetDevice(&dev);
   // (the raised dynamic-LDS limit is set once per instantiation and size)
-#define VBMC_LAUNCH_WS(G, P)                                                                              \
+#define VBMC_LAUNCH_WS(G, P, X)                                                                           \
   do {                                                                                                    \
-    auto kern = entmc_ws_kernel<DP, KTMAX, G, P>;                                                         \
+    auto kern = entmc_ws_kernel<DP, KTMAX, G, P, X>;                                                      \
     static size_t lds_limit[64] = {};  /* per device: function attributes are per device */              \
     if (lds > 32 * 1024 && lds > lds_limit[dev & 63]) {                                                   \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -522,10 +575,12 @@ void launch_one(hipStream_t st, const EntArgs& a, const double* d_table, hipEven
     }                                                                                                     \
     hipExtLaunchKernelGGL(kern, grid, block, (std::uint32_t)lds, st, e0, e1, 0u, a, d_table);             \
   } while (0)
+  // resident draws of full-width rows arrive through LDS one batch ahead (EXACT)
+  const bool exact = !philox && a.ml.D == DP && (DP % 2) == 0 && ((uintptr_t)a.eps & 15) == 0;
   if (a.want_grad) {
-    if (philox) VBMC_LAUNCH_WS(true, true); else VBMC_LAUNCH_WS(true, false);
+    if (philox) VBMC_LAUNCH_WS(true, true, false); else if (exact) VBMC_LAUNCH_WS(true, false, true); else VBMC_LAUNCH_WS(true, false, false);
   } else {
-    if (philox) VBMC_LAUNCH_WS(false, true); else VBMC_LAUNCH_WS(false, false);
+    if (philox) VBMC_LAUNCH_WS(false, true, false); else if (exact) VBMC_LAUNCH_WS(false, false, true); else VBMC_LAUNCH_WS(false, false, false);
   }
 #undef VBMC_LAUNCH_WS
 }
