@@ -142,6 +142,19 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
     own share -- one rank's part of a sharded job (``ctx.last_elbo_raw`` then holds its additive
     entropy accumulator).
     """
+    # ---- the optimiser's inner call, second evaluation onwards: same objects, same shape of request ----
+    # (everything between two evaluations is on the step's critical path with the device idle; a record of the
+    # last fused call -- the OBJECTS it was made with, held, so identities cannot be recycled -- lets a repeat go
+    # straight to the C call.  Whatever may have changed behind an unchanged identity is still looked at:
+    # the optimise flags, the GP records' identities, the bounds' arrays and scalars; contents of the GP arrays
+    # are checksummed by the library while the device works, as on the general path.)
+    fs = _fast_last[0]
+    if (fs is not None and fs.vp is vp and fs.gp is gp and fs.bnd is theta_bnd and Ns == fs.Ns and beta == 0.0
+            and compute_grad is fs.cg and not compute_var and not separate_K and ctx is fs.ctx_arg and rng == fs.rng
+            and eps_half is None and rows is None and type(theta) is np.ndarray and theta.size == fs.n_theta):
+        rc = fs.call(theta, seed)
+        if rc is not None:
+            return rc
     if not math.isfinite(beta):
         beta = 0
     if compute_var is None:
@@ -155,6 +168,7 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
             "Computing the gradient of variational parameters and "
             "requesting per-component results at the same time."
         )
+    ctx_arg = ctx
     ctx = ctx_of(vp, ctx)
     K, D = vp.K, vp.D
 
@@ -204,6 +218,8 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
     # fc.released() once its launches are out and the device is at work (vbmc_set_release_callback), so they cost
     # nothing between two evaluations; whatever path did not get there applies them after the call.
     fc.side = (vp, theta, mask, K)
+    _fast_last[0] = (_FastElbo(ctx_arg, ctx, fc, vp, gp, theta_bnd, Ns, compute_grad, rng, mask, D, K, n_theta, mode)
+                     if (rows is None and eps_half is None and (ns == 0 or mode == _lib.EPS_PHILOX) and type(compute_grad) is bool) else None)
     try:
         rc = fc.fn(*fc.args)
         if rc != 0:
@@ -251,6 +267,67 @@ def _neg_elcbo_batch(thetas, gp, vp, theta_bnd=None, *, ctx=None, return_parts=F
 
 
 _RELEASE_CB = os.environ.get("VBMC_RELEASE_CB", "1") != "0"  # measurement aid: 0 = side effects after the call
+_FAST_PATH = os.environ.get("VBMC_FAST_PATH", "1") != "0"    # measurement aid: 0 = every call takes the general path
+_fast_last = [None]  # the last fused Monte-Carlo / lower-bound call's record (_FastElbo), or None
+
+
+class _FastElbo:
+    """What a repeat of the last fused ``_neg_elcbo`` call needs: the argument block, and the objects and values the
+    general path derived it from.  ``call`` re-checks everything that can change behind an unchanged identity and
+    returns None (the caller then takes the general path) unless all of it still holds."""
+
+    __slots__ = ("ctx_arg", "ctx", "fc", "vp", "gp", "bnd", "Ns", "cg", "rng", "mask", "D", "K", "n_theta", "philox",
+                 "lb", "ub", "tol", "wthr", "wpen", "fused_last")
+
+    def __init__(self, ctx_arg, ctx, fc, vp, gp, bnd, Ns, cg, rng, mask, D, K, n_theta, mode):
+        self.ctx_arg, self.ctx, self.fc, self.vp, self.gp, self.bnd = ctx_arg, ctx, fc, vp, gp, bnd
+        self.Ns, self.cg, self.rng, self.mask, self.D, self.K, self.n_theta = Ns, cg, rng, mask, D, K, n_theta
+        self.philox = Ns > 0 and mode == _lib.EPS_PHILOX
+        self.fused_last = ctx.__dict__.get("_fused_last")
+        if bnd is not None:
+            self.lb, self.ub = bnd["lb"], bnd["ub"]
+            self.tol, self.wthr, self.wpen = bnd["tol_con"], bnd.get("weight_threshold", 0.0), bnd.get("weight_penalty", 0.0)
+            if not fc.direct:  # the bounds were copied (not float64 / not contiguous): the general path re-copies them
+                self.vp = None
+
+    def call(self, theta, seed):
+        if not _FAST_PATH:
+            return None
+        vp, ctx, fc, bnd = self.vp, self.ctx, self.fc, self.bnd
+        if (((1 if vp.optimize_mu else 0) | (2 if vp.optimize_sigma else 0) | (4 if vp.optimize_lambd else 0)
+             | (8 if vp.optimize_weights else 0)) != self.mask or vp.D != self.D or vp.K != self.K
+                or ctx.__dict__.get("_fused_last") is not self.fused_last or getattr(ctx, "D", None) != self.D
+                or getattr(ctx, "K", None) != self.K or ctx_of(vp, self.ctx_arg) is not ctx):
+            return None
+        if self.mask != 15:
+            return None  # (a block that is not optimised comes from vp's attributes: upload_vp on the general path)
+        if bnd is not None and (bnd["lb"] is not self.lb or bnd["ub"] is not self.ub or bnd["tol_con"] != self.tol
+                                or bnd.get("weight_threshold", 0.0) != self.wthr or bnd.get("weight_penalty", 0.0) != self.wpen):
+            return None
+        gp = self.gp
+        ps, X = gp.posteriors, gp.X
+        quick = [id(ps), id(X), X.shape[0]]
+        for p in ps:
+            quick += (id(p), id(p.alpha), id(p.hyp))
+        if quick != ctx.__dict__.get("_gp_quick"):
+            return None
+        fc.th[:] = theta
+        if self.philox:
+            fc.opts.seed = philox_seed(ctx) if seed is None else seed
+        fc.side = (vp, theta, self.mask, self.K)
+        try:
+            rc = fc.fn(*fc.args)
+            if rc != 0:
+                if rc == _lib.W_GP_CHANGED:
+                    upload_gp(gp, ctx)
+                    rc = fc.fn(*fc.args)
+                if rc != 0:
+                    ctx.check(rc)
+            if fc.side is not None:
+                fc.apply_side_effects()
+        finally:
+            fc.side = None
+        return fc.F.value, (fc.dF.copy() if self.cg else None), fc.G.value, fc.H.value, 0
 
 
 class _FusedCall:
