@@ -32,6 +32,9 @@
 #include "fastmath.h"
 #include "entropy_args.h"
 #include "philox.h"
+#include "glj_block.h"
+#include "finish_body.h"
+#include "ws_table.h"
 
 using namespace adam_dev;
 
@@ -186,6 +189,209 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamDev a, int do_step, 
   }
 }
 
+// ---------------------------------------------------------------------------
+// adam_tail_kernel: everything between two entropy launches in ONE launch (the two-launch iteration, below).
+//   blocks [0, n_main)            the entropy reduction (finish_body.h), results written through to the state block; the
+//                                 last block to count publishes the iteration's sequence number at agent scope
+//   blocks [n_main, n_main + K)   block j waits for that word, then does -- every one of them, identically -- what
+//                                 adam_step_kernel does (Jacobians, dF, Adam update, set_parameters, the pack: in LDS) and
+//                                 from that pack row j of the entropy kernel's (j,k) table.  Block 0 of them (the writer)
+//                                 also puts theta, the attributes, m, v, the iterate's row of x_tab / y_tab and the pack into
+//                                 memory -- m and v once every block has read the old ones (one counter), so nobody can
+//                                 read an updated moment
+//   the rest                      the next iteration's draws
+// A launch boundary costs ~1.5 us and the hand-off inside the launch ~2; the four-launch iteration paid four boundaries and
+// ran the reduction, the step and the table one behind the other with a kernel's fill and drain each.
+struct TailArgs {
+  const double* partial = nullptr;
+  int chunks = 0, stride = 0, mu_from_w = 0;
+  double inv_ns = 0.0;
+  DoneSignal red;             // dev mode: counter, flag, sequence number of the reduction
+  int DP = 0, K4 = 0;
+  double* table = nullptr;
+  unsigned long long* rd_cnt = nullptr;  // table blocks that are through with the old moments (monotonic)
+  unsigned long long rd_target = 0;
+  unsigned long long timeout = 2000000;  // wall-clock ticks (100 MHz): 20 ms
+  GenSlice gen;
+};
+
+__global__ __launch_bounds__(256) void adam_tail_kernel(AdamDev a, TailArgs t) {
+  extern __shared__ double sh[];
+  __shared__ double red[16];
+  __shared__ int s_ok;
+  const int D = a.D, K = a.K, tid = threadIdx.x, n = a.n_theta;
+  const AdamLayout& L = a.lay;
+  const int n_main = (L.n_raw + 3) / 4;
+  if ((int)blockIdx.x < n_main + K) __builtin_amdgcn_s_setprio(3);  // the chain's blocks before the draws' on every SIMD they share
+  if ((int)blockIdx.x < n_main) {
+    entmc_finish_body(t.partial, t.chunks, t.stride, a.mix, a.ml, t.inv_ns, 1, t.mu_from_w, a.state + L.o_raw(), GenSlice(), t.red);
+    return;
+  }
+  const int tb = (int)blockIdx.x - n_main;
+  if (tb >= K) {
+    gen_slice_block(t.gen, tb - K, tid);
+    return;
+  }
+  const bool writer = tb == 0;
+  // ---- wait for the reduction (bounded) ----
+  if (tid == 0) {
+    const unsigned long long t0 = wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_load(t.red.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != t.red.seq) {
+      if (wall_clock64() - t0 > t.timeout) {
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_ok = ok;
+  }
+  __syncthreads();
+  if (!s_ok) {
+    if (tid == 0) atomicOr(a.status, 8);
+    return;
+  }
+  // LDS: theta n | aux | ee K | pack | table scratch K4 DP | new m, new v (writer)
+  double* theta = sh;
+  double* aux = sh + n;
+  double* ee = aux + L.n_aux;
+  double* pack = ee + K;
+  double* tsc = pack + a.ml.total;
+  double* new_m = tsc + t.K4 * t.DP;
+  double* new_v = new_m + n;
+  const double* raw = a.state + L.o_raw();
+  const bool o_mu = a.mask & 1, o_sg = a.mask & 2, o_lm = a.mask & 4, o_w = a.mask & 8;
+  const int p_sg = o_mu ? D * K : 0, p_lm = p_sg + (o_sg ? K : 0), p_w = n - K;
+  const int f_w = 1 + D * K + K + D;
+
+  constexpr int U = 4;
+  double r_raw[U], r_pre[U], r_m[U], r_v[U], r_lo[U], r_hi[U];
+  double rw = 0.0;
+  const int iter = a.iter_base[0] + a.it_off;
+  if (o_w && tid < K) rw = raw[f_w + tid];
+  for (int i = tid; i < L.o_hyp(); i += 256) sh[i] = a.state[i];  // theta | aux
+  auto raw_index = [&](int i) -> int {
+    if (o_mu && i < D * K) return 1 + i;
+    if (o_sg && i >= p_sg && i < p_sg + K) return 1 + D * K + (i - p_sg);
+    if (o_lm && i >= p_lm && i < p_lm + D) return 1 + D * K + K + (i - p_lm);
+    return f_w + (i - p_w);
+  };
+  auto load_chunk = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * 256 + tid;
+      const bool in = i < n;
+      r_raw[u] = in ? raw[raw_index(i)] : 0.0;
+      r_pre[u] = in ? a.pre[i] : 0.0;
+      r_m[u] = in ? a.state[L.o_m() + i] : 0.0;
+      r_v[u] = in ? a.state[L.o_v() + i] : 0.0;
+      r_lo[u] = (in && a.has_box) ? a.state[L.o_xlb() + i] : 0.0;
+      r_hi[u] = (in && a.has_box) ? a.state[L.o_xub() + i] : 0.0;
+    }
+  };
+  load_chunk(0);
+  const double it1 = (double)(iter + 1);
+  const double c1 = 1.0 / (1.0 - fm::exp2_fast(it1 * a.l2_beta1));
+  const double c2 = 1.0 / (1.0 - fm::exp2_fast(it1 * a.l2_beta2));
+  const double step = a.master_min + (a.master_max - a.master_min) * fm::exp2_fast(-it1 * a.l2e_over_decay);
+  double* x_row = a.x_tab + (size_t)iter * n;
+  double* y_out = a.y_tab + 3 * (size_t)iter;
+  __syncthreads();
+  {
+    const double* sg = aux + K * D;
+    const double* lm = sg + K;
+    const double* eta = lm + D + K;
+    double sm_s = 1.0, sm_dot = 0.0;
+    if (o_w) {
+      double ps = 0.0, pd = 0.0;
+      for (int k = tid; k < K; k += 256) {
+        const double e = fm::exp2_fast(0x1.71547652b82fep+0 * eta[k]);
+        ee[k] = e;
+        ps += e;
+        pd += e * (k == tid ? rw : raw[f_w + k]);
+      }
+      ps = wave_sum(ps);
+      pd = wave_sum(pd);
+      if ((tid & 63) == 0) {
+        red[tid >> 6] = ps;
+        red[4 + (tid >> 6)] = pd;
+      }
+      __syncthreads();
+      sm_s = (red[0] + red[1]) + (red[2] + red[3]);
+      sm_dot = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+    if (writer && tid == 0) {
+      const double G = a.pre[n], loss = a.pre[n + 1], H = raw[0];
+      y_out[0] = -G - H + loss;
+      y_out[1] = G;
+      y_out[2] = H;
+    }
+    for (int base = 0; base < n; base += 256 * U) {
+      if (base > 0) load_chunk(base);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * 256 + tid;
+        if (i >= n) continue;
+        double g;
+        if (o_mu && i < D * K) {
+          g = r_pre[u] - r_raw[u];
+        } else if (o_sg && i >= p_sg && i < p_sg + K) {
+          g = r_pre[u] - r_raw[u] * sg[i - p_sg];
+        } else if (o_lm && i >= p_lm && i < p_lm + D) {
+          g = r_pre[u] - r_raw[u] * lm[i - p_lm];
+        } else {
+          const double e = ee[i - p_w];
+          g = r_pre[u] + (e * sm_dot / (sm_s * sm_s) - e * r_raw[u] / sm_s);
+        }
+        const double m = a.beta1 * r_m[u] + (1.0 - a.beta1) * g;
+        const double v = a.beta2 * r_v[u] + (1.0 - a.beta2) * (g * g);
+        if (writer) {
+          new_m[i] = m;
+          new_v[i] = v;
+        }
+        const double m_hat = m * c1, v_hat = v * c2;
+        double x = theta[i] - step * m_hat / (sqrt(v_hat) + a.fudge);
+        if (a.has_box) x = fmin(r_hi[u], fmax(r_lo[u], x));
+        theta[i] = x;
+        if (writer) x_row[i] = x;
+      }
+    }
+    __syncthreads();
+  }
+  // this block is through with the old moments (every load above has been consumed)
+  if (tid == 0) __hip_atomic_fetch_add(t.rd_cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  pack_from_theta(a, theta, aux, red, pack);
+  __syncthreads();
+  ws_table_row_block(pack, a.ml, tb, t.DP, t.K4, t.table, tsc);
+  if (!writer) return;
+  // ---- the writer: the new iterate goes to memory, the moments once every block has read the old ones ----
+  for (int i = tid; i < a.ml.total; i += 256) a.mix[i] = pack[i];  // (read by the reduction blocks only: they are done)
+  if (tid == 0) {
+    const unsigned long long t0 = wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_load(t.rd_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t.rd_target) {
+      if (wall_clock64() - t0 > t.timeout) {
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    s_ok = ok;
+  }
+  __syncthreads();
+  if (!s_ok) {
+    if (tid == 0) atomicOr(a.status, 8);
+    return;
+  }
+  for (int i = tid; i < L.o_hyp(); i += 256) a.state[i] = sh[i];  // theta | aux
+  for (int i = tid; i < n; i += 256) {
+    a.state[L.o_m() + i] = new_m[i];
+    a.state[L.o_v() + i] = new_v[i];
+  }
+}
+
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
 
 }  // namespace
@@ -228,6 +434,17 @@ struct AdamState {
   double* d_xch = nullptr;
   size_t xch_cap = 0;
   unsigned long long* d_flags = nullptr;  // [256]
+  // the two-launch iteration (adam_tail_kernel): its own (j,k) table, which the tail launch of iteration i fills for
+  // iteration i + 1, and the words its hand-offs use -- [0] GP-sum word, [1] reduction word, [2] readers' counter,
+  // ints at [8]: GP-sum counter, [9]: reduction counter
+  double* d_table = nullptr;
+  size_t table_cap = 0;
+  bool table_valid = false;   // d_table holds the rows of the current iterate
+  unsigned long long* d_sync = nullptr;
+  unsigned long long sync_seq = 0, tail_launches = 0;
+  size_t tail_lds_bytes = 0;
+  bool tail_ok = false;
+  int last_form = 0;          // launches per iteration of the last batch (2 or 4)
 };
 
 static size_t fused_backup_len(const AdamDev& a) { return (size_t)a.lay.o_hyp() + 2 * (size_t)a.n_theta + (size_t)a.ml.total; }
@@ -261,6 +478,8 @@ void adam_free(vbmc_ctx* ctx) {
   if (st->d_args) (void)hipFree(st->d_args);
   if (st->d_xch) (void)hipFree(st->d_xch);
   if (st->d_flags) (void)hipFree(st->d_flags);
+  if (st->d_table) (void)hipFree(st->d_table);
+  if (st->d_sync) (void)hipFree(st->d_sync);
   delete st;
   ctx->adam = nullptr;
 }
@@ -458,6 +677,29 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
       st->eps_cap = st->n_eps;
     }
   }
+  // the two-launch iteration (adam_tail_kernel): words of its hand-offs, LDS plan
+  {
+    if (!st->d_sync) HIP_TRY(ctx, hipMalloc((void**)&st->d_sync, 16 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(st->d_sync, 0, 16 * sizeof(unsigned long long), sm));
+    st->sync_seq = st->tail_launches = 0;
+    st->table_valid = false;
+    const int DPp = [&] { const int dps[] = {2, 4, 6, 8, 10, 12, 16, 20, 24, 32}; for (int dp : dps) if (D <= dp) return dp; return 0; }();
+    const size_t n_tab = (size_t)ws_table_rows(K) * (size_t)DPp;
+    st->tail_lds_bytes = sizeof(double) * ((size_t)L.o_hyp() + K + (size_t)ctx->ml.total + n_tab + 2 * (size_t)n_theta);
+    st->tail_ok = DPp > 0 && K <= 128 && st->tail_lds_bytes <= 150 * 1024;
+    if (st->tail_ok && st->tail_lds_bytes > 48 * 1024)
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)adam_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)st->tail_lds_bytes));
+    if (st->tail_ok) {
+      const size_t need_t = (size_t)K * (size_t)ws_table_rows(K) * (size_t)(DPp + 6);
+      if (st->table_cap < need_t) {
+        if (st->d_table) HIP_TRY(ctx, hipFree(st->d_table));
+        st->d_table = nullptr;
+        st->table_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&st->d_table, sizeof(double) * need_t));
+        st->table_cap = need_t;
+      }
+    }
+  }
   // the fused loop where its shape applies (adam_fused.hip)
   st->fused = false;
   st->fused_gave_up = 0;
@@ -510,13 +752,87 @@ static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool
     return make_gen_slice(st->d_eps1, ctx->K, ctx->D, st->row_count, st->ns / 2, st->row_begin,
                           st->seed + (uint64_t)seed_off, st->d_status + 1, f0, f1);
   };
+  const bool try_tail = ctx->opt_adam_tail && !multi && st->tail_ok;
+  static const int tail_gp_per_slot = [] {
+    const char* e = getenv("VBMC_TAIL_GP_PER_SLOT");  // measurement aid
+    return e ? atoi(e) : 2;
+  }();
   for (int it = 0; it < n_iters; ++it) {
     PrepArgs pa;
     glj_fill_prep(ctx, 1, st->state + st->lay.o_res(), nullptr, pa);
     EntPlan plan;
     int rc = entmc_plan(ctx, st->ns, use_gen ? VBMC_EPS_RESIDENT : st->eps_mode, st->seed + (uint64_t)(i0 + it),
-                        st->row_begin, st->row_count, 1, plan);
+                        st->row_begin, st->row_count, 1, plan, try_tail ? pa.n_glj : 0, true, try_tail ? tail_gp_per_slot : 0);
     if (rc) return rc;
+    // ---- two launches per iteration (adam_tail_kernel): the wave-split kernel in span mode with the GP sums and the
+    // pre workgroup in its free slots, then everything up to the next table in one launch ----
+    if (try_tail && plan.ws && plan.a.sp.cus > 0 && plan.gp_in_ws && pa.n_glj > 0 &&
+        (use_gen || st->eps_mode == VBMC_EPS_RESIDENT)) {
+      if (use_gen) {
+        plan.a.eps = st->d_eps1;
+        plan.a.eps_rows = st->row_count;
+      }
+      plan.table = st->d_table;
+      if (!st->table_valid || (use_gen && !st->eps_started)) {
+        // first iteration of a run (or after a batch in the other form): the table of the current iterate and the
+        // part of its draws that is not there yet, by a prep launch of their own
+        PrepArgs pt;
+        entmc_fill_prep(ctx, plan, pt);
+        if (st->table_valid) pt.n_table = 0;
+        if (use_gen && !st->eps_started) pt.gen = slice(it, 0.0, 1.0);
+        rc = launch_prep(ctx, pt);
+        if (rc) return rc;
+      }
+      const unsigned long long seq = ++st->sync_seq;
+      PrepArgs gp = pa;
+      gp.n_table = 0;
+      gp.gen = GenSlice();
+      gp.mix = ctx->d_mix;
+      gp.done = DoneSignal();
+      gp.done.cnt = (int*)(st->d_sync + 8);
+      gp.done.flag = (uint64_t*)st->d_sync;
+      gp.done.seq = seq;
+      gp.done.dev = 1;
+      plan.a.gp = gp;
+      plan.a.gp_items = gp.n_glj;
+      plan.a.extra = st->d_args;
+      plan.a.extra_lds = (st->pre_lds && st->pre_lds_bytes <= 60 * 1024) ? (int)(st->pre_lds_bytes / sizeof(double)) : 0;
+      rc = entmc_launch_main(ctx, plan);
+      if (rc) return rc;
+      TailArgs t;
+      t.partial = plan.a.partial;
+      t.chunks = plan.a.chunks;
+      t.stride = plan.a.stride;
+      t.mu_from_w = 1;
+      t.inv_ns = plan.inv_ns;
+      t.red.cnt = (int*)(st->d_sync + 8) + 2;
+      t.red.flag = (uint64_t*)(st->d_sync + 1);
+      t.red.seq = seq;
+      t.red.dev = 1;
+      t.DP = plan.DP;
+      t.K4 = ws_table_rows(ctx->K);
+      t.table = st->d_table;
+      t.rd_cnt = st->d_sync + 2;
+      t.rd_target = (unsigned long long)ctx->K * (++st->tail_launches);
+      static const int gen_mode = [] {
+        const char* e = getenv("VBMC_TAIL_GEN");  // measurement aid: 0 = no draws (timing only: wrong values), 2 = a launch of their own behind the tail launch
+        return e ? atoi(e) : 1;
+      }();
+      if (use_gen && gen_mode == 1) t.gen = slice(it + 1, 0.0, 1.0);
+      a.it_off = it;
+      const int n_main = (raw_len(ctx->D, ctx->K) + 3) / 4;
+      hipLaunchKernelGGL(adam_tail_kernel, dim3(n_main + ctx->K + t.gen.n_blocks), dim3(256), st->tail_lds_bytes, sm, a, t);
+      if (use_gen && gen_mode == 2) {
+        rc = launch_eps_gen(ctx, sm, slice(it + 1, 0.0, 1.0));
+        if (rc) return rc;
+      }
+      st->table_valid = true;
+      if (use_gen) st->eps_started = true;
+      st->last_form = 2;
+      continue;
+    }
+    st->table_valid = false;
+    st->last_form = 4;
     if (use_gen) {
       plan.a.eps = st->d_eps1;
       plan.a.eps_rows = st->row_count;
@@ -657,6 +973,10 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
   if (status & 4) {  // (cannot happen: the second pass does not wait for anybody)
     st->active = false;
     return vbmc_fail(ctx, VBMC_E_HIP, "adam_run: a workgroup of the fused loop did not publish within 20 ms");
+  }
+  if (status & 8) {
+    st->active = false;
+    return vbmc_fail(ctx, VBMC_E_HIP, "adam_run: a hand-off inside the two-launch iteration did not arrive within 20 ms");
   }
   if (status) {
     st->active = false;

@@ -189,6 +189,7 @@ struct vbmc_ctx {
   void (*release_cb)(void*) = nullptr;  // vbmc_set_release_callback
   void* release_cb_user = nullptr;
   int opt_adam_fused = 1;     // the optimiser loop as one launch per batch where its shape applies (adam_fused.hip)
+  int opt_adam_tail = 1;      // the optimiser loop at large sample counts as two launches per iteration (adam.hip adam_tail_kernel)
   int opt_ident_test = 0;     // test hook: n > 0 = the n-th identity check from now fails (the recovery path runs)
   bool ident_retry = false;   // inside the re-evaluation after a failed identity check
   int opt_elbo_arm = 1;     // queue the next host-driven evaluation's launches ahead of its theta (armed evaluation)
@@ -295,6 +296,9 @@ struct DoneSignal {
   const uint64_t* ident_src = nullptr;
   uint64_t* ident_dst = nullptr;
   uint64_t ident_seed = 0;
+  // Device-side hand-over (optimiser loop, adam.hip): results AND flag are device memory and the reader is another
+  // workgroup of the same launch -- write-through (agent-scope) stores, drained, then the flag at agent scope; no host copy
+  int dev = 0;
 };
 
 // Order-independent 64-bit checksum of a block of doubles: sum_i bits(v_i) * (odd_i) mod 2^64.  Every
@@ -412,8 +416,9 @@ int launch_prep_on(vbmc_ctx* ctx, hipStream_t stream, const PrepArgs& a);
 struct EntPlan;
 // gp_items: GP expected-log-joint items the caller would like this launch to carry in spare workgroup slots (the plan
 // says whether it does: EntPlan::gp_in_ws); allow_span = false keeps the chunk grid (the Adam loop's extra row)
+// gp_per_slot > 0 (the optimiser loop): that many items per workgroup and one more free slot, for its pre workgroup
 int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, int64_t row_begin,
-               int64_t row_count, int want_grad, EntPlan& p, int gp_items = 0, bool allow_span = true);
+               int64_t row_count, int want_grad, EntPlan& p, int gp_items = 0, bool allow_span = true, int gp_per_slot = 0);
 void entmc_fill_prep(const vbmc_ctx* ctx, const EntPlan& p, PrepArgs& a);
 int entmc_pregen(vbmc_ctx* ctx, EntPlan& p, PrepArgs& a);
 

@@ -196,15 +196,10 @@ __global__ __launch_bounds__(WG) void entmc_valu_kernel(EntArgs a) {
   }
 }
 
-// Finish: reduce the per-workgroup partial rows in a fixed order (bit-reproducible) and
-// combine them into the raw accumulator vector
-//     [H | mu (K blocks of D) | sigma (K) | lambda (D) | w (K)]
-// (entmc_vbmc.py:80,98,102-112 with the 1/Ns and w_j factors applied).
-// One wave per output element; lanes run over the (component j, chunk c) rows it sums.
-// `raw` may be device memory or device-visible pinned host memory.
 #ifdef FIN_TIMES
-__device__ unsigned long long g_fin_times[4 + 3 * 64];  // [3] launch counter; per launch n % 64: start of block 0, publish, latest end
+#define FIN_TIMES_HERE
 #endif
+#include "finish_body.h"
 __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restrict__ partial,
                                                            int chunks, int stride,
                                                            const double* __restrict__ mix,
@@ -212,143 +207,7 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
                                                            int want_grad, int mu_from_w,
                                                            double* __restrict__ raw, GenSlice gen,
                                                            DoneSignal done) {
-  if (done.cancel != nullptr && __hip_atomic_load(done.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ~(uint64_t)0)
-    return;  // armed evaluation that was cancelled (common.h ArmedEval)
-  const int D = ml.D, K = ml.K;
-#ifdef FIN_TIMES
-  if (blockIdx.x == 0 && threadIdx.x == 0) { g_fin_times[0] = wall_clock64(); g_fin_times[2] = 0; }
-  struct EndStamp { __device__ ~EndStamp() { if (threadIdx.x == 0 && ((blockIdx.x & 127) == 0 || blockIdx.x + 8 >= gridDim.x)) atomicMax(&g_fin_times[2], wall_clock64()); } } end_stamp;
-  // history: the slot of this launch is claimed by the publishing block (below); block 0's start and the
-  // running end maximum are copied there by the last-numbered block, which is dispatched last
-#endif
-  {
-    // spare workgroups after the reduction's own: a slice of the next draws (host-driven step, Adam loop)
-    const int n_main = (1 + D * K + 2 * K + D + 3) / 4;
-    if ((int)blockIdx.x >= n_main) {
-      gen_slice_block(gen, blockIdx.x - n_main, threadIdx.x);
-      return;
-    }
-  }
-  const double* w = mix + ml.o_w;
-  const double* sig = mix + ml.o_sig;
-  const double* ilam = mix + ml.o_ilam;
-  const int n = 1 + D * K + 2 * K + D;
-  const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (t >= n && !done.flag) return;  // (with a completion word every wave of the block meets at the barrier below)
-  double v = 0.0;
-  // v = step(v, coef(i), partial[at(i)]) for i = lane, lane + 64, ... < total, in that order -- with the
-  // loads of four steps issued together (indices clamped, coefficients zeroed past the end, which
-  // leaves v unchanged): a wave's 8 steps at K * chunks = 500 cost two memory latencies instead of
-  // eight, and this reduction is on the path between the entropy kernel and the completion word
-  // (32-bit element offsets: the launcher refuses a partial block of 2^31 elements or more)
-#ifndef FIN_FOLD_U
-#define FIN_FOLD_U 10
-#endif
-  constexpr int FOLD_U = FIN_FOLD_U;
-  auto fold = [&](double acc, int total, auto&& coef, auto&& at, auto&& step) {
-    for (int b = 0; b < total; b += FOLD_U * 64) {
-      double c[FOLD_U], x[FOLD_U];
-#pragma unroll
-      for (int u = 0; u < FOLD_U; ++u) {
-        const int i = b + 64 * u + lane;
-        const int ic = min(i, total - 1);
-        x[u] = partial[at(ic)];
-        c[u] = coef(ic);
-        if (i >= total) c[u] = 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < FOLD_U; ++u) acc = step(acc, c[u], x[u]);
-    }
-    return acc;
-  };
-  const auto add_prod = [](double a, double c, double x) { return a + c * x; };
-  if (t >= n) {
-  } else if (t == 0) {
-    v = fold(0.0, K * chunks, [&](int i) { return w[i / chunks]; }, [&](int i) { return (unsigned)(i * stride); },
-             [](double a, double c, double x) { return a - c * x; });
-    v = wave_sum(v) * inv_ns;
-  } else if (want_grad) {
-    int u = t - 1;
-    if (u < D * K) {
-      const int j = u / D, d = u - j * D;
-      for (int c = lane; c < chunks; c += 64) v += partial[((int64_t)j * chunks + c) * stride + 1 + d];
-      if (mu_from_w) {
-        // wave-split kernel: the Delta part of the mean gradient comes from the W sums,
-        //   sum_k w_k/sigma_k^2 (mu'_jd - mu'_kd) W_jk   (entropy_ws.hip, pass 2)
-        const double* mup = mix + ml.o_mup;
-        const double* is2 = mix + ml.o_is2;
-        // lanes run over k within one partial row (coalesced), then over the chunks
-        const double mjd = mup[j * D + d];
-        v = fold(v, K * chunks,
-                 [&](int i) { const int k = i % K; return w[k] * is2[k] * (mjd - mup[k * D + d]); },
-                 [&](int i) { const int c = i / K, k = i - c * K; return (unsigned)((j * chunks + c) * stride + 2 + 2 * D + k); },
-                 [](double a, double c, double x) { return fma(c, x, a); });
-      }
-      v = wave_sum(v) * w[j] * inv_ns * ilam[d];
-    } else if ((u -= D * K) < K) {
-      for (int c = lane; c < chunks; c += 64) v += partial[((int64_t)u * chunks + c) * stride + 1 + D];
-      v = wave_sum(v) * w[u] * inv_ns;
-    } else if ((u -= K) < D) {
-      v = fold(0.0, K * chunks, [&](int i) { const int j = i / chunks; return w[j] * sig[j]; },
-               [&](int i) { return (unsigned)(i * stride + 2 + D + u); }, add_prod);
-      v = wave_sum(v) * inv_ns * ilam[u];
-    } else {
-      u -= D;
-      double sl = 0.0;
-      for (int c = lane; c < chunks; c += 64) sl += partial[((int64_t)u * chunks + c) * stride];
-      double s = fold(0.0, K * chunks, [&](int i) { return w[i / chunks]; },
-                      [&](int i) { return (unsigned)(i * stride + 2 + 2 * D + u); }, add_prod);
-      s = wave_sum(s);
-      sl = wave_sum(sl);
-      v = -inv_ns * (sl + s);
-    }
-  }
-  if (!done.flag) {
-    if (lane == 0) raw[t] = v;
-    return;
-  }
-  // `raw` is pinned host memory and the host polls `done.flag` instead of waiting for the stream.
-  // No fence: a system-scope release would write back every dirty L2 line.  Instead each result
-  // goes out as a write-through (sc0 sc1) store and its wave waits until the store has been
-  // acknowledged; then the workgroup meets at a barrier and counts itself with ONE atomic (611
-  // increments of a single word would take ~7 us: a word saturates at ~88 atomics per us), and the
-  // last workgroup to count publishes the sequence number the same way (MI355X_MICROARCH.md,
-  // hand-off with a drained sc1 payload and flag).
-  const bool staged = done.host_out != nullptr;  // raw is device memory; the last workgroup ships it
-  if (lane == 0 && t < n) {
-    if (staged) __hip_atomic_store(raw + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else __hip_atomic_store(raw + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  }
-  __shared__ int s_last;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int n_main = (n + 3) / 4;
-    s_last = __hip_atomic_fetch_add(done.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_main - 1;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  if (done.ident_dst && threadIdx.x == 255) {  // what this result block was computed from (DoneSignal)
-    __hip_atomic_store(done.ident_dst, *done.ident_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(done.ident_dst + 1, done.ident_seed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (!staged) __builtin_amdgcn_s_waitcnt(0x0F70);  // (the staged copy below drains them with its own stores)
-  }
-  if (staged) {  // one coalesced copy to the host instead of n single PCIe writes (DoneSignal)
-    staged_copy_to_host(raw, done.host_out, done.host_n);
-  }
-  if (staged || done.ident_dst) __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(done.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#ifdef FIN_TIMES
-    g_fin_times[1] = wall_clock64();
-    const unsigned long long slot = g_fin_times[3]++ & 63;
-    g_fin_times[4 + 3 * slot] = g_fin_times[0];
-    g_fin_times[4 + 3 * slot + 1] = g_fin_times[1];
-    g_fin_times[4 + 3 * slot + 2] = g_glj_stamp;  // (the GP word of the PREVIOUS launch: it is published later than this)
-#endif
-  }
+  entmc_finish_body(partial, chunks, stride, mix, ml, inv_ns, want_grad, mu_from_w, raw, gen, done);
 }
 #ifdef FIN_TIMES
 }  // namespace
@@ -536,7 +395,7 @@ static int ws_front_default(int DP, int KT) {
 
 // Decide the launch geometry and carve the scratch buffer.
 int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, int64_t row_begin,
-               int64_t row_count, int want_grad, EntPlan& p, int gp_items, bool allow_span) {
+               int64_t row_count, int want_grad, EntPlan& p, int gp_items, bool allow_span, int gp_per_slot) {
   const int D = ctx->D, K = ctx->K;
   p.DP = padded_d(D);
   if (p.DP < 0) return vbmc_fail(ctx, VBMC_E_UNSUP, "entmc: D=%d > 32 not supported", D);
@@ -635,11 +494,26 @@ int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
       return e ? atoi(e) : 0;
     }();
     int WS_GP_SLOTS = 10;
-    if (slots_env > 0) WS_GP_SLOTS = slots_env;
-    else if (gp_items > 50 && gp_items <= 500) WS_GP_SLOTS = (gp_items + 4) / 5;
-    if (WS_GP_SLOTS > cus / 2) WS_GP_SLOTS = cus / 2;
-    const int gp_wgs = gp_items > 0 ? std::min(WS_GP_SLOTS, (gp_items + 4) / 5) : 0;
-    const bool gp_here = waves == 2 && gp_wgs > 0 && gp_items <= 6 * WS_GP_SLOTS;
+    int gp_wgs = 0;
+    bool gp_here = false;
+    if (gp_per_slot > 0) {
+      // the optimiser loop's two-launch iteration (adam.hip): the pre workgroup of the same launch waits for these sums
+      // and must itself be done before the entropy parts are, so the sums get gp_per_slot items per workgroup and the
+      // pre workgroup a slot of its own
+      gp_wgs = (gp_items + gp_per_slot - 1) / gp_per_slot;
+      WS_GP_SLOTS = std::max(10, gp_wgs + 1);
+      gp_here = waves == 2 && gp_wgs > 0 && WS_GP_SLOTS <= cus / 2;
+      if (!gp_here) {
+        WS_GP_SLOTS = 10;
+        gp_wgs = 0;
+      }
+    } else {
+      if (slots_env > 0) WS_GP_SLOTS = slots_env;
+      else if (gp_items > 50 && gp_items <= 500) WS_GP_SLOTS = (gp_items + 4) / 5;
+      if (WS_GP_SLOTS > cus / 2) WS_GP_SLOTS = cus / 2;
+      gp_wgs = gp_items > 0 ? std::min(WS_GP_SLOTS, (gp_items + 4) / 5) : 0;
+      gp_here = waves == 2 && gp_wgs > 0 && gp_items <= 6 * WS_GP_SLOTS;
+    }
     sp.pb = waves == 2 ? cus - WS_GP_SLOTS : 0;
     if (sp.pb == 0) sp.front = 1000;
     const int64_t min_part = sp.front > 0 ? (sp.pb > 0 ? 1000 - sp.front : sp.front) * sp.T / sp.W() : 0;

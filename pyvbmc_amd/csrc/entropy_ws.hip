@@ -146,6 +146,23 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
     if (a.extra != nullptr && (span ? (int)blockIdx.x == a.sp.n_parts() + (a.gp_items > 0 ? a.gp_wgs : 0) : blockIdx.y == 0)) {
       if (span || blockIdx.x == 0) {
         const adam_dev::AdamDev& pa = *(const adam_dev::AdamDev*)a.extra;
+        if (a.gp_items > 0 && a.gp.done.dev) {
+          // the GP sums this workgroup finalises are made by workgroups of this very launch (dispatched in front of
+          // it): wait for their word, then drop this CU's cached lines (hand-off with drained write-through stores
+          // and an agent-scope flag).  Bounded: after 20 ms the status word says so and the host gives the run up.
+          if (threadIdx.x == 0) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(a.gp.done.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.gp.done.seq) {
+              if (wall_clock64() - t0 > 2000000ull) {
+                atomicOr(pa.status, 8);
+                break;
+              }
+              __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          }
+          __syncthreads();
+        }
         if (a.extra_lds > 0) adam_dev::adam_pre_body<true>(pa, dyn, &sRed[0][0], pa.pre);
         else adam_dev::adam_pre_body<false>(pa, nullptr, &sRed[0][0], pa.pre);
       }

@@ -86,7 +86,8 @@ __device__ __forceinline__ void glj_block(const PrepArgs& a, int b, double* lds)
   __syncthreads();
   double* out = a.res + ((size_t)s * K + k) * (1 + 2 * D);
   const bool sig = a.done.flag != nullptr;
-  const bool staged = sig && a.done.host_out != nullptr;  // a.res is device memory; the last block ships it
+  const bool dev = sig && a.done.dev != 0;  // a.res and the flag are device memory, read by a workgroup of this launch (DoneSignal)
+  const bool staged = (sig && a.done.host_out != nullptr) || dev;  // a.res is device memory; the last block ships it
   auto put = [&](double* p, double v) {
     if (staged) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through (sc1): read by another workgroup
     else if (sig) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // write-through to pinned memory
@@ -148,13 +149,14 @@ __device__ __forceinline__ void glj_block(const PrepArgs& a, int b, double* lds)
   __syncthreads();
   if (sMisc[0] == 0.0) return;
   // last block to count: every block's sums are in memory (drained write-through stores)
-  if (staged) {
+  if (staged && !dev) {
     staged_copy_to_host(a.res, a.done.host_out, a.done.host_n);
     __syncthreads();
   }
   if (tid == 0) {
     __hip_atomic_store(a.done.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(a.done.flag, a.done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (dev) __hip_atomic_store(a.done.flag, a.done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(a.done.flag, a.done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef GLJ_STAMP
     GLJ_STAMP();
 #endif

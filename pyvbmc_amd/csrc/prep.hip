@@ -14,6 +14,7 @@
 #include "fastmath.h"
 #include "philox.h"
 #include "glj_block.h"
+#include "ws_table.h"
 
 namespace {
 
@@ -85,36 +86,7 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
     // ---- table row block: T[j][k] = [Delta_jk (DP) | c0 | a | w | w/sigma_k^2 | pad pad], where
     // c0 + a (sigma_j^2 |eps|^2 +- 2 sigma_j Delta.eps) is the log2 density of component k at
     // mu_j +- sigma_j lambda eps:  a = -log2(e)/(2 sigma_k^2),  c0 = a |Delta|^2 + log2 c_k ----
-    const int j = blockIdx.x;
-    const int DP = a.DP, TS = a.DP + 6, K4 = a.K4;
-    const double* mup = a.mix + a.ml.o_mup;
-    // all lanes on the (k, d) differences (coalesced row writes), then one lane per k on the tail
-    double* sV2 = lds;  // [K4][DP] squared differences
-    for (int idx = tid; idx < K4 * DP; idx += 256) {
-      const int k = idx / DP, d = idx - k * DP;
-      const double v = (d < D && k < K) ? (mup[j * D + d] - mup[k * D + d]) : 0.0;
-      a.table[((size_t)j * K4 + k) * TS + d] = v;
-      sV2[idx] = v * v;
-    }
-    __syncthreads();
-    for (int k = tid; k < K4; k += 256) {
-      double* row = a.table + ((size_t)j * K4 + k) * TS;
-      double s = 0.0;
-      for (int d = 0; d < DP; ++d) s += sV2[k * DP + d];
-      if (k < K) {
-        const double is2 = a.mix[a.ml.o_is2 + k];
-        const double w = a.mix[a.ml.o_w + k];
-        const double ak = -0.5 * 0x1.71547652b82fep+0 * is2;  // -log2(e) / (2 sigma_k^2)
-        row[DP + 0] = fma(ak, s, a.mix[a.ml.o_lrc + k]);      // log2 density of component k at mu_j
-        row[DP + 1] = ak;
-        row[DP + 2] = w;
-        row[DP + 3] = w * is2;
-      } else {  // padding component: density exactly 0
-        row[DP + 0] = -2000.0; row[DP + 1] = 0.0; row[DP + 2] = 0.0; row[DP + 3] = 0.0;
-      }
-      row[DP + 4] = 0.0;
-      row[DP + 5] = 0.0;
-    }
+    ws_table_row_block(a.mix, a.ml, (int)blockIdx.x, a.DP, a.K4, a.table, lds);
     return;
   }
 

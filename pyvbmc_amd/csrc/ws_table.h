@@ -1,0 +1,40 @@
+// Row j of the (j,k) constant table of the wave-split entropy kernel (entropy_ws.hip), by one 256-thread workgroup:
+// T[j][k] = [Delta_jk (DP) | c0 | a | w | w/sigma_k^2 | pad pad], where c0 + a (sigma_j^2 |eps|^2 +- 2 sigma_j Delta.eps)
+// is the log2 density of component k at mu_j +- sigma_j lambda eps:  a = -log2(e)/(2 sigma_k^2),  c0 = a |Delta|^2 + log2 c_k.
+// Shared by the prep launch (prep.hip) and the optimiser loop's tail launch (adam.hip), where `mix` is the pack the
+// workgroup has just made in its own LDS.  lds: K4 * DP doubles of scratch.
+#pragma once
+#include "common.h"
+
+__device__ __forceinline__ void ws_table_row_block(const double* mix, const MixLayout& ml, int j, int DP, int K4,
+                                                   double* table, double* lds) {
+  const int D = ml.D, K = ml.K, tid = threadIdx.x, TS = DP + 6;
+  const double* mup = mix + ml.o_mup;
+  // all lanes on the (k, d) differences (coalesced row writes), then one lane per k on the tail
+  double* sV2 = lds;  // [K4][DP] squared differences
+  for (int idx = tid; idx < K4 * DP; idx += 256) {
+    const int k = idx / DP, d = idx - k * DP;
+    const double v = (d < D && k < K) ? (mup[j * D + d] - mup[k * D + d]) : 0.0;
+    table[((size_t)j * K4 + k) * TS + d] = v;
+    sV2[idx] = v * v;
+  }
+  __syncthreads();
+  for (int k = tid; k < K4; k += 256) {
+    double* row = table + ((size_t)j * K4 + k) * TS;
+    double s = 0.0;
+    for (int d = 0; d < DP; ++d) s += sV2[k * DP + d];
+    if (k < K) {
+      const double is2 = mix[ml.o_is2 + k];
+      const double w = mix[ml.o_w + k];
+      const double ak = -0.5 * 0x1.71547652b82fep+0 * is2;  // -log2(e) / (2 sigma_k^2)
+      row[DP + 0] = fma(ak, s, mix[ml.o_lrc + k]);          // log2 density of component k at mu_j
+      row[DP + 1] = ak;
+      row[DP + 2] = w;
+      row[DP + 3] = w * is2;
+    } else {  // padding component: density exactly 0
+      row[DP + 0] = -2000.0; row[DP + 1] = 0.0; row[DP + 2] = 0.0; row[DP + 3] = 0.0;
+    }
+    row[DP + 4] = 0.0;
+    row[DP + 5] = 0.0;
+  }
+}
