@@ -257,8 +257,8 @@ class Context:
         sized to end together, csrc/entropy_args.h) rather than on equal chunks."""
         out = (C.c_int * 4)()
         self.check(self._lib.vbmc_last_entmc_plan(self._h, out))
-        return {"kernel": ("valu", "ws", "small", "mfma", "adam_fused", "ws")[out[0]] if out[0] >= 0 else None, "rg": out[1],
-                "chunks": out[2], "resident_draws": bool(out[3]), "span": out[0] == 5}
+        return {"kernel": ("valu", "ws", "small", "mfma", "adam_fused", "ws", "ws")[out[0]] if out[0] >= 0 else None, "rg": out[1],
+                "chunks": out[2], "resident_draws": bool(out[3]), "span": out[0] in (5, 6), "adam_tail": out[0] == 6}
 
     def philox_normals(self, K, n_half, D, seed, row_begin=0, row_count=None):
         """[K][row_count][D] draws of the device generator (vbmc_philox_normals)."""

@@ -213,7 +213,9 @@ struct TailArgs {
   unsigned long long rd_target = 0;
   unsigned long long timeout = 2000000;  // wall-clock ticks (100 MHz): 20 ms
   GenSlice gen;
+  unsigned long long* times = nullptr;  // optional [8] stamps of the writer block (VBMC_TAIL_TIMES=1)
 };
+#define TAIL_STAMP(i) do { if (t.times && writer && tid == 0) t.times[i] = wall_clock64(); } while (0)
 
 __global__ __launch_bounds__(256) void adam_tail_kernel(AdamDev a, TailArgs t) {
   extern __shared__ double sh[];
@@ -233,6 +235,7 @@ __global__ __launch_bounds__(256) void adam_tail_kernel(AdamDev a, TailArgs t) {
     return;
   }
   const bool writer = tb == 0;
+  TAIL_STAMP(0);
   // ---- wait for the reduction (bounded) ----
   if (tid == 0) {
     const unsigned long long t0 = wall_clock64();
@@ -242,9 +245,8 @@ __global__ __launch_bounds__(256) void adam_tail_kernel(AdamDev a, TailArgs t) {
         ok = 0;
         break;
       }
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(8);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     s_ok = ok;
   }
   __syncthreads();
@@ -252,6 +254,7 @@ __global__ __launch_bounds__(256) void adam_tail_kernel(AdamDev a, TailArgs t) {
     if (tid == 0) atomicOr(a.status, 8);
     return;
   }
+  TAIL_STAMP(1);
   // LDS: theta n | aux | ee K | pack | table scratch K4 DP | new m, new v (writer)
   double* theta = sh;
   double* aux = sh + n;
@@ -260,7 +263,10 @@ __global__ __launch_bounds__(256) void adam_tail_kernel(AdamDev a, TailArgs t) {
   double* tsc = pack + a.ml.total;
   double* new_m = tsc + t.K4 * t.DP;
   double* new_v = new_m + n;
-  const double* raw = a.state + L.o_raw();
+  // the raw vector was written through by the reduction's blocks of this launch: read past this CU's L1 (agent-scope loads;
+  // an acquire fence instead costs ~2 us on the chain); everything else read here was written by earlier launches
+  const double* raw_p = a.state + L.o_raw();
+  auto raw = [&](int i) { return __hip_atomic_load(raw_p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   const bool o_mu = a.mask & 1, o_sg = a.mask & 2, o_lm = a.mask & 4, o_w = a.mask & 8;
   const int p_sg = o_mu ? D * K : 0, p_lm = p_sg + (o_sg ? K : 0), p_w = n - K;
   const int f_w = 1 + D * K + K + D;
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(256) void adam_tail_kernel(AdamDev a, TailArgs t) {
   double r_raw[U], r_pre[U], r_m[U], r_v[U], r_lo[U], r_hi[U];
   double rw = 0.0;
   const int iter = a.iter_base[0] + a.it_off;
-  if (o_w && tid < K) rw = raw[f_w + tid];
+  if (o_w && tid < K) rw = raw(f_w + tid);
   for (int i = tid; i < L.o_hyp(); i += 256) sh[i] = a.state[i];  // theta | aux
   auto raw_index = [&](int i) -> int {
     if (o_mu && i < D * K) return 1 + i;
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(256) void adam_tail_kernel(AdamDev a, TailArgs t) {
     for (int u = 0; u < U; ++u) {
       const int i = base + u * 256 + tid;
       const bool in = i < n;
-      r_raw[u] = in ? raw[raw_index(i)] : 0.0;
+      r_raw[u] = in ? raw(raw_index(i)) : 0.0;
       r_pre[u] = in ? a.pre[i] : 0.0;
       r_m[u] = in ? a.state[L.o_m() + i] : 0.0;
       r_v[u] = in ? a.state[L.o_v() + i] : 0.0;
@@ -298,6 +304,7 @@ __global__ __launch_bounds__(256) void adam_tail_kernel(AdamDev a, TailArgs t) {
   double* x_row = a.x_tab + (size_t)iter * n;
   double* y_out = a.y_tab + 3 * (size_t)iter;
   __syncthreads();
+  TAIL_STAMP(2);
   {
     const double* sg = aux + K * D;
     const double* lm = sg + K;
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(256) void adam_tail_kernel(AdamDev a, TailArgs t) {
         const double e = fm::exp2_fast(0x1.71547652b82fep+0 * eta[k]);
         ee[k] = e;
         ps += e;
-        pd += e * (k == tid ? rw : raw[f_w + k]);
+        pd += e * (k == tid ? rw : raw(f_w + k));
       }
       ps = wave_sum(ps);
       pd = wave_sum(pd);
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(256) void adam_tail_kernel(AdamDev a, TailArgs t) {
       sm_dot = (red[4] + red[5]) + (red[6] + red[7]);
     }
     if (writer && tid == 0) {
-      const double G = a.pre[n], loss = a.pre[n + 1], H = raw[0];
+      const double G = a.pre[n], loss = a.pre[n + 1], H = raw(0);
       y_out[0] = -G - H + loss;
       y_out[1] = G;
       y_out[2] = H;
@@ -361,11 +368,14 @@ __global__ __launch_bounds__(256) void adam_tail_kernel(AdamDev a, TailArgs t) {
   }
   // this block is through with the old moments (every load above has been consumed)
   if (tid == 0) __hip_atomic_fetch_add(t.rd_cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  TAIL_STAMP(3);
 
   pack_from_theta(a, theta, aux, red, pack);
   __syncthreads();
+  TAIL_STAMP(4);
   ws_table_row_block(pack, a.ml, tb, t.DP, t.K4, t.table, tsc);
   if (!writer) return;
+  TAIL_STAMP(5);
   // ---- the writer: the new iterate goes to memory, the moments once every block has read the old ones ----
   for (int i = tid; i < a.ml.total; i += 256) a.mix[i] = pack[i];  // (read by the reduction blocks only: they are done)
   if (tid == 0) {
@@ -385,11 +395,13 @@ __global__ __launch_bounds__(256) void adam_tail_kernel(AdamDev a, TailArgs t) {
     if (tid == 0) atomicOr(a.status, 8);
     return;
   }
+  TAIL_STAMP(6);
   for (int i = tid; i < L.o_hyp(); i += 256) a.state[i] = sh[i];  // theta | aux
   for (int i = tid; i < n; i += 256) {
     a.state[L.o_m() + i] = new_m[i];
     a.state[L.o_v() + i] = new_v[i];
   }
+  TAIL_STAMP(7);
 }
 
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
@@ -609,7 +621,7 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
   {
     // LDS plan: each kernel keeps its working set in LDS when it fits
     const size_t cap = 150 * 1024 / sizeof(double);  // (beyond it the kernels work from global memory: config 5's shape)
-    const size_t n_pre = (size_t)L.o_raw() + n_work, n_step = (size_t)L.o_hyp() + K;
+    const size_t n_pre = (size_t)L.o_blb() + n_work, n_step = (size_t)L.o_hyp() + K;
     st->pre_lds = n_pre <= cap;
     st->step_lds = n_step <= cap;
     st->pre_lds_bytes = sizeof(double) * n_pre;
@@ -752,11 +764,19 @@ static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool
     return make_gen_slice(st->d_eps1, ctx->K, ctx->D, st->row_count, st->ns / 2, st->row_begin,
                           st->seed + (uint64_t)seed_off, st->d_status + 1, f0, f1);
   };
-  const bool try_tail = ctx->opt_adam_tail && !multi && st->tail_ok;
-  static const int tail_gp_per_slot = [] {
+  // The two-launch iteration where it gains (measured, config 3's shape: 20 000 samples per component 97.5 -> 93 us per
+  // iteration; 8 192: 61 -> 64; 4 096: 48 -> 52 -- below ~40 us of entropy kernel the GP sums and the pre workgroup in its
+  // launch outlast the entropy parts, and the hand-off inside the tail launch costs what the two boundaries it replaces
+  // cost): jobs of at least 250 000 antithetic rows.  Option "adam_tail" = 2 forces it wherever its shape applies (tests).
+  const bool try_tail = ctx->opt_adam_tail && !multi && st->tail_ok &&
+                        (ctx->opt_adam_tail == 2 || (int64_t)ctx->K * st->row_count >= 250000);
+  // GP items per workgroup of the entropy launch: two where the entropy parts run long enough to cover two items and the
+  // pre workgroup behind them (~25 us), one below that
+  static const int gp_per_slot_env = [] {
     const char* e = getenv("VBMC_TAIL_GP_PER_SLOT");  // measurement aid
-    return e ? atoi(e) : 2;
+    return e ? atoi(e) : 0;
   }();
+  const int tail_gp_per_slot = gp_per_slot_env > 0 ? gp_per_slot_env : ((int64_t)ctx->K * st->row_count >= 250000 ? 2 : 1);
   for (int it = 0; it < n_iters; ++it) {
     PrepArgs pa;
     glj_fill_prep(ctx, 1, st->state + st->lay.o_res(), nullptr, pa);
@@ -820,15 +840,33 @@ static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool
       }();
       if (use_gen && gen_mode == 1) t.gen = slice(it + 1, 0.0, 1.0);
       a.it_off = it;
+      static const bool want_times = [] {
+        const char* e = getenv("VBMC_TAIL_TIMES");  // measurement aid: the writer block's stamps of the batch's last iteration to stderr
+        return e && e[0] == '1';
+      }();
+      static unsigned long long* d_tt = nullptr;
+      if (want_times) {
+        if (!d_tt) HIP_TRY(ctx, hipMalloc((void**)&d_tt, 16 * sizeof(unsigned long long)));
+        t.times = d_tt;
+      }
       const int n_main = (raw_len(ctx->D, ctx->K) + 3) / 4;
       hipLaunchKernelGGL(adam_tail_kernel, dim3(n_main + ctx->K + t.gen.n_blocks), dim3(256), st->tail_lds_bytes, sm, a, t);
       if (use_gen && gen_mode == 2) {
         rc = launch_eps_gen(ctx, sm, slice(it + 1, 0.0, 1.0));
         if (rc) return rc;
       }
+      if (want_times && it == n_iters - 1) {
+        unsigned long long tt[8];
+        HIP_TRY(ctx, hipStreamSynchronize(sm));
+        HIP_TRY(ctx, hipMemcpy(tt, d_tt, sizeof(tt), hipMemcpyDeviceToHost));
+        fprintf(stderr, "tail launch, writer block, us: (%.0f) start -> word %.2f | loads %.2f | update %.2f | pack %.2f | table row %.2f | pack out + readers %.2f | write-back %.2f | total %.2f\n",
+                0.0, (tt[1] - tt[0]) * 0.01, (tt[2] - tt[1]) * 0.01, (tt[3] - tt[2]) * 0.01, (tt[4] - tt[3]) * 0.01, (tt[5] - tt[4]) * 0.01,
+                (tt[6] - tt[5]) * 0.01, (tt[7] - tt[6]) * 0.01, (tt[7] - tt[0]) * 0.01);
+      }
       st->table_valid = true;
       if (use_gen) st->eps_started = true;
       st->last_form = 2;
+      ctx->last_plan[0] = 6;  // vbmc_last_entmc_plan: the wave-split kernel in span mode inside the two-launch iteration
       continue;
     }
     st->table_valid = false;

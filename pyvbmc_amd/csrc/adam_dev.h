@@ -100,7 +100,9 @@ static __device__ __forceinline__ double wave_sum(double v) {
 //   GP-sum finalisation (host twin: api_gp.hip glj_finalize), soft bounds + weight penalty
 //   (api_elbo.hip), their Jacobians, and the softmax Jacobian of the entropy-free part of the
 //   weight gradient (the Jacobian is linear, so the entropy part is added by the step kernel).
-// LDS = true: the state prefix [theta | aux | hyp | res | bounds] and the scratch live in LDS;
+// LDS = true: the state prefix [theta | aux | hyp | res] and the scratch live in LDS (the 2 n_bnd doubles of the soft
+// bounds, read once each, do not: with them the working set of BASELINE config 3 was 62 KB, past what two entropy
+// workgroups per CU leave, and the workgroup ran from global memory at twice the time);
 // compile-time so that every access is a true ds_* or global access (a pointer that may be
 // either at run time makes the compiler emit flat_* instructions, several times slower on LDS).
 // PRELOADED (with LDS): sh already holds the state prefix (the fused loop, adam_fused.hip, keeps it there
@@ -112,7 +114,7 @@ static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red, 
   const int st = 1 + 2 * D;
   const AdamLayout& L = a.lay;
   if (LDS && !PRELOADED) {
-    const int cnt = L.o_raw();
+    const int cnt = L.o_blb();  // theta | aux | hyp | res -- the soft bounds are read once each, straight from memory
     constexpr int U = 24;  // BASELINE config 3 (4 493 doubles) in one batch of loads
     for (int base = 0; base < cnt; base += 256 * U) {
       double r[U];
@@ -134,9 +136,9 @@ static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red, 
   const double* aux = base + L.o_aux();
   const double* hyp = base + L.o_hyp();
   const double* res = base + L.o_res();
-  const double* bnd_lb = base + L.o_blb();
-  const double* bnd_ub = base + L.o_bub();
-  double* work = LDS ? sh + L.o_raw() : a.work;
+  const double* bnd_lb = a.state + L.o_blb();
+  const double* bnd_ub = a.state + L.o_bub();
+  double* work = LDS ? sh + L.o_blb() : a.work;
 
   const bool o_mu = a.mask & 1, o_sg = a.mask & 2, o_lm = a.mask & 4, o_w = a.mask & 8;
   const int p_sg = o_mu ? D * K : 0, p_lm = p_sg + (o_sg ? K : 0), p_w = n - K;

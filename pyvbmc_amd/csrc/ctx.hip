@@ -65,7 +65,7 @@ static void options_from_env(vbmc_ctx* c) {
   e = getenv("VBMC_ADAM_FUSED");
   c->opt_adam_fused = e ? atoi(e) : 1;  // (3: the release / acquire form of its exchange)
   e = getenv("VBMC_ADAM_TAIL");
-  c->opt_adam_tail = !(e && e[0] == '0');
+  c->opt_adam_tail = e ? atoi(e) : 1;  // (2: wherever its shape applies, whatever the job's size)
   e = getenv("VBMC_WS_SPAN");
   c->opt_ws_span = !(e && e[0] == '0');
   e = getenv("VBMC_WS_FRONT");
@@ -224,7 +224,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "ws_front")) ctx->opt_ws_front = value < 0 ? 0 : value > 990 ? 990 : value;
   else if (!strcmp(key, "elbo_arm")) ctx->opt_elbo_arm = value != 0;
   else if (!strcmp(key, "acq_poll")) ctx->opt_acq_poll = value != 0;
-  else if (!strcmp(key, "adam_tail")) ctx->opt_adam_tail = value != 0;  // the optimiser loop's two-launch iteration (adam.hip)
+  else if (!strcmp(key, "adam_tail")) ctx->opt_adam_tail = value;  // the optimiser loop's two-launch iteration (adam.hip)
   else if (!strcmp(key, "adam_fused")) ctx->opt_adam_fused = value;  // 2: test hook, see FusedArgs::test_absent; 3: release / acquire flags (FusedArgs::rel_acq)
   else return vbmc_fail(ctx, VBMC_E_ARG, "vbmc_set_option: unknown key '%s'", key);
   return VBMC_OK;

@@ -517,7 +517,8 @@ int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
     sp.pb = waves == 2 ? cus - WS_GP_SLOTS : 0;
     if (sp.pb == 0) sp.front = 1000;
     const int64_t min_part = sp.front > 0 ? (sp.pb > 0 ? 1000 - sp.front : sp.front) * sp.T / sp.W() : 0;
-    if (min_part >= 3 && sp.T < ((int64_t)1 << 40)) {
+    // (the optimiser loop's two-launch iteration exists in span mode only and gains more than short parts cost: from 2 batches)
+    if (min_part >= (gp_per_slot > 0 ? 2 : 3) && sp.T < ((int64_t)1 << 40)) {
       int R = 1;
       int longest = 0;
       for (int j = 0; j < K; ++j) {

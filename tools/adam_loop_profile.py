@@ -12,8 +12,9 @@ vp = VariationalPosterior(wl.D, wl.K); vp.mu = wl.mu.copy(); vp.sigma = wl.sigma
 g = gpm.GP(wl.D, gpm.SquaredExponential(), gpm.NegativeQuadratic(), gpm.GaussianNoise(constant_add=True)); g.ctx = ctx
 g.update(X_new=wl.X, y_new=wl.y, hyp=wl.hyp)
 bnd = synthetic.default_theta_bnd(wl)
+NSK = int(sys.argv[1]) if len(sys.argv) > 1 else wl.NsK
 kw = dict(max_iter=200, master_min=0.001, master_max=0.1, master_decay=200, use_early_stopping=False)
 for r in range(3):
     t0 = time.perf_counter()
-    out = minimize_adam_elbo(wl.theta.copy(), g, vp, wl.NsK, bnd, seed=11, rng="philox", **kw)
+    out = minimize_adam_elbo(wl.theta.copy(), g, vp, NSK, bnd, seed=11, rng="philox", **kw)
     print("per-iter us", (time.perf_counter() - t0) / 200 * 1e6, out[3][0], out[3][-1])
