@@ -17,8 +17,8 @@ LIB_PATH = Path(os.environ.get("VBMC_HIP_LIB", _HERE / "libvbmc_hip.so"))
 EPS_RESIDENT, EPS_PHILOX = 0, 1
 MEAN_ZERO, MEAN_CONST, MEAN_NEGQUAD = 0, 1, 2
 E_ARG, E_HIP, E_RCCL, E_NODEV, E_UNSUP, E_NONFINITE = -1, -2, -3, -4, -5, -6
-W_GP_CHANGED = 1
-W_NOT_FUSED = 2  # vbmc_neg_elcbo: the watched GP arrays changed under it (vbmc_set_gp_watch)
+W_GP_CHANGED = 1  # vbmc_neg_elcbo: the watched GP arrays changed under it (vbmc_set_gp_watch)
+W_NOT_FUSED = 2   # vbmc_adam_run_auto: the one-launch loop does not apply (or gave up): run batches with vbmc_adam_run
 
 
 class VbmcHipError(RuntimeError):

@@ -415,7 +415,8 @@ int launch_prep_on(vbmc_ctx* ctx, hipStream_t stream, const PrepArgs& a);
 // staged launch of the Monte-Carlo entropy (entropy.hip)
 struct EntPlan;
 // gp_items: GP expected-log-joint items the caller would like this launch to carry in spare workgroup slots (the plan
-// says whether it does: EntPlan::gp_in_ws); allow_span = false keeps the chunk grid (the Adam loop's extra row)
+// says whether it does: EntPlan::gp_in_ws); allow_span = false keeps the chunk grid (no caller does: the optimiser loop's pre
+// workgroup is the LAST block of a span-mode launch and finds one of the slots the plan leaves free)
 // gp_per_slot > 0 (the optimiser loop): that many items per workgroup and one more free slot, for its pre workgroup
 int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, int64_t row_begin,
                int64_t row_count, int want_grad, EntPlan& p, int gp_items = 0, bool allow_span = true, int gp_per_slot = 0);

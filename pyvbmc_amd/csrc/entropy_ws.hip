@@ -237,7 +237,7 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   first_stretch = false;
   const int j = span ? (int)(g / nbv) : j_chunk;
   const int ib0 = (int)(g - (int64_t)j * nbv);  // first batch of the stretch within component j (or a padding slot >= nb)
-  if (ib0 >= nb) {                               // padding behind component j: no work
+  if (span && ib0 >= nb) {                       // padding behind component j: no work (chunk mode: an empty chunk falls through with n_it = 0 and writes its zero row)
     g = (int64_t)(j + 1) * nbv;
     continue;
   }

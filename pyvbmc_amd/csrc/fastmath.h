@@ -41,6 +41,10 @@ __device__ __forceinline__ double exp2_fast(double x) {
 // float64 oracle at BASELINE config 3: H 1.2e-15, gradients 1.6e-15 relative, against 7.0e-16 / 1.5e-15 with degree
 // 10 (the interpolation error equi-oscillates around zero in f and averages out over the draws).  Rounds 1-3 used degree 10 (4.1e-16); each degree is one FMA of the ~70 instructions per evaluated
 // (pair, component): 73.7 -> 70.2 us per launch at config 3 (profiles/r04_exp2_degree.md).
+// The guarantee without any averaging (the same kernels serve calls of a few rows per component): every density within 1.07e-12
+// relative, hence log q within 1.1e-12 and H within 1.1e-12 ABSOLUTE, gradients within 2.2e-12 of their terms' scale; the fused
+// optimiser loop (adam_fused.hip) keeps exp2_fast, so the two forms of the loop agree to ~1e-12, not to rounding -- tests on
+// small-sample shapes assert at 1e-10 or looser.
 #define VBMC_ENT_EXP2_N 8
 #define VBMC_ENT_EXP2_COEFFS                                                                                        \
   {0x1.62e42fef84cf0p-1, 0x1.ebfbdff823cedp-3, 0x1.c6b08dd6fd234p-5, 0x1.3b2ab7181b755p-7, 0x1.5d8745a728441p-10, \

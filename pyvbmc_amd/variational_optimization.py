@@ -362,7 +362,6 @@ class _FusedCall:
         """vp.set_parameters(theta)'s effects from the arrays the library filled (store_mixture() through views shaped
         once), and the max-shifted eta tail of the caller's theta (variational_optimization.py:1082-1085)."""
         vp, theta, mask, K = self.side
-        self.side = None
         vp.mu, vp.sigma, vp.lambd, vp.w = self.mu_T.copy(), self.sg_row.copy(), self.lm_col.copy(), self.w_row.copy()
         if mask & 8:
             vp.eta = self.eta_row.copy()
@@ -370,11 +369,17 @@ class _FusedCall:
                 theta[-K:] = self.th[-K:]
         if hasattr(vp, "_mode"):
             vp._mode = None  # set_parameters drops the cached mode (variational_posterior.py:759)
+        self.side = None  # (only now: an assignment that raised leaves them to be applied -- and to raise -- after the call)
 
     def _released(self, _user):
-        # called by the library from inside vbmc_neg_elcbo, launches released, device at work
+        # called by the library from inside vbmc_neg_elcbo, launches released, device at work.  ctypes swallows an
+        # exception raised in a callback: a failure here (a vp whose attribute refuses the assignment) leaves
+        # self.side set, so the caller applies the side effects again after the C call returns and the error surfaces
         if self.side is not None:
-            self.apply_side_effects()
+            try:
+                self.apply_side_effects()
+            except Exception:
+                pass
 
     def bind_bounds(self, theta_bnd):
         o = self.opts

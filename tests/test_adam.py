@@ -281,13 +281,14 @@ def test_device_loop_global_memory_kernels(ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [dict(D=20, K=12, N=60, S=3, NsK=40), dict(D=3, K=70, N=90, S=2, NsK=28),
-                                   dict(D=17, K=5, N=40, S=1, NsK=130)],
-                         ids=["D20-S3", "K70-S2", "D17"])
+                                   dict(D=17, K=5, N=40, S=1, NsK=130), dict(D=3, K=130, N=40, S=1, NsK=6)],
+                         ids=["D20-S3", "K70-S2", "D17", "K130-standalone-pre"])
 def test_device_loop_other_shapes(ctx, shape):
     """Shapes away from the BASELINE configurations: more than 16 dimensions (the 16-lane
     dimension groups of the pre workgroup and of the GP sums take a second round), several GP
-    hyper-parameter samples, a component count that is not a multiple of four, and the
-    optimiser's default sample count (ns_ent = 100 K^(2/3), advanced_vbmc_options.ini:43)."""
+    hyper-parameter samples, a component count that is not a multiple of four, the
+    optimiser's default sample count (ns_ent = 100 K^(2/3), advanced_vbmc_options.ini:43), and K > 128: the generic
+    entropy kernel has no extra row, so the pre workgroup runs as a launch of its own (adam.hip launch_pre)."""
     from pyvbmc_amd.minimize_adam import minimize_adam_elbo
 
     wl = synthetic.make_workload(5, S=shape["S"], D=shape["D"], K=shape["K"], N=shape["N"],

@@ -303,3 +303,24 @@ def test_small_batches_take_the_small_kernels(ctx, low_noise):
     yb = vp.pdf(big, orig_flag=False, log_flag=True)
     ys = vp.pdf(big[:1000], orig_flag=False, log_flag=True)
     assert rel_err(ys, yb[:1000]) < 1e-13
+
+
+def test_empty_row_slice_contributes_zero(ctx):
+    """A rank whose slice of the antithetic rows is empty (n_half < world, or rows=(b, 0)): every entropy workgroup's
+    partial row must still be WRITTEN -- as zeros -- because the finish kernel sums all of them (the
+    wave-split kernel's chunk mode skipped an empty chunk and left stale scratch rows behind)."""
+    from pyvbmc_amd import entmc_vbmc
+
+    wl, wd = case(6, 20, 30, 4000)
+    vp, _ = objects(wd, ctx)
+    # a full evaluation first: the scratch rows of the next launch then hold this one's values
+    _, _, full = entmc_vbmc(vp, wl.NsK, (True,) * 4, True, rng="philox", seed=3, return_raw=True)
+    assert np.abs(full).max() > 0
+    for begin in (0, 7, wl.NsK // 2):
+        _, _, raw = entmc_vbmc(vp, wl.NsK, (True,) * 4, True, rng="philox", seed=3, return_raw=True, rows=(begin, 0))
+        assert np.array_equal(raw, np.zeros_like(raw)), (begin, np.abs(raw).max())
+    # and the two halves still add up to the whole
+    h = wl.NsK // 2
+    _, _, a = entmc_vbmc(vp, wl.NsK, (True,) * 4, True, rng="philox", seed=3, return_raw=True, rows=(0, h // 3))
+    _, _, b = entmc_vbmc(vp, wl.NsK, (True,) * 4, True, rng="philox", seed=3, return_raw=True, rows=(h // 3, h - h // 3))
+    assert rel_err(a + b, full) < 1e-13

@@ -123,3 +123,63 @@ def test_repeat_path_is_the_general_path_bit_for_bit(ctx, golden):
     # and the sequence is not constant (the changes were seen at all)
     assert len({r[0] for r in fast}) >= 10
     philox_seed(ctx)
+
+
+def test_side_effects_with_and_without_the_release_callback(ctx, golden):
+    """``vp.set_parameters(theta)``'s side effects are applied by a callback the library makes once its launches are out
+    (vbmc_set_release_callback) or, with VBMC_RELEASE_CB=0, after the C call: same values either way, also through the
+    W_GP_CHANGED re-evaluation; and a vp that refuses an assignment raises in both (ctypes swallows exceptions raised
+    inside a callback: the mirror then applies -- and raises -- after the call)."""
+    from pyvbmc_amd import variational_optimization as vo
+
+    g = golden("c1")
+    wl = synthetic.make_workload(1, S=1)
+    bnd = synthetic.default_theta_bnd(wl)
+    th0 = g["theta_out"].copy()
+
+    def run(cb):
+        vo._RELEASE_CB = cb
+        vo._fast_last[0] = None
+        for k in ("_fused_last", "_fused_cache"):
+            ctx.__dict__.pop(k, None)
+        gp = PlainGP(oracle_gp(g, g["hyp"][:1]))
+        vp = PlainVP(g)
+        out = []
+        for i in range(3):
+            th = th0 + 1e-2 * i
+            r = vo._neg_elcbo(th, gp, vp, 0.0, 40, True, False, bnd, rng="philox", seed=5 + i)
+            out.append((r[0], r[1].copy(), th.copy(), vp.mu.copy(), vp.sigma.copy(), vp.lambd.copy(), vp.w.copy(), vp.eta.copy()))
+        gp.posteriors[0].alpha[2, 0] *= 1.0 + 1e-3  # in place: the library answers W_GP_CHANGED, the mirror re-evaluates
+        th = th0.copy()
+        r = vo._neg_elcbo(th, gp, vp, 0.0, 40, True, False, bnd, rng="philox", seed=9)
+        out.append((r[0], r[1].copy(), th.copy(), vp.mu.copy(), vp.sigma.copy(), vp.lambd.copy(), vp.w.copy(), vp.eta.copy()))
+
+        class Refusing(PlainVP):
+            __slots__ = ()
+
+            def __setattr__(self, name, value):
+                if name == "sigma" and getattr(self, "armed", False):
+                    raise RuntimeError("no")
+                object.__setattr__(self, name, value)
+
+            armed = False
+
+        bad = Refusing(g)
+        Refusing.armed = True
+        try:
+            with pytest.raises(RuntimeError):
+                vo._neg_elcbo(th0.copy(), gp, bad, 0.0, 40, True, False, bnd, rng="philox", seed=10)
+        finally:
+            Refusing.armed = False
+        return out
+
+    try:
+        on, off = run(True), run(False)
+    finally:
+        vo._RELEASE_CB = True
+        vo._fast_last[0] = None
+        for k in ("_fused_last", "_fused_cache"):
+            ctx.__dict__.pop(k, None)
+    for i, (a, b) in enumerate(zip(on, off)):
+        for x, y in zip(a, b):
+            assert np.array_equal(np.asarray(x), np.asarray(y)), i

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """When does the finish launch publish its completion word, and when does its last workgroup end?
 (library built with SRC=entropy.hip tools/gp_variants.sh fin "-DFIN_TIMES")
-    VBMC_HIP_LIB=variants/libvbmc_fin.so [VBMC_AHEAD_MODE=..] python tools/fin_times.py"""
+    VBMC_HIP_LIB=variants/libvbmc_fin.so python tools/fin_times.py"""
 import ctypes as C
 import sys
 from pathlib import Path
