@@ -31,6 +31,12 @@ class NoDeviceError(VbmcHipError):
     pass
 
 
+class UnsupportedShape(NotImplementedError):
+    """VBMC_E_UNSUP: a shape the kernels do not cover (D > 32, a GP too large for the LDS plans ...).  A
+    ``NotImplementedError`` -- there is no CPU fallback inside this package -- that ``pyvbmc_amd.patch`` recognises:
+    under the drop-in such a call goes back to the reference callable it replaced (pyvbmc_amd/dropin.py)."""
+
+
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
 
@@ -224,7 +230,7 @@ class Context:
         if rc != 0:
             msg = (self._lib.vbmc_last_error(self._h) or b"").decode()
             if rc == E_UNSUP:
-                raise NotImplementedError(msg)
+                raise UnsupportedShape(msg)
             if rc == E_ARG:
                 raise ValueError(msg)
             if rc == E_NODEV:

@@ -19,17 +19,44 @@ with the same names):
 
 Everything falls back to the per-call path when a precondition of the batched / device-resident
 form does not hold (Monte-Carlo entropy in the sieve, a variance term, candidates that differ in a
-block that is not optimised, an objective that is not that closure).  ``unpatch(vo)`` restores the
+block that is not optimised, an objective that is not that closure).  A shape the kernels do not cover
+at all (``_lib.UnsupportedShape``: D > 32 -- the reference's loops take any D,
+entropy/entmc_vbmc.py:64-112 -- or a GP beyond the LDS plans) goes back to the REFERENCE callable
+``patch`` replaced, with the reference's own arguments: the drop-in never turns a run the reference could do
+into an error, and never routes anywhere but to the reference's own code.  ``unpatch(vo)`` restores the
 module.  Nothing here imports the reference: ``vo`` is passed in (or imported on request).
 """
 import numpy as np
 
+from . import _lib
 from . import entropy as _entropy
 from . import minimize_adam as _adam
 from . import variational_optimization as _avo
 
 _SAVED = "_pyvbmc_amd_saved"
 _LEAVES = ("entmc_vbmc", "entlb_vbmc", "_gp_log_joint", "_neg_elcbo")
+
+
+_MIRROR_ONLY_KW = ("rng", "seed", "eps_half", "ctx", "rows", "return_raw")  # keyword-only extras of the mirrors
+
+
+def _with_reference_fallback(fast, ref):
+    """``fast`` with ``ref`` -- the reference callable of the same name -- behind it for shapes the device path
+    does not cover.  The mirrors raise before they have touched ``vp`` (the C call fails while planning; the reference's
+    in-place max-shift of theta's eta tail is idempotent), so the reference simply starts over."""
+
+    def call(*a, **kw):
+        try:
+            return fast(*a, **kw)
+        except _lib.UnsupportedShape:
+            for k in _MIRROR_ONLY_KW:
+                kw.pop(k, None)
+            return ref(*a, **kw)
+
+    call.__name__ = getattr(fast, "__name__", "call")
+    call.__doc__ = getattr(fast, "__doc__", None)
+    call.__wrapped__ = fast
+    return call
 
 
 def _apply_vp_side_effects(vp0, theta):
@@ -101,9 +128,13 @@ def make_sieve(vo, ref_sieve, batch_eval=None):
             order = np.argsort(F)
             return (vp0_vec[order], vp0_type[order]) + tuple(out[2:])
         thetas = np.stack([t for t, _ in rec])
+        F = None
         if _same_fixed_blocks(vps):
-            F = np.asarray(batch_eval(thetas, state["gp"], vps[0], state["bnd"]), dtype=np.float64)
-        else:  # candidates differ in a block the batched call would take from one vp: one call each
+            try:
+                F = np.asarray(batch_eval(thetas, state["gp"], vps[0], state["bnd"]), dtype=np.float64)
+            except _lib.UnsupportedShape:
+                F = None  # a shape the batch kernels do not cover: one call each (which routes on to the reference)
+        if F is None:  # candidates differ in a block the batched call would take from one vp: one call each
             F = np.array([real(t.copy(), state["gp"], v, 0, 0, 0, False, state["bnd"])[0] for t, v in rec])
         order = np.argsort(F)  # (:789-792)
         return (vp0_vec[order], vp0_type[order]) + tuple(out[2:])
@@ -140,11 +171,14 @@ def make_minimize_adam(vo, loop=None):
                       master_decay=200, use_early_stopping=True):
         parts = _objective_parts(f)
         # the device loop evaluates the MIRROR's objective: only when the module still routes there
-        if parts is not None and vo._neg_elcbo is _avo._neg_elcbo:
+        if parts is not None and getattr(vo._neg_elcbo, "__wrapped__", vo._neg_elcbo) is _avo._neg_elcbo:
             gp, vp0, beta, ns, compute_var, theta_bnd = parts
             if ns > 0 and not compute_var and (not beta or not np.isfinite(beta)):
-                return loop(np.array(x0, dtype=np.float64), gp, vp0, ns, theta_bnd, 0.0, lb, ub, tol_fun, max_iter,
-                            master_min, master_max, master_decay, use_early_stopping)
+                try:
+                    return loop(np.array(x0, dtype=np.float64), gp, vp0, ns, theta_bnd, 0.0, lb, ub, tol_fun, max_iter,
+                                master_min, master_max, master_decay, use_early_stopping)
+                except _lib.UnsupportedShape:
+                    pass  # the host loop below around f, whose _neg_elcbo routes on to the reference
         return _adam.minimize_adam(f, x0, lb, ub, tol_fun, max_iter, master_min, master_max, master_decay,
                                    use_early_stopping)
 
@@ -164,8 +198,10 @@ def patch(vo=None, sieve=True, adam=True, _batch_eval=None, _loop=None):
         unpatch(vo)
     saved = {n: getattr(vo, n) for n in _LEAVES + ("_sieve", "minimize_adam") if hasattr(vo, n)}
     setattr(vo, _SAVED, saved)
-    vo.entmc_vbmc, vo.entlb_vbmc = _entropy.entmc_vbmc, _entropy.entlb_vbmc
-    vo._gp_log_joint, vo._neg_elcbo = _avo._gp_log_joint, _avo._neg_elcbo
+    mirrors = {"entmc_vbmc": _entropy.entmc_vbmc, "entlb_vbmc": _entropy.entlb_vbmc,
+               "_gp_log_joint": _avo._gp_log_joint, "_neg_elcbo": _avo._neg_elcbo}
+    for n, fast in mirrors.items():
+        setattr(vo, n, _with_reference_fallback(fast, saved[n]) if callable(saved.get(n)) else fast)
     if sieve and "_sieve" in saved:
         vo._sieve = make_sieve(vo, saved["_sieve"], _batch_eval)
     if adam and "minimize_adam" in saved:
