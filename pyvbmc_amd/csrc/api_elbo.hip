@@ -200,12 +200,25 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   // time-out -- which every device-wide wait elsewhere in the process (another library's hipFree,
   // process teardown) then has to sit through.  So: no arming after an evaluation of more than
   // ARM_MAX_EVAL_US, and the wait is capped whatever the evaluation took.
-  constexpr double ARM_MAX_EVAL_US = 1000.0, ARM_MAX_LIMIT_MS = 2.5;
-  const bool arm_next = can_poll && !multi && ctx->opt_elbo_arm && ctx->opt_mix_bar && !ctx->timing &&
+  // And not on a device this context shares: a prep kernel that polls for its go word holds workgroup slots and makes
+  // every device-wide wait of another user sit through its time-out.  By default (elbo_arm = 1) evaluations are armed
+  // only while this is the process's only context on the device; elbo_arm = 2 arms regardless (a user who knows the GPU
+  // is theirs although several contexts exist), 0 never.  Other processes cannot be seen from here: for them the
+  // device-side wait is short -- ARM_DEVICE_WAIT_MS, 30 host turnarounds -- where rounds 2-4 waited 2 to 5 ms.
+  constexpr double ARM_MAX_EVAL_US = 1000.0, ARM_LIMIT_MS = 0.3, ARM_DEVICE_WAIT_MS = 0.5;
+  const bool arm_allowed = ctx->opt_elbo_arm >= 2 || (ctx->opt_elbo_arm == 1 && vbmc_live_contexts_on(ctx->device) <= 1);
+  const bool arm_next = can_poll && !multi && arm_allowed && ctx->opt_mix_bar && !ctx->timing &&
                         opts->eps_mode == VBMC_EPS_PHILOX && ctx->host_us[4] <= ARM_MAX_EVAL_US;
-  // an armed evaluation is used within max(1 ms, 2.5 x the last evaluation's duration) -- at most
-  // ARM_MAX_LIMIT_MS -- of its arming; its prep kernel waits twice that before it gives up by itself
-  const double arm_limit_ms = std::min(ARM_MAX_LIMIT_MS, std::max(1.0, 2.5e-3 * ctx->host_us[4]));
+  // The host's clock for an armed evaluation starts when it is queued, i.e. at the start of THIS evaluation; the armed
+  // prep kernel's own clock starts when it starts to run, i.e. when this evaluation's launches are through.  The host
+  // therefore uses an armed evaluation within (this evaluation's expected duration + ARM_LIMIT_MS) of arming -- the
+  // optimiser comes back 20-100 us after the result -- and treats a go word written later than ARM_LATE_SLACK_MS after
+  // that as late (drain and re-evaluate); the device gives up ARM_DEVICE_WAIT_MS after it started waiting.  Should this
+  // evaluation end much earlier than the last one did, the device may give up first: it says so (the dead word) and the
+  // evaluation is redone unarmed -- slower, never wrong.
+  constexpr double ARM_LATE_SLACK_MS = 0.15;
+  const double arm_limit_ms = 1e-3 * ctx->host_us[4] + ARM_LIMIT_MS;
+  static_assert(ARM_LIMIT_MS + ARM_LATE_SLACK_MS < ARM_DEVICE_WAIT_MS, "the host's cut-off must come before the device's");
 
   // Plan and queue the launches of ONE evaluation with Philox seed `seed`.  spin = false: for this
   // call's theta (the pack is in ctx->h_pack); spin = true: armed -- the prep kernel waits for the
@@ -294,7 +307,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
       __builtin_ia32_sfence();
       pa.go = ctl;
       pa.go_seq = seq_out;
-      pa.go_timeout = (uint64_t)(2.0 * arm_limit_ms * 1e5);  // ticks of 10 ns
+      pa.go_timeout = (uint64_t)(ARM_DEVICE_WAIT_MS * 1e5);  // ticks of 10 ns
       pa.dead = ctx->hd_done + 5;
       plan.a.cancel = ctl;
     }
@@ -376,7 +389,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
       ctx->pack_valid = true;
       sp.armed = false;
       const bool force_late = ctx->opt_arm_late_test > 0 && --ctx->opt_arm_late_test == 0;  // test hook
-      if (!force_late && std::chrono::duration<double, std::milli>(clk::now() - sp.t_armed).count() < 1.5 * sp.limit_ms) {
+      if (!force_late && std::chrono::duration<double, std::milli>(clk::now() - sp.t_armed).count() < sp.limit_ms + ARM_LATE_SLACK_MS) {
         ++sp.hits;
         used_armed = true;
         polled = true;
@@ -384,7 +397,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
         check_ident = sp.ident;
         HSTAMP(1);
       } else {
-        // This thread lost the CPU between the age check and the go word: the prep kernel's 2 ms
+        // This thread lost the CPU between the age check and the go word: the prep kernel's
         // time-out may have fired around the same moment.  Whatever ran is discarded: drain the
         // queue, clear the completion counters, put the speculative-draw bookkeeping back to what it
         // was before arming (still true: that evaluation only READ the draws it was planned on)

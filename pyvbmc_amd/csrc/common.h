@@ -192,7 +192,9 @@ struct vbmc_ctx {
   int opt_adam_tail = 1;      // the optimiser loop at large sample counts as two launches per iteration (adam.hip adam_tail_kernel)
   int opt_ident_test = 0;     // test hook: n > 0 = the n-th identity check from now fails (the recovery path runs)
   bool ident_retry = false;   // inside the re-evaluation after a failed identity check
-  int opt_elbo_arm = 1;     // queue the next host-driven evaluation's launches ahead of its theta (armed evaluation)
+  int opt_elbo_arm = 1;     // queue the next host-driven evaluation's launches ahead of its theta (armed evaluation): 0 never, 1 while
+                            // this context is the only one on its device in the process, 2 always
+  bool counted = false;     // this context is in the per-device count of live contexts (ctx.hip)
   int opt_ws_span = 1;      // entropy kernel: span mode (entropy_args.h WsSpan: front / filler parts sized to end together); 0 = equal chunks
   int opt_ws_front = 0;     // span mode: the front workgroup's share of a CU's batches, per mille (0 = the built-in value)
   int opt_ws_pad = -1;      // span mode: padding slots behind every component (-1 = the built-in value)
@@ -221,6 +223,7 @@ struct vbmc_ctx {
   void* adam = nullptr;  // device-resident optimiser state (adam.hip)
   void* acq_is = nullptr;  // resident importance-sampling state of AcqFcnVIQR / IMIQR (api_acq_is.hip)
 };
+int vbmc_live_contexts_on(int device);  // ctx.hip
 void adam_free(vbmc_ctx* ctx);
 void acq_is_free(vbmc_ctx* ctx);
 

@@ -51,6 +51,11 @@ int ensure_pinned(vbmc_ctx* ctx, size_t n) {
   return 0;
 }
 
+// live contexts per device in this process (the armed evaluation is for a context that has its device to itself)
+#include <atomic>
+static std::atomic<int> g_live_ctx[64];
+int vbmc_live_contexts_on(int device) { return device >= 0 && device < 64 ? g_live_ctx[device].load() : 2; }
+
 static void options_from_env(vbmc_ctx* c) {
   const char* e = getenv("VBMC_ENTMC_KERNEL");
   c->opt_entmc_valu = (e && e[0] == 'v') ? 1 : 0;  // VBMC_ENTMC_KERNEL=valu
@@ -59,7 +64,7 @@ static void options_from_env(vbmc_ctx* c) {
   e = getenv("VBMC_ELBO_AHEAD");
   c->opt_elbo_ahead = !(e && e[0] == '0');
   e = getenv("VBMC_ELBO_ARM");
-  c->opt_elbo_arm = !(e && e[0] == '0');
+  c->opt_elbo_arm = e ? atoi(e) : 1;  // 0 off; 1 (default) when this context is the only one on its device; 2 always
   e = getenv("VBMC_ACQ_POLL");
   c->opt_acq_poll = !(e && e[0] == '0');
   e = getenv("VBMC_ADAM_FUSED");
@@ -140,6 +145,8 @@ int vbmc_ctx_create(int device_id, vbmc_ctx** out) {
     vbmc_ctx_destroy(ctx);
     return rc;
   }
+  if (device_id < 64) g_live_ctx[device_id].fetch_add(1);
+  ctx->counted = true;
   *out = ctx;
   return VBMC_OK;
 }
@@ -150,6 +157,7 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
     delete ctx;
     return;
   }
+  if (ctx->counted && ctx->device < 64) g_live_ctx[ctx->device].fetch_sub(1);
   (void)hipSetDevice(ctx->device);
   spec_disarm(ctx);
   if (getenv("VBMC_DEBUG_ARM")) fprintf(stderr, "[vbmc] armed evaluations: %llu used, %llu cancelled\n", (unsigned long long)ctx->spec.hits, (unsigned long long)ctx->spec.cancels);
@@ -222,7 +230,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "ws_span")) ctx->opt_ws_span = value != 0;
   else if (!strcmp(key, "ws_pad")) ctx->opt_ws_pad = value > 8 ? 8 : value;
   else if (!strcmp(key, "ws_front")) ctx->opt_ws_front = value < 0 ? 0 : value > 990 ? 990 : value;
-  else if (!strcmp(key, "elbo_arm")) ctx->opt_elbo_arm = value != 0;
+  else if (!strcmp(key, "elbo_arm")) ctx->opt_elbo_arm = value < 0 ? 0 : value > 2 ? 2 : value;  // 1: only while this context is alone on its device; 2: always
   else if (!strcmp(key, "acq_poll")) ctx->opt_acq_poll = value != 0;
   else if (!strcmp(key, "adam_tail")) ctx->opt_adam_tail = value;  // the optimiser loop's two-launch iteration (adam.hip)
   else if (!strcmp(key, "adam_fused")) ctx->opt_adam_fused = value;  // 2: test hook, see FusedArgs::test_absent; 3: release / acquire flags (FusedArgs::rel_acq)

@@ -425,6 +425,66 @@ def test_armed_evaluation_cancel_paths(ctx):
             assert F == F0 and G == G0 and H == H0 and np.array_equal(dF, dF0), (arm, disturb, i)
 
 
+def test_armed_evaluation_on_a_shared_device(ctx):
+    """Arming is for a context that has its device to itself.  With a second context alive on
+    the same device the default (`elbo_arm` = 1) does not arm at all; forced (`elbo_arm` = 2) it does, and what the other
+    context then pays for a device-wide wait -- freeing a buffer makes the runtime wait for every queue, the armed prep
+    kernel's included -- is bounded by that kernel's own 0.5 ms time-out (rounds 2-4: 2 to 5 ms)."""
+    import time
+
+    from pyvbmc_amd import _lib
+    from pyvbmc_amd.variational_optimization import _neg_elcbo
+
+    wl = synthetic.make_workload(3, S=1, N=120)
+    g = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,
+             s2=wl.s2 if wl.s2 is not None else np.zeros(0))
+    gp = make_gp(g, ctx, wl.hyp)
+    vp = make_vp(g, ctx)
+    th0 = vp.get_parameters()
+    NsK = 2 * 64 * 9
+
+    def evals(n, seed0):
+        out = []
+        for i in range(n):
+            out.append(_neg_elcbo(th0 + 1e-3 * i, gp, vp, 0.0, NsK, True, False, None, rng="philox", seed=seed0 + i)[0])
+        return out
+
+    def hits(n, seed0):
+        h0 = ctx.armed_stats()["hits"]
+        vals = evals(n, seed0)
+        return ctx.armed_stats()["hits"] - h0, vals
+
+    alone, v_alone = hits(10, 100)
+    assert alone >= 8, alone  # this context alone: consecutive seeds are armed evaluations
+    other = _lib.Context(ctx.device)
+    try:
+        shared, v_shared = hits(10, 100)
+        assert shared == 0, shared  # default: no arming beside another context
+        assert v_shared == v_alone  # (same values either way)
+        ctx.set_option("elbo_arm", 2)
+        forced, v_forced = hits(10, 100)
+        assert forced >= 8 and v_forced == v_alone
+        # the other context's device-wide wait while an evaluation of ours sits armed
+        def grow_and_free():
+            big = np.zeros((2, 64, 4))
+            t = []
+            for rep in range(6):
+                evals(3, 300 + 10 * rep)  # leaves an armed evaluation waiting for its theta
+                t0 = time.perf_counter()
+                other.set_eps(np.zeros((2, 64 * (rep + 2), 4)))  # a larger buffer: the old one is freed (device-wide wait)
+                t.append(time.perf_counter() - t0)
+            return float(np.median(t))
+        t_armed = grow_and_free()
+        ctx.set_option("elbo_arm", 0)
+        t_plain = grow_and_free()
+        assert t_armed - t_plain <= 0.9e-3, (t_armed, t_plain)  # <= the 0.5 ms device-side wait (+ noise); was 2-5 ms
+    finally:
+        ctx.set_option("elbo_arm", 1)
+        other.close()
+    again, _ = hits(10, 100)
+    assert again >= 8  # alone again: armed again
+
+
 def test_armed_evaluation_soak(ctx):
     """VBMC_SOAK_S seconds (default 60) of evaluations with seeds that repeat, jump and follow on, other
     entry points, pauses and stream waits thrown in at random -- under a CPU hog: a busy process pinned
