@@ -79,7 +79,7 @@ def parse():
     p.add_argument("--cpu-sample-nsk", type=int, default=0,
                    help="per-component samples of the CPU-baseline run (0 = a sample sized for ~10-30 s of "
                         "host work: the whole workload at configs 2 and 3, a fifth of it at config 5)")
-    p.add_argument("--cpu-reps", type=int, default=2)
+    p.add_argument("--cpu-reps", type=int, default=3, help="CPU-baseline runs; the MEDIAN is reported (SURVEY 8d: median of >= 3)")
     return p.parse_args()
 
 
@@ -92,7 +92,7 @@ def algorithmic_flops(D, K, ns_rows_total, grad=True):
     return float(f)
 
 
-def cpu_baseline(wl, sample_nsk, reps=2):
+def cpu_baseline(wl, sample_nsk, reps=3):
     """The oracle (a NumPy port structurally identical to the reference's loops)
     timed on a bounded sample of the same workload on this box's host cores."""
     from oracle import elbo_ref, gp_ref, mixture_ref
@@ -109,7 +109,7 @@ def cpu_baseline(wl, sample_nsk, reps=2):
         t0 = time.perf_counter()
         elbo_ref.neg_elcbo(wl.theta.copy(), ogp, mix, 0.0, sample_nsk, True, False, bnd, eps_half=eps)
         dts.append(time.perf_counter() - t0)
-    dt = min(dts)
+    dt = float(np.median(dts))
     scale = wl.NsK / sample_nsk  # cost is linear in the sample count (entropy > 99 %)
     # threads actually used: process CPU time over wall time (NumPy's element-wise kernels, which
     # dominate this path exactly as in the reference, run on one thread whatever the core count)
@@ -125,7 +125,7 @@ def cpu_baseline(wl, sample_nsk, reps=2):
         "cores": cores,
         "kind": "port",
         "sample": f"{len(dts)} value+grad evals at NsK={sample_nsk} per component ({sample_nsk * wl.K} samples; "
-                  f"{', '.join('%.2f' % t for t in dts)} s, best taken)"
+                  f"{', '.join('%.2f' % t for t in dts)} s, median taken)"
                   + (f", scaled x{scale:.1f} to NsK={wl.NsK}" if scale != 1.0 else "")
                   + f"; NumPy default threading, {busy:.2f} threads busy on average of {avail} available",
     }
@@ -469,9 +469,14 @@ def main():
     flops = algorithmic_flops(D, K, ns_job / world, grad=True)  # per launch (this rank's rows)
     achieved = flops / (k_ms * 1e-3) / 1e12
     achieved_e2e = flops / (ms_per_step * 1e-3) / 1e12
-    # the draws the entropy kernel reads: resident, or (Philox mode) generated into HBM ahead of it
-    # -- unless VBMC_ELBO_PREGEN=0 keeps the generation inside the entropy kernel
-    eps_bytes = (ns_job / world / 2) * D * 8 if plan["resident_draws"] else 0.0
+    # Algorithmic HBM bytes of the entropy launch: the antithetic half of the draws when they are INPUT
+    # (--rng resident: parity mode), ~0 with the device generator.  What the step really moves in Philox mode is reported
+    # beside it (step_hbm_bytes): the generator writes the draws into HBM one evaluation ahead and the kernel reads them
+    # back -- traffic the implementation adds, hidden behind a compute-bound kernel but not algorithmic.
+    draws_bytes = (ns_job / world / 2) * D * 8
+    eps_bytes = draws_bytes if (plan["resident_draws"] and a.rng == "resident") else 0.0
+    step_hbm_bytes = {"generator_writes": draws_bytes if a.rng == "philox" and plan["resident_draws"] else 0.0,
+                      "entropy_kernel_reads": draws_bytes if plan["resident_draws"] else 0.0}
     traffic, traffic_from = None, None
     try:  # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc passes, see profiles/README.md)
         tj = json.load(open(ROOT / "profiles" / "traffic.json"))
@@ -536,6 +541,7 @@ def main():
                               f"timed steps ({m['n_kern']} launches)",
             "algorithmic_flops_per_launch": flops,
             "hbm_bytes_per_launch_algorithmic": eps_bytes,
+            "step_hbm_bytes": step_hbm_bytes,
             "hbm_achieved_GBs": (eps_bytes / (k_ms * 1e-3) / 1e9) if eps_bytes else 0.0,
             "hbm_peak_GBs": HBM_PEAK_GBS,
         },

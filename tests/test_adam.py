@@ -624,7 +624,7 @@ def test_fused_loop_soak_is_deterministic(ctx):
     th2 = threading.Thread(target=disturb)
     th2.start()
     first, n_runs, n_iter, n_fallback = {}, 0, 0, 0
-    soak_s = float(os.environ.get("VBMC_FUSED_SOAK_S", "30"))
+    soak_s = float(os.environ.get("VBMC_FUSED_SOAK_S", "10"))
     t0 = time.time()
     try:
         while time.time() - t0 < soak_s and not err:
