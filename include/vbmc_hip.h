@@ -282,6 +282,19 @@ int vbmc_set_eps(vbmc_ctx* ctx, int K, int64_t n_half, int D, const double* eps_
 int vbmc_mt19937_randn(uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out,
                        int64_t n, int n_threads);
 
+/* The same stream generated on the DEVICE (csrc/device_randn.hip: MT19937 with a GF(2) jump-ahead per workgroup, the
+ * polar method's attempts as position-pure work items, a prefix sum over the accepted pairs) and copied to `out`.
+ * Words, accept / reject decisions and the state handed back are bit-identical to np.random.randn's; the values use the
+ * device's log and agree with NumPy's to one unit in the last place.  What vbmc_set_eps_numpy uses (without the copy)
+ * when the context holds all rows.  Reference: entropy/entmc_vbmc.py:64-68. */
+int vbmc_mt19937_randn_dev(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out,
+                           int64_t n);
+/* Host twins of that jump for the CPU tests: the MT19937 block that starts n_words (>= 1) words after key_in[0], by the
+ * polynomial t^(n_words-1) mod the characteristic polynomial (found by Berlekamp-Massey, csrc/mt_jump.h); and the
+ * polynomials t^(m stride - 1), m = 1 .. count, as [count][624] words. */
+int vbmc_mt_jump_host(const uint32_t* key_in, uint64_t n_words, uint32_t* key_out);
+int vbmc_mt_jump_polys(uint64_t stride_words, int count, uint32_t* out);
+
 /* vbmc_mt19937_randn + vbmc_set_eps in one call: the next K*n_half*D values of NumPy's legacy
  * stream (= np.random.randn(n_half, D) for j = 0..K-1, the reference's draw order) are generated
  * into a pinned buffer the ctx keeps and rows [row_begin, +row_count) of every component are

@@ -93,6 +93,12 @@ SIGNATURES = {
         C.c_int,
         [C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp, C.c_int64, C.c_int],
     ),
+    "vbmc_mt19937_randn_dev": (
+        C.c_int,
+        [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp, C.c_int64],
+    ),
+    "vbmc_mt_jump_host": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32)]),
+    "vbmc_mt_jump_polys": (C.c_int, [C.c_uint64, C.c_int, C.POINTER(C.c_uint32)]),
     "vbmc_set_eps_numpy": (
         C.c_int,
         [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_int, C.c_int64, C.c_int,

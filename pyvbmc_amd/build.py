@@ -32,6 +32,7 @@ SOURCES = [
     "sample.hip",
     "comm.hip",
     "host_randn.hip",
+    "device_randn.hip",
 ]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [

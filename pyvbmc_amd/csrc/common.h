@@ -222,10 +222,16 @@ struct vbmc_ctx {
   ElboScratch elbo;      // api_elbo.hip
   void* adam = nullptr;  // device-resident optimiser state (adam.hip)
   void* acq_is = nullptr;  // resident importance-sampling state of AcqFcnVIQR / IMIQR (api_acq_is.hip)
+  void* randn_dev = nullptr;  // buffers of the device-side NumPy stream (device_randn.hip)
+  int opt_randn_dev = 1;      // vbmc_set_eps_numpy: the reference's stream generated on the device (0: on the host cores + PCIe)
 };
 int vbmc_live_contexts_on(int device);  // ctx.hip
 void adam_free(vbmc_ctx* ctx);
 void acq_is_free(vbmc_ctx* ctx);
+void randn_dev_free(vbmc_ctx* ctx);
+// device_randn.hip: the next n values of NumPy's legacy randn stream into d_out (device memory), state advanced as
+// vbmc_mt19937_randn does; VBMC_W_NOT_FUSED = not this path's size (the caller uses the host generator)
+int randn_device(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double* gauss, double* d_out, int64_t n);
 
 // error helpers -----------------------------------------------------------
 int vbmc_fail(vbmc_ctx* ctx, int code, const char* fmt, ...);

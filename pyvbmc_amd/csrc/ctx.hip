@@ -69,6 +69,8 @@ static void options_from_env(vbmc_ctx* c) {
   c->opt_acq_poll = !(e && e[0] == '0');
   e = getenv("VBMC_ADAM_FUSED");
   c->opt_adam_fused = e ? atoi(e) : 1;  // (3: the release / acquire form of its exchange)
+  e = getenv("VBMC_RANDN_DEVICE");
+  c->opt_randn_dev = !(e && e[0] == '0');
   e = getenv("VBMC_ADAM_TAIL");
   c->opt_adam_tail = e ? atoi(e) : 1;  // (2: wherever its shape applies, whatever the job's size)
   e = getenv("VBMC_WS_SPAN");
@@ -166,6 +168,7 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   vbmc_comm_destroy(ctx);
   adam_free(ctx);
   acq_is_free(ctx);
+  randn_dev_free(ctx);
   double* bufs[] = {ctx->d_mix, ctx->d_mix_fg, ctx->d_acq_fg, ctx->d_stage, ctx->d_eps, ctx->d_scratch, ctx->d_out, ctx->gp.d_X, ctx->gp.d_XT,
                     ctx->gp.d_alpha, ctx->gp.d_L, ctx->gp.d_Linv, ctx->gp.d_LinvP, ctx->gp.d_sW, ctx->gp.d_hyp,
                     ctx->gp.d_xc, ctx->gp.d_smeta};
@@ -232,6 +235,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "ws_front")) ctx->opt_ws_front = value < 0 ? 0 : value > 990 ? 990 : value;
   else if (!strcmp(key, "elbo_arm")) ctx->opt_elbo_arm = value < 0 ? 0 : value > 2 ? 2 : value;  // 1: only while this context is alone on its device; 2: always
   else if (!strcmp(key, "acq_poll")) ctx->opt_acq_poll = value != 0;
+  else if (!strcmp(key, "randn_device")) ctx->opt_randn_dev = value != 0;  // vbmc_set_eps_numpy: the NumPy stream on the device (device_randn.hip)
   else if (!strcmp(key, "adam_tail")) ctx->opt_adam_tail = value;  // the optimiser loop's two-launch iteration (adam.hip)
   else if (!strcmp(key, "adam_fused")) ctx->opt_adam_fused = value;  // 2: test hook, see FusedArgs::test_absent; 3: release / acquire flags (FusedArgs::rel_acq)
   else return vbmc_fail(ctx, VBMC_E_ARG, "vbmc_set_option: unknown key '%s'", key);
@@ -605,6 +609,26 @@ int vbmc_set_eps_numpy(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, d
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // every rank draws the whole job's values (the reference's stream has one order) and ships its rows
   const size_t n_all = (size_t)K * (size_t)n_half * (size_t)D;
+  {
+    const bool whole = row_begin == 0 && row_count == n_half && n_all > 0;
+    if (whole) {
+      const int erc = ensure_dev(ctx, &ctx->d_eps, &ctx->d_eps_cap, n_all);
+      if (erc) return erc;
+    }
+  if (whole && ctx->opt_randn_dev && n_all >= ((size_t)1 << 16) && ctx->world == 1) {
+      // the stream generated where it is consumed (device_randn.hip): no host cores, no PCIe
+      const int drc = randn_device(ctx, key, pos, has_gauss, gauss, ctx->d_eps, (int64_t)n_all);
+      if (drc != VBMC_W_NOT_FUSED) {
+        if (drc) return drc;
+        ctx->eps_K = K;
+        ctx->eps_D = D;
+        ctx->eps_rows = row_count;
+        ctx->eps_row_begin = row_begin;
+        ctx->eps_n_half = n_half;
+        return VBMC_OK;
+      }
+    }
+  }
   if (ctx->h_eps_cap < n_all || !ctx->h_eps) {
     if (ctx->h_eps) {
       HIP_TRY(ctx, stream_wait(ctx));

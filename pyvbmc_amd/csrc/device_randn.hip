@@ -1,0 +1,552 @@
+// The reference's draw stream, generated on the device: the next n values of np.random.randn (reference
+// entropy/entmc_vbmc.py:64-68 -- NumPy's legacy global RandomState: MT19937 words -> 53-bit uniforms -> Marsaglia's
+// polar method with its cached second value) written straight into HBM, and the state NumPy would be left in handed
+// back.  The drop-in's default (rng="numpy") then needs neither the host cores (csrc/host_randn.hip: 3 ms for config
+// 3's 5e6 normals on 64 cores, 48 ms with np.random.randn itself) nor 40 MB over PCIe per evaluation.
+//
+// MT19937 is sequential only in its recurrence; S streams of J = 80 blocks (49 920 words) run side by side once every
+// stream has its first block, and that block is a jump over GF(2) (mt_jump.h): each of its 624 words is the XOR of the
+// ~10 000 words x_(1+i+j), g_i = 1, of ONE window of 20 560 words behind the current state, the same for all streams.
+//   mt_window_kernel   one workgroup: the window, by the plain recurrence (33 blocks)
+//   mt_stream_kernel<false>  workgroup m: jump to block m * 80 (window in LDS, the polynomial's exponents through scalar loads), store that
+//                      state, then its blocks by the recurrence, 40 at a time in LDS, and the number of accepted polar
+//                      attempts among the attempts that START in its words (attempt t reads stream words
+//                      [pos + 4 t, pos + 4 t + 4) whether it is accepted or not: csrc/host_randn.hip)
+//   mt_scan_kernel     exclusive prefix sum of the S counts
+//   mt_values_kernel   workgroup m again from its stored state: ranks of its accepted attempts by a block scan, the
+//                      pair (f x2, f x1), f = sqrt(-2 log(r2) / r2), written where it belongs; the workgroup that holds
+//                      the request's last pair hands back the block and position NumPy's state ends at and that
+//                      attempt's (x1, x2, r2) -- the cached second value is then formed on the HOST with libm, so the
+//                      state handed back to NumPy is bit-identical to the one np.random.randn leaves.
+// Integer stream, accept / reject decisions, counts and final state: bit-exact.  Values: NumPy's expression, IEEE
+// multiply / divide / sqrt, and a logarithm rounded from a double-double value (mt_log_dd) -- neither it nor glibc's log
+// is correctly rounded everywhere, so about one value in a thousand differs from np.random.randn's by one to three units
+// in the last place; tests/test_device_randn.py says so.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "common.h"
+#include "mt_jump.h"
+
+namespace {
+
+constexpr int MT_N = 624, MT_M = 397;
+constexpr int BLK_PER_STREAM = 80, BLK_PER_PASS = 40;
+constexpr int J_WORDS = BLK_PER_STREAM * MT_N;                    // 49 920
+constexpr int WIN_WORDS = 33 * MT_N;                               // x_0 .. x_20591 (x_1 .. x_20560 are used)
+constexpr int PASS_WORDS = (BLK_PER_PASS + 1) * MT_N;              // 25 584 words = 102 KB: the blocks of a pass
+constexpr int TAP_OFF = 33 * MT_N + 640;                           // (words) the jump's exponent list behind the window and its zero block
+constexpr int LDS_WORDS = TAP_OFF + 19968 / 2;                     // 31 216 words = 125 KB
+constexpr int NT = 1024;
+constexpr int TAP_U = 16;                  // LDS reads in flight per thread in the jump
+constexpr int TAP_STRIDE = 19968;          // entries per polynomial: 19 937 rounded up to a multiple of TAP_U
+constexpr int TAP_PAD = WIN_WORDS;         // exponent whose window words are zeros (sm[1 + TAP_PAD + j], j < 624)
+static_assert(LDS_WORDS >= PASS_WORDS && TAP_OFF >= WIN_WORDS + MT_N + 1, "LDS plan");
+static_assert(TAP_STRIDE % TAP_U == 0 && TAP_PAD < 65536 && TAP_U == 16, "tap list layout");
+
+__device__ __forceinline__ uint32_t mt_twist(uint32_t hi, uint32_t lo) {
+  const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+  return (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+}
+// d = the block after s (both in LDS; all NT threads call it)
+__device__ __forceinline__ void mt_next_block_lds(const uint32_t* s, uint32_t* d) {
+  const int i = threadIdx.x;
+  if (i < MT_N - MT_M) d[i] = s[i + MT_M] ^ mt_twist(s[i], s[i + 1]);
+  __syncthreads();
+  if (i >= MT_N - MT_M && i < 2 * (MT_N - MT_M)) d[i] = d[i - (MT_N - MT_M)] ^ mt_twist(s[i], s[i + 1]);
+  __syncthreads();
+  if (i >= 2 * (MT_N - MT_M) && i < MT_N - 1) d[i] = d[i - (MT_N - MT_M)] ^ mt_twist(s[i], s[i + 1]);
+  __syncthreads();
+  if (i == MT_N - 1) d[i] = d[MT_M - 1] ^ mt_twist(s[MT_N - 1], d[0]);
+  __syncthreads();
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+__device__ __forceinline__ double mt_double(uint32_t w0, uint32_t w1) {
+  const int32_t a = (int32_t)(mt_temper(w0) >> 5), b = (int32_t)(mt_temper(w1) >> 6);
+  return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+// legacy_gauss's loop body on four consecutive words (host twin: host_randn.hip attempt_at); contraction is off
+__device__ __forceinline__ bool mt_attempt(const uint32_t* u, double& x1, double& x2, double& r2) {
+  x1 = 2.0 * mt_double(u[0], u[1]) - 1.0;
+  x2 = 2.0 * mt_double(u[2], u[3]) - 1.0;
+  r2 = x1 * x1 + x2 * x2;
+  return !(r2 >= 1.0 || r2 == 0.0);
+}
+
+// ln(x) for normal x > 0, rounded from a double-double value: within ~0.001 ulp of the exact value before the final
+// rounding, i.e. the correctly rounded result for all but ~0.2 % of the arguments (those whose logarithm lies that close to
+// a rounding boundary).  glibc's log (NumPy's) is that good too and misses the correctly rounded result in ~0.06 % -- so
+// the two differ, by one unit in the last place, in about one draw of 500, which f = sqrt(-2 l / r2) and the product f x
+// turn into one to three units (measured: 99.9 % of 1.2e6 values bit-identical, 1 061 / 200 / 1 off by 1 / 2 / 3 ulp).
+// The device library's own log (<= 1 ulp) left a tenth of the values off.
+//   x = 2^e m, m in [sqrt(1/2), sqrt(2));  ln m = 2 atanh(s), s = (m - 1) / (m + 1) as head + tail
+__device__ __forceinline__ double mt_log_dd(double x) {
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  if (m < 0x1.6a09e667f3bcdp-1) {
+    m *= 2.0;
+    e -= 1;
+  }
+  const double num = m - 1.0;          // exact
+  const double dh = m + 1.0;           // head of m + 1 ...
+  const double dl = m - (dh - 1.0);    // ... and its tail (exact: fast two-sum, |m| <= 2)
+  const double sh = num / dh;
+  const double res = fma(-sh, dh, num);               // num - sh dh, exact
+  const double sl = (res - sh * dl) / dh;              // tail of the quotient
+  const double u = sh * sh;
+  double p = 1.0 / 27.0;
+  p = fma(p, u, 1.0 / 25.0);
+  p = fma(p, u, 1.0 / 23.0);
+  p = fma(p, u, 1.0 / 21.0);
+  p = fma(p, u, 1.0 / 19.0);
+  p = fma(p, u, 1.0 / 17.0);
+  p = fma(p, u, 1.0 / 15.0);
+  p = fma(p, u, 1.0 / 13.0);
+  p = fma(p, u, 1.0 / 11.0);
+  p = fma(p, u, 1.0 / 9.0);
+  p = fma(p, u, 1.0 / 7.0);
+  p = fma(p, u, 1.0 / 5.0);
+  p = fma(p, u, 1.0 / 3.0);
+  const double tail = fma(sh * u, p, sl);  // s^3/3 + s^5/5 + ... + the quotient's tail
+  const double A = 2.0 * sh, B = 2.0 * tail;
+  const double ed = (double)e;
+  const double L1 = ed * 0x1.62e42fefa38p-1;            // e * ln2_hi: exact (ln2_hi has 11 trailing zero bits)
+  const double L2 = ed * 0x1.ef35793c7673p-45;           // e * ln2_lo
+  // (L1 + A) as head + tail (two-sum), then everything small
+  const double S = L1 + A;
+  const double bb = S - L1;
+  const double Sl = (L1 - (S - bb)) + (A - bb);
+  return S + (Sl + (B + L2));
+}
+
+struct RandnArgs {
+  const uint32_t* key;   // [624] the current block
+  uint32_t* win;         // [WIN_WORDS]
+  const uint16_t* taps;  // [S - 1][TAP_STRIDE]: the set exponents of G_m, m = 1 .., padded with TAP_PAD
+  const int* n_taps;     // [S - 1]: entries used of each list (a multiple of TAP_U)
+  uint32_t* states;      // [S][624]
+  unsigned long long* counts;  // [S + 1]: accepted attempts per stream, then (after the scan) exclusive prefix sums; [S] = total
+  int S;
+  int pos0;               // NumPy's position inside the current block (0 .. 624)
+  long long attempts;     // attempts the streams cover: t < attempts
+  long long pairs;        // accepted attempts to consume
+  long long rest;         // values to write (2 pairs or 2 pairs - 1)
+  double* out;            // first value's address
+  // hand-back (written by the workgroup that holds the last pair)
+  uint32_t* end_key;      // [624]
+  long long* end_info;    // [0] word index behind the last attempt (pos0 + 4 (t_end + 1)), [1] 1 = written
+  double* end_vals;       // x1, x2, r2 of the last attempt
+};
+
+__global__ __launch_bounds__(NT) void mt_window_kernel(RandnArgs a) {
+  extern __shared__ uint32_t sm[];
+  for (int i = threadIdx.x; i < MT_N; i += NT) sm[i] = a.key[i];
+  __syncthreads();
+  for (int b = 1; b < WIN_WORDS / MT_N; ++b) mt_next_block_lds(sm + (b - 1) * MT_N, sm + b * MT_N);
+  for (int i = threadIdx.x; i < WIN_WORDS; i += NT) a.win[i] = sm[i];
+}
+
+// The stream's first block into sm[0 .. 624): the key itself (m = 0), the jump (COUNT pass), or the stored state.
+__device__ __forceinline__ void stream_start(const RandnArgs& a, int m, bool from_states, uint32_t* sm) {
+  const int tid = threadIdx.x;
+  if (m == 0) {
+    for (int i = tid; i < MT_N; i += NT) sm[i] = a.key[i];
+    __syncthreads();
+    return;
+  }
+  if (from_states) {
+    for (int i = tid; i < MT_N; i += NT) sm[i] = a.states[(size_t)m * MT_N + i];
+    __syncthreads();
+    return;
+  }
+  for (int i = tid; i < WIN_WORDS; i += NT) sm[i] = a.win[i];
+  for (int i = WIN_WORDS + tid; i < WIN_WORDS + MT_N + 1; i += NT) sm[i] = 0;  // what the padding taps read
+  __syncthreads();
+  // x_(m J + j) = XOR_{i : g_i} x_(1 + i + j), j < 624.  The polynomial comes as the list of its set exponents (16-bit,
+  // padded to a multiple of TAP_U with the exponent of a block of zeros) and is staged in LDS; per step a thread reads 16
+  // exponents (broadcast) and has 32 independent window reads in flight.  Measured on the way: walking the bits of the
+  // polynomial's words, one dependent read at a time: 400 us per jump; the list read from memory inside the loop: 230;
+  // from LDS, one word per thread on 10 waves: 150; two words per thread on 15 waves (below): ~100 -- the LDS-bandwidth
+  // floor of 6.2e6 four-byte reads per jump is 80.
+  uint32_t acc = 0;
+  const int n_tap = a.n_taps[m - 1];  // multiple of TAP_U
+  {
+    // the list into LDS first (40 KB; read from memory inside the loop, every step waited ~0.3 us for its 32 bytes)
+    const uint32_t* tg = (const uint32_t*)(a.taps + (size_t)(m - 1) * TAP_STRIDE);
+    for (int i = tid; i < n_tap / 2; i += NT) sm[TAP_OFF + i] = tg[i];
+  }
+  __syncthreads();
+  // three groups of 312 threads, a third of the exponents each, two words (j, j + 312) per thread: 15 of the 16 waves
+  // read LDS (one word per thread over all exponents kept 10 waves busy at half the LDS rate)
+  constexpr int GRP = MT_N / 2, NGRP = 3;
+  const int grp = tid / GRP, j = tid - grp * GRP;
+  uint32_t acc1 = 0;
+  if (grp < NGRP) {
+    const uint32_t* base = sm + 1 + j;
+    const uint4* tl = (const uint4*)(sm + TAP_OFF);
+    const int steps = n_tap / TAP_U;
+    for (int t = grp; t < steps; t += NGRP) {
+      const uint4 p0 = tl[2 * t], p1 = tl[2 * t + 1];  // 16 exponents, the same for every thread of the group (broadcast reads)
+      const uint32_t pw[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+      uint32_t v[TAP_U], w[TAP_U];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t* r0 = base + (pw[q] & 0xFFFFu);
+        const uint32_t* r1 = base + (pw[q] >> 16);
+        v[2 * q] = r0[0];
+        w[2 * q] = r0[GRP];
+        v[2 * q + 1] = r1[0];
+        w[2 * q + 1] = r1[GRP];
+      }
+#pragma unroll
+      for (int q = 0; q < TAP_U; ++q) {
+        acc ^= v[q];
+        acc1 ^= w[q];
+      }
+    }
+  }
+  __syncthreads();  // every read of the window is done: the partial sums go where the exponent list was
+  uint32_t* part = sm + TAP_OFF;
+  if (grp < NGRP) {
+    part[grp * MT_N + j] = acc;
+    part[grp * MT_N + GRP + j] = acc1;
+  }
+  __syncthreads();
+  if (tid < MT_N) {
+    const uint32_t x = part[tid] ^ part[MT_N + tid] ^ part[2 * MT_N + tid];
+    sm[tid] = x;
+    a.states[(size_t)m * MT_N + tid] = x;
+  }
+  __syncthreads();
+}
+
+// Attempts that start in stream m: t in [t_lo, t_hi) with pos0 + 4 t in [m J, (m + 1) J), t < attempts.
+__device__ __forceinline__ void stream_attempts(const RandnArgs& a, int m, long long& t_lo, long long& t_hi) {
+  const long long w_lo = (long long)m * J_WORDS, w_hi = w_lo + J_WORDS;
+  t_lo = w_lo <= a.pos0 ? 0 : (w_lo - a.pos0 + 3) / 4;
+  t_hi = w_hi <= a.pos0 ? 0 : (w_hi - a.pos0 + 3) / 4;
+  if (t_hi > a.attempts) t_hi = a.attempts;
+  if (t_lo > t_hi) t_lo = t_hi;
+}
+
+template <bool VALUES>
+__global__ __launch_bounds__(NT) void mt_stream_kernel(RandnArgs a) {
+  extern __shared__ uint32_t sm[];
+  __shared__ unsigned long long s_red[NT / 64];
+  __shared__ unsigned long long s_scan[NT / 64];
+  __shared__ int s_end_blk;
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  long long t_lo, t_hi;
+  stream_attempts(a, m, t_lo, t_hi);
+  unsigned long long base_pair = VALUES ? a.counts[m] : 0;  // accepted attempts in front of this stream
+  if (VALUES && (t_lo >= t_hi || (long long)base_pair >= a.pairs)) return;  // nothing of the request lies here
+  if (tid == 0) s_end_blk = -1;
+  stream_start(a, m, VALUES, sm);
+  unsigned long long total = 0;
+  for (int pass = 0; pass < BLK_PER_STREAM / BLK_PER_PASS; ++pass) {
+    // blocks [pass * PB, pass * PB + PB] of the stream (one more than the pass owns: an attempt may straddle into it)
+    if (pass > 0) {
+      for (int i = tid; i < MT_N; i += NT) sm[i] = sm[BLK_PER_PASS * MT_N + i];
+      __syncthreads();
+    }
+    for (int b = 1; b <= BLK_PER_PASS; ++b) mt_next_block_lds(sm + (b - 1) * MT_N, sm + b * MT_N);
+    // this pass's attempts: first word in [w0, w0 + PB * 624) of the block sequence
+    const long long w0 = (long long)m * J_WORDS + (long long)pass * BLK_PER_PASS * MT_N, w1 = w0 + (long long)BLK_PER_PASS * MT_N;
+    long long p_lo = w0 <= a.pos0 ? 0 : (w0 - a.pos0 + 3) / 4, p_hi = w1 <= a.pos0 ? 0 : (w1 - a.pos0 + 3) / 4;
+    p_lo = p_lo < t_lo ? t_lo : p_lo;
+    p_hi = p_hi > t_hi ? t_hi : p_hi;
+    const int n_att = p_hi > p_lo ? (int)(p_hi - p_lo) : 0;
+    // a contiguous chunk of attempts per thread (ranks then follow attempt order)
+    const int per = (n_att + NT - 1) / NT;
+    const int c0 = min(tid * per, n_att), c1 = min(c0 + per, n_att);
+    int cnt = 0;
+    for (int c = c0; c < c1; ++c) {
+      const long long t = p_lo + c;
+      const uint32_t* u = sm + (int)(a.pos0 + 4 * t - w0);
+      double x1, x2, r2;
+      cnt += mt_attempt(u, x1, x2, r2) ? 1 : 0;
+    }
+    if (!VALUES) {
+      unsigned long long v = (unsigned long long)cnt;
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) s_red[wave] = v;
+      __syncthreads();
+      if (tid == 0)
+        for (int q = 0; q < NT / 64; ++q) total += s_red[q];
+      __syncthreads();
+    } else {
+      // exclusive scan of the per-thread counts over the workgroup
+      unsigned long long v = (unsigned long long)cnt, incl = v;
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+      }
+      if (lane == 63) s_red[wave] = incl;
+      __syncthreads();
+      if (tid == 0) {
+        unsigned long long run = 0;
+        for (int q = 0; q < NT / 64; ++q) {
+          s_scan[q] = run;
+          run += s_red[q];
+        }
+        s_red[0] = run;  // the pass's total
+      }
+      __syncthreads();
+      unsigned long long p = base_pair + s_scan[wave] + (incl - v);
+      const unsigned long long pass_total = s_red[0];
+      for (int c = c0; c < c1; ++c) {
+        const long long t = p_lo + c;
+        const int off = (int)(a.pos0 + 4 * t - w0);
+        double x1, x2, r2;
+        if (!mt_attempt(sm + off, x1, x2, r2)) continue;
+        if ((long long)p < a.pairs) {
+          const double f = sqrt(-2.0 * mt_log_dd(r2) / r2);  // (division and square root are correctly rounded on the device too)
+          const long long o = 2 * (long long)p;
+          a.out[o] = f * x2;
+          if (o + 1 < a.rest) a.out[o + 1] = f * x1;
+          if ((long long)p == a.pairs - 1) {  // the request's last pair: what NumPy's state ends at
+            a.end_vals[0] = x1;
+            a.end_vals[1] = x2;
+            a.end_vals[2] = r2;
+            a.end_info[0] = a.pos0 + 4 * (t + 1);
+            s_end_blk = (off + 3) / MT_N;  // the block (of this pass's buffer) holding the last word read
+          }
+        }
+        ++p;
+      }
+      __syncthreads();
+      if (s_end_blk >= 0) {
+        for (int i = tid; i < MT_N; i += NT) a.end_key[i] = sm[s_end_blk * MT_N + i];
+        __syncthreads();
+        if (tid == 0) {
+          __threadfence();
+          a.end_info[1] = 1;
+        }
+        return;
+      }
+      base_pair += pass_total;
+      if ((long long)base_pair >= a.pairs) return;
+    }
+  }
+  if (!VALUES && tid == 0) a.counts[m] = total;
+}
+
+__global__ __launch_bounds__(256) void mt_scan_kernel(RandnArgs a) {
+  // exclusive prefix sum of the S counts by one workgroup: a contiguous chunk per thread, then a scan of the 256 chunk sums
+  __shared__ unsigned long long s_w[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (a.S + 255) / 256;
+  const int c0 = min(tid * per, a.S), c1 = min(c0 + per, a.S);
+  unsigned long long sum = 0;
+  for (int m = c0; m < c1; ++m) sum += a.counts[m];
+  unsigned long long incl = sum;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  unsigned long long run = incl - sum;
+  for (int q = 0; q < wave; ++q) run += s_w[q];
+  for (int m = c0; m < c1; ++m) {
+    const unsigned long long c = a.counts[m];
+    a.counts[m] = run;
+    run += c;
+  }
+  if (tid == 255) a.counts[a.S] = run;
+}
+
+struct RandnDev {
+  uint32_t* d_key = nullptr;
+  uint32_t* d_win = nullptr;
+  uint16_t* d_taps = nullptr;
+  int* d_ntaps = nullptr;
+  int poly_count = 0;  // polynomials on the device (G_1 .. G_count)
+  uint32_t* d_states = nullptr;
+  unsigned long long* d_counts = nullptr;
+  int cap_S = 0;
+  uint32_t* d_end_key = nullptr;
+  long long* d_end_info = nullptr;
+  double* d_end_vals = nullptr;
+  uint32_t* h_stage = nullptr;  // pinned: key up (624), then end_key (624) | end_info (2 x 8 B) | end_vals (3 x 8 B) | total (8 B) down
+  std::vector<uint32_t> polys;  // host copy
+};
+
+RandnDev* randn_of(vbmc_ctx* ctx) {
+  if (!ctx->randn_dev) ctx->randn_dev = new RandnDev();
+  return (RandnDev*)ctx->randn_dev;
+}
+
+}  // namespace
+
+void randn_dev_free(vbmc_ctx* ctx) {
+  RandnDev* r = (RandnDev*)ctx->randn_dev;
+  if (!r) return;
+  void* bufs[] = {r->d_key, r->d_win, r->d_taps, r->d_ntaps, r->d_states, r->d_counts, r->d_end_key, r->d_end_info, r->d_end_vals};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (r->h_stage) (void)hipHostFree(r->h_stage);
+  delete r;
+  ctx->randn_dev = nullptr;
+}
+
+// n values of the stream into d_out (device memory), state advanced.  VBMC_W_NOT_FUSED: not applicable (the caller
+// takes the host generator).
+int randn_device(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double* gauss, double* d_out, int64_t n) {
+  if (!key || !pos || !has_gauss || !gauss || n < 0 || *pos < 0 || *pos > MT_N) return VBMC_E_ARG;
+  if (n == 0) return VBMC_OK;
+  RandnDev* r = randn_of(ctx);
+  hipStream_t sm = ctx->stream;
+  int64_t produced = 0;
+  if (*has_gauss) {
+    HIP_TRY(ctx, hipMemcpyAsync(d_out, gauss, sizeof(double), hipMemcpyHostToDevice, sm));
+    HIP_TRY(ctx, hipStreamSynchronize(sm));
+    produced = 1;
+    *has_gauss = 0;
+    *gauss = 0.0;
+  }
+  const int64_t rest = n - produced;
+  if (rest == 0) return VBMC_OK;
+  const int64_t pairs = (rest + 1) / 2;
+  const double expect = (double)pairs / 0.7853981633974483;
+  const int64_t attempts_need = (int64_t)(expect + 6.0 * std::sqrt(expect) + 64.0);
+  const int pos0 = *pos;
+  const int64_t words = (int64_t)pos0 + 4 * attempts_need + 4;
+  const int64_t S64 = (words + J_WORDS - 1) / J_WORDS;
+  if (S64 > 16384) return VBMC_W_NOT_FUSED;  // (> 8e8 words: not this path's size)
+  const int S = (int)S64;
+  const int64_t attempts = ((int64_t)S * J_WORDS - pos0 - 3) / 4;  // every attempt whose four words the streams hold... of stream S-1's extra block too
+  // ---- polynomials (once per process and size) ----
+  if (r->poly_count < S - 1) {
+    const int want = std::max(S - 1, 255);
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    int nthreads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    if (!mtj::jump_polys((uint64_t)J_WORDS, want, nthreads, r->polys)) return vbmc_fail(ctx, VBMC_E_HIP, "randn: MT19937's characteristic polynomial was not found");
+    // the polynomials as lists of their set exponents
+    std::vector<uint16_t> taps((size_t)want * TAP_STRIDE, (uint16_t)TAP_PAD);
+    std::vector<int> ntaps(want);
+    for (int m = 0; m < want; ++m) {
+      const uint32_t* g = r->polys.data() + (size_t)m * MT_N;
+      uint16_t* tp = taps.data() + (size_t)m * TAP_STRIDE;
+      int n = 0;
+      for (int i = 0; i < mtj::DEG; ++i)
+        if ((g[i >> 5] >> (i & 31)) & 1u) tp[n++] = (uint16_t)i;
+      ntaps[m] = (n + TAP_U - 1) / TAP_U * TAP_U;
+    }
+    if (r->d_taps) HIP_TRY(ctx, hipFree(r->d_taps));
+    if (r->d_ntaps) HIP_TRY(ctx, hipFree(r->d_ntaps));
+    r->d_taps = nullptr;
+    r->d_ntaps = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&r->d_taps, sizeof(uint16_t) * taps.size()));
+    HIP_TRY(ctx, hipMalloc((void**)&r->d_ntaps, sizeof(int) * (size_t)want));
+    HIP_TRY(ctx, hipMemcpy(r->d_taps, taps.data(), sizeof(uint16_t) * taps.size(), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(r->d_ntaps, ntaps.data(), sizeof(int) * (size_t)want, hipMemcpyHostToDevice));
+    r->poly_count = want;
+  }
+  if (!r->d_key) {
+    HIP_TRY(ctx, hipMalloc((void**)&r->d_key, sizeof(uint32_t) * MT_N));
+    HIP_TRY(ctx, hipMalloc((void**)&r->d_win, sizeof(uint32_t) * WIN_WORDS));
+    HIP_TRY(ctx, hipMalloc((void**)&r->d_end_key, sizeof(uint32_t) * MT_N));
+    HIP_TRY(ctx, hipMalloc((void**)&r->d_end_info, sizeof(long long) * 2));
+    HIP_TRY(ctx, hipMalloc((void**)&r->d_end_vals, sizeof(double) * 4));
+    HIP_TRY(ctx, hipHostMalloc((void**)&r->h_stage, sizeof(uint32_t) * 2 * MT_N + 64, hipHostMallocDefault));
+    const size_t lds = sizeof(uint32_t) * LDS_WORDS;
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)mt_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)mt_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)mt_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  if (r->cap_S < S) {
+    if (r->d_states) HIP_TRY(ctx, hipFree(r->d_states));
+    if (r->d_counts) HIP_TRY(ctx, hipFree(r->d_counts));
+    r->d_states = nullptr;
+    r->d_counts = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&r->d_states, sizeof(uint32_t) * (size_t)S * MT_N));
+    HIP_TRY(ctx, hipMalloc((void**)&r->d_counts, sizeof(unsigned long long) * ((size_t)S + 1)));
+    r->cap_S = S;
+  }
+  std::memcpy(r->h_stage, key, sizeof(uint32_t) * MT_N);
+  HIP_TRY(ctx, hipMemcpyAsync(r->d_key, r->h_stage, sizeof(uint32_t) * MT_N, hipMemcpyHostToDevice, sm));
+  HIP_TRY(ctx, hipMemsetAsync(r->d_end_info, 0, sizeof(long long) * 2, sm));
+  RandnArgs a;
+  a.key = r->d_key;
+  a.win = r->d_win;
+  a.taps = r->d_taps;
+  a.n_taps = r->d_ntaps;
+  a.states = r->d_states;
+  a.counts = r->d_counts;
+  a.S = S;
+  a.pos0 = pos0;
+  a.attempts = attempts;
+  a.pairs = pairs;
+  a.rest = rest;
+  a.out = d_out + produced;
+  a.end_key = r->d_end_key;
+  a.end_info = r->d_end_info;
+  a.end_vals = r->d_end_vals;
+  const size_t lds = sizeof(uint32_t) * LDS_WORDS;
+  hipLaunchKernelGGL(mt_window_kernel, dim3(1), dim3(NT), lds, sm, a);
+  hipLaunchKernelGGL(mt_stream_kernel<false>, dim3(S), dim3(NT), lds, sm, a);
+  hipLaunchKernelGGL(mt_scan_kernel, dim3(1), dim3(256), 0, sm, a);
+  hipLaunchKernelGGL(mt_stream_kernel<true>, dim3(S), dim3(NT), lds, sm, a);
+  HIP_TRY(ctx, hipGetLastError());
+  // hand-back: end block, word index, the last attempt's numbers, the total
+  uint32_t* h_end_key = r->h_stage + MT_N;
+  long long* h_info = (long long*)(r->h_stage + 2 * MT_N);
+  double* h_vals = (double*)(h_info + 2);
+  unsigned long long* h_total = (unsigned long long*)(h_vals + 3);
+  HIP_TRY(ctx, hipMemcpyAsync(h_end_key, r->d_end_key, sizeof(uint32_t) * MT_N, hipMemcpyDeviceToHost, sm));
+  HIP_TRY(ctx, hipMemcpyAsync(h_info, r->d_end_info, sizeof(long long) * 2, hipMemcpyDeviceToHost, sm));
+  HIP_TRY(ctx, hipMemcpyAsync(h_vals, r->d_end_vals, sizeof(double) * 3, hipMemcpyDeviceToHost, sm));
+  HIP_TRY(ctx, hipMemcpyAsync(h_total, r->d_counts + S, sizeof(unsigned long long), hipMemcpyDeviceToHost, sm));
+  HIP_TRY(ctx, stream_wait(ctx));
+  if ((int64_t)*h_total < pairs || h_info[1] != 1)
+    return vbmc_fail(ctx, VBMC_E_HIP, "randn: %lld accepted attempts for %lld pairs (6 sigma margin exceeded)", (long long)*h_total, (long long)pairs);
+  const int64_t w = h_info[0];            // word index behind the final attempt, >= 4
+  const int64_t b = (w - 1) / MT_N;       // the block holding the last word read
+  if (b > 0) std::memcpy(key, h_end_key, sizeof(uint32_t) * MT_N);
+  *pos = (int)(w - b * MT_N);
+  if (rest & 1) {
+    // NumPy's cached second value, with the host's libm: bit-identical to what legacy_gauss would hold
+    const double r2 = h_vals[2];
+    const double f = std::sqrt(-2.0 * std::log(r2) / r2);
+    *has_gauss = 1;
+    *gauss = f * h_vals[0];
+  }
+  return VBMC_OK;
+}
+
+extern "C" int vbmc_mt19937_randn_dev(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out,
+                                       int64_t n) {
+  if (!ctx || (n > 0 && !out)) return VBMC_E_ARG;
+  NEED_DEVICE(ctx);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_dev(ctx, &ctx->d_scratch, &ctx->d_scratch_cap, (size_t)n + 2);
+  if (rc) return rc;
+  rc = randn_device(ctx, key, pos, has_gauss, gauss, ctx->d_scratch, n);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpy(out, ctx->d_scratch, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  return VBMC_OK;
+}
+
+// host twin of the jump (CPU tests): key_out = the block that starts n_words words after key_in[0]
+extern "C" int vbmc_mt_jump_host(const uint32_t* key_in, uint64_t n_words, uint32_t* key_out) {
+  if (!key_in || !key_out || n_words < 1) return VBMC_E_ARG;
+  return mtj::jump_host(key_in, n_words, key_out) ? VBMC_OK : VBMC_E_HIP;
+}
+// the polynomial chain the device uses, for the same tests: out[count][624]
+extern "C" int vbmc_mt_jump_polys(uint64_t stride_words, int count, uint32_t* out) {
+  if (!out || count < 1) return VBMC_E_ARG;
+  std::vector<uint32_t> v;
+  if (!mtj::jump_polys(stride_words, count, 8, v)) return VBMC_E_HIP;
+  std::memcpy(out, v.data(), sizeof(uint32_t) * v.size());
+  return VBMC_OK;
+}

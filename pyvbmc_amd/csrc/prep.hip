@@ -30,7 +30,6 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
 #ifdef FIN_TIMES
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_prep_times[2 + (g_prep_times[0]++ & 63)] = wall_clock64();
 #endif
-  const int D = a.ml.D, K = a.ml.K;
   const int tid = threadIdx.x;
   if (a.gen.n_blocks > 0 && (int)blockIdx.x >= a.n_table + a.n_glj && (int)blockIdx.x < a.n_table + a.n_glj + a.gen.n_blocks) {
     // ---- draw-generation block (philox.h): depends on the seed only, never waits for theta ----
