@@ -187,11 +187,13 @@ def test_multibatch_vs_oracle(ctx, D, K, rg, draws, ws_mode):
                                         (20, 72, "mfma"), (20, 90, "mfma"), (20, 60, "mfma"), (20, 97, "mfma"), (20, 120, "mfma"), (18, 100, "mfma"),
                                         (16, 100, "mfma"), (13, 44, "mfma"), (16, 40, "ws"), (24, 60, "mfma"), (32, 100, "mfma"), (29, 48, "mfma"),
                                         (10, 100, "mfma"), (9, 90, "mfma"), (12, 120, "mfma"), (11, 60, "mfma"), (11, 50, "ws")])
-def test_every_register_array_size_vs_oracle(ctx, D, K, kernel):
+def test_every_register_array_size_vs_oracle(ctx, D, K, kernel, ws_mode):
     """One case per register-array size of the wave-split kernel (4, 8, 10, 13, 16, 20, 25, 32 components
     per wave: the table is padded to the array size with zero-density components, entropy_args.h) and
     per padded D (12 with tables 10 and 12 wide, 16, 20, 24, 32) and k-tile count (3 to 8) of the matrix-pipe form,
     K NOT a multiple of the array size: H and every gradient entry against the oracle, several batches per workgroup."""
+    if kernel == "mfma" and ws_mode == "chunks":
+        pytest.skip("the matrix-pipe form has no span mode: the same launch as the [span] case")
     from pyvbmc_amd import VariationalPosterior, entmc_vbmc
 
     cus = ctx.device_info()["cu_count"]
