@@ -37,10 +37,6 @@ __device__ __forceinline__ void entmc_finish_body(const double* __restrict__ par
       return;
     }
   }
-#ifndef FIN_NO_PRIO
-  // the reduction's waves before the draw generator's on every SIMD they share: the completion word is on the step's path
-  if (gen.n_blocks > 0) __builtin_amdgcn_s_setprio(3);
-#endif
   const double* w = mix + ml.o_w;
   const double* sig = mix + ml.o_sig;
   const double* ilam = mix + ml.o_ilam;
