@@ -770,13 +770,14 @@ static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool
   // cost): jobs of at least 250 000 antithetic rows.  Option "adam_tail" = 2 forces it wherever its shape applies (tests).
   const bool try_tail = ctx->opt_adam_tail && !multi && st->tail_ok &&
                         (ctx->opt_adam_tail == 2 || (int64_t)ctx->K * st->row_count >= 250000);
-  // GP items per workgroup of the entropy launch: two where the entropy parts run long enough to cover two items and the
-  // pre workgroup behind them (~25 us), one below that
+  // GP items per workgroup of the entropy launch: four where the entropy parts run long enough (>= ~60 us) to cover four
+  // items (28 us) and the pre workgroup behind them (10 us from LDS) -- 2 / 3 / 4 / 5 items: 91.6 / 91.2 / 90.4 / 96.0 us per
+  // iteration at config 3 --, one below that
   static const int gp_per_slot_env = [] {
     const char* e = getenv("VBMC_TAIL_GP_PER_SLOT");  // measurement aid
     return e ? atoi(e) : 0;
   }();
-  const int tail_gp_per_slot = gp_per_slot_env > 0 ? gp_per_slot_env : ((int64_t)ctx->K * st->row_count >= 250000 ? 2 : 1);
+  const int tail_gp_per_slot = gp_per_slot_env > 0 ? gp_per_slot_env : ((int64_t)ctx->K * st->row_count >= 250000 ? 4 : 1);
   for (int it = 0; it < n_iters; ++it) {
     PrepArgs pa;
     glj_fill_prep(ctx, 1, st->state + st->lay.o_res(), nullptr, pa);
