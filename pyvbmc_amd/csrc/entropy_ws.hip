@@ -121,8 +121,13 @@ __device__ unsigned long long g_ws_times[1024 * 4];  // per workgroup: start, ba
 #else
 #define WS_STAMP(i) (void)0
 #endif
-// EXACT (resident draws only): D == D_p and the draws are 16-byte aligned -- every even D; the host checks (launch_one)
-template <int DP, int KTMAX, bool GRAD, bool PHILOX, bool EXACT = false>
+// STAGE (resident draws only; the host chooses, launch_one): how a batch's 64 rows of draws -- one contiguous block of
+// 512 D bytes -- reach the waves.  1: D == D_p and 16-byte aligned (every even D): LDS-direct 16-byte loads one batch
+// ahead; 2: any D: the same with rows D doubles apart in LDS (16-byte loads when the block starts 16-byte aligned, else
+// 2 D instructions of 256 bytes);
+// 0: each wave fetches its rows itself with guarded loads (in-line Philox builds: unused)
+constexpr int ws_dprev(int dp) { return dp <= 12 ? dp - 2 : dp == 16 ? 12 : dp == 20 ? 16 : dp == 24 ? 20 : 24; }
+template <int DP, int KTMAX, bool GRAD, bool PHILOX, int STAGE = 0>
 __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_kernel(
     EntArgs a, const double* __restrict__ T) {
   constexpr int TS = DP + 6;
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   WS_STAMP(0);
-  constexpr bool eps_exact = !PHILOX && EXACT;
+  constexpr bool eps_exact = !PHILOX && STAGE != 0;
 
   double ec[EN];
   {
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   // LDS-direct copy of batch ib's rows into sE[buf]: D_p / 2 instructions of 1 KB, dealt over the waves.  The compiler
   // does not count these loads: the wave drains them (vmcnt) in front of the batch's barrier, one batch after issue.
   auto ws_fill = [&](int ib, int buf) {
-    if constexpr (!PHILOX) {
+    if constexpr (!PHILOX && STAGE == 1) {
       const char* base = (const char*)(a.eps + ((int64_t)j * a.eps_rows + ((int64_t)ib << 6)) * DP);
       const int64_t left = (a.row_count - ((int64_t)ib << 6)) * (DP * 8) - 16;  // last 16 bytes of the slice, relative
       const unsigned last = (unsigned)(left < 64 * DP * 8 - 16 ? left : 64 * DP * 8 - 16);
@@ -268,6 +273,29 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
         voff = voff < last ? voff : last;
         const unsigned dst = (unsigned)(uintptr_t)&sE[buf][0][0] + (unsigned)(c * 1024);
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(dst) : "memory");
+      }
+    } else if constexpr (!PHILOX && STAGE == 2) {
+      const char* base = (const char*)(a.eps + ((int64_t)j * a.eps_rows + ((int64_t)ib << 6)) * D);
+      const int64_t left = (a.row_count - ((int64_t)ib << 6)) * (int64_t)(D * 8);  // bytes of the slice from here on
+      const int blk = 64 * D * 8;
+      // 16-byte loads need the block's start AND its end on 16-byte boundaries (a lane's 16 bytes land at ITS LDS slot
+      // wherever they were read from: the clamped tail below cannot deliver a trailing half)
+      if ((((uintptr_t)base) & 15) == 0 && (left >= blk || (left >= 16 && (left & 15) == 0))) {
+        const unsigned last = (unsigned)((left < blk ? left : blk) - 16);
+        for (int c = wave; c < (D + 1) / 2; c += WAVES) {  // 1 KB per instruction
+          unsigned voff = (unsigned)(c * 1024 + lane * 16);
+          voff = voff < last ? voff : last;
+          const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)&sE[buf][0][0] + (unsigned)(c * 1024)));
+          asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(dst) : "memory");
+        }
+      } else {
+        const unsigned last = (unsigned)((left < blk ? left : blk) - 4);
+        for (int c = wave; c < 2 * D; c += WAVES) {  // 256 bytes per instruction
+          unsigned voff = (unsigned)(c * 256 + lane * 4);
+          voff = voff < last ? voff : last;
+          const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)&sE[buf][0][0] + (unsigned)(c * 256)));
+          asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(base), "s"(dst) : "memory");
+        }
       }
     }
   };
@@ -298,12 +326,22 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
         // wave's path, every row fetched once per workgroup instead of once per wave); rows beyond the slice hold
         // copies of its last 16 bytes -- they only have to be finite, every sum they enter is masked (valid) below
         if (it + 1 < n_it) ws_fill(ib0 + it + 1, (it + 1) & 1);
-        const double2* rp = (const double2*)&sE[it & 1][0][0] + lane * (DP / 2);
+        if constexpr (STAGE == 1) {
+          const double2* rp = (const double2*)&sE[it & 1][0][0] + lane * (DP / 2);
 #pragma unroll
-        for (int d = 0; d < DP / 2; ++d) {
-          const double2 v = rp[d];
-          e[2 * d] = v.x;
-          e[2 * d + 1] = v.y;
+          for (int d = 0; d < DP / 2; ++d) {
+            const double2 v = rp[d];
+            e[2 * d] = v.x;
+            e[2 * d + 1] = v.y;
+          }
+        } else {
+          // rows D doubles apart: D_p reads whatever D is (what lies behind a row is never used: dimensions >= D are set
+          // to zero; only those above the next smaller padded width can be >= D at all)
+          const double* rp = &sE[it & 1][0][0] + lane * D;
+#pragma unroll
+          for (int d = 0; d < DP; ++d) e[d] = rp[d];
+#pragma unroll
+          for (int d = ws_dprev(DP) + 1; d < DP; ++d) e[d] = d < D ? e[d] : 0.0;
         }
       } else if (valid) {
         const double* rp = a.eps + ((int64_t)j * a.eps_rows + i_loc) * D;
@@ -592,12 +630,12 @@ void launch_one(hipStream_t st, const EntArgs& a, const double* d_table, hipEven
     }                                                                                                     \
     hipExtLaunchKernelGGL(kern, grid, block, (std::uint32_t)lds, st, e0, e1, 0u, a, d_table);             \
   } while (0)
-  // resident draws of full-width rows arrive through LDS one batch ahead (EXACT)
+  // resident draws arrive through LDS one batch ahead: 16-byte loads for full-width aligned rows, 4-byte loads otherwise
   const bool exact = !philox && a.ml.D == DP && (DP % 2) == 0 && ((uintptr_t)a.eps & 15) == 0;
   if (a.want_grad) {
-    if (philox) VBMC_LAUNCH_WS(true, true, false); else if (exact) VBMC_LAUNCH_WS(true, false, true); else VBMC_LAUNCH_WS(true, false, false);
+    if (philox) VBMC_LAUNCH_WS(true, true, 0); else if (exact) VBMC_LAUNCH_WS(true, false, 1); else VBMC_LAUNCH_WS(true, false, 2);
   } else {
-    if (philox) VBMC_LAUNCH_WS(false, true, false); else if (exact) VBMC_LAUNCH_WS(false, false, true); else VBMC_LAUNCH_WS(false, false, false);
+    if (philox) VBMC_LAUNCH_WS(false, true, 0); else if (exact) VBMC_LAUNCH_WS(false, false, 1); else VBMC_LAUNCH_WS(false, false, 2);
   }
 #undef VBMC_LAUNCH_WS
 }
