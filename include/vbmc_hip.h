@@ -99,7 +99,10 @@ int vbmc_synchronize(vbmc_ctx* ctx);
 /* Switch the HIP event pair around the dominant kernels on or off (default: off).
  * A record between two dependent kernels puts a barrier packet into the queue, which
  * costs ~6 us per record on MI355X -- measurement harnesses switch it on for the
- * launches they want timed, production callers leave it off. */
+ * launches they want timed, production callers leave it off.
+ * on = 2 additionally records the pair around gp_predict's variance product (which = 5 below): those two records sit
+ * BETWEEN predict's launches and lengthen the interval which = 3 reports by their own ~12 us, so a harness reads
+ * which = 3 at on = 1 and which = 5 at on = 2. */
 int vbmc_set_timing(vbmc_ctx* ctx, int on);
 
 /* Duration in milliseconds of the most recent TIMED launch (vbmc_set_timing) of the
@@ -155,6 +158,10 @@ int vbmc_set_release_callback(vbmc_ctx* ctx, void (*fn)(void*), void* user);
  *   "predict_dma"  [VBMC_PREDICT_DMA]: 1 = gp_predict's variance product for batches of > 32
  *                  points on Cholesky samples runs in the LDS-direct kernel (default), 0 = the
  *                  plain 64 x 64-tile kernel (cross-check)
+ *   "predict_fused" [VBMC_PREDICT_FUSED_FINISH]: gp_predict's third stage (fmu / fs2 from the partial sums)
+ *                  in the LDS-direct product kernel's epilogue, by an arrival ticket per 64-point row tile --
+ *                  two launches instead of three, bit-identical results: 1 = where the product grid is one
+ *                  round of workgroups (default), 2 = always, 0 = never (the finish launch)
  *   "elbo_arm"     [VBMC_ELBO_ARM]: 1 = after a polled Philox evaluation the launches of the next one
  *                  (seed + 1, same shapes) are queued at once and wait on the device for the next
  *                  call's theta (default); any other use of the context cancels them.  Never after an

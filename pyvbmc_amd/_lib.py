@@ -255,8 +255,9 @@ class Context:
         self.check(self._lib.vbmc_synchronize(self._h))
 
     def set_timing(self, on):
-        """HIP event pair around the dominant kernels (off by default: each record costs ~6 us)."""
-        self.check(self._lib.vbmc_set_timing(self._h, 1 if on else 0))
+        """HIP event pair around the dominant kernels (off by default: each record costs ~6 us).  ``on=2`` also records
+        the pair around predict's variance product (``last_kernel_ms(5)``), which sits between predict's launches."""
+        self.check(self._lib.vbmc_set_timing(self._h, int(on) if on else 0))
 
     def set_option(self, key, value):
         """Per-context test / measurement switch (vbmc_set_option in include/vbmc_hip.h)."""

@@ -164,6 +164,8 @@ struct vbmc_ctx {
   size_t d_scratch_cap = 0;
   double* d_out = nullptr;  // small result vectors
   size_t d_out_cap = 0;
+  double* d_ptick = nullptr;  // predict: one arrival ticket (int) per 64-point row tile and GP sample (gp.hip, the fused finish)
+  size_t d_ptick_cap = 0;
   double* h_pinned = nullptr;  // pinned host staging for results (also written directly by kernels)
   double* h_eps = nullptr;     // pinned host buffer the reference-stream draws are generated into (vbmc_set_eps_numpy)
   size_t h_eps_cap = 0;
@@ -174,7 +176,7 @@ struct vbmc_ctx {
   bool pack_valid = false;     // d_mix holds the pack of the host copies (mu, sigma, lambd, w)
   bool defer_mix_upload = false;  // set_mixture_host packs but leaves the copy to upload_packed_mixture
   double* hp_dev = nullptr;    // device-side address of h_pinned (cached: the query is an API call)
-  bool timing = false;         // record the HIP event pair around the dominant kernel (vbmc_set_timing)
+  int timing = 0;              // 1: record the HIP event pair around the dominant kernel (vbmc_set_timing); 2: also the pair INSIDE predict
   double host_us[5] = {0, 0, 0, 0, 0};  // see vbmc_last_host_us
   double step_marks[4] = {0, 0, 0, 0};  // see vbmc_last_step_marks
   int gp_where = 0;  // where the GP sums of the launches issued last run: 0 prep launch, 1 finish launch, 2 entropy launch
@@ -184,6 +186,7 @@ struct vbmc_ctx {
   int opt_elbo_pregen = 1;  // Philox draws generated ahead of the entropy kernel
   int opt_elbo_ahead = 1;   // ... and those of seed+1 speculatively behind the finish kernel
   int opt_predict_dma = 1;  // predict's variance product through the LDS-direct kernel (batches on Cholesky samples)
+  int opt_predict_fused = 1;  // ... with predict's finish in its epilogue: 0 never, 1 for one-round product grids, 2 always (gp.hip)
   int opt_arm_late_test = 0;  // test hook: n > 0 = the n-th use of an armed evaluation from now takes the late-go recovery path
   int opt_acq_poll = 1;       // small acquisition batches: points written by the CPU, results polled (api_acq.hip)
   void (*release_cb)(void*) = nullptr;  // vbmc_set_release_callback
@@ -468,7 +471,8 @@ inline int predict_ld(int N) { return (N + 63) / 64 * 64; }
 inline size_t predict_ks_elems(int S, int64_t mb, int N) {
   return (size_t)S * (size_t)((mb + 63) / 64 * 64) * (size_t)predict_ld(N);
 }
-int launch_gp_predict_products(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* d_Ks, double* d_part);
+int launch_gp_predict_products(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* d_Ks, double* d_part,
+                               const void* fin = nullptr, bool* fin_done = nullptr);
 int launch_gp_predict_all(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* d_Ks, double* d_part,
                           int add_noise, double* d_fmu, double* d_fs2, int64_t ld);
 // c[n][m] = |a_n - b_m|^2 (centred expansion, cross term on the FP64 matrix cores), optional

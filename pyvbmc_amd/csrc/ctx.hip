@@ -83,6 +83,8 @@ static void options_from_env(vbmc_ctx* c) {
   c->opt_mix_bar = !(e && e[0] == '0');
   e = getenv("VBMC_PREDICT_DMA");
   c->opt_predict_dma = !(e && e[0] == '0');
+  e = getenv("VBMC_PREDICT_FUSED_FINISH");
+  if (e) c->opt_predict_fused = atoi(e);
 }
 
 extern "C" {
@@ -169,7 +171,7 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   adam_free(ctx);
   acq_is_free(ctx);
   randn_dev_free(ctx);
-  double* bufs[] = {ctx->d_mix, ctx->d_mix_fg, ctx->d_acq_fg, ctx->d_stage, ctx->d_eps, ctx->d_scratch, ctx->d_out, ctx->gp.d_X, ctx->gp.d_XT,
+  double* bufs[] = {ctx->d_mix, ctx->d_mix_fg, ctx->d_acq_fg, ctx->d_stage, ctx->d_eps, ctx->d_scratch, ctx->d_out, ctx->d_ptick, ctx->gp.d_X, ctx->gp.d_XT,
                     ctx->gp.d_alpha, ctx->gp.d_L, ctx->gp.d_Linv, ctx->gp.d_LinvP, ctx->gp.d_sW, ctx->gp.d_hyp,
                     ctx->gp.d_xc, ctx->gp.d_smeta};
   for (double* b : bufs)
@@ -229,6 +231,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "elbo_pregen")) ctx->opt_elbo_pregen = value != 0;
   else if (!strcmp(key, "elbo_ahead")) ctx->opt_elbo_ahead = value != 0;
   else if (!strcmp(key, "predict_dma")) ctx->opt_predict_dma = value != 0;
+  else if (!strcmp(key, "predict_fused")) ctx->opt_predict_fused = value < 0 ? 0 : value > 2 ? 2 : value;
   else if (!strcmp(key, "mix_bar")) ctx->opt_mix_bar = value != 0;
   else if (!strcmp(key, "ws_span")) ctx->opt_ws_span = value != 0;
   else if (!strcmp(key, "ws_pad")) ctx->opt_ws_pad = value > 8 ? 8 : value;
@@ -269,7 +272,7 @@ int vbmc_last_entmc_plan(const vbmc_ctx* ctx, int out[4]) {
 
 int vbmc_set_timing(vbmc_ctx* ctx, int on) {
   if (!ctx) return VBMC_E_ARG;
-  ctx->timing = on != 0;
+  ctx->timing = on < 0 ? 0 : on > 2 ? 2 : on;
   return VBMC_OK;
 }
 

@@ -7,7 +7,9 @@
 //     thousands of ELBO evaluations of one variational optimisation);
 //   * GP.predict of gpyreg (third party): K* block, mean,
 //     variance via the same L^-1.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -405,6 +407,39 @@ __global__ __launch_bounds__(256) void predict_var_mfma_kernel(const double* __r
 //   * column tiles are folded so that every workgroup has (nearly) the same number of panels
 //     (see the kernel); a workgroup's items are one panel sequence through the pipeline.
 // One barrier per panel; the DMA of panel i+1 is in flight during the matrix work of panel i.
+// predict, stage 3 for one point (also predict_finish_kernel's body): fmu = mean(x*) + the stage-1 partial means,
+// fs2 = max(0, sf^2 -/+ the stage-2 partial row sums) (+ noise); s and f are those sums.
+struct PredFin {
+  int* tick = nullptr;  // non-null: predict_var_dma_kernel finishes the points itself (arrival ticket per row tile)
+  const double* hyp_all = nullptr;
+  const double* smeta = nullptr;
+  const double* xs = nullptr;
+  double* fmu = nullptr;
+  double* fs2 = nullptr;
+  int64_t ld = 0;
+  int D = 0, P = 0, mean_kind = 0, add_noise = 0;
+};
+__device__ __forceinline__ void predict_point_finish(const PredFin& fin, int smp, int64_t m, double s, double f) {
+  const double* hyp = fin.hyp_all + (size_t)smp * fin.P;
+  const int D = fin.D;
+  const bool chol = fin.smeta[3 * smp] != 0.0;
+  const double sf2 = exp(2.0 * hyp[D]);
+  const double add = fin.add_noise ? exp(2.0 * hyp[D + 1]) * fin.smeta[3 * smp + 1] : 0.0;
+  fin.fs2[(size_t)smp * fin.ld + m] = fmax(chol ? sf2 - s : sf2 + s, 0.0) + add;
+  // mean function at x* (variational_optimization.py:1383-1392 layout)
+  double mean = 0.0;
+  const double* hm = hyp + D + 2;
+  if (fin.mean_kind == VBMC_MEAN_CONST) mean = hm[0];
+  if (fin.mean_kind == VBMC_MEAN_NEGQUAD) {
+    mean = hm[0];
+    for (int d = 0; d < D; ++d) {
+      const double t = (fin.xs[m * D + d] - hm[1 + d]) * exp(-hm[1 + D + d]);
+      mean -= 0.5 * t * t;
+    }
+  }
+  fin.fmu[(size_t)smp * fin.ld + m] = mean + f;
+}
+
 constexpr int DK = 32;                        // panel depth
 constexpr int DMA_STAGE = 2 * TS * DK * 8;    // bytes of one stage: A panel, then B panel
 constexpr int DMA_LDS = 2 * DMA_STAGE + TS * 2 * 8;
@@ -424,8 +459,10 @@ __global__ __launch_bounds__(256, 2) void predict_var_dma_kernel(const double* _
                                                                  int64_t M, int N, int ld,
                                                                  int64_t a_stride,
                                                                  double* __restrict__ part,
-                                                                 int64_t part_stride, int nrt, int G) {
+                                                                 int64_t part_stride, int nrt, int G, PredFin fin) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  __shared__ int sLast;
+  const unsigned bid = blockIdx.x;
   const int nct = (N + TS - 1) / TS;
   // Work assignment.  The triangular skip makes column tile c cost min(N, 64 c + 64) / 32 panels,
   // two workgroups are resident per CU and a CU's matrix pipes are shared by whatever runs there,
@@ -441,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void predict_var_dma_kernel(const double* _
   // lived in 20 bytes of scratch)
   int it_c0 = 0, it_c1 = 0, it_g0 = 0, it_g1 = 0, nitem = 0;
   {
-    const int x = blockIdx.x & 7, o = blockIdx.x >> 3;
+    const int x = bid & 7, o = bid >> 3;
     const int ngr = (G + 1) / 2;
     const int cnt = x < ngr ? (ngr - x + 7) / 8 : 0;  // groups of this XCD
     if (o >= cnt * (nct + 1)) return;
@@ -464,9 +501,10 @@ __global__ __launch_bounds__(256, 2) void predict_var_dma_kernel(const double* _
     if (nitem == 0) return;
   }
 #ifdef DMA_ABL_TIMES
-  if (threadIdx.x == 0 && blockIdx.x < 8192) {
-    g_dma_times[blockIdx.x * 4] = wall_clock64();
-    g_dma_times[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+  const unsigned tb_ = bid;
+  if (threadIdx.x == 0 && tb_ < 8192) {
+    g_dma_times[tb_ * 4] = wall_clock64();
+    g_dma_times[tb_ * 4 + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
   }
 #endif
   const int tid = threadIdx.x, lane = tid & 63;
@@ -579,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void predict_var_dma_kernel(const double* _
 #endif
   // row sums of T^2 over an item's 64 columns (the padding columns of B are zero)
   double* sRow = (double*)(dsm + 2 * DMA_STAGE);  // [64][2]
-  auto finish_item = [&](int q) {
+  auto finish_item = [&](int q) __attribute__((always_inline)) {
     const int g = q ? it_g1 : it_g0, c = q ? it_c1 : it_c0;
     const int z = g / nrt;
     const int64_t m0 = (int64_t)(g - z * nrt) * TS;
@@ -596,8 +634,37 @@ __global__ __launch_bounds__(256, 2) void predict_var_dma_kernel(const double* _
         acc[mt][1][r] = 0.0;
       }
     __syncthreads();
+    if (fin.tick == nullptr) {
+      if (tid < TS && m0 + tid < M)
+        part[(size_t)z * part_stride + (size_t)c * M + m0 + tid] = sRow[tid * 2] + sRow[tid * 2 + 1];
+      return;
+    }
+    // Fused finish (round 5): the partial row sums are stored write-through; the workgroup that completes a row
+    // tile's ticket -- every workgroup holding items of row tile g arrives once, after its last item of g -- adds
+    // the tile's nct slots up in slot order (bit-identical to predict_finish_kernel) and writes fmu / fs2.  No
+    // fence: write-through stores, drained before the relaxed ticket; the reader's loads bypass its L1 / L2 lines
+    // the same way (adam_fused.hip's exchange).
     if (tid < TS && m0 + tid < M)
-      part[(size_t)z * part_stride + (size_t)c * M + m0 + tid] = sRow[tid * 2] + sRow[tid * 2 + 1];
+      __hip_atomic_store(part + (size_t)z * part_stride + (size_t)c * M + m0 + tid, sRow[tid * 2] + sRow[tid * 2 + 1],
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last_of_g = q == nitem - 1 || it_g0 != it_g1;
+    if (!last_of_g) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const int expect = 1 + (nct - 1) / 2 + ((nct & 1) ? 0 : 1);
+      sLast = __hip_atomic_fetch_add(fin.tick + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1;
+    }
+    __syncthreads();
+    if (sLast && tid < TS && m0 + tid < M) {
+      const double* pz = part + (size_t)z * part_stride;
+      double sv = 0.0, fv = 0.0;
+      for (int t = 0; t < nct; ++t) {
+        sv += __hip_atomic_load(pz + (size_t)t * M + m0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fv += __hip_atomic_load(pz + (size_t)(nct + t) * M + m0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // stage 1's partial means
+      }
+      predict_point_finish(fin, z, m0 + tid, sv, fv);
+    }
   };
   {
     const char* ag = base_a(0);
@@ -632,9 +699,9 @@ __global__ __launch_bounds__(256, 2) void predict_var_dma_kernel(const double* _
   }
   finish_item(nitem - 1);
 #ifdef DMA_ABL_TIMES
-  if (threadIdx.x == 0 && blockIdx.x < 8192) {
-    g_dma_times[blockIdx.x * 4 + 1] = wall_clock64();
-    g_dma_times[blockIdx.x * 4 + 3] = P;
+  if (threadIdx.x == 0 && tb_ < 8192) {
+    g_dma_times[tb_ * 4 + 1] = wall_clock64();
+    g_dma_times[tb_ * 4 + 3] = P;
   }
 #endif
 }
@@ -739,7 +806,9 @@ __global__ __launch_bounds__(256) void predict_kstar_mfma_kernel(
     const double* __restrict__ X, const double* __restrict__ xs, const double* __restrict__ alpha,
     const double* __restrict__ sW, const double* __restrict__ hyp, const double* __restrict__ cen,
     const double* __restrict__ smeta, int P, int N, int D, int64_t M, double* __restrict__ Ks,
-    int lda, int64_t ks_stride, double* __restrict__ fpart, int64_t part_stride) {
+    int lda, int64_t ks_stride, double* __restrict__ fpart, int64_t part_stride, int* __restrict__ tick) {
+  // tick (may be null): arrival tickets of predict_var_dma_kernel's fused finish, one per row tile and sample, zeroed here
+  if (tick != nullptr && blockIdx.x == 0 && threadIdx.x == 0) tick[(size_t)blockIdx.z * gridDim.y + blockIdx.y] = 0;
   // blockIdx.z = GP hyper-parameter sample: all S samples in one launch.  Ks: row stride lda,
   // sample stride ks_stride; lda > N (predict_var_dma_kernel's layout): columns N..lda-1 are zeroed.
   {
@@ -1004,37 +1073,18 @@ __global__ void sq_dist_argmin_kernel(const double* __restrict__ pmin, const int
 // predict, stage 3: fmu[m] = mean(x*_m) + sum of the stage-1 partial means,
 // fs2[m] = max(0, sf^2 -/+ sum of the stage-2 partial row sums) (+ noise).
 __global__ void predict_finish_kernel(const double* __restrict__ part_all, int64_t part_stride, int ntiles,
-                                      int64_t M, int D, int P, int mean_kind, const double* __restrict__ hyp_all,
-                                      const double* __restrict__ smeta, const double* __restrict__ xs,
-                                      int add_noise, double* __restrict__ fmu, double* __restrict__ fs2,
-                                      int64_t ld) {
+                                      int64_t M, PredFin fin) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
   const int smp = blockIdx.y;  // GP sample
   const double* part = part_all + (size_t)smp * part_stride;
   const double* fpart = part + (size_t)ntiles * M;
-  const double* hyp = hyp_all + (size_t)smp * P;
-  const bool chol = smeta[3 * smp] != 0.0;
-  const double sf2 = exp(2.0 * hyp[D]);
-  const double add = add_noise ? exp(2.0 * hyp[D + 1]) * smeta[3 * smp + 1] : 0.0;
   double s = 0.0, f = 0.0;
   for (int t = 0; t < ntiles; ++t) {
     s += part[(size_t)t * M + m];
     f += fpart[(size_t)t * M + m];
   }
-  fs2[(size_t)smp * ld + m] = fmax(chol ? sf2 - s : sf2 + s, 0.0) + add;
-  // mean function at x* (variational_optimization.py:1383-1392 layout)
-  double mean = 0.0;
-  const double* hm = hyp + D + 2;
-  if (mean_kind == VBMC_MEAN_CONST) mean = hm[0];
-  if (mean_kind == VBMC_MEAN_NEGQUAD) {
-    mean = hm[0];
-    for (int d = 0; d < D; ++d) {
-      const double t = (xs[m * D + d] - hm[1 + d]) * exp(-hm[1 + D + d]);
-      mean -= 0.5 * t * t;
-    }
-  }
-  fmu[(size_t)smp * ld + m] = mean + f;
+  predict_point_finish(fin, smp, m, s, f);
 }
 
 }  // namespace
@@ -1124,26 +1174,45 @@ int launch_trinv(vbmc_ctx* ctx) {
   return launch_pad_linv(ctx);
 }
 
-// All S GP samples, one batch of M points already on the device: three launches in total
 // (grid.z / grid.y = sample).  d_Ks: S * M * N doubles; d_part: S * 2 * ntiles * M doubles;
 // d_fmu / d_fs2: [S][ld].
 // predict, stages 1 and 2 for all GP samples: K* (+ the partial means) and the variance product's partial row sums
-int launch_gp_predict_products(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* d_Ks, double* d_part) {
+// `fin` (may be null): the caller wants fmu / fs2 themselves; where the LDS-direct product kernel runs it then finishes the
+// points in its epilogue and *fin_done = true; otherwise the caller launches predict_finish_kernel on the partial sums.
+int launch_gp_predict_products(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* d_Ks, double* d_part,
+                               const void* fin_v, bool* fin_done) {
   const GpState& g = ctx->gp;
   const int N = g.N, D = g.D, S = g.S;
   const int ntiles = (N + TS - 1) / TS;
   const int64_t pstride = 2 * (int64_t)ntiles * M;
   const dim3 grid(ntiles, (unsigned)((M + TS - 1) / TS), S);
+  if (fin_done) *fin_done = false;
   // M > 32 on Cholesky samples: the LDS-direct kernel on padded operands; otherwise the plain layout
   bool dma = ctx->opt_predict_dma && !(M <= 32 && N <= 3000) && g.d_LinvP;
   for (int s = 0; s < S && dma; ++s) dma = g.L_chol[s] != 0;
   const int lda = dma ? ntiles * TS : N;
   const int64_t ks_stride = dma ? (int64_t)((M + TS - 1) / TS) * TS * lda : M * N;
+  const int nrt = (int)((M + TS - 1) / TS), G = nrt * S;
+  PredFin fin;
+  // The finish in the product's epilogue (two launches instead of three) pays where the product grid is ONE round of
+  // workgroups (two per CU): the arrival costs every workgroup an atomic's round trip at its end, once per round --
+  // M = 8192, S = 1: 61.1 -> 59.6 us between events; S = 4 (four rounds): 187 -> 205 us, so those keep the finish
+  // launch.  Not while the product alone is being timed (vbmc_set_timing(2)).
+  const int fuse_mode = ctx->opt_predict_fused;
+  const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+  const int nprod = 8 * (((G + 1) / 2 + 7) / 8) * (ntiles + 1);
+  if (dma && fin_v != nullptr && ctx->timing < 2 && (fuse_mode == 2 || (fuse_mode == 1 && nprod <= 2 * cus))) {
+    const int rc = ensure_dev(ctx, &ctx->d_ptick, &ctx->d_ptick_cap, (size_t)(G + 1) / 2 + 1);
+    if (rc) return rc;
+    fin = *(const PredFin*)fin_v;
+    fin.tick = (int*)ctx->d_ptick;
+    *fin_done = true;
+  }
   hipLaunchKernelGGL(predict_kstar_mfma_kernel, grid, dim3(256), 0, ctx->stream, g.d_X, d_xs,
                      (const double*)g.d_alpha, (const double*)g.d_sW, (const double*)g.d_hyp,
                      (const double*)g.d_xc, (const double*)g.d_smeta, g.P, N, D, M, d_Ks, lda, ks_stride,
-                     d_part + (size_t)ntiles * M, pstride);
-  if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[10], ctx->stream));
+                     d_part + (size_t)ntiles * M, pstride, fin.tick);
+  if (ctx->timing >= 2) HIP_TRY(ctx, hipEventRecord(ctx->ev[10], ctx->stream));
   if (dma) {
     static bool lds_set[64] = {};
     int dev = 0;
@@ -1153,11 +1222,10 @@ int launch_gp_predict_products(vbmc_ctx* ctx, int64_t M, const double* d_xs, dou
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS));
       lds_set[dev & 63] = true;
     }
-    const int nrt = (int)((M + TS - 1) / TS), G = nrt * S;
     const int ngr = (G + 1) / 2;
     const dim3 pgrid((unsigned)(8 * ((ngr + 7) / 8) * (ntiles + 1)));
     hipLaunchKernelGGL(predict_var_dma_kernel, pgrid, dim3(256), DMA_LDS, ctx->stream, (const double*)d_Ks,
-                       (const double*)g.d_LinvP, M, N, lda, ks_stride, d_part, pstride, nrt, G);
+                       (const double*)g.d_LinvP, M, N, lda, ks_stride, d_part, pstride, nrt, G, fin);
   } else if (M <= 32 && N <= 3000) {  // a handful of points: see predict_var_small_kernel (LDS <= 128 KB)
     const dim3 sgrid(ntiles, (unsigned)((M + 3) / 4), S);
     const size_t lds = sizeof(double) * ((size_t)4 * N + 16 * 4 * 64);
@@ -1172,7 +1240,7 @@ int launch_gp_predict_products(vbmc_ctx* ctx, int64_t M, const double* d_xs, dou
                        (const double*)g.d_Linv, M, N, 0, d_part, (double*)nullptr, (const double*)g.d_L,
                        (const double*)g.d_smeta, pstride);
   }
-  if (ctx->timing) {
+  if (ctx->timing >= 2) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev[11], ctx->stream));
     ctx->ev_valid[5] = true;
   }
@@ -1180,17 +1248,31 @@ int launch_gp_predict_products(vbmc_ctx* ctx, int64_t M, const double* d_xs, dou
   return 0;
 }
 
+// All S GP samples, one batch of M points already on the device: K*, the variance product with the finish in its epilogue
+// (batches on Cholesky samples: two launches) or K*, product, finish (three).
 int launch_gp_predict_all(vbmc_ctx* ctx, int64_t M, const double* d_xs, double* d_Ks, double* d_part,
                           int add_noise, double* d_fmu, double* d_fs2, int64_t ld) {
   const GpState& g = ctx->gp;
   const int N = g.N, D = g.D, S = g.S;
   const int ntiles = (N + TS - 1) / TS;
   const int64_t pstride = 2 * (int64_t)ntiles * M;
-  const int rc = launch_gp_predict_products(ctx, M, d_xs, d_Ks, d_part);
+  PredFin fin;
+  fin.hyp_all = g.d_hyp;
+  fin.smeta = g.d_smeta;
+  fin.xs = d_xs;
+  fin.fmu = d_fmu;
+  fin.fs2 = d_fs2;
+  fin.ld = ld;
+  fin.D = D;
+  fin.P = g.P;
+  fin.mean_kind = g.mean_kind;
+  fin.add_noise = add_noise;
+  bool done = false;
+  const int rc = launch_gp_predict_products(ctx, M, d_xs, d_Ks, d_part, &fin, &done);
   if (rc) return rc;
-  hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((M + 255) / 256), S), dim3(256), 0, ctx->stream,
-                     (const double*)d_part, pstride, ntiles, M, D, g.P, g.mean_kind, (const double*)g.d_hyp,
-                     (const double*)g.d_smeta, d_xs, add_noise, d_fmu, d_fs2, ld);
+  if (!done)
+    hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((M + 255) / 256), S), dim3(256), 0, ctx->stream,
+                       (const double*)d_part, pstride, ntiles, M, fin);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }

@@ -156,6 +156,29 @@ def test_predict_lds_direct_product(ctx, N, M, S):
     assert np.max(np.abs(fmu - omu)) <= 1e-10 * max(1.0, np.max(np.abs(omu)))
 
 
+@pytest.mark.parametrize("N,M,S", [(17, 33, 1), (64, 64, 2), (130, 333, 3), (449, 1000, 2), (512, 129, 1), (700, 2100, 1),
+                                   (400, 8192, 1)])
+def test_predict_finish_in_the_product_epilogue(ctx, N, M, S):
+    """`predict_fused`: the product kernel's last-arriving workgroup of a 64-point row tile adds the tile's partial
+    sums up in slot order and writes fmu / fs2 (two launches) -- bit-identical to predict_finish_kernel (three), for
+    row tiles whose column tiles are folded into one workgroup, shared between two, and the even-count middle tile;
+    repeated calls reuse the tickets."""
+    wl, wd = case(3, 5, N, 40, S=S)
+    _, gp = objects(wd, ctx)
+    xs = np.random.default_rng(N + M).standard_normal((M, 3))
+    out = {}
+    try:
+        for mode in (0, 2, 1, 2):
+            ctx.set_option("predict_fused", mode)
+            out.setdefault(mode, []).append(gp.predict(xs, separate_samples=True))
+    finally:
+        ctx.set_option("predict_fused", 1)
+    mu0, s0 = out[0][0]
+    for mode in (1, 2):
+        for mu, s2 in out[mode]:
+            assert np.array_equal(mu, mu0) and np.array_equal(s2, s0)
+
+
 @pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 129])
 def test_gp_sizes_around_the_tiles(ctx, N):
     """_gp_log_joint (+variance), predict and the fused objective for N around the 64-wide
