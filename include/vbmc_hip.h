@@ -140,7 +140,8 @@ int vbmc_set_release_callback(vbmc_ctx* ctx, void (*fn)(void*), void* user);
  *   "acq_poll"     [VBMC_ACQ_POLL]: 1 = vbmc_acq_eval with at most 256 points has the CPU write the points into host-writable
  *                  device memory and polls a completion word for the results (default), 0 = copies + stream wait
  *   "adam_fused"   [VBMC_ADAM_FUSED]: 1 = vbmc_adam_run runs a batch of iterations as ONE launch where the shape allows
- *                  (one rank, K <= 64, D <= 16, <= 64 antithetic rows per component, LDS plan fits; default),
+ *                  (one rank, K <= 64, D <= 24, <= 64 antithetic rows per component, LDS plan fits -- with X^T resident in
+ *                  the GP workgroups' LDS, or read from memory where that does not fit; default),
  *                  0 = always four launches per iteration; 2 = test hook (the launch also waits for a workgroup
  *                  that does not exist, must give up by its 20 ms limit, and the batch is redone as four launches)
  *                  3 = the one-launch form with its exchange written as agent-scope release stores / acquire fences

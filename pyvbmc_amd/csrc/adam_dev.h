@@ -77,6 +77,7 @@ struct FusedArgs {
   int test_absent = 0;            // test hook (option "adam_fused" = 2): also wait for a workgroup that does not exist
   int o_pack = 0, o_ee = 0, o_recs = 0, o_eps = 0, o_part = 0, o_out = 0, o_gp = 0, o_xt = 0,
       o_alpha = 0;  // LDS carve, in doubles (adam_fused_plan)
+  int part_waves = 8;  // waves whose per-lane sums are laid down side by side in the entropy workgroups' reduction scratch (adam_fused_plan)
 };
 size_t adam_fused_plan(FusedArgs& f);
 int adam_fused_launch(vbmc_ctx* ctx, hipStream_t st, const FusedArgs& f, size_t lds_bytes);

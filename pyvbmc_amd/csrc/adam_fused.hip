@@ -35,7 +35,7 @@
 // raises status bit 4 and every workgroup leaves without writing the state back; the host then runs
 // four launches per iteration from the same state).
 //
-// Used when the loop runs on one rank, K <= 64, D <= 16, at most 64 antithetic rows per component and
+// Used when the loop runs on one rank, K <= 64, D <= 24 (round 5: was 16), at most 64 antithetic rows per component and
 // the LDS plan fits (adam_fused_plan); everything else keeps the four-launch iteration.  Same draws
 // (Philox(seed + i), philox.h), same formulas: tests/test_adam.py runs both against the oracle loop.
 // Measured steps and the phase times: DESIGN.md section 4.6b.
@@ -71,7 +71,7 @@ __device__ __forceinline__ double sumw(const double* r) {
   return v;
 }
 
-// adam_dev::pack_from_theta for K <= 64, D <= 16: set_parameters (variational_posterior.py:680-759) with the
+// adam_dev::pack_from_theta for K <= 64, D <= 64 (lane = d): set_parameters (variational_posterior.py:680-759) with the
 // eta max-shift (variational_optimization.py:1082-1085) and the mixture pack.  EVERY wave computes the
 // per-component and per-dimension quantities itself (lane = k, lane = d) and so owns the four wave-wide
 // reductions: one barrier (before theta's eta tail is shifted in place) instead of five.  The waves share the
@@ -188,16 +188,19 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
   double* part = sh + f.o_part;   // entropy workgroups' reduction scratch, laid over recs | gsc | sXT | sAl (dead / unused there)
   double* out = sh + f.o_out;      // [1 + 2D] a GP block's sums
   double* gsc = sh + f.o_gp;
-  double* sXT = sh + f.o_xt;
+  // X^T: resident in the GP workgroups' LDS where the plan has room for it, else read from memory (L2) by both passes
+  const double* sXT = f.o_xt >= 0 ? sh + f.o_xt : f.XT;
   double* sAl = sh + f.o_alpha;
 
   // ---- what persists across the iterations of this launch ----
   for (int i = tid; i < L.o_res(); i += NT) sh[i] = a.state[i];  // theta | aux | hyp
   for (int i = tid; i < ml.total; i += NT) pack[i] = a.mix[i];
-  // Adam's moments of this thread's entries of theta (n_theta <= 2 NT, adam_fused_plan)
-  double r_m[2], r_v[2];
+  // Adam's moments of this thread's entries of theta (n_theta <= NU NT, adam_fused_plan; the third entry only in the
+  // builds for D > 16, whose theta reaches 1 536 entries: the narrower builds keep their register count)
+  constexpr int NU = DP > 16 ? 3 : 2;
+  double r_m[NU], r_v[NU];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int i = u * NT + tid;
     r_m[u] = i < n ? a.state[L.o_m() + i] : 0.0;
     r_v[u] = i < n ? a.state[L.o_v() + i] : 0.0;
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
     for (int i = tid; i < L.o_hyp(); i += NT) b[i] = a.state[i];
     b += L.o_hyp();
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int i = u * NT + tid;
       if (i < n) {
         b[i] = r_m[u];
@@ -235,7 +238,8 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
     for (int i = tid; i < ml.total; i += NT) b[i] = a.mix[i];
   }
   if (g >= f.n_ent) {
-    for (int i = tid; i < D * N; i += NT) sXT[i] = f.XT[i];
+    if (f.o_xt >= 0)
+      for (int i = tid; i < D * N; i += NT) sh[f.o_xt + i] = f.XT[i];
     for (int i = tid; i < S * N; i += NT) sAl[i] = f.alpha[i];
   }
   __syncthreads();
@@ -349,20 +353,31 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
       const int NI = 2 * D + 1;
       asm volatile("" ::: "memory");  // (sigma_j is read again rather than held across the row loop: the <16> build's last spill)
       const double sig_j = pack[ml.o_sig + j];
-      double* pc = part;                      // [SW][2D + 1][K]
-      double* pW = pc + (size_t)SW * NI * K;  // [SW][64]
-      double* pS = pW + SW * 64;              // [SW] slog
-      if (live) {
-        double sl = 0.0;
+      // (f.part_waves = SW / 2 where [SW][2D + 1][K] does not fit the LDS plan -- D = 20, K = 50: 131 KB --: the upper half of
+      // the waves lays its values down first, the lower half adds its own to them behind a barrier)
+      const int PWV = DP > 16 ? f.part_waves : SW;  // (a constant in the builds for D <= 16: they keep their code)
+      double* pc = part;                       // [PWV][2D + 1][K]
+      double* pW = pc + (size_t)PWV * NI * K;  // [SW][64]
+      double* pS = pW + SW * 64;               // [SW] slog
+      for (int pass = (PWV == SW ? 1 : 0); pass < 2; ++pass) {
+        const bool mine = PWV == SW || (pass == 0 ? wave >= PWV : wave < PWV);
+        const bool add = PWV != SW && pass == 1;
+        const int slot = wave >= PWV ? wave - PWV : wave;
+        if (live && mine) {
+          double sl = 0.0;
+          double* pq = pc + (size_t)slot * NI * K + lane;
 #pragma unroll
-        for (int d = 0; d < DP; ++d)
-          if (d < D) {
-            const double cl = fma(sig_j, B[d], dl[d] * A[d]);
-            pc[((size_t)wave * NI + d) * K + lane] = fma(sig_j, A[d], (wis2 * dl[d]) * W);
-            pc[((size_t)wave * NI + D + d) * K + lane] = cl;
-            sl += cl;
-          }
-        pc[((size_t)wave * NI + 2 * D) * K + lane] = sl;  // item 2D: sigma_j's entry is the sum of the lambda items
+          for (int d = 0; d < DP; ++d)
+            if (d < D) {
+              const double cl = fma(sig_j, B[d], dl[d] * A[d]);
+              const double cm = fma(sig_j, A[d], (wis2 * dl[d]) * W);
+              pq[(size_t)d * K] = add ? pq[(size_t)d * K] + cm : cm;
+              pq[(size_t)(D + d) * K] = add ? pq[(size_t)(D + d) * K] + cl : cl;
+              sl += cl;
+            }
+          pq[(size_t)(2 * D) * K] = add ? pq[(size_t)(2 * D) * K] + sl : sl;  // item 2D: sigma_j's entry is the sum of the lambda items
+        }
+        if (pass == 0) __syncthreads();
       }
       pW[wave * 64 + lane] = W;
       if (lane == 0) pS[wave] = slog;
@@ -376,7 +391,8 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
           double v = 0.0;
           if (live) {
 #pragma unroll
-            for (int wv = 0; wv < SW; ++wv) v += pc[((size_t)wv * NI + c) * K + lane];
+            for (int wv = 0; wv < SW; ++wv)
+              if (wv < PWV) v += pc[((size_t)wv * NI + c) * K + lane];
           }
           v = fm::wave_sum_dpp(v);
           if (lane == 0) {
@@ -674,10 +690,11 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
         red[3 * SW] = pd;
       }
     } else if (wave <= 4) {
-      // per dimension (one 16-lane group each; D <= 16): lambda's sums over (s, k), the soft bounds folded onto lambda
-      const int ns = tid & 15, d = (tid - 64) >> 4;
+      // per dimension (a 16-lane group each, sixteen groups; D > 16: a second round): lambda's sums over (s, k), the soft
+      // bounds folded onto lambda
+      const int ns = tid & 15;
       const int sc0 = o_mu ? D * K : 0;
-      if (d < D) {
+      for (int d = (tid - 64) >> 4; d < D; d += 16) {
         double acc = 0.0, accb = 0.0;
         for (int idx = ns; idx < n_blocks; idx += 16) acc += crec[(size_t)idx * RC + D + d];
         if (a.has_bnd && o_lm)
@@ -743,7 +760,7 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
       }
       double* x_row = a.x_tab + (size_t)iter * n;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < NU; ++u) {
         const int i = u * NT + tid;
         if (i >= n) continue;
         double gr;  // dF_i
@@ -857,7 +874,7 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
     for (int i = tid; i < L.o_hyp(); i += NT) a.state[i] = sh[i];  // theta | aux
     for (int i = tid; i < ml.total; i += NT) a.mix[i] = pack[i];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int i = u * NT + tid;
       if (i < n) {
         a.state[L.o_m() + i] = r_m[u];
@@ -882,7 +899,7 @@ int launch_fused(vbmc_ctx* ctx, hipStream_t st, const FusedArgs& f, size_t lds) 
   return 0;
 }
 
-int fused_dp(int D) { return D <= 2 ? 2 : D <= 4 ? 4 : D <= 6 ? 6 : D <= 8 ? 8 : D <= 10 ? 10 : D <= 12 ? 12 : 16; }
+int fused_dp(int D) { return D <= 2 ? 2 : D <= 4 ? 4 : D <= 6 ? 6 : D <= 8 ? 8 : D <= 10 ? 10 : D <= 12 ? 12 : D <= 16 ? 16 : D <= 20 ? 20 : 24; }
 
 }  // namespace
 
@@ -893,7 +910,7 @@ namespace adam_dev {
 size_t adam_fused_plan(FusedArgs& f) {
   const AdamDev& a = f.a;
   const int D = a.D, K = a.K, S = a.S, N = f.N;
-  if (K > 64 || D > 16 || f.rows < 1 || f.rows > 64 || a.n_theta > 1024 || N < 1) return 0;
+  if (K > 64 || D > 24 || f.rows < 1 || f.rows > 64 || a.n_theta > (D > 16 ? 3 : 2) * NT || N < 1) return 0;
   const int DP = fused_dp(D);
   const int RE = 2 + 2 * D + K, RG = 1 + 2 * D, RC = 2 * D + 4;
   f.n_ent = K;
@@ -914,13 +931,29 @@ size_t adam_fused_plan(FusedArgs& f) {
   f.o_recs = take((size_t)K * RE + (size_t)S * K * RC);
   f.o_part = f.o_recs;
   f.o_gp = take((size_t)2 * D + N + SW + 4);
-  f.o_xt = take((size_t)D * N);
   f.o_alpha = take((size_t)S * N);
-  const size_t need_part = (size_t)SW * (2 * D + 1) * K + (size_t)SW * 64 + SW + 2;
-  if (o - (size_t)f.o_recs < need_part) o = (size_t)f.o_recs + need_part;
+  size_t need_part = (size_t)SW * (2 * D + 1) * K + (size_t)SW * 64 + SW + 2;
+  f.part_waves = SW;
+  // dynamic LDS: the CU's 160 KB less the kernel's static arrays (8 984 B in every build: -Rpass-analysis=kernel-resource-usage;
+  // the 154 KB of rounds 3-4 overshot that by 2.8 KB -- a plan between 151 and 154 KB would have failed at launch)
+  constexpr size_t LDS_MAX = (160 - 9) * 1024;
+  if (D > 16 && (f.o_recs + need_part) * sizeof(double) > LDS_MAX) {  // (see the kernel: two half-rounds through half the scratch)
+    f.part_waves = SW / 2;
+    need_part = (size_t)(SW / 2) * (2 * D + 1) * K + (size_t)SW * 64 + SW + 2;
+  }
   (void)DP;
+  // X^T (D N doubles: 64 KB at D = 20, N = 400) stays in LDS when everything fits; else the GP workgroups read it from
+  // memory in their two passes (round 5: D = 20, K = 50 fits N <= 270 with it and N ~ 2000 without; D = 10, K = 50: 900 / ~5000)
+  const size_t o_before = o;
+  f.o_xt = take((size_t)D * N);
+  if (o - (size_t)f.o_recs < need_part) o = (size_t)f.o_recs + need_part;
+  if (o * sizeof(double) > LDS_MAX) {
+    f.o_xt = -1;
+    o = o_before;
+    if (o - (size_t)f.o_recs < need_part) o = (size_t)f.o_recs + need_part;
+  }
   const size_t bytes = o * sizeof(double);
-  return bytes <= 154 * 1024 ? bytes : 0;  // + 4.5 KB of static arrays <= 160 KB
+  return bytes <= LDS_MAX ? bytes : 0;
 }
 
 int adam_fused_launch(vbmc_ctx* ctx, hipStream_t st, const FusedArgs& f, size_t lds) {
@@ -931,7 +964,9 @@ int adam_fused_launch(vbmc_ctx* ctx, hipStream_t st, const FusedArgs& f, size_t 
     case 8: return launch_fused<8>(ctx, st, f, lds);
     case 10: return launch_fused<10>(ctx, st, f, lds);
     case 12: return launch_fused<12>(ctx, st, f, lds);
-    default: return launch_fused<16>(ctx, st, f, lds);
+    case 16: return launch_fused<16>(ctx, st, f, lds);
+    case 20: return launch_fused<20>(ctx, st, f, lds);
+    default: return launch_fused<24>(ctx, st, f, lds);
   }
 }
 

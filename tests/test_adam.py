@@ -381,7 +381,13 @@ FUSED_SHAPES = [dict(cfg=3, D=10, K=50, N=400, S=1, NsK=28), dict(cfg=5, D=16, K
                 # the widest builds at full register pressure (<12>, <16>: 0 B of scratch since round 4), theta near
                 # its 1 024-entry limit, and the largest training set whose LDS plan fits at D = 10
                 dict(cfg=3, D=12, K=40, N=300, S=2, NsK=28), dict(cfg=3, D=16, K=30, N=100, S=1, NsK=6),
-                dict(cfg=3, D=10, K=50, N=800, S=1, NsK=28)]
+                dict(cfg=3, D=10, K=50, N=800, S=1, NsK=28),
+                # round 5: the builds for D = 17 .. 24 (theta beyond 1 024 entries: three per thread; the per-dimension sums in
+                # two rounds of 16-lane groups), X^T resident (N = 200) and read from memory (N = 400 at D = 20; N = 2000 at
+                # D = 10: beyond the old plan's N ~ 900)
+                dict(cfg=5, D=20, K=50, N=400, S=1, NsK=22), dict(cfg=5, D=20, K=24, N=200, S=2, NsK=28),
+                dict(cfg=3, D=24, K=40, N=150, S=1, NsK=10), dict(cfg=3, D=18, K=64, N=100, S=1, NsK=28),
+                dict(cfg=3, D=10, K=50, N=2000, S=1, NsK=28)]
 
 
 @pytest.mark.gpu
@@ -461,14 +467,15 @@ def test_fused_loop_partial_masks_box_and_resident_draws(ctx, flags):
 
 @pytest.mark.gpu
 def test_fused_loop_applies_only_to_its_shapes(ctx):
-    """K > 64, D > 16, more than 64 rows per component, a row slice (virtual rank) or an LDS plan that does not
-    fit keep the four-launch iteration; a non-finite iterate is reported as before."""
+    """K > 64, D > 24, more than 64 rows per component, a row slice (virtual rank) or an LDS plan that does not
+    fit even with X^T left in memory keep the four-launch iteration; a non-finite iterate is reported as before."""
     from pyvbmc_amd.minimize_adam import minimize_adam_elbo
 
     for kwargs, fused in ((dict(D=10, K=50, N=400, NsK=28), True), (dict(D=10, K=50, N=800, NsK=28), True),
                           (dict(D=10, K=65, N=100, NsK=28), False),
-                          (dict(D=17, K=10, N=100, NsK=28), False), (dict(D=10, K=20, N=100, NsK=130), False),
-                          (dict(D=16, K=40, N=1200, NsK=28), False)):
+                          (dict(D=17, K=10, N=100, NsK=28), True), (dict(D=25, K=10, N=100, NsK=28), False),
+                          (dict(D=10, K=20, N=100, NsK=130), False),
+                          (dict(D=16, K=40, N=1200, NsK=28), True), (dict(D=24, K=64, N=9000, NsK=28), False)):
         wl = synthetic.make_workload(3, S=1, D=kwargs["D"], K=kwargs["K"], N=kwargs["N"], Ns_total=kwargs["NsK"] * kwargs["K"])
         wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,
                   hyp=wl.hyp, s2=np.zeros(0))
