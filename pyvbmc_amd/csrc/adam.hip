@@ -445,7 +445,7 @@ struct AdamState {
   size_t fused_lds = 0;
   double* d_xch = nullptr;
   size_t xch_cap = 0;
-  unsigned long long* d_flags = nullptr;  // [256]
+  unsigned long long* d_flags = nullptr;  // [512]
   // the two-launch iteration (adam_tail_kernel): its own (j,k) table, which the tail launch of iteration i fills for
   // iteration i + 1, and the words its hand-offs use -- [0] GP-sum word, [1] reduction word, [2] readers' counter,
   // ints at [8]: GP-sum counter, [9]: reduction counter
@@ -721,13 +721,17 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
     f.a = a;
     f.N = ctx->gp.N;
     f.rows = (int)st->row_count;
-    const size_t lds = st->row_count <= 64 ? adam_fused_plan(f) : 0;
+    f.cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    // (up to 160 rows per component: beyond that the lane-per-component row loop of the fused kernel loses to the wave-split
+    // kernel's 64 rows per instruction -- K = 50, D = 10, NsK = 130 / 256 / 1 024 / 4 096: 22.5 / 27.0 / 38.0 / 100 us per
+    // iteration against 33.3 / 33.3 / 34.5 / 46.8 with four launches, tools/adam_d20_probe.py)
+    const size_t lds = st->row_count <= 160 ? adam_fused_plan(f) : 0;
     if (lds) {
-      const size_t rt = (size_t)K * (2 + 2 * D + K) + (size_t)S * K * (2 * D + 4);
+      const size_t rt = (size_t)f.n_ent * (2 + 2 * D + K) + (size_t)S * K * (2 * D + 4);  // (n_ent = K R: R planes of entropy records)
       // (behind the records: the copy of the state a launch starts from, restored if it gives up waiting)
       rc = ensure_dev(ctx, &st->d_xch, &st->xch_cap, 2 * rt + fused_backup_len(a));
       if (rc) return rc;
-      if (!st->d_flags) HIP_TRY(ctx, hipMalloc((void**)&st->d_flags, 256 * sizeof(unsigned long long)));
+      if (!st->d_flags) HIP_TRY(ctx, hipMalloc((void**)&st->d_flags, 512 * sizeof(unsigned long long)));
       f.XT = ctx->gp.d_XT;
       f.alpha = ctx->gp.d_alpha;
       f.eps_mode = st->eps_mode;
@@ -944,7 +948,7 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
     f.n_iters = n_iters;
     f.test_absent = ctx->opt_adam_fused == 2 ? 1 : 0;
     f.rel_acq = ctx->opt_adam_fused == 3 ? 1 : 0;
-    HIP_TRY(ctx, hipMemsetAsync(st->d_flags, 0, 256 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(st->d_flags, 0, 512 * sizeof(unsigned long long), ctx->stream));
     static const bool want_times = [] {
       const char* e = getenv("VBMC_FUSED_TIMES");  // measurement aid: phase stamps of two workgroups to stderr
       return e && e[0] == '1';
@@ -1052,7 +1056,7 @@ extern "C" int vbmc_adam_run_auto(vbmc_ctx* ctx, int max_iters, double tol_fun, 
   f.n_done = st->d_status + 2;
   f.test_absent = ctx->opt_adam_fused == 2 ? 1 : 0;
   f.rel_acq = ctx->opt_adam_fused == 3 ? 1 : 0;
-  HIP_TRY(ctx, hipMemsetAsync(st->d_flags, 0, 256 * sizeof(unsigned long long), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(st->d_flags, 0, 512 * sizeof(unsigned long long), ctx->stream));
   int rc = adam_fused_launch(ctx, ctx->stream, f, st->fused_lds);
   if (rc) return rc;
   ctx->last_plan[0] = 4;

@@ -60,7 +60,9 @@ struct FusedArgs {
   int eps_mode = 0;               // VBMC_EPS_PHILOX: Philox(seed + iteration), else the resident block eps
   const double* eps = nullptr;    // [K][eps_rows][D]
   long long eps_rows = 0, n_half = 0, row_begin = 0;
-  int rows = 0;                   // antithetic rows per component
+  int rows = 0;                   // antithetic rows per entropy WORKGROUP (adam_fused_plan: in = per component)
+  int rows_total = 0;             // antithetic rows per component
+  int cus = 0;                    // compute units of the device (every workgroup of the launch must be resident)
   unsigned long long seed = 0;
   double inv_ns = 0.0;
   double* xch = nullptr;                 // [2][K (2 + 2D + K) + S K (2D + 4)] exchange records
@@ -68,7 +70,7 @@ struct FusedArgs {
   unsigned long long* flags = nullptr;   // [n_ent + n_gp], zeroed before the launch: the iteration a workgroup has published
   unsigned long long timeout = 2000000;  // wall-clock ticks (100 MHz) a workgroup waits for the others: 20 ms
   unsigned long long* times = nullptr;   // optional [2][64][16] phase stamps (VBMC_FUSED_TIMES=1)
-  int n_ent = 0, n_gp = 0;        // workgroups: K entropy + n_gp GP-sum workers
+  int n_ent = 0, n_gp = 0;        // workgroups: K R entropy (R row slices per component) + n_gp GP-sum workers
   int i0 = 0, n_iters = 0;
   int stop_rule = 0;              // 1: every workgroup applies minimize_adam's stopping rule itself (vbmc_adam_run_auto)
   double tol_fun = 0.0;

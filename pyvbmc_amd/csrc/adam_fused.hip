@@ -174,7 +174,12 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
   const int RE = 2 + 2 * D + K;       // entropy record: slog | raw mu_j (D) | raw sigma_j | lam_j (D) | W_j (K)
   const int RC = 2 * D + 4;           // GP contribution record: gmu (D) | glm (D) | gs | nu | b0 | qbar
   const int n_blocks = S * K;
-  const int RT = K * RE + n_blocks * RC;
+  const int RT = K * RE + n_blocks * RC;  // the gathered records (LDS)
+  // Round 5: R = n_ent / K workgroups per component, each with a slice of the component's rows (plane r = g / K holds the
+  // partial records of slice r: every entry of an entropy record is a sum over rows, so the gather adds the planes up).
+  const int R = f.n_ent / K;
+  const int KRE = K * RE;
+  const int RTX = R * KRE + n_blocks * RC;  // the exchange buffer: R planes of entropy records, then the GP records
 
   // ---- LDS carve: [theta | aux | hyp] as in the state block, then this kernel's own arrays ----
   double* theta = sh + L.o_theta();
@@ -252,15 +257,18 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
   };
 
   // the normals of component g's rows at iteration `it` (philox.h: row j n_half + row_begin + i, block d / 4)
+  const int pl = g < f.n_ent ? g / K : 0, jc = g - pl * K;  // entropy workgroup: its plane (row slice) and component
+  const int row0 = pl * f.rows;                              // first row of the slice; rows_here of them
+  const int rows_here = g < f.n_ent ? (f.rows_total - row0 < f.rows ? (f.rows_total - row0 > 0 ? f.rows_total - row0 : 0) : f.rows) : 0;
   auto make_draws = [&](int it, int tid) {
-    const int rows = f.rows;
+    const int rows = rows_here;
     if (f.eps_mode == VBMC_EPS_PHILOX) {
       const int nb = (D + 3) >> 2;
       const uint64_t seed = f.seed + (uint64_t)it;
       // two threads per Philox block, one Box-Muller pair each (the block itself is computed twice: it is the short part)
       for (int q = tid; q < 2 * rows * nb; q += NT) {
         const int h = q & 1, ib = q >> 1, i = ib / nb, b = ib - i * nb;
-        const uint64_t row = (uint64_t)g * (uint64_t)f.n_half + (uint64_t)(f.row_begin + i);
+        const uint64_t row = (uint64_t)jc * (uint64_t)f.n_half + (uint64_t)(f.row_begin + row0 + i);
         const Philox4 r = philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)b, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
         double z0, z1;
         philox_bm32(h ? r.x[2] : r.x[0], h ? r.x[3] : r.x[1], z0, z1);
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
         if (d0 + 1 < D) sE[i * D + d0 + 1] = z1;
       }
     } else if (it == f.i0) {  // resident draws: the same block every iteration
-      const double* src = f.eps + (int64_t)g * f.eps_rows * D;
+      const double* src = f.eps + ((int64_t)jc * f.eps_rows + row0) * D;
       for (int i = tid; i < rows * D; i += NT) sE[i] = src[i];
     }
   };
@@ -283,14 +291,14 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
     asm volatile("v_mov_b32 %0, %1" : "=v"(tid) : "v"(tid_launch));
     const int lane = tid & 63;
     const int iter = f.i0 + t;
-    double* xb = f.xch + (size_t)(t & 1) * RT;
+    double* xb = f.xch + (size_t)(t & 1) * RTX;
     stamp(t, 0);
 
     if (g < f.n_ent) {
       // ================= phase A, entropy of component j (entropy_small.hip; entmc_vbmc.py:64-112) =================
-      const int j = g, k = lane;
+      const int j = jc, k = lane;
       const bool live = k < K;
-      const int rows = f.rows;
+      const int rows = rows_here;
       // the lane's table row (prep.hip's table block, from the pack in LDS)
       const double* mup = pack + ml.o_mup;
       double sj2, two_sj;
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
       stamp(t, 11);
       // item c is summed over the waves and the lanes by wave c % SW, whose lane 0 stores the record entry itself
       {
-        double* rec = xb + (size_t)j * RE;
+        double* rec = xb + (size_t)g * RE;  // plane pl, component j
         const double sc = pack[ml.o_w + j] * f.inv_ns;
         for (int c = wave; c < NI; c += SW) {
           double v = 0.0;
@@ -480,7 +488,7 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
           const double inv_S = cst[2];
           const double wk = pack[ml.o_w + k];
           double c_gs = 0.0, c_nu = 0.0, c_qb = 0.0;
-          double* rec = xb + (size_t)K * RE + (size_t)b * RC;
+          double* rec = xb + (size_t)R * KRE + (size_t)b * RC;
           if (lane < D) {
             const int d = lane;
             const double lam = pack[ml.o_lam + d], m = sMu[d];
@@ -622,14 +630,33 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
     if (!s_ok) return;
     if (f.rel_acq) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     stamp(t, 3);
-    for (int base = 0; base < RT; base += NT * 10) {
-      double v[10];
+    if (R == 1) {
+      for (int base = 0; base < RT; base += NT * 10) {
+        double v[10];
 #pragma unroll
-      for (int u = 0; u < 10; ++u) v[u] = ld_wt(xb + min(base + u * NT + tid, RT - 1));
+        for (int u = 0; u < 10; ++u) v[u] = ld_wt(xb + min(base + u * NT + tid, RT - 1));
 #pragma unroll
-      for (int u = 0; u < 10; ++u) {
-        const int i = base + u * NT + tid;
-        if (i < RT) recs[i] = v[u];  // entropy records, then the GP contribution records
+        for (int u = 0; u < 10; ++u) {
+          const int i = base + u * NT + tid;
+          if (i < RT) recs[i] = v[u];  // entropy records, then the GP contribution records
+        }
+      }
+    } else {
+      // the planes of an entropy entry are added up in plane order (R <= 4: twenty loads in flight)
+      for (int base = 0; base < RT; base += NT * 5) {
+        double v[5][4];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int i = min(base + u * NT + tid, RT - 1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            v[u][r] = (r == 0 || (r < R && i < KRE)) ? ld_wt(xb + (i < KRE ? (size_t)r * KRE + i : (size_t)(R - 1) * KRE + i)) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int i = base + u * NT + tid;
+          if (i < RT) recs[i] = ((v[u][0] + v[u][1]) + v[u][2]) + v[u][3];
+        }
       }
     }
     __syncthreads();
@@ -910,11 +937,29 @@ namespace adam_dev {
 size_t adam_fused_plan(FusedArgs& f) {
   const AdamDev& a = f.a;
   const int D = a.D, K = a.K, S = a.S, N = f.N;
-  if (K > 64 || D > 24 || f.rows < 1 || f.rows > 64 || a.n_theta > (D > 16 ? 3 : 2) * NT || N < 1) return 0;
+  if (K > 64 || D > 24 || f.rows < 1 || a.n_theta > (D > 16 ? 3 : 2) * NT || N < 1) return 0;
+  // Round 5: more than 64 antithetic rows per component are split over R <= 4 workgroups per component (every workgroup must
+  // be resident: K R + n_gp <= CUs).  The caller (adam.hip) uses it up to 160 rows per component, where it still beats
+  // four launches.  f.rows comes in as the rows per component and goes out as the rows per workgroup.
+  f.rows_total = f.rows;
+  int R = 1;
+  if (f.rows > 64) {
+    const int cus = f.cus > 0 ? f.cus : 256;
+    const int gp_min = S * K < 32 ? S * K : 32;
+    const int r_max = (cus - gp_min) / K < 4 ? (cus - gp_min) / K : 4;
+    R = f.rows > 128 ? r_max : (r_max < 2 ? r_max : 2);  // (as many slices as fit: shorter row loops)
+    if (R < 1 || (f.rows + R - 1) / R > 512) return 0;
+    f.rows = (f.rows + R - 1) / R;
+  }
   const int DP = fused_dp(D);
   const int RE = 2 + 2 * D + K, RG = 1 + 2 * D, RC = 2 * D + 4;
-  f.n_ent = K;
+  f.n_ent = K * R;
   f.n_gp = S * K < 128 ? S * K : 128;
+  if (R > 1) {
+    const int cus = f.cus > 0 ? f.cus : 256;
+    if (f.n_gp > cus - f.n_ent) f.n_gp = cus - f.n_ent;
+    if (f.n_gp < 1) return 0;
+  }
   size_t o = (size_t)a.lay.o_res() + (size_t)a.n_bnd + 2 * (size_t)K + 2 * (size_t)D;  // theta | aux | hyp | phase B scratch
   auto take = [&](size_t cnt) {
     const size_t at = o;

@@ -387,7 +387,11 @@ FUSED_SHAPES = [dict(cfg=3, D=10, K=50, N=400, S=1, NsK=28), dict(cfg=5, D=16, K
                 # D = 10: beyond the old plan's N ~ 900)
                 dict(cfg=5, D=20, K=50, N=400, S=1, NsK=22), dict(cfg=5, D=20, K=24, N=200, S=2, NsK=28),
                 dict(cfg=3, D=24, K=40, N=150, S=1, NsK=10), dict(cfg=3, D=18, K=64, N=100, S=1, NsK=28),
-                dict(cfg=3, D=10, K=50, N=2000, S=1, NsK=28)]
+                dict(cfg=3, D=10, K=50, N=2000, S=1, NsK=28),
+                # round 5: more than 64 rows per component, split over R workgroups per component whose partial records the
+                # gather adds up -- two slices (65 rows), four (160 rows), three at K = 64 with a ragged last one (151 rows)
+                dict(cfg=3, D=10, K=50, N=400, S=1, NsK=130), dict(cfg=3, D=10, K=50, N=400, S=1, NsK=320),
+                dict(cfg=2, D=6, K=64, N=100, S=2, NsK=302)]
 
 
 @pytest.mark.gpu
@@ -408,7 +412,7 @@ def test_fused_loop_vs_four_launch_loop_and_oracle(ctx, shape):
     theta0 = wl.theta.copy()
     theta0[0] += 4.0  # one coordinate outside its soft bound
     kw = dict(tol_fun=1e-9, master_min=0.001, master_max=0.1, master_decay=200)
-    n_it = 47  # two full batches and a short one
+    n_it = shape.get("n_it", 47)  # two full batches and a short one
     runs = {}
     for fused in (1, 0):
         ctx.set_option("adam_fused", fused)
@@ -467,14 +471,14 @@ def test_fused_loop_partial_masks_box_and_resident_draws(ctx, flags):
 
 @pytest.mark.gpu
 def test_fused_loop_applies_only_to_its_shapes(ctx):
-    """K > 64, D > 24, more than 64 rows per component, a row slice (virtual rank) or an LDS plan that does not
+    """K > 64, D > 24, more than 160 rows per component, a row slice (virtual rank) or an LDS plan that does not
     fit even with X^T left in memory keep the four-launch iteration; a non-finite iterate is reported as before."""
     from pyvbmc_amd.minimize_adam import minimize_adam_elbo
 
     for kwargs, fused in ((dict(D=10, K=50, N=400, NsK=28), True), (dict(D=10, K=50, N=800, NsK=28), True),
                           (dict(D=10, K=65, N=100, NsK=28), False),
                           (dict(D=17, K=10, N=100, NsK=28), True), (dict(D=25, K=10, N=100, NsK=28), False),
-                          (dict(D=10, K=20, N=100, NsK=130), False),
+                          (dict(D=10, K=20, N=100, NsK=130), True), (dict(D=10, K=20, N=100, NsK=322), False),
                           (dict(D=16, K=40, N=1200, NsK=28), True), (dict(D=24, K=64, N=9000, NsK=28), False)):
         wl = synthetic.make_workload(3, S=1, D=kwargs["D"], K=kwargs["K"], N=kwargs["N"], Ns_total=kwargs["NsK"] * kwargs["K"])
         wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,

@@ -5,7 +5,8 @@ import subprocess
 import sys
 
 SHAPES = [(5, 20, 50, 400, 22), (5, 20, 50, 800, 22), (5, 20, 64, 800, 24), (3, 24, 40, 300, 28), (3, 10, 50, 2000, 28),
-          (3, 16, 40, 1200, 28), (3, 10, 50, 400, 28)]
+          (3, 16, 40, 1200, 28), (3, 10, 50, 400, 28), (3, 10, 50, 400, 130), (3, 10, 50, 400, 256), (3, 10, 50, 400, 1024),
+          (3, 10, 50, 400, 2048), (3, 10, 50, 400, 4096)]
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import time
 
