@@ -69,13 +69,13 @@ def main():
     D, K, N = wl1.D, wl1.K, wl1.N
 
     def mkvp(wl):
-        vp = VariationalPosterior(D, K)
+        vp = VariationalPosterior(wl.D, wl.K)
         vp.mu, vp.sigma, vp.lambd = wl.mu.copy(), wl.sigma.reshape(1, -1), wl.lambd.reshape(-1, 1)
         vp.w, vp.eta = wl.w.reshape(1, -1), wl.eta.reshape(1, -1)
         return vp
 
     def mkgp(wl):
-        g = gpm.GP(D, gpm.SquaredExponential(), gpm.NegativeQuadratic(),
+        g = gpm.GP(wl.D, gpm.SquaredExponential(), gpm.NegativeQuadratic(),
                    gpm.GaussianNoise(constant_add=True, user_provided_add=wl.s2 is not None))
         g.update(X_new=wl.X, y_new=wl.y, s2_new=wl.s2, hyp=wl.hyp)
         return g
@@ -211,6 +211,25 @@ def main():
          f"NsK={nsk_ref} K={K} N={N} iters=400", per[1][0], tc_entmc_grad * nsk_ref / wl1.NsK,
          "oracle entropy value+grad of one evaluation, scaled to this NsK", rel(per[1][1][3], per[0][1][3]),
          {"four_launch_iteration_ms": 1e3 * per[0][0], "fused_vs_four_launches": per[0][0] / per[1][0], "kernels": [per[0][2], per[1][2]]})
+    # the same loop at BASELINE config 5's dimension and training-set size (D = 20, N = 800) with the reference's ns_ent: K = 50
+    # and K = 64 run as one launch per batch since round 5 (csrc/adam_fused.hip: builds for D <= 24, X^T read from memory);
+    # config 5's own K = 100 is beyond the fused kernel (lane = component) and keeps four launches -- both rows are here
+    for Kx in (50, 64, 100):
+        nskx = 2 * max(1, int(round(100.0 * Kx ** (2.0 / 3.0) / Kx / 2.0)))
+        wlx = synthetic.make_workload(5, S=1, D=20, K=Kx, N=800, Ns_total=nskx * Kx)
+        gx, bndx = mkgp(wlx), synthetic.default_theta_bnd(wlx)
+        perx = {}
+        for fused in (0, 1):
+            ctx.set_option("adam_fused", fused)
+            vx = mkvp(wlx)
+            tt, oo = med(lambda: minimize_adam_elbo(wlx.theta.copy(), gx, vx, nskx, bndx, seed=11, rng="philox", **kw2), reps=3, warm=1)
+            perx[fused] = (tt / 400, oo, ctx.last_entmc_plan()["kernel"])
+        ctx.set_option("adam_fused", 1)
+        emit("8f-2c minimize_adam at the reference's ns_ent, D=20 N=800 (per iteration)",
+             "vbmc/minimize_adam.py:84-137; option_configs/advanced_vbmc_options.ini:43", f"NsK={nskx} D=20 K={Kx} N=800 iters=400",
+             perx[1][0], float("nan"), "not timed (see 8f-2b)", rel(perx[1][1][3], perx[0][1][3]),
+             {"four_launch_iteration_ms": 1e3 * perx[0][0], "fused_vs_four_launches": perx[0][0] / perx[1][0],
+              "kernels": [perx[0][2], perx[1][2]]})
     # ---- the three stages of optimize_vp together, at the counts it uses (examples/optimize_vp_demo.py) ----
     nc = 50 * K
     cands = thetas  # the sieve row's candidates
