@@ -65,7 +65,7 @@ def upload_reference_eps(ctx, K, D, ns, eps_half=None):
     r0 = h * ctx.rank // ctx.world
     r1 = h * (ctx.rank + 1) // ctx.world
     if eps_half is None:
-        if K * h * D >= _HOST_RANDN_MIN and ctx.set_eps_numpy(K, h, D, r0, r1 - r0):
+        if K * h * D >= _HOST_RANDN_MIN and ctx.set_eps_numpy(K, h, D, r0, r1 - r0, view=_np_fingerprint):
             return
         eps_half = draw_eps_half(K, D, ns)
     eps_half = np.ascontiguousarray(eps_half, dtype=np.float64)

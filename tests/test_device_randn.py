@@ -173,3 +173,45 @@ def test_default_draw_source_uses_the_device_generator(ctx):
         assert np.max(np.abs(a[1] - b[1])) <= 1e-11 * np.max(np.abs(b[1]))
     sa, sb = res[1][1], res[0][1]
     assert np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+
+
+@pytest.mark.gpu
+def test_state_hand_off_in_place(ctx):
+    """Round 5: from the second ``rng="numpy"`` evaluation on, NumPy's key and position are read and written back through
+    the bit generator's ctypes view instead of get_state / set_state (``Context.set_eps_numpy(view=...)``) -- only while the
+    state is exactly what the previous call left and that call left no cached second value.  The sequence below walks
+    through every case: repeats (in place), an odd number of values (the cached value goes in through set_state, the next
+    call takes get_state again), the stream consumed by someone else in between (fingerprint changed), a value drawn from
+    the cache only (invisible to the fingerprint -- which is why a call that left a cached value never takes the view), a
+    re-seed.  After every step NumPy's full state equals what np.random.randn itself would have left."""
+    from pyvbmc_amd.entropy import _np_fingerprint, upload_reference_eps
+
+    def ours(K, D, ns):
+        upload_reference_eps(ctx, K, D, ns)
+
+    def numpys(K, D, ns):
+        for _ in range(K):
+            np.random.randn(ns // 2, D)
+
+    steps = [("draw", 20, 6, 5000), ("draw", 20, 6, 5000), ("draw", 20, 6, 5000),  # 300 000 values: even
+             ("draw", 7, 3, 6246),                                                  # 7 * 3123 * 3 = 65 583: odd
+             ("draw", 20, 6, 5000), ("draw", 20, 6, 5000),
+             ("foreign", lambda: np.random.randint(0, 10, size=3)), ("draw", 20, 6, 5000), ("draw", 20, 6, 5000),
+             ("draw", 7, 3, 6246), ("foreign", lambda: np.random.randn()),          # consumes the cached value only
+             ("draw", 20, 6, 5000), ("foreign", lambda: np.random.seed(5)), ("draw", 20, 6, 5000), ("draw", 20, 6, 5000)]
+    states = {}
+    for who, fn in (("numpy", numpys), ("ours", ours)):
+        np.random.seed(123)
+        seq = []
+        for st in steps:
+            if st[0] == "foreign":
+                st[1]()
+            else:
+                fn(*st[1:])
+            s = np.random.get_state()
+            seq.append((s[1].copy(), s[2], s[3], s[4]))
+        states[who] = seq
+    for i, (a, b) in enumerate(zip(states["numpy"], states["ours"])):
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:], (i, steps[i][0], a[1:], b[1:])
+    assert _np_fingerprint() is not None  # (the view is bound in this process: the in-place branch did run)
+    assert ctx.__dict__.get("_np_left") == _np_fingerprint()
