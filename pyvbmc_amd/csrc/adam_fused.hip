@@ -946,7 +946,7 @@ size_t adam_fused_plan(FusedArgs& f) {
   if (f.rows > 64) {
     const int cus = f.cus > 0 ? f.cus : 256;
     const int gp_min = S * K < 32 ? S * K : 32;
-    const int r_max = (cus - gp_min) / K < 4 ? (cus - gp_min) / K : 4;
+    const int r_max = (cus - 8 - gp_min) / K < 4 ? (cus - 8 - gp_min) / K : 4;
     R = f.rows > 128 ? r_max : (r_max < 2 ? r_max : 2);  // (as many slices as fit: shorter row loops)
     if (R < 1 || (f.rows + R - 1) / R > 512) return 0;
     f.rows = (f.rows + R - 1) / R;
@@ -957,7 +957,7 @@ size_t adam_fused_plan(FusedArgs& f) {
   f.n_gp = S * K < 128 ? S * K : 128;
   if (R > 1) {
     const int cus = f.cus > 0 ? f.cus : 256;
-    if (f.n_gp > cus - f.n_ent) f.n_gp = cus - f.n_ent;
+    if (f.n_gp > cus - 8 - f.n_ent) f.n_gp = cus - 8 - f.n_ent;  // (a few CUs' margin: every workgroup must become resident)
     if (f.n_gp < 1) return 0;
   }
   size_t o = (size_t)a.lay.o_res() + (size_t)a.n_bnd + 2 * (size_t)K + 2 * (size_t)D;  // theta | aux | hyp | phase B scratch
