@@ -39,6 +39,7 @@
 // the LDS plan fits (adam_fused_plan); everything else keeps the four-launch iteration.  Same draws
 // (Philox(seed + i), philox.h), same formulas: tests/test_adam.py runs both against the oracle loop.
 // Measured steps and the phase times: DESIGN.md section 4.6b.
+#include <cstdio>
 #include <cstdlib>
 
 #include "adam_dev.h"
@@ -998,6 +999,10 @@ size_t adam_fused_plan(FusedArgs& f) {
     if (o - (size_t)f.o_recs < need_part) o = (size_t)f.o_recs + need_part;
   }
   const size_t bytes = o * sizeof(double);
+  static const bool dbg = getenv("VBMC_FUSED_PLAN_DEBUG") != nullptr;  // measurement aid: the carve on stderr
+  if (dbg)
+    fprintf(stderr, "[vbmc] fused plan D=%d K=%d S=%d N=%d rows=%d/%d R=%d: state %d pack %d recs %d gp %d alpha %d xt %d part_waves %d need_part %zu -> %zu B (limit %zu)\n",
+            D, K, S, N, f.rows, f.rows_total, R, (int)a.lay.o_res(), f.o_pack, f.o_recs, f.o_gp, f.o_alpha, f.o_xt, f.part_waves, need_part, bytes, LDS_MAX);
   return bytes <= LDS_MAX ? bytes : 0;
 }
 
