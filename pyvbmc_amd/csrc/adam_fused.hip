@@ -333,13 +333,28 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
         double e[DP], e2 = 0.0;
 #pragma unroll
         for (int d = 0; d < DP; ++d) {
-          e[d] = (d < D) ? rp[d] : 0.0;
+          // (a row's normals are the same in every lane: the builds for D > 16 keep them in scalar registers -- 40 / 48 vector
+          // registers they do not have: with them and Delta_jk in vector registers those builds carried 152 / 276 B of scratch per
+          // thread, ran 1.5 / 3.5 us per iteration faster -- and about one launch in 10^5 gave the one-launch form up after its
+          // 20 ms wait, which no scratch-free build has ever done: profiles/r05_notes.md)
+          e[d] = (d < D) ? (DP > 16 ? to_sgpr(rp[d]) : rp[d]) : 0.0;
           e2 = fma(e[d], e[d], e2);
         }
         const double bq = sj2 * e2;
         double c = 0.0;
+        if constexpr (DP > 16) {
+          // (the builds for D > 16 do not hold Delta_jk across the row loop either: re-formed from the pack in LDS, behind an
+          // opaque zero offset so that the reads stay inside the loop -- 40 / 48 more vector registers)
+          int zoff;
+          asm volatile("v_mov_b32 %0, 0" : "=v"(zoff));
+          const double* mq = mup + zoff;
 #pragma unroll
-        for (int d = 0; d < DP; ++d) c = fma(dl[d], e[d], c);
+          for (int d = 0; d < DP; ++d)
+            if (d < D) c = fma(live ? mq[j * D + d] - mq[k * D + d] : 0.0, e[d], c);
+        } else {
+#pragma unroll
+          for (int d = 0; d < DP; ++d) c = fma(dl[d], e[d], c);
+        }
         const double sp = fma(two_sj, c, bq), sm = fma(-two_sj, c, bq);
         const double r1 = fm::exp2_fast(fma(ak, sp, c0)), r2 = fm::exp2_fast(fma(ak, sm, c0));
         const double qp = fm::wave_sum_dpp(wk * r1), qm = fm::wave_sum_dpp(wk * r2);
@@ -378,8 +393,9 @@ __global__ __launch_bounds__(NT) void adam_fused_kernel(FusedArgs f) {
 #pragma unroll
           for (int d = 0; d < DP; ++d)
             if (d < D) {
-              const double cl = fma(sig_j, B[d], dl[d] * A[d]);
-              const double cm = fma(sig_j, A[d], (wis2 * dl[d]) * W);
+              const double dld = DP > 16 ? mup[j * D + d] - mup[k * D + d] : dl[d];  // (live lanes only here)
+              const double cl = fma(sig_j, B[d], dld * A[d]);
+              const double cm = fma(sig_j, A[d], (wis2 * dld) * W);
               pq[(size_t)d * K] = add ? pq[(size_t)d * K] + cm : cm;
               pq[(size_t)(D + d) * K] = add ? pq[(size_t)(D + d) * K] + cl : cl;
               sl += cl;
