@@ -96,3 +96,36 @@ def test_kernel_timing_is_opt_in():
     H2 = entmc_vbmc(vp, wl.NsK, (True,) * 4, True, rng="philox", seed=1, ctx=ctx)[0]
     assert H1 == H2
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_predict_timing_levels():
+    """vbmc_set_timing(1) brackets predict's launches with one event pair and records nothing between them; level 2 adds the
+    pair around the variance product (which = 5) -- two records between dependent launches, which is why a harness reads the
+    whole interval at level 1 (round 5: rounds 2-4 read it with the inner pair on, ~5 us longer).  Results do not depend on
+    the level (level 2 keeps the separate finish launch so that the product is timed alone)."""
+    from pyvbmc_amd import _lib
+    from pyvbmc_amd import gp as gpm
+
+    ctx = _lib.Context(0)
+    wl = synthetic.make_workload(3, S=1)
+    gp = gpm.GP(wl.D, gpm.SquaredExponential(), gpm.NegativeQuadratic(), gpm.GaussianNoise(constant_add=True))
+    gp.ctx = ctx
+    gp.update(X_new=wl.X, y_new=wl.y, hyp=wl.hyp)
+    xs = np.random.default_rng(3).standard_normal((4096, wl.D))
+    ref = gp.predict(xs, separate_samples=True)
+    with pytest.raises(ValueError):
+        ctx.last_kernel_ms(3)  # nothing was timed
+    ctx.set_timing(1)
+    out1 = gp.predict(xs, separate_samples=True)
+    t_all = ctx.last_kernel_ms(3)
+    with pytest.raises(ValueError):
+        ctx.last_kernel_ms(5)  # level 1 records no pair inside
+    ctx.set_timing(2)
+    out2 = gp.predict(xs, separate_samples=True)
+    t_var, t_all2 = ctx.last_kernel_ms(5), ctx.last_kernel_ms(3)
+    ctx.set_timing(0)
+    assert 0.0 < t_var < t_all2 < 1.0 and 0.0 < t_all < 1.0
+    for o in (out1, out2):
+        assert np.array_equal(o[0], ref[0]) and np.array_equal(o[1], ref[1])
+    ctx.close()
