@@ -48,8 +48,10 @@ enum {
   VBMC_W_GP_CHANGED = 1, /* vbmc_neg_elcbo only: the watched GP arrays changed (vbmc_set_gp_watch);
                            the outputs were computed on the GP of the last vbmc_set_gp: discard them,
                            upload the GP again and repeat the call                               */
-  VBMC_W_NOT_FUSED = 2   /* vbmc_adam_run_auto only: this run does not have the one-launch form (shape, ranks,
-                           or a launch that gave up waiting); nothing was done: use vbmc_adam_run in batches */
+  VBMC_W_NOT_FUSED = 2   /* vbmc_adam_run_auto: this run does not have the one-launch form (shape, ranks,
+                           or a launch that gave up waiting); nothing was done: use vbmc_adam_run in batches.
+                           vbmc_mt19937_randn_dev: the request is not the device generator's; the state is
+                           untouched: draw with vbmc_mt19937_randn                                        */
 };
 
 /* GP mean functions understood by the path
@@ -108,8 +110,11 @@ int vbmc_set_timing(vbmc_ctx* ctx, int on);
 /* Duration in milliseconds of the most recent TIMED launch (vbmc_set_timing) of the
  * dominant kernel of the given entry point, from HIP events on the ctx's own stream.
  * which: 0 = entmc main kernel, 1 = gp_log_joint, 2 = mixture pdf,
- *        3 = gp_predict (its three launches), 4 = whole last vbmc_neg_elcbo device section,
- *        5 = gp_predict's variance product kernel alone. */
+ *        3 = gp_predict (all its launches), 4 = whole last vbmc_neg_elcbo device section,
+ *        5 = gp_predict's variance product kernel alone -- recorded at vbmc_set_timing(ctx, 2) ONLY, and that pass runs
+ *            the product WITHOUT the finish in its epilogue (three launches where production runs two): it measures
+ *            the product kernel, not the production configuration; a predict at level 0 / 1 invalidates the record
+ *            (VBMC_E_ARG "no timed launch recorded", never a stale interval). */
 int vbmc_last_kernel_ms(vbmc_ctx* ctx, int which, double* ms_out);
 
 /* Host-side wall-clock breakdown (microseconds) of the most recent vbmc_neg_elcbo:
@@ -292,9 +297,13 @@ int vbmc_mt19937_randn(uint32_t* key, int* pos, int* has_gauss, double* gauss, d
 
 /* The same stream generated on the DEVICE (csrc/device_randn.hip: MT19937 with a GF(2) jump-ahead per workgroup, the
  * polar method's attempts as position-pure work items, a prefix sum over the accepted pairs) and copied to `out`.
- * Words, accept / reject decisions and the state handed back are bit-identical to np.random.randn's; the values use the
- * device's log and agree with NumPy's to one unit in the last place.  What vbmc_set_eps_numpy uses (without the copy)
- * when the context holds all rows.  Reference: entropy/entmc_vbmc.py:64-68. */
+ * Words, accept / reject decisions and the state handed back are bit-identical to np.random.randn's; the VALUES use a
+ * double-double logarithm on the device and about 0.1 % of them differ from NumPy's (glibc's log) by 1-3 units in the
+ * last place (neither logarithm is correctly rounded everywhere; histogram in the source).  What vbmc_set_eps_numpy
+ * uses (without the copy) when the context holds all rows.  The caller's state is written only on success.  Returns
+ * VBMC_W_NOT_FUSED, state untouched, when the request is not this path's (more than 8e8 words, or fewer accepted
+ * attempts than pairs inside the 6-sigma word margin: ~1e-9 per call) -- draw with vbmc_mt19937_randn then.
+ * Reference: entropy/entmc_vbmc.py:64-68. */
 int vbmc_mt19937_randn_dev(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out,
                            int64_t n);
 /* Host twins of that jump for the CPU tests: the MT19937 block that starts n_words (>= 1) words after key_in[0], by the
@@ -307,7 +316,14 @@ int vbmc_mt_jump_polys(uint64_t stride_words, int count, uint32_t* out);
  * stream (= np.random.randn(n_half, D) for j = 0..K-1, the reference's draw order) are generated
  * into a pinned buffer the ctx keeps and rows [row_begin, +row_count) of every component are
  * uploaded as the resident draws.  The generator state advances by the whole job's values on
- * every rank. */
+ * every rank.
+ * WHICH GENERATOR RUNS, and what that means for parity: a single-rank context that holds all rows and asks for
+ * >= 65 536 values draws ON THE DEVICE (vbmc_mt19937_randn_dev: state, words and accept / reject decisions
+ * bit-identical to NumPy, ~0.1 % of the values 1-3 ulp off); a row shard, a multi-rank context, a smaller request, or
+ * the device pass answering VBMC_W_NOT_FUSED draws on the host cores (vbmc_mt19937_randn: every value bit-identical).
+ * F and dF computed from the two therefore agree to ~1e-15 relative, not bit for bit.  Strict parity switch:
+ * vbmc_set_option(ctx, "randn_device", 0) or VBMC_RANDN_DEVICE=0 in the environment -- always the host generator.
+ * The caller's state is written only when the draw succeeded. */
 int vbmc_set_eps_numpy(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double* gauss, int K,
                        int64_t n_half, int D, int64_t row_begin, int64_t row_count, int n_threads);
 

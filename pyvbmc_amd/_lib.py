@@ -6,6 +6,7 @@ requested, the import / call raises -- it never silently computes elsewhere.
 """
 import ctypes as C
 import os
+import sys
 import threading
 from pathlib import Path
 
@@ -223,6 +224,15 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
+            # argument blocks built for this handle (variational_optimization._FusedCall) and the repeat record that
+            # points at one of them must not outlive it
+            self.__dict__.pop("_fused_last", None)
+            self.__dict__.pop("_fused_cache", None)
+            vo = sys.modules.get(__package__ + ".variational_optimization")
+            if vo is not None:
+                fs = vo._fast_last[0]
+                if fs is not None and fs.ctx is self:
+                    vo._fast_last[0] = None
             self._lib.vbmc_ctx_destroy(self._h)
             self._h = None
 

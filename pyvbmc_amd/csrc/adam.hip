@@ -437,7 +437,9 @@ struct AdamState {
   size_t n_eps = 0;          // doubles per iteration
   double* d_eps1 = nullptr;  // [K][row_count][D]
   size_t eps_cap = 0;        // doubles allocated
-  bool eps_started = false;  // the buffer already holds the finish/step slices of the next iteration
+  double eps_have = 0.0;     // the share [0, eps_have) of the NEXT iteration's draws that earlier launches already put into
+                             // the buffer: 0 at the start of a run (and after a batch in the one-launch form), f_step behind a
+                             // four-launch iteration (its finish and step launches), 1 behind a two-launch iteration
   // the fused loop (adam_fused.hip): one launch per batch at the reference's own sample counts
   bool fused = false;
   int fused_gave_up = 0;  // batches redone as four launches per iteration after a bounded wait ran out
@@ -680,7 +682,7 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
   {
     st->n_eps = (size_t)K * (size_t)st->row_count * D;
     st->pregen = st->eps_mode == VBMC_EPS_PHILOX && st->n_eps > 0 && st->n_eps <= ((size_t)1 << 32);
-    st->eps_started = false;
+    st->eps_have = 0.0;
     if (st->pregen && st->eps_cap < st->n_eps) {
       if (st->d_eps1) HIP_TRY(ctx, hipFree(st->d_eps1));
       st->d_eps1 = nullptr;
@@ -798,13 +800,14 @@ static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool
         plan.a.eps_rows = st->row_count;
       }
       plan.table = st->d_table;
-      if (!st->table_valid || (use_gen && !st->eps_started)) {
-        // first iteration of a run (or after a batch in the other form): the table of the current iterate and the
-        // part of its draws that is not there yet, by a prep launch of their own
+      if (!st->table_valid || (use_gen && st->eps_have < 1.0)) {
+        // first iteration of a run (or after an iteration in another form): the table of the current iterate and the
+        // part of its draws that is not there yet -- everything at the start of a run, [f_step, 1) behind a four-launch
+        // iteration (whose finish and step launches made [0, f_step): ADVICE r05) --, by a prep launch of their own
         PrepArgs pt;
         entmc_fill_prep(ctx, plan, pt);
         if (st->table_valid) pt.n_table = 0;
-        if (use_gen && !st->eps_started) pt.gen = slice(it, 0.0, 1.0);
+        if (use_gen && st->eps_have < 1.0) pt.gen = slice(it, st->eps_have, 1.0);
         rc = launch_prep(ctx, pt);
         if (rc) return rc;
       }
@@ -869,7 +872,7 @@ static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool
                 (tt[6] - tt[5]) * 0.01, (tt[7] - tt[6]) * 0.01, (tt[7] - tt[0]) * 0.01);
       }
       st->table_valid = true;
-      if (use_gen) st->eps_started = true;
+      st->eps_have = (use_gen && gen_mode != 0) ? 1.0 : 0.0;
       st->last_form = 2;
       ctx->last_plan[0] = 6;  // vbmc_last_entmc_plan: the wave-split kernel in span mode inside the two-launch iteration
       continue;
@@ -879,9 +882,10 @@ static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool
     if (use_gen) {
       plan.a.eps = st->d_eps1;
       plan.a.eps_rows = st->row_count;
-      // this iteration's remaining draws (all of them when no earlier launch began the buffer)
-      pa.gen = slice(it, st->eps_started ? f_step : 0.0, 1.0);
-      st->eps_started = true;
+      // this iteration's remaining draws (all of them when no earlier launch began the buffer, none behind a two-launch
+      // iteration, whose tail launch made them all)
+      if (st->eps_have < 1.0) pa.gen = slice(it, st->eps_have, 1.0);
+      st->eps_have = f_step;  // (what this iteration's finish and step launches below put in for the next one)
     }
     entmc_fill_prep(ctx, plan, pa);
     rc = launch_prep(ctx, pa);
@@ -961,6 +965,9 @@ extern "C" int vbmc_adam_run(vbmc_ctx* ctx, int n_iters, double* y_tab_out, doub
     }
     rc = adam_fused_launch(ctx, ctx->stream, f, st->fused_lds);
     ctx->last_plan[0] = 4;  // vbmc_last_plan: the fused loop
+    // (the iterate moves without the other forms' side buffers following it: their table and any draws made ahead are stale)
+    st->table_valid = false;
+    st->eps_have = 0.0;
     if (want_times && !rc) {
       std::vector<unsigned long long> tt(2 * 64 * 16);
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -70,7 +70,7 @@ static void options_from_env(vbmc_ctx* c) {
   e = getenv("VBMC_ADAM_FUSED");
   c->opt_adam_fused = e ? atoi(e) : 1;  // (3: the release / acquire form of its exchange)
   e = getenv("VBMC_RANDN_DEVICE");
-  c->opt_randn_dev = !(e && e[0] == '0');
+  c->opt_randn_dev = e ? (e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1) : 1;  // VBMC_RANDN_DEVICE=0: strict parity with np.random.randn (host generator)
   e = getenv("VBMC_ADAM_TAIL");
   c->opt_adam_tail = e ? atoi(e) : 1;  // (2: wherever its shape applies, whatever the job's size)
   e = getenv("VBMC_WS_SPAN");
@@ -238,7 +238,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "ws_front")) ctx->opt_ws_front = value < 0 ? 0 : value > 990 ? 990 : value;
   else if (!strcmp(key, "elbo_arm")) ctx->opt_elbo_arm = value < 0 ? 0 : value > 2 ? 2 : value;  // 1: only while this context is alone on its device; 2: always
   else if (!strcmp(key, "acq_poll")) ctx->opt_acq_poll = value != 0;
-  else if (!strcmp(key, "randn_device")) ctx->opt_randn_dev = value != 0;  // vbmc_set_eps_numpy: the NumPy stream on the device (device_randn.hip)
+  else if (!strcmp(key, "randn_device")) ctx->opt_randn_dev = value < 0 ? 0 : value > 2 ? 2 : value;  // vbmc_set_eps_numpy: the NumPy stream on the device (device_randn.hip); 0 = strict parity (host generator, values bit-identical to np.random.randn); 2 = test hook: the device pass reports its margin exceeded
   else if (!strcmp(key, "adam_tail")) ctx->opt_adam_tail = value;  // the optimiser loop's two-launch iteration (adam.hip)
   else if (!strcmp(key, "adam_fused")) ctx->opt_adam_fused = value;  // 2: test hook, see FusedArgs::test_absent; 3: release / acquire flags (FusedArgs::rel_acq)
   else return vbmc_fail(ctx, VBMC_E_ARG, "vbmc_set_option: unknown key '%s'", key);
@@ -279,7 +279,9 @@ int vbmc_set_timing(vbmc_ctx* ctx, int on) {
 int vbmc_last_kernel_ms(vbmc_ctx* ctx, int which, double* ms_out) {
   if (!ctx || which < 0 || which > 5 || !ms_out) return VBMC_E_ARG;
   NEED_DEVICE(ctx);
-  if (!ctx->ev_valid[which]) return vbmc_fail(ctx, VBMC_E_ARG, "no timed launch recorded for %d", which);
+  if (!ctx->ev_valid[which])
+    return vbmc_fail(ctx, VBMC_E_ARG, which == 5 ? "no timed launch recorded for 5 (gp_predict's product alone is timed at vbmc_set_timing(ctx, 2) only)"
+                                                 : "no timed launch recorded for %d", which);
   HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2 * which + 1]));
   float ms = 0.f;
   HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[2 * which], ctx->ev[2 * which + 1]));

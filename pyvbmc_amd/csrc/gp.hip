@@ -1243,6 +1243,8 @@ int launch_gp_predict_products(vbmc_ctx* ctx, int64_t M, const double* d_xs, dou
   if (ctx->timing >= 2) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev[11], ctx->stream));
     ctx->ev_valid[5] = true;
+  } else {
+    ctx->ev_valid[5] = false;  // (no pair around this product: an interval left by an earlier level-2 call is not this call's)
   }
   HIP_TRY(ctx, hipGetLastError());
   return 0;

@@ -217,4 +217,5 @@ def unpatch(vo):
     for n, v in saved.items():
         setattr(vo, n, v)
     delattr(vo, _SAVED)
+    _avo.clear_fast_path()  # (the repeat record holds the last call's vp, gp and context)
     return vo

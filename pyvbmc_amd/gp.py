@@ -14,6 +14,7 @@ names so the hot-path functions accept either it or a real ``gpyreg.GP``:
 * ``predict`` runs on the MI355X (vbmc_gp_predict).
 """
 import ctypes as C
+import sys
 from types import SimpleNamespace
 
 import numpy as np
@@ -177,6 +178,9 @@ def invalidate_gp(ctx=None):
     editing GP arrays in place in a way the fingerprint cannot see (see ``_gp_fingerprint``)."""
     ctx = _lib.default_context() if ctx is None else ctx
     ctx._gp_key = ctx._gp_ref = ctx._gp_ck = ctx._gp_quick = None
+    vo = sys.modules.get(__package__ + ".variational_optimization")
+    if vo is not None:
+        vo.clear_fast_path()
 
 
 def upload_gp(gp, ctx, lazy=False):

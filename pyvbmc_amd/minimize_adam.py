@@ -83,7 +83,7 @@ def minimize_adam(f, x0, lb=None, ub=None, tol_fun=0.001, max_iter=10000, master
 def minimize_adam_elbo(theta0, gp, vp, Ns, theta_bnd=None, beta=0.0, lb=None, ub=None, tol_fun=0.001,
                        max_iter=10000, master_min=0.001, master_max=0.1, master_decay=200,
                        use_early_stopping=True, *, rng=None, seed=None, eps_half=None, ctx=None,
-                       return_parts=False, rows=None, device_stop=True):
+                       return_parts=False, rows=None, device_stop=True, _between_batches=None):
     """``minimize_adam(lambda t: _neg_elcbo(t, gp, vp, beta, Ns, True, theta_bnd=theta_bnd)[:2],
     theta0, lb, ub, ...)`` with the whole inner loop on the device.
 
@@ -94,7 +94,8 @@ def minimize_adam_elbo(theta0, gp, vp, Ns, theta_bnd=None, beta=0.0, lb=None, ub
     draws from the NumPy stream that every iteration reuses (common random numbers).  On return ``vp``
     holds the parameters of the last iterate (the reference leaves those of the last
     *evaluated* iterate; its caller overwrites them right away, :283-300).  ``device_stop=False`` keeps the
-    stopping rule on the host (batches of 20 iterations) also where the device can apply it itself."""
+    stopping rule on the host (batches of 20 iterations) also where the device can apply it itself.
+    ``_between_batches(done)`` (tests): called after every batch of the host-driven form."""
     if beta != 0 and np.isfinite(beta):
         raise NotImplementedError("Computation of the gradient of ELBO with full variance not supported")
     ctx = ctx_of(vp, ctx)
@@ -159,6 +160,8 @@ def minimize_adam_elbo(theta0, gp, vp, Ns, theta_bnd=None, beta=0.0, lb=None, ub
                                         _lib.ptr(G_tab[done:]), _lib.ptr(H_tab[done:])))
             done += step
             i = done - 1
+            if _between_batches is not None:
+                _between_batches(done)
             if use_early_stopping and done % b == 0 and done >= 2 * b:
                 if _window_stop(y_tab[i - b + 1 : i + 1], x_rows[i - 2 * b + 1 : i + 1 - b].mean(axis=0),
                                 x_rows[i - b + 1 : i + 1].mean(axis=0), tol_fun):

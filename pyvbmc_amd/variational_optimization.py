@@ -155,6 +155,10 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
         rc = fs.call(theta, seed)
         if rc is not None:
             return rc
+    # (general path from here on: the repeat record is dropped FIRST -- _fused_call below re-binds the shared
+    # argument block's bounds, and an exception between there and the C call must not leave a record behind that
+    # still passes its identity checks against the old arguments; a new one is published only after a successful call)
+    _fast_last[0] = None
     if not math.isfinite(beta):
         beta = 0
     if compute_var is None:
@@ -218,8 +222,6 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
     # fc.released() once its launches are out and the device is at work (vbmc_set_release_callback), so they cost
     # nothing between two evaluations; whatever path did not get there applies them after the call.
     fc.side = (vp, theta, mask, K)
-    _fast_last[0] = (_FastElbo(ctx_arg, ctx, fc, vp, gp, theta_bnd, Ns, compute_grad, rng, mask, D, K, n_theta, mode)
-                     if (rows is None and eps_half is None and (ns == 0 or mode == _lib.EPS_PHILOX) and type(compute_grad) is bool) else None)
     try:
         rc = fc.fn(*fc.args)
         if rc != 0:
@@ -233,6 +235,8 @@ def _neg_elcbo(theta, gp, vp, beta=0.0, Ns=0, compute_grad=True, compute_var=Non
             fc.apply_side_effects()
     finally:
         fc.side = None
+    if rows is None and eps_half is None and (ns == 0 or mode == _lib.EPS_PHILOX) and type(compute_grad) is bool:
+        _fast_last[0] = _FastElbo(ctx_arg, ctx, fc, vp, gp, theta_bnd, Ns, compute_grad, rng, mask, D, K, n_theta, mode)
     return fc.F.value, (fc.dF.copy() if compute_grad else None), fc.G.value, fc.H.value, 0
 
 
@@ -269,6 +273,12 @@ def _neg_elcbo_batch(thetas, gp, vp, theta_bnd=None, *, ctx=None, return_parts=F
 _RELEASE_CB = os.environ.get("VBMC_RELEASE_CB", "1") != "0"  # measurement aid: 0 = side effects after the call
 _FAST_PATH = os.environ.get("VBMC_FAST_PATH", "1") != "0"    # measurement aid: 0 = every call takes the general path
 _fast_last = [None]  # the last fused Monte-Carlo / lower-bound call's record (_FastElbo), or None
+
+
+def clear_fast_path():
+    """Drop the repeat record of the last fused ``_neg_elcbo`` call (it holds that call's ``vp``, ``gp`` and context):
+    called by ``unpatch``, ``invalidate_gp`` and ``Context.close``; the next call takes the general path."""
+    _fast_last[0] = None
 
 
 class _FastElbo:

@@ -375,6 +375,50 @@ def test_two_launch_iteration_vs_four_launch_loop_and_oracle(ctx, shape):
     ref = oracle_philox_run(wl, wd, theta0, bnd, 77, 8, **kw)  # (the oracle takes seconds per iteration at these sizes)
     assert rel_err(a[2][:, :8], ref[2][:, :8]) < 1e-7 and rel_err(a[3][:8], ref[3][:8]) < 1e-7
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("first", [0, 2], ids=["four-then-two", "two-then-four"])
+def test_forms_switched_between_batches(ctx, first):
+    """a two-launch iteration that follows a four-launch iteration in the same run (and the other way round).
+    The four-launch iteration's finish and step launches make the share [0, 0.67) of the next iteration's draws; the
+    two-launch iteration's prep launch has to make the rest (it used to assume its own kind had made them all, and
+    read stale rows), and its table must be rebuilt after a batch in the other form.  Forms alternate batch by batch
+    (batches of 20, the host's stopping rule with a tolerance it never meets) and the run must equal the all-four-launch
+    run."""
+    from pyvbmc_amd.minimize_adam import minimize_adam_elbo
+
+    shape = TAIL_SHAPES[0]
+    wl = synthetic.make_workload(shape["cfg"], S=shape["S"], D=shape["D"], K=shape["K"], N=shape["N"],
+                                 Ns_total=shape["NsK"] * shape["K"])
+    wd = dict(D=wl.D, K=wl.K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,
+              hyp=wl.hyp, s2=np.zeros(0) if wl.s2 is None else wl.s2)
+    bnd = synthetic.default_theta_bnd(wl)
+    theta0 = wl.theta.copy()
+    theta0[1] += 3.0
+    kw = dict(tol_fun=0.0, master_min=0.001, master_max=0.1, master_decay=200, use_early_stopping=True, device_stop=False)
+    n_it = 70  # three full batches and a partial one
+    forms = []
+
+    def switch(done):
+        forms.append((done, ctx.last_entmc_plan()["adam_tail"]))  # the form the batch just done ran in
+        ctx.set_option("adam_tail", 2 - first if (done // 20) % 2 == 1 else first)
+
+    try:
+        ctx.set_option("adam_tail", 0)
+        vp, gp = device_objects(wd, ctx)
+        want = minimize_adam_elbo(theta0.copy(), gp, vp, wl.NsK, bnd, max_iter=n_it, seed=91, rng="philox", **kw)
+        ctx.set_option("adam_tail", first)
+        vp, gp = device_objects(wd, ctx)
+        got = minimize_adam_elbo(theta0.copy(), gp, vp, wl.NsK, bnd, max_iter=n_it, seed=91, rng="philox",
+                                 _between_batches=switch, **kw)
+    finally:
+        ctx.set_option("adam_tail", 1)
+    # the batches really ran in alternating forms
+    assert [f for _, f in forms] == [first == 2, first != 2, first == 2, first != 2], forms
+    assert got[4] == want[4] == n_it
+    assert rel_err(got[2], want[2]) < 1e-10 and rel_err(got[3], want[3]) < 1e-10, (rel_err(got[2], want[2]), rel_err(got[3], want[3]))
+
+
 FUSED_SHAPES = [dict(cfg=3, D=10, K=50, N=400, S=1, NsK=28), dict(cfg=5, D=16, K=12, N=60, S=3, NsK=40),
                 dict(cfg=2, D=4, K=20, N=200, S=2, NsK=22), dict(cfg=3, D=7, K=64, N=90, S=1, NsK=2),
                 dict(cfg=5, D=11, K=1, N=50, S=1, NsK=128), dict(cfg=3, D=6, K=20, N=60, S=8, NsK=28),

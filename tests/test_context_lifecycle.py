@@ -124,6 +124,12 @@ def test_predict_timing_levels():
     ctx.set_timing(2)
     out2 = gp.predict(xs, separate_samples=True)
     t_var, t_all2 = ctx.last_kernel_ms(5), ctx.last_kernel_ms(3)
+    # a predict at a lower level invalidates the product's record (it used to leave the level-2 interval
+    # of an EARLIER call to be read as this call's)
+    ctx.set_timing(1)
+    gp.predict(xs, separate_samples=True)
+    with pytest.raises(ValueError, match="vbmc_set_timing"):
+        ctx.last_kernel_ms(5)
     ctx.set_timing(0)
     assert 0.0 < t_var < t_all2 < 1.0 and 0.0 < t_all < 1.0
     for o in (out1, out2):

@@ -176,6 +176,41 @@ def test_default_draw_source_uses_the_device_generator(ctx):
 
 
 @pytest.mark.gpu
+def test_margin_fall_back_leaves_the_state_alone(ctx):
+    """the device pass must not touch the caller's state unless it succeeds.  ``randn_device`` = 2 makes it
+    report its word margin exceeded after the kernels ran (about once in 1e9 calls otherwise): the direct entry point
+    answers VBMC_W_NOT_FUSED with key, position and the cached value exactly as they came in, and vbmc_set_eps_numpy
+    then draws on the host cores -- NumPy ends in the state np.random.randn would have left, cached value included."""
+    np.random.seed(19)
+    np.random.randn(3)  # leaves a cached second value
+    st = np.random.get_state(legacy=True)
+    assert st[3] == 1
+    key = np.array(st[1], dtype=np.uint32)
+    key0 = key.copy()
+    pos, hg, g = C.c_int(int(st[2])), C.c_int(int(st[3])), C.c_double(float(st[4]))
+    out = np.empty(100_000)
+    ctx.set_option("randn_device", 2)
+    try:
+        rc = ctx._lib.vbmc_mt19937_randn_dev(ctx._h, key.ctypes.data_as(U32P), C.byref(pos), C.byref(hg), C.byref(g),
+                                             _lib.ptr(out), out.size)
+        assert rc == _lib.W_NOT_FUSED
+        assert np.array_equal(key, key0) and (pos.value, hg.value, g.value) == (int(st[2]), 1, float(st[4]))
+        # through the mirror: 7 * 3123 * 3 = 65 583 values (odd: a cached value goes in AND one comes out)
+        from pyvbmc_amd.entropy import upload_reference_eps
+
+        np.random.set_state(st)
+        upload_reference_eps(ctx, 7, 3, 6246)
+        got = np.random.get_state()
+        np.random.set_state(st)
+        for _ in range(7):
+            np.random.randn(3123, 3)
+        want = np.random.get_state()
+        assert np.array_equal(got[1], want[1]) and got[2:] == want[2:]
+    finally:
+        ctx.set_option("randn_device", 1)
+
+
+@pytest.mark.gpu
 def test_state_hand_off_in_place(ctx):
     """Round 5: from the second ``rng="numpy"`` evaluation on, NumPy's key and position are read and written back through
     the bit generator's ctypes view instead of get_state / set_state (``Context.set_eps_numpy(view=...)``) -- only while the

@@ -183,3 +183,47 @@ def test_side_effects_with_and_without_the_release_callback(ctx, golden):
     for i, (a, b) in enumerate(zip(on, off)):
         for x, y in zip(a, b):
             assert np.array_equal(np.asarray(x), np.asarray(y)), i
+
+
+def test_a_raise_on_the_general_path_leaves_no_repeat_record(ctx, golden):
+    """the general path re-binds the shared argument block's soft bounds (``_fused_call``) before it can
+    still raise (``rows=`` with the wrong draw source here).  The repeat record of the call BEFORE must not survive
+    that: it would pass every identity check of the next call with the original arguments and evaluate with the
+    other call's bounds (with ``theta_bnd=None`` in between: no bound penalty at all).  Also: ``Context.close``,
+    ``unpatch`` and ``invalidate_gp`` drop the record (it holds vp, gp and the context)."""
+    from pyvbmc_amd import variational_optimization as vo
+    from pyvbmc_amd.gp import invalidate_gp
+
+    g = golden("c1")
+    wl = synthetic.make_workload(1, S=1)
+    bnd = synthetic.default_theta_bnd(wl)
+    bnd["lb"] = bnd["lb"] + 0.5  # (tight enough that the penalty is not zero)
+    gp = PlainGP(oracle_gp(g, g["hyp"][:1]))
+    vp = PlainVP(g)
+    th0 = g["theta_out"].copy()
+    vo._fast_last[0] = None
+
+    def ev(b):
+        return vo._neg_elcbo(th0.copy(), gp, vp, 0.0, 40, True, False, b, rng="philox", seed=21)
+
+    want = ev(bnd)
+    assert vo._fast_last[0] is not None
+    free = ev(None)
+    assert want[0] != free[0]  # the bounds matter at this theta
+    again = ev(bnd)
+    assert again[0] == want[0]
+    rec = vo._fast_last[0]
+    assert rec is not None and rec.bnd is bnd
+    # a call with other bounds that raises AFTER the argument block was re-bound
+    with pytest.raises(ValueError):
+        vo._neg_elcbo(th0.copy(), gp, vp, 0.0, 40, True, False, None, rng="numpy", rows=(0, 10))
+    assert vo._fast_last[0] is None
+    got = ev(bnd)  # (with the stale record: the fast path, n_bnd = 0, no penalty)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1])
+    # the record does not outlive what it points at
+    assert vo._fast_last[0] is not None
+    invalidate_gp(ctx)
+    assert vo._fast_last[0] is None
+    ev(bnd)
+    vo.clear_fast_path()
+    assert vo._fast_last[0] is None
