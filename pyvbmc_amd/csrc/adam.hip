@@ -461,6 +461,19 @@ struct AdamState {
   int last_form = 0;          // launches per iteration of the last batch (2 or 4)
 };
 
+// How much dynamic LDS the pre workgroup may ask of the entropy launch it rides in (its working set then sits in LDS: ~10 us
+// against 25-30 from global memory).  The launch's dynamic LDS is the same for all of its workgroups: where the entropy
+// kernel runs two workgroups per CU the pre workgroup's share must leave room for both (60 KB: rounds 4-5); the builds that
+// run ONE workgroup per CU -- the matrix-pipe form and the wave-split instantiations at one wave per SIMD, i.e. the large
+// K D shapes whose working set is the largest -- have the CU's LDS to themselves (round 6: config 5's own shape, D = 20,
+// K = 100, N = 800, went from 33 to ~15 us per entropy launch of the four-launch iteration).
+static size_t pre_lds_limit(const vbmc_ctx* ctx, const EntPlan& plan) {
+  if (!plan.ws) return 0;
+  if (plan.a.sp.cus == 0 && !entmc_small_applies(plan.a, plan.DP) && ctx->opt_entmc_mfma && entmc_mfma_applies(plan.a, plan.DP))
+    return 158 * 1024;  // (its static arrays are 1 056 B)
+  return ws_min_waves(plan.DP, ws_ktmax_for(ctx->K), true) >= 2 ? 60 * 1024 : 110 * 1024;  // (the widest build holds 38 KB of static LDS)
+}
+
 static size_t fused_backup_len(const AdamDev& a) { return (size_t)a.lay.o_hyp() + 2 * (size_t)a.n_theta + (size_t)a.ml.total; }
 
 // A fused launch that gave up waiting may have got as far as its write-back in workgroup 0 (the others can run out of
@@ -622,7 +635,10 @@ extern "C" int vbmc_adam_begin(vbmc_ctx* ctx, const double* theta0, int n_theta,
   const size_t n_work = work_len(D, K, S, st->n_bnd);
   {
     // LDS plan: each kernel keeps its working set in LDS when it fits
-    const size_t cap = 150 * 1024 / sizeof(double);  // (beyond it the kernels work from global memory: config 5's shape)
+    // (beyond it the kernels work from global memory.  158 KB: the CU's 160 KB less the static arrays of the kernels that
+    // host these working sets -- adam_pre_kernel / adam_step_kernel 128 B, the matrix-pipe entropy kernel 1 056 B; round 6:
+    // was 150 KB, 3 KB short of config 5's own shape at S = 1 -- D = 20, K = 100: 153.5 KB)
+    const size_t cap = 158 * 1024 / sizeof(double);
     const size_t n_pre = (size_t)L.o_blb() + n_work, n_step = (size_t)L.o_hyp() + K;
     st->pre_lds = n_pre <= cap;
     st->step_lds = n_step <= cap;
@@ -824,7 +840,7 @@ static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool
       plan.a.gp = gp;
       plan.a.gp_items = gp.n_glj;
       plan.a.extra = st->d_args;
-      plan.a.extra_lds = (st->pre_lds && st->pre_lds_bytes <= 60 * 1024) ? (int)(st->pre_lds_bytes / sizeof(double)) : 0;
+      plan.a.extra_lds = (st->pre_lds && st->pre_lds_bytes <= pre_lds_limit(ctx, plan)) ? (int)(st->pre_lds_bytes / sizeof(double)) : 0;
       rc = entmc_launch_main(ctx, plan);
       if (rc) return rc;
       TailArgs t;
@@ -895,8 +911,8 @@ static int enqueue_batch(vbmc_ctx* ctx, AdamState* st, int i0, int n_iters, bool
     const bool pre_row = plan.ws && plan.a.eps_mode != VBMC_EPS_PHILOX;
     if (pre_row) {
       plan.a.extra = st->d_args;
-      // its working set in LDS when two entropy workgroups per CU still fit beside it
-      plan.a.extra_lds = (st->pre_lds && st->pre_lds_bytes <= 60 * 1024) ? (int)(st->pre_lds_bytes / sizeof(double)) : 0;
+      // its working set in LDS when the launch's entropy workgroups still fit beside it (pre_lds_limit)
+      plan.a.extra_lds = (st->pre_lds && st->pre_lds_bytes <= pre_lds_limit(ctx, plan)) ? (int)(st->pre_lds_bytes / sizeof(double)) : 0;
     } else {
       launch_pre(*st, sm, a);
     }

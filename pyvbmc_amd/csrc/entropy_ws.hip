@@ -99,20 +99,30 @@ __device__ __forceinline__ double wave_sum(double v) { return fm::wave_sum_dpp(v
 // (AGPRs as spill space) beats spilling to scratch memory.
 // (ws_min_waves: entropy_args.h -- the host uses the same rule to count free workgroup slots)
 
-// End-of-workgroup reduction through an LDS transpose: every wave writes its per-lane accumulators
-// as rows [item][lane] (stride 65), then one THREAD sums one row.  A wave reduction costs ~30
-// dependent VALU instructions per accumulator even on DPP, and a workgroup has 4 x (1 + 2 DP + KT)
-// of them -- 3 us of the ~40 us a workgroup lives at BASELINE config 3; this way it is 64 pipelined
-// LDS reads per row.  Two half-size passes bound the buffer (35 KB at D_p = 10, KT = 13); it lives
-// in the dynamic LDS region (which the Adam loop's pre workgroup uses instead, adam_dev.h).
-// Returns the buffer size in doubles, 0 = keep the DPP reductions (buffer too large for the
-// kernel's occupancy).
-constexpr int ws_epi_half(int dp, int ktmax) { return (1 + 2 * dp + ktmax + 1) / 2; }
-constexpr int ws_epi_doubles(int dp, int ktmax, bool grad) {
+// End-of-workgroup reduction: every wave holds 1 + 2 DP + KT per-lane accumulators whose 64 lanes have to be added up.
+// Round 6 form: NQ DPP steps add each accumulator up inside groups of 2^NQ neighbouring lanes (independent across the
+// accumulators: they pipeline), the 64 / 2^NQ group sums of every (wave, item) go through LDS as one row [NV (+1)], ONE
+// thread per row adds them up in a fixed order, and the output stage adds the four waves.  NQ is the smallest step count
+// whose buffer fits the kernel's occupancy (one step, 32 values per row, 36 KB at D_p = 10, KT = 13).
+// Measured at BASELINE config 3's shape (profiles/r06_notes.md): rounds 3-5 laid all 64 lanes down (rows of 65, in two
+// half-size passes to bound the buffer, a thread per row): 3.1 us per workgroup behind its last batch at EVERY problem
+// size by in-kernel stamps, 3.2 us of the 64 us launch by ablation; NQ = 1 / 2 / 3: 62.5 / 62.7 / 63.0 us per launch
+// against 64.0-64.5, 12.1 / 12.3 / 12.9 against 13.6 us at 1 024 samples per component.  Full DPP wave reductions
+// (~20 dependent instructions per accumulator) remain the fallback where no buffer fits.
+// The buffer lives in the dynamic LDS region (which the Adam loop's pre workgroup uses instead, adam_dev.h).
+constexpr int ws_epi_cap_doubles(int dp, int ktmax, bool grad) { return (ws_min_waves(dp, ktmax, grad) >= 2 ? 44 : 100) * 1024 / 8; }
+// DPP steps in front of the LDS pass (0: no buffer fits -- DPP reductions all the way)
+constexpr int ws_epi_nq(int dp, int ktmax, bool grad) {
   if (!grad) return 0;
-  const int n = WAVES * ws_epi_half(dp, ktmax) * 65;
-  const int cap = (ws_min_waves(dp, ktmax, grad) >= 2 ? 44 : 100) * 1024 / 8;
-  return n <= cap ? n : 0;
+  const int ni = 1 + 2 * dp + ktmax;
+  for (int nq = 1; nq <= 3; ++nq)
+    if (WAVES * ni * ((64 >> nq) + 1) <= ws_epi_cap_doubles(dp, ktmax, grad)) return nq;
+  return 0;
+}
+// the buffer's size in doubles (0 = none)
+constexpr int ws_epi_doubles(int dp, int ktmax, bool grad) {
+  const int nq = ws_epi_nq(dp, ktmax, grad);
+  return nq == 0 ? 0 : WAVES * (1 + 2 * dp + ktmax) * ((64 >> nq) + 1);
 }
 
 #if defined(WS_TIMES) && VBMC_DP == 10
@@ -510,44 +520,58 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   WS_STAMP(2);
   // ---- workgroup reduction ----
   if constexpr (EPI > 0) {
-    constexpr int NI = 1 + 2 * DP + KTMAX, HALF = ws_epi_half(DP, KTMAX);
-#pragma unroll
-    for (int ph = 0; ph < 2; ++ph) {
-      const int i0 = ph * HALF;
-      double* mine = dyn + ((long)wave * HALF - i0) * 65 + lane;  // mine[it * 65], it in [i0, i0 + HALF)
-      if (ph == 0) mine[0] = slog_acc;
+    constexpr int NQ = ws_epi_nq(DP, KTMAX, GRAD);  // DPP steps: groups of 2 / 4 / 8 lanes
+    constexpr int GL = 1 << NQ, NV = 64 / GL;        // values per accumulator and wave that go through LDS
+    constexpr int NI = 1 + 2 * DP + KTMAX, RS = NV + 1;
+    static_assert(NQ >= 1 && NQ <= 3 && WAVES * NI * RS == EPI, "epilogue buffer");
+    auto group = [](double v) {
+      v += fm::dpp_get<0xB1, 0xf>(v);                          // quad_perm [1,0,3,2]
+      if constexpr (NQ >= 2) v += fm::dpp_get<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+      if constexpr (NQ >= 3) v += fm::dpp_get<0x141, 0xf>(v);  // row_half_mirror
+      return v;
+    };
+    {
+      double* mine = dyn + (size_t)wave * NI * RS + (lane / GL);  // mine[item * RS]
+      const bool wr = (lane & (GL - 1)) == 0;
+      double v = group(slog_acc);
+      if (wr) mine[0] = v;
 #pragma unroll
       for (int d = 0; d < DP; ++d) {
-        if (1 + d >= i0 && 1 + d < i0 + HALF) mine[(1 + d) * 65] = mu_acc[d];
-        if (1 + DP + d >= i0 && 1 + DP + d < i0 + HALF) mine[(1 + DP + d) * 65] = lam_acc[d];
+        v = group(mu_acc[d]);
+        if (wr) mine[(1 + d) * RS] = v;
+        v = group(lam_acc[d]);
+        if (wr) mine[(1 + DP + d) * RS] = v;
       }
 #pragma unroll
-      for (int kk = 0; kk < KTMAX; ++kk)
-        if (1 + 2 * DP + kk >= i0 && 1 + 2 * DP + kk < i0 + HALF) mine[(1 + 2 * DP + kk) * 65] = Wacc[kk];
-      __syncthreads();
-      for (int r = tid; r < WAVES * HALF; r += WG) {
-        const int wv = r / HALF, it = i0 + (r - wv * HALF);
-        if (it < NI) {
-          const double* row = dyn + (size_t)r * 65;
-          double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-          for (int l = 0; l < 64; l += 4) {
-            s0 += row[l];
-            s1 += row[l + 1];
-            s2 += row[l + 2];
-            s3 += row[l + 3];
-          }
-          const double sum = (s0 + s1) + (s2 + s3);
-          if (it <= 2 * DP) {
-            sRed[wv][it] = sum;
-          } else {
-            const int kk = it - 1 - 2 * DP;
-            sW[4 * kk + wv] = sum;
-          }
-        }
+      for (int kk = 0; kk < KTMAX; ++kk) {
+        v = group(Wacc[kk]);
+        if (wr) mine[(1 + 2 * DP + kk) * RS] = v;
       }
-      __syncthreads();
     }
+    __syncthreads();
+    for (int r = tid; r < WAVES * NI; r += WG) {
+      const int wv = r / NI, it = r - wv * NI;
+      const double* row = dyn + (size_t)r * RS;
+      double x[NV];
+#pragma unroll
+      for (int l = 0; l < NV; ++l) x[l] = row[l];
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int l = 0; l < NV; l += 4) {
+        s0 += x[l];
+        s1 += x[l + 1];
+        s2 += x[l + 2];
+        s3 += x[l + 3];
+      }
+      const double sum = (s0 + s1) + (s2 + s3);
+      if (it <= 2 * DP) {
+        sRed[wv][it] = sum;
+      } else {
+        const int kk = it - 1 - 2 * DP;
+        sW[4 * kk + wv] = sum;
+      }
+    }
+    __syncthreads();
   } else {
     {
       const double v = wave_sum(slog_acc);
