@@ -563,6 +563,8 @@ def main():
                         f"value+grad _neg_elcbo with soft bounds, eps={a.rng}",
             "evals_per_s_job": evals_per_s,
             "parallelism": f"sample-sharded x{world}, 1 RCCL all-reduce/eval" if world > 1 else "single GPU",
+            "host_thread": (lambda b, n: f"{'narrowed to' if b else 'left on'} {n} CPUs "
+                            f"({'the device-local NUMA node, by vbmc_ctx_create' if b else 'affinity untouched'})")(*ctx.host_affinity()),
             "timed_region": f"{repeats} x {a.steps} steps back to back (>= {min_timed} s), one barrier + "
                             f"synchronize on either side",
             "entropy_launch": plan,

@@ -87,6 +87,15 @@ int vbmc_device_count(int* n_out);
 int vbmc_ctx_create(int device_id, vbmc_ctx** out);
 void vbmc_ctx_destroy(vbmc_ctx* ctx);
 
+/* Host placement.  The polled evaluation is a latency chain over PCIe, and on a two-socket host it is 2.5 us (3 %) per
+ * evaluation shorter from the device's own NUMA node (csrc/ctx.hip bind_host_thread).  vbmc_ctx_create therefore narrows
+ * the CALLING THREAD's CPU affinity to the CPUs local to the device (sysfs local_cpulist of its PCI function) before it
+ * allocates its pinned buffers.  It only removes CPUs from the thread's current set and leaves a set alone that is
+ * already inside the node or entirely outside it; VBMC_HOST_AFFINITY=0 in the environment disables it.  This reports what
+ * happened: *bound_out = 1 when this context narrowed the set, *n_cpus_out = CPUs in the thread's set afterwards
+ * (0: the device's CPU list could not be read).  No counterpart in the reference (a NumPy program). */
+int vbmc_host_affinity(const vbmc_ctx* ctx, int* bound_out, int* n_cpus_out);
+
 /* Last error text of `ctx` (or of the failed vbmc_ctx_create when ctx==NULL). */
 const char* vbmc_last_error(const vbmc_ctx* ctx);
 

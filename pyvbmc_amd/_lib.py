@@ -71,6 +71,7 @@ SIGNATURES = {
         C.c_int,
         [_vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)],
     ),
+    "vbmc_host_affinity": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vbmc_synchronize": (C.c_int, [_vp]),
     "vbmc_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "vbmc_last_entmc_plan": (C.c_int, [_vp, C.POINTER(C.c_int)]),
@@ -260,6 +261,13 @@ class Context:
         self.check(self._lib.vbmc_device_info(self._h, name, 256, C.byref(cu), C.byref(clk), C.byref(mem)))
         return {"name": name.value.decode(), "cu_count": cu.value, "clock_khz": clk.value,
                 "hbm_bytes": mem.value}
+
+    def host_affinity(self):
+        """``(bound, n_cpus)``: whether creating this context narrowed the calling thread's CPU affinity to the device's
+        NUMA node (vbmc_host_affinity; ``VBMC_HOST_AFFINITY=0`` disables it), and the CPUs in the thread's set afterwards."""
+        b, n = C.c_int(), C.c_int()
+        self.check(self._lib.vbmc_host_affinity(self._h, C.byref(b), C.byref(n)))
+        return bool(b.value), n.value
 
     def synchronize(self):
         self.check(self._lib.vbmc_synchronize(self._h))

@@ -4,6 +4,11 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <sched.h>
+
+#include <cctype>
+#include <cstdio>
+
 #include "common.h"
 
 thread_local std::string g_create_err;
@@ -102,6 +107,71 @@ int vbmc_device_count(int* n_out) {
   return VBMC_OK;
 }
 
+}  // extern "C"
+
+// The host side of the polled step is a latency chain over PCIe (pack and go word out, completion word and results back,
+// host-visible device memory written by the CPU): on the two-socket hosts of an 8 x MI355X node it matters which socket
+// the calling thread runs on -- BASELINE config 3's step, same box, alternating: 85.3 us from the GPU's own NUMA node,
+// 87.8 us from the other one, 85.7-89.5 us wherever the scheduler puts an unpinned thread (profiles/r06_notes.md).
+// So a context NARROWS the calling thread's affinity to the CPUs local to its device
+// (/sys/bus/pci/devices/<bus id>/local_cpulist), before it allocates its pinned buffers (first touch then lands them on
+// that node too).  It only ever removes CPUs from the thread's current set -- a set the user already confined to the
+// device's node, or to CPUs that are all on the other node, is left alone -- and VBMC_HOST_AFFINITY=0 switches it off.
+// One process per GPU (the multi-GPU layout) thereby gets the usual per-rank NUMA binding without a launcher's help.
+static void bind_host_thread(vbmc_ctx* ctx) {
+  const char* e = getenv("VBMC_HOST_AFFINITY");
+  if (e && e[0] == '0') return;
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, ctx->device) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  for (char* c = bus; *c; ++c) *c = (char)tolower((unsigned char)*c);
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bus);
+  FILE* f = fopen(path, "r");
+  if (!f) return;
+  char list[1024] = {0};
+  const bool got = fgets(list, sizeof(list), f) != nullptr;
+  fclose(f);
+  if (!got) return;
+  cpu_set_t local, cur, both;
+  CPU_ZERO(&local);
+  for (char* p = list; *p;) {  // "0-63,128-191"
+    char* end = nullptr;
+    const long a = strtol(p, &end, 10);
+    if (end == p) break;
+    long b = a;
+    p = end;
+    if (*p == '-') {
+      b = strtol(p + 1, &end, 10);
+      if (end == p + 1) break;
+      p = end;
+    }
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+      if (c >= 0) CPU_SET((int)c, &local);
+    while (*p == ',' || *p == ' ' || *p == '\n') ++p;
+  }
+  if (CPU_COUNT(&local) == 0 || sched_getaffinity(0, sizeof(cur), &cur) != 0) return;
+  CPU_AND(&both, &cur, &local);
+  const int n_both = CPU_COUNT(&both), n_cur = CPU_COUNT(&cur);
+  ctx->host_cpus = n_cur;
+  if (n_both == 0 || n_both == n_cur) return;  // all on the other node (the user's choice), or local already
+  if (sched_setaffinity(0, sizeof(both), &both) == 0) {
+    ctx->host_bound = true;
+    ctx->host_cpus = n_both;
+  }
+}
+
+extern "C" {
+
+int vbmc_host_affinity(const vbmc_ctx* ctx, int* bound_out, int* n_cpus_out) {
+  if (!ctx) return VBMC_E_ARG;
+  if (bound_out) *bound_out = ctx->host_bound ? 1 : 0;
+  if (n_cpus_out) *n_cpus_out = ctx->host_cpus;
+  return VBMC_OK;
+}
+
 int vbmc_ctx_create(int device_id, vbmc_ctx** out) {
   if (!out) return vbmc_fail(nullptr, VBMC_E_ARG, "vbmc_ctx_create: out is NULL");
   *out = nullptr;
@@ -129,6 +199,7 @@ int vbmc_ctx_create(int device_id, vbmc_ctx** out) {
   options_from_env(ctx);
   e = hipSetDevice(device_id);
   if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_id);
+  if (e == hipSuccess) bind_host_thread(ctx);  // (before the pinned allocations below: they follow the thread's node)
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   for (int i = 0; i < 12 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
   if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_done, 64, hipHostMallocDefault);

@@ -2,6 +2,7 @@
 problem shapes (every scratch buffer regrows / is reused), objects pickled without their
 handles, and results that do not depend on any of it."""
 import pickle
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -9,6 +10,8 @@ from helpers import oracle_gp, oracle_mix
 
 from oracle import elbo_ref, philox_ref
 from pyvbmc_amd import synthetic
+
+ROOT = Path(__file__).resolve().parent.parent
 
 pytestmark = pytest.mark.gpu
 
@@ -135,3 +138,65 @@ def test_predict_timing_levels():
     for o in (out1, out2):
         assert np.array_equal(o[0], ref[0]) and np.array_equal(o[1], ref[1])
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_context_binds_the_calling_thread_to_the_devices_numa_node():
+    """Round 6: vbmc_ctx_create narrows the CALLING thread's CPU affinity to the CPUs local to its device (the polled step
+    is a PCIe latency chain: 85.3 us from the GPU's node, 87.8 us from the other socket).  It only removes CPUs; a set
+    that is already inside the node, or wholly outside it, is left alone; VBMC_HOST_AFFINITY=0 disables it.  Run in
+    child processes: affinity is per thread and sticky."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    child = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+from pyvbmc_amd import _lib
+pre = sys.argv[1]
+if pre != "all":
+    os.sched_setaffinity(0, {int(c) for c in pre.split(",")})
+else:  # (the parent -- pytest, after its first context -- may itself have been narrowed: children inherit that)
+    try:
+        os.sched_setaffinity(0, set(range(os.cpu_count())))
+    except OSError:
+        pass
+before = sorted(os.sched_getaffinity(0))
+ctx = _lib.Context(0)
+bound, n = ctx.host_affinity()
+after = sorted(os.sched_getaffinity(0))
+ctx.close()
+print(json.dumps({"before": before, "after": after, "bound": bound, "n": n}))
+""" % str(ROOT)
+
+    def run(pre, env=None):
+        e = dict(os.environ)
+        e.pop("VBMC_HOST_AFFINITY", None)
+        e.update(env or {})
+        out = subprocess.run([sys.executable, "-c", child, pre], env=e, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+
+    free = run("all")
+    assert set(free["after"]) <= set(free["before"])  # never adds CPUs
+    if not free["bound"]:
+        # (a single-node host, or a launcher that already confined us to the device's node: nothing to narrow)
+        assert free["after"] == free["before"]
+        pytest.skip("the calling thread is already inside the device's NUMA node")
+    local = free["after"]
+    assert 0 < len(local) < len(free["before"]) and free["n"] == len(local)
+    # switched off
+    off = run("all", {"VBMC_HOST_AFFINITY": "0"})
+    assert not off["bound"] and off["after"] == off["before"]
+    # a set already inside the node: untouched
+    inside = run(",".join(str(c) for c in local[:4]))
+    assert not inside["bound"] and inside["after"] == inside["before"]
+    # a set wholly on the other node: the user's choice, untouched
+    other = [c for c in free["before"] if c not in set(local)]
+    far = run(",".join(str(c) for c in other[:4]))
+    assert not far["bound"] and far["after"] == far["before"]
+    # a set that straddles the nodes: narrowed to its local part
+    mixed = run(",".join(str(c) for c in local[:3] + other[:3]))
+    assert mixed["bound"] and mixed["after"] == sorted(local[:3])
