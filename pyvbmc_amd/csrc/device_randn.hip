@@ -8,12 +8,14 @@
 // stream has its first block, and that block is a jump over GF(2) (mt_jump.h): each of its 624 words is the XOR of the
 // ~10 000 words x_(1+i+j), g_i = 1, of ONE window of 20 560 words behind the current state, the same for all streams.
 //   mt_window_kernel   one workgroup: the window, by the plain recurrence (33 blocks)
-//   mt_stream_kernel<false>  workgroup m: jump to block m * 80 (window in LDS, the polynomial's exponents through scalar loads), store that
-//                      state, then its blocks by the recurrence, 40 at a time in LDS, and the number of accepted polar
-//                      attempts among the attempts that START in its words (attempt t reads stream words
-//                      [pos + 4 t, pos + 4 t + 4) whether it is accepted or not: csrc/host_randn.hip)
-//   mt_scan_kernel     exclusive prefix sum of the S counts
-//   mt_values_kernel   workgroup m again from its stored state: ranks of its accepted attempts by a block scan, the
+//   mt_stream_kernel   workgroup m: jump to block m * 80 (window and the polynomial's exponent list in LDS), then its blocks
+//                      by the recurrence, 40 at a time in LDS, and per half stream the number of accepted polar attempts
+//                      among the attempts that START in its words (attempt t reads words [pos + 4 t, pos + 4 t + 4) of the
+//                      sequence whether it is accepted or not: csrc/host_randn.hip).  Round 6: it leaves its blocks' words
+//                      in memory (one flat sequence, 51 MB at config 3), so that nothing sequential is left for the values:
+//   mt_scan_kernel     exclusive prefix sum of the 2 S counts
+//   mt_values_kernel   one workgroup per half stream (2 S of them; round 5's second pass ran the 80 blocks of every stream
+//                      AGAIN on S workgroups: 73 us): the half stream's words through LDS, ranks of its accepted attempts by a block scan, the
 //                      pair (f x2, f x1), f = sqrt(-2 log(r2) / r2), written where it belongs; the workgroup that holds
 //                      the request's last pair hands back the block and position NumPy's state ends at and that
 //                      attempt's (x1, x2, r2) -- the cached second value is then formed on the HOST with libm, so the
@@ -128,12 +130,12 @@ __device__ __forceinline__ double mt_log_dd(double x) {
 }
 
 struct RandnArgs {
-  const uint32_t* key;   // [624] the current block
+  uint32_t* key;         // [624] the current block (device copy: written by mt_window_kernel from its argument)
   uint32_t* win;         // [WIN_WORDS]
   const uint16_t* taps;  // [S - 1][TAP_STRIDE]: the set exponents of G_m, m = 1 .., padded with TAP_PAD
   const int* n_taps;     // [S - 1]: entries used of each list (a multiple of TAP_U)
-  uint32_t* states;      // [S][624]
-  unsigned long long* counts;  // [S + 1]: accepted attempts per stream, then (after the scan) exclusive prefix sums; [S] = total
+  unsigned long long* counts;  // [2 S + 1]: accepted attempts per half stream (m, pass), then (after the scan) exclusive prefix sums; [2 S] = total
+  uint32_t* words;       // [S J_WORDS + 624]: every stream's blocks as one sequence (word w of the stream sequence that starts at the key's word 0)
   int S;
   int pos0;               // NumPy's position inside the current block (0 .. 624)
   long long attempts;     // attempts the streams cover: t < attempts
@@ -141,29 +143,33 @@ struct RandnArgs {
   long long rest;         // values to write (2 pairs or 2 pairs - 1)
   double* out;            // first value's address
   // hand-back (written by the workgroup that holds the last pair)
+  // (round 6: these point into pinned HOST memory -- the kernels store there directly and the host reads it after its one
+  // wait for the stream; round 5 copied a key up, cleared two words and copied four pieces back: six copy launches, ~25 us)
   uint32_t* end_key;      // [624]
   long long* end_info;    // [0] word index behind the last attempt (pos0 + 4 (t_end + 1)), [1] 1 = written
   double* end_vals;       // x1, x2, r2 of the last attempt
+  unsigned long long* end_total;  // accepted attempts in all streams (the scan's last entry)
 };
 
-__global__ __launch_bounds__(NT) void mt_window_kernel(RandnArgs a) {
+struct KeyArg {
+  uint32_t k[MT_N];  // NumPy's current block, as a kernel argument (2 496 B)
+};
+__global__ __launch_bounds__(NT) void mt_window_kernel(RandnArgs a, KeyArg key) {
   extern __shared__ uint32_t sm[];
-  for (int i = threadIdx.x; i < MT_N; i += NT) sm[i] = a.key[i];
+  for (int i = threadIdx.x; i < MT_N; i += NT) {
+    sm[i] = key.k[i];
+    a.key[i] = key.k[i];  // stream 0 starts from it (mt_stream_kernel, the next launch)
+  }
   __syncthreads();
   for (int b = 1; b < WIN_WORDS / MT_N; ++b) mt_next_block_lds(sm + (b - 1) * MT_N, sm + b * MT_N);
   for (int i = threadIdx.x; i < WIN_WORDS; i += NT) a.win[i] = sm[i];
 }
 
-// The stream's first block into sm[0 .. 624): the key itself (m = 0), the jump (COUNT pass), or the stored state.
-__device__ __forceinline__ void stream_start(const RandnArgs& a, int m, bool from_states, uint32_t* sm) {
+// The stream's first block into sm[0 .. 624): the key itself (m = 0) or the jump.
+__device__ __forceinline__ void stream_start(const RandnArgs& a, int m, uint32_t* sm) {
   const int tid = threadIdx.x;
   if (m == 0) {
     for (int i = tid; i < MT_N; i += NT) sm[i] = a.key[i];
-    __syncthreads();
-    return;
-  }
-  if (from_states) {
-    for (int i = tid; i < MT_N; i += NT) sm[i] = a.states[(size_t)m * MT_N + i];
     __syncthreads();
     return;
   }
@@ -223,7 +229,6 @@ __device__ __forceinline__ void stream_start(const RandnArgs& a, int m, bool fro
   if (tid < MT_N) {
     const uint32_t x = part[tid] ^ part[MT_N + tid] ^ part[2 * MT_N + tid];
     sm[tid] = x;
-    a.states[(size_t)m * MT_N + tid] = x;
   }
   __syncthreads();
 }
@@ -237,34 +242,48 @@ __device__ __forceinline__ void stream_attempts(const RandnArgs& a, int m, long 
   if (t_lo > t_hi) t_lo = t_hi;
 }
 
-template <bool VALUES>
+constexpr int N_PASS = BLK_PER_STREAM / BLK_PER_PASS;  // half streams per stream
+static_assert(N_PASS == 2, "two passes per stream");
+
+// attempts of half stream (m, pass): first word in [w0, w0 + PB * 624) of the sequence, inside the stream's range [t_lo, t_hi)
+__device__ __forceinline__ void pass_attempts(const RandnArgs& a, int m, int pass, long long t_lo, long long t_hi, long long& p_lo,
+                                              long long& p_hi) {
+  const long long w0 = (long long)m * J_WORDS + (long long)pass * BLK_PER_PASS * MT_N, w1 = w0 + (long long)BLK_PER_PASS * MT_N;
+  p_lo = w0 <= a.pos0 ? 0 : (w0 - a.pos0 + 3) / 4;
+  p_hi = w1 <= a.pos0 ? 0 : (w1 - a.pos0 + 3) / 4;
+  p_lo = p_lo < t_lo ? t_lo : p_lo;
+  p_hi = p_hi > t_hi ? t_hi : p_hi;
+}
+
+// Workgroup m: the jump to its first block, its 80 blocks by the recurrence (40 at a time in LDS), every block's words
+// to memory, and the number of accepted attempts of each of its two halves.
+// (Measured and not kept, round 6: the jump, the recurrence on four-wave workgroups and the counts as three kernels --
+// 141 + 50 + 17.5 us against this kernel's 187.)
 __global__ __launch_bounds__(NT) void mt_stream_kernel(RandnArgs a) {
   extern __shared__ uint32_t sm[];
   __shared__ unsigned long long s_red[NT / 64];
-  __shared__ unsigned long long s_scan[NT / 64];
-  __shared__ int s_end_blk;
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   long long t_lo, t_hi;
   stream_attempts(a, m, t_lo, t_hi);
-  unsigned long long base_pair = VALUES ? a.counts[m] : 0;  // accepted attempts in front of this stream
-  if (VALUES && (t_lo >= t_hi || (long long)base_pair >= a.pairs)) return;  // nothing of the request lies here
-  if (tid == 0) s_end_blk = -1;
-  stream_start(a, m, VALUES, sm);
-  unsigned long long total = 0;
-  for (int pass = 0; pass < BLK_PER_STREAM / BLK_PER_PASS; ++pass) {
+  stream_start(a, m, sm);
+  for (int pass = 0; pass < N_PASS; ++pass) {
     // blocks [pass * PB, pass * PB + PB] of the stream (one more than the pass owns: an attempt may straddle into it)
     if (pass > 0) {
       for (int i = tid; i < MT_N; i += NT) sm[i] = sm[BLK_PER_PASS * MT_N + i];
       __syncthreads();
     }
     for (int b = 1; b <= BLK_PER_PASS; ++b) mt_next_block_lds(sm + (b - 1) * MT_N, sm + b * MT_N);
-    // this pass's attempts: first word in [w0, w0 + PB * 624) of the block sequence
-    const long long w0 = (long long)m * J_WORDS + (long long)pass * BLK_PER_PASS * MT_N, w1 = w0 + (long long)BLK_PER_PASS * MT_N;
-    long long p_lo = w0 <= a.pos0 ? 0 : (w0 - a.pos0 + 3) / 4, p_hi = w1 <= a.pos0 ? 0 : (w1 - a.pos0 + 3) / 4;
-    p_lo = p_lo < t_lo ? t_lo : p_lo;
-    p_hi = p_hi > t_hi ? t_hi : p_hi;
+    // the pass's own blocks to memory (the last stream's last pass: the block behind them too -- an attempt may end there)
+    const long long w0 = (long long)m * J_WORDS + (long long)pass * BLK_PER_PASS * MT_N;
+    {
+      const int n_w = (BLK_PER_PASS + ((m == a.S - 1 && pass == N_PASS - 1) ? 1 : 0)) * MT_N;
+      uint32_t* dst = a.words + w0;
+      for (int i = tid; i < n_w; i += NT) dst[i] = sm[i];
+    }
+    long long p_lo, p_hi;
+    pass_attempts(a, m, pass, t_lo, t_hi, p_lo, p_hi);
     const int n_att = p_hi > p_lo ? (int)(p_hi - p_lo) : 0;
-    // a contiguous chunk of attempts per thread (ranks then follow attempt order)
+    // a contiguous chunk of attempts per thread
     const int per = (n_att + NT - 1) / NT;
     const int c0 = min(tid * per, n_att), c1 = min(c0 + per, n_att);
     int cnt = 0;
@@ -274,77 +293,114 @@ __global__ __launch_bounds__(NT) void mt_stream_kernel(RandnArgs a) {
       double x1, x2, r2;
       cnt += mt_attempt(u, x1, x2, r2) ? 1 : 0;
     }
-    if (!VALUES) {
-      unsigned long long v = (unsigned long long)cnt;
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) s_red[wave] = v;
-      __syncthreads();
-      if (tid == 0)
-        for (int q = 0; q < NT / 64; ++q) total += s_red[q];
-      __syncthreads();
-    } else {
-      // exclusive scan of the per-thread counts over the workgroup
-      unsigned long long v = (unsigned long long)cnt, incl = v;
-      for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-      }
-      if (lane == 63) s_red[wave] = incl;
-      __syncthreads();
-      if (tid == 0) {
-        unsigned long long run = 0;
-        for (int q = 0; q < NT / 64; ++q) {
-          s_scan[q] = run;
-          run += s_red[q];
-        }
-        s_red[0] = run;  // the pass's total
-      }
-      __syncthreads();
-      unsigned long long p = base_pair + s_scan[wave] + (incl - v);
-      const unsigned long long pass_total = s_red[0];
-      for (int c = c0; c < c1; ++c) {
-        const long long t = p_lo + c;
-        const int off = (int)(a.pos0 + 4 * t - w0);
-        double x1, x2, r2;
-        if (!mt_attempt(sm + off, x1, x2, r2)) continue;
-        if ((long long)p < a.pairs) {
-          const double f = sqrt(-2.0 * mt_log_dd(r2) / r2);  // (division and square root are correctly rounded on the device too)
-          const long long o = 2 * (long long)p;
-          a.out[o] = f * x2;
-          if (o + 1 < a.rest) a.out[o + 1] = f * x1;
-          if ((long long)p == a.pairs - 1) {  // the request's last pair: what NumPy's state ends at
-            a.end_vals[0] = x1;
-            a.end_vals[1] = x2;
-            a.end_vals[2] = r2;
-            a.end_info[0] = a.pos0 + 4 * (t + 1);
-            s_end_blk = (off + 3) / MT_N;  // the block (of this pass's buffer) holding the last word read
-          }
-        }
-        ++p;
-      }
-      __syncthreads();
-      if (s_end_blk >= 0) {
-        for (int i = tid; i < MT_N; i += NT) a.end_key[i] = sm[s_end_blk * MT_N + i];
-        __syncthreads();
-        if (tid == 0) {
-          __threadfence();
-          a.end_info[1] = 1;
-        }
-        return;
-      }
-      base_pair += pass_total;
-      if ((long long)base_pair >= a.pairs) return;
+    unsigned long long v = (unsigned long long)cnt;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long total = 0;
+      for (int q = 0; q < NT / 64; ++q) total += s_red[q];
+      a.counts[(size_t)m * N_PASS + pass] = total;
+    }
+    __syncthreads();
+  }
+}
+
+// Workgroup u = (m, pass): the values of the accepted attempts of that half stream, from the words in memory.
+constexpr int NTV = 1024;
+__global__ __launch_bounds__(NTV) void mt_values_kernel(RandnArgs a) {
+  extern __shared__ uint32_t sm[];  // the half stream's words (+ the block behind them): PASS_WORDS
+  __shared__ unsigned long long s_red[NTV / 64];
+  __shared__ unsigned long long s_scan[NTV / 64];
+  __shared__ long long s_end_blk;
+  const int u_ = blockIdx.x, m = u_ / N_PASS, pass = u_ - m * N_PASS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long base_pair = a.counts[u_];  // accepted attempts in front of this half stream
+  if ((long long)base_pair >= a.pairs) return;       // the request ends in front of it
+  long long t_lo, t_hi, p_lo, p_hi;
+  stream_attempts(a, m, t_lo, t_hi);
+  pass_attempts(a, m, pass, t_lo, t_hi, p_lo, p_hi);
+  const int n_att = p_hi > p_lo ? (int)(p_hi - p_lo) : 0;
+  if (n_att == 0) return;
+  if (tid == 0) s_end_blk = -1;
+  // the words through LDS, coalesced (a thread's attempts are 4 * per CONSECUTIVE words: read straight from memory every
+  // load instruction touched 64 different lines and the working set of a CU's waves did not fit its L1 -- 77 us, as long as
+  // the second recurrence pass this kernel replaces)
+  const long long w0 = (long long)m * J_WORDS + (long long)pass * BLK_PER_PASS * MT_N;
+  {
+    const uint4* src = (const uint4*)(a.words + w0);  // (w0 is a multiple of 624 words = 2 496 bytes: 16-byte aligned)
+    uint4* dst = (uint4*)sm;
+    for (int i = tid; i < PASS_WORDS / 4; i += NTV) dst[i] = src[i];
+  }
+  __syncthreads();
+  // a contiguous chunk of attempts per thread (ranks then follow attempt order)
+  const int per = (n_att + NTV - 1) / NTV;
+  const int c0 = min(tid * per, n_att), c1 = min(c0 + per, n_att);
+  const uint32_t* wbase = sm + (int)(a.pos0 + 4 * p_lo - w0);  // attempt c of the pass reads wbase[4 c .. 4 c + 4)
+  int cnt = 0;
+  unsigned acc_mask = 0;  // which of the thread's attempts are accepted (per <= 32: 6 240 attempts on 1 024 threads are 7)
+  for (int c = c0; c < c1; ++c) {
+    double x1, x2, r2;
+    const bool ok = mt_attempt(wbase + 4 * (long long)c, x1, x2, r2);
+    cnt += ok ? 1 : 0;
+    acc_mask |= (ok ? 1u : 0u) << ((c - c0) & 31);
+  }
+  // exclusive scan of the per-thread counts over the workgroup
+  unsigned long long v = (unsigned long long)cnt, incl = v;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) s_red[wave] = incl;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long run = 0;
+    for (int q = 0; q < NTV / 64; ++q) {
+      s_scan[q] = run;
+      run += s_red[q];
     }
   }
-  if (!VALUES && tid == 0) a.counts[m] = total;
+  __syncthreads();
+  unsigned long long p = base_pair + s_scan[wave] + (incl - v);
+  for (int c = c0; c < c1; ++c) {
+    if (per <= 32 && !((acc_mask >> ((c - c0) & 31)) & 1u)) continue;
+    const long long t = p_lo + c;
+    double x1, x2, r2;
+    if (!mt_attempt(wbase + 4 * (long long)c, x1, x2, r2)) continue;
+    if ((long long)p < a.pairs) {
+      const double f = sqrt(-2.0 * mt_log_dd(r2) / r2);  // (division and square root are correctly rounded on the device too)
+      const long long o = 2 * (long long)p;
+      a.out[o] = f * x2;
+      if (o + 1 < a.rest) a.out[o + 1] = f * x1;
+      if ((long long)p == a.pairs - 1) {  // the request's last pair: what NumPy's state ends at
+        a.end_vals[0] = x1;
+        a.end_vals[1] = x2;
+        a.end_vals[2] = r2;
+        a.end_info[0] = a.pos0 + 4 * (t + 1);
+        s_end_blk = (a.pos0 + 4 * t + 3) / MT_N;  // the block of the sequence holding the last word read
+      }
+    }
+    ++p;
+  }
+  __syncthreads();
+  if (s_end_blk >= 0) {
+    const uint32_t* src = a.words + s_end_blk * MT_N;  // (from memory: the block may be the one behind this half stream's)
+    for (int i = tid; i < MT_N; i += NTV) a.end_key[i] = src[i];
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      a.end_info[1] = 1;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void mt_scan_kernel(RandnArgs a) {
-  // exclusive prefix sum of the S counts by one workgroup: a contiguous chunk per thread, then a scan of the 256 chunk sums
+  // exclusive prefix sum of the 2 S counts by one workgroup: a contiguous chunk per thread, then a scan of the 256 chunk sums
   __shared__ unsigned long long s_w[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (a.S + 255) / 256;
-  const int c0 = min(tid * per, a.S), c1 = min(c0 + per, a.S);
+  const int n = N_PASS * a.S;
+  const int per = (n + 255) / 256;
+  const int c0 = min(tid * per, n), c1 = min(c0 + per, n);
   unsigned long long sum = 0;
   for (int m = c0; m < c1; ++m) sum += a.counts[m];
   unsigned long long incl = sum;
@@ -361,7 +417,10 @@ __global__ __launch_bounds__(256) void mt_scan_kernel(RandnArgs a) {
     a.counts[m] = run;
     run += c;
   }
-  if (tid == 255) a.counts[a.S] = run;
+  if (tid == 255) {
+    a.counts[n] = run;
+    *a.end_total = run;
+  }
 }
 
 struct RandnDev {
@@ -370,13 +429,11 @@ struct RandnDev {
   uint16_t* d_taps = nullptr;
   int* d_ntaps = nullptr;
   int poly_count = 0;  // polynomials on the device (G_1 .. G_count)
-  uint32_t* d_states = nullptr;
   unsigned long long* d_counts = nullptr;
+  uint32_t* d_words = nullptr;
   int cap_S = 0;
-  uint32_t* d_end_key = nullptr;
-  long long* d_end_info = nullptr;
-  double* d_end_vals = nullptr;
-  uint32_t* h_stage = nullptr;  // pinned: key up (624), then end_key (624) | end_info (2 x 8 B) | end_vals (3 x 8 B) | total (8 B) down
+  uint32_t* h_stage = nullptr;  // pinned, written by the kernels: end_key (624) | end_info (2 x 8 B) | end_vals (3 x 8 B) | total (8 B)
+  uint32_t* hd_stage = nullptr;  // its device-side address
   std::vector<uint32_t> polys;  // host copy
   double first_val = 0.0;       // NumPy's cached second value on its way to the device
 };
@@ -391,7 +448,7 @@ RandnDev* randn_of(vbmc_ctx* ctx) {
 void randn_dev_free(vbmc_ctx* ctx) {
   RandnDev* r = (RandnDev*)ctx->randn_dev;
   if (!r) return;
-  void* bufs[] = {r->d_key, r->d_win, r->d_taps, r->d_ntaps, r->d_states, r->d_counts, r->d_end_key, r->d_end_info, r->d_end_vals};
+  void* bufs[] = {r->d_key, r->d_win, r->d_taps, r->d_ntaps, r->d_counts, r->d_words};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (r->h_stage) (void)hipHostFree(r->h_stage);
@@ -462,58 +519,57 @@ int randn_device(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double*
   if (!r->d_key) {
     HIP_TRY(ctx, hipMalloc((void**)&r->d_key, sizeof(uint32_t) * MT_N));
     HIP_TRY(ctx, hipMalloc((void**)&r->d_win, sizeof(uint32_t) * WIN_WORDS));
-    HIP_TRY(ctx, hipMalloc((void**)&r->d_end_key, sizeof(uint32_t) * MT_N));
-    HIP_TRY(ctx, hipMalloc((void**)&r->d_end_info, sizeof(long long) * 2));
-    HIP_TRY(ctx, hipMalloc((void**)&r->d_end_vals, sizeof(double) * 4));
-    HIP_TRY(ctx, hipHostMalloc((void**)&r->h_stage, sizeof(uint32_t) * 2 * MT_N + 64, hipHostMallocDefault));
+    HIP_TRY(ctx, hipHostMalloc((void**)&r->h_stage, sizeof(uint32_t) * MT_N + 64, hipHostMallocDefault));
+    HIP_TRY(ctx, hipHostGetDevicePointer((void**)&r->hd_stage, r->h_stage, 0));
     const size_t lds = sizeof(uint32_t) * LDS_WORDS;
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)mt_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)mt_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)mt_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)mt_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)mt_values_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * PASS_WORDS)));
   }
   if (r->cap_S < S) {
-    if (r->d_states) HIP_TRY(ctx, hipFree(r->d_states));
     if (r->d_counts) HIP_TRY(ctx, hipFree(r->d_counts));
-    r->d_states = nullptr;
+    if (r->d_words) HIP_TRY(ctx, hipFree(r->d_words));
     r->d_counts = nullptr;
-    HIP_TRY(ctx, hipMalloc((void**)&r->d_states, sizeof(uint32_t) * (size_t)S * MT_N));
-    HIP_TRY(ctx, hipMalloc((void**)&r->d_counts, sizeof(unsigned long long) * ((size_t)S + 1)));
+    r->d_words = nullptr;
+    r->cap_S = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&r->d_counts, sizeof(unsigned long long) * ((size_t)N_PASS * S + 1)));
+    HIP_TRY(ctx, hipMalloc((void**)&r->d_words, sizeof(uint32_t) * ((size_t)S * J_WORDS + 2 * MT_N)));
     r->cap_S = S;
   }
-  std::memcpy(r->h_stage, key, sizeof(uint32_t) * MT_N);
-  HIP_TRY(ctx, hipMemcpyAsync(r->d_key, r->h_stage, sizeof(uint32_t) * MT_N, hipMemcpyHostToDevice, sm));
-  HIP_TRY(ctx, hipMemsetAsync(r->d_end_info, 0, sizeof(long long) * 2, sm));
+  // hand-back block in pinned memory (nothing of an earlier call is in flight: every call ends with a wait for the stream)
+  uint32_t* h_end_key = r->h_stage;
+  long long* h_info = (long long*)(r->h_stage + MT_N);
+  double* h_vals = (double*)(h_info + 2);
+  unsigned long long* h_total = (unsigned long long*)(h_vals + 3);
+  h_info[0] = h_info[1] = 0;
+  *h_total = 0;
+  KeyArg karg;
+  std::memcpy(karg.k, key, sizeof(uint32_t) * MT_N);
   RandnArgs a;
   a.key = r->d_key;
   a.win = r->d_win;
   a.taps = r->d_taps;
   a.n_taps = r->d_ntaps;
-  a.states = r->d_states;
   a.counts = r->d_counts;
+  a.words = r->d_words;
   a.S = S;
   a.pos0 = pos0;
   a.attempts = attempts;
   a.pairs = pairs;
   a.rest = rest;
   a.out = d_out + produced;
-  a.end_key = r->d_end_key;
-  a.end_info = r->d_end_info;
-  a.end_vals = r->d_end_vals;
+  a.end_key = r->hd_stage;
+  a.end_info = (long long*)(r->hd_stage + MT_N);
+  a.end_vals = (double*)(a.end_info + 2);
+  a.end_total = (unsigned long long*)(a.end_vals + 3);
   const size_t lds = sizeof(uint32_t) * LDS_WORDS;
-  hipLaunchKernelGGL(mt_window_kernel, dim3(1), dim3(NT), lds, sm, a);
-  hipLaunchKernelGGL(mt_stream_kernel<false>, dim3(S), dim3(NT), lds, sm, a);
+  hipLaunchKernelGGL(mt_window_kernel, dim3(1), dim3(NT), lds, sm, a, karg);
+  hipLaunchKernelGGL(mt_stream_kernel, dim3(S), dim3(NT), lds, sm, a);
   hipLaunchKernelGGL(mt_scan_kernel, dim3(1), dim3(256), 0, sm, a);
-  hipLaunchKernelGGL(mt_stream_kernel<true>, dim3(S), dim3(NT), lds, sm, a);
+  hipLaunchKernelGGL(mt_values_kernel, dim3(N_PASS * S), dim3(NTV), sizeof(uint32_t) * PASS_WORDS, sm, a);
   HIP_TRY(ctx, hipGetLastError());
   // hand-back: end block, word index, the last attempt's numbers, the total
-  uint32_t* h_end_key = r->h_stage + MT_N;
-  long long* h_info = (long long*)(r->h_stage + 2 * MT_N);
-  double* h_vals = (double*)(h_info + 2);
-  unsigned long long* h_total = (unsigned long long*)(h_vals + 3);
-  HIP_TRY(ctx, hipMemcpyAsync(h_end_key, r->d_end_key, sizeof(uint32_t) * MT_N, hipMemcpyDeviceToHost, sm));
-  HIP_TRY(ctx, hipMemcpyAsync(h_info, r->d_end_info, sizeof(long long) * 2, hipMemcpyDeviceToHost, sm));
-  HIP_TRY(ctx, hipMemcpyAsync(h_vals, r->d_end_vals, sizeof(double) * 3, hipMemcpyDeviceToHost, sm));
-  HIP_TRY(ctx, hipMemcpyAsync(h_total, r->d_counts + S, sizeof(unsigned long long), hipMemcpyDeviceToHost, sm));
+  // (the kernels stored end block, word index, the last attempt's numbers and the total into the pinned block themselves)
   HIP_TRY(ctx, stream_wait(ctx));
   // fewer accepted attempts than pairs in the words the streams cover (the 6 sigma margin: ~1e-9 per call): nothing
   // of the caller's state has been touched -- the host generator takes the request over (vbmc_set_eps_numpy)
