@@ -135,6 +135,7 @@ struct RandnArgs {
   const uint16_t* taps;  // [S - 1][TAP_STRIDE]: the set exponents of G_m, m = 1 .., padded with TAP_PAD
   const int* n_taps;     // [S - 1]: entries used of each list (a multiple of TAP_U)
   unsigned long long* counts;  // [2 S + 1]: accepted attempts per half stream (m, pass), then (after the scan) exclusive prefix sums; [2 S] = total
+  uint32_t* masks;       // [2 S][NT]: which of a thread's attempts of a half stream were accepted (bit c - c0), from the count pass
   uint32_t* words;       // [S J_WORDS + 624]: every stream's blocks as one sequence (word w of the stream sequence that starts at the key's word 0)
   int S;
   int pos0;               // NumPy's position inside the current block (0 .. 624)
@@ -287,12 +288,16 @@ __global__ __launch_bounds__(NT) void mt_stream_kernel(RandnArgs a) {
     const int per = (n_att + NT - 1) / NT;
     const int c0 = min(tid * per, n_att), c1 = min(c0 + per, n_att);
     int cnt = 0;
+    uint32_t acc_mask = 0;  // bit c - c0: attempt c was accepted (per <= MAX_PER: the values pass does not try them again)
     for (int c = c0; c < c1; ++c) {
       const long long t = p_lo + c;
       const uint32_t* u = sm + (int)(a.pos0 + 4 * t - w0);
       double x1, x2, r2;
-      cnt += mt_attempt(u, x1, x2, r2) ? 1 : 0;
+      const bool ok = mt_attempt(u, x1, x2, r2);
+      cnt += ok ? 1 : 0;
+      acc_mask |= (ok ? 1u : 0u) << (c - c0);
     }
+    a.masks[((size_t)m * N_PASS + pass) * NT + tid] = acc_mask;
     unsigned long long v = (unsigned long long)cnt;
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if (lane == 0) s_red[wave] = v;
@@ -308,6 +313,8 @@ __global__ __launch_bounds__(NT) void mt_stream_kernel(RandnArgs a) {
 
 // Workgroup u = (m, pass): the values of the accepted attempts of that half stream, from the words in memory.
 constexpr int NTV = 1024;
+constexpr int MAX_PER = (BLK_PER_PASS * (MT_N / 4) + 1 + NTV - 1) / NTV;  // attempts per thread and half stream: 7
+static_assert(NTV == NT && MAX_PER <= 32, "the count pass and the values pass cut a half stream's attempts the same way; a bit per attempt");
 __global__ __launch_bounds__(NTV) void mt_values_kernel(RandnArgs a) {
   extern __shared__ uint32_t sm[];  // the half stream's words (+ the block behind them): PASS_WORDS
   __shared__ unsigned long long s_red[NTV / 64];
@@ -337,14 +344,9 @@ __global__ __launch_bounds__(NTV) void mt_values_kernel(RandnArgs a) {
   const int per = (n_att + NTV - 1) / NTV;
   const int c0 = min(tid * per, n_att), c1 = min(c0 + per, n_att);
   const uint32_t* wbase = sm + (int)(a.pos0 + 4 * p_lo - w0);  // attempt c of the pass reads wbase[4 c .. 4 c + 4)
-  int cnt = 0;
-  unsigned acc_mask = 0;  // which of the thread's attempts are accepted (per <= 32: 6 240 attempts on 1 024 threads are 7)
-  for (int c = c0; c < c1; ++c) {
-    double x1, x2, r2;
-    const bool ok = mt_attempt(wbase + 4 * (long long)c, x1, x2, r2);
-    cnt += ok ? 1 : 0;
-    acc_mask |= (ok ? 1u : 0u) << ((c - c0) & 31);
-  }
+  // which of the thread's attempts were accepted: the count pass (mt_stream_kernel, the same chunking) left a bit each
+  const uint32_t acc_mask = a.masks[(size_t)u_ * NTV + tid] & (c1 > c0 ? (0xFFFFFFFFu >> (32 - (c1 - c0))) : 0u);
+  const int cnt = __popc(acc_mask);
   // exclusive scan of the per-thread counts over the workgroup
   unsigned long long v = (unsigned long long)cnt, incl = v;
   for (int o = 1; o < 64; o <<= 1) {
@@ -363,10 +365,10 @@ __global__ __launch_bounds__(NTV) void mt_values_kernel(RandnArgs a) {
   __syncthreads();
   unsigned long long p = base_pair + s_scan[wave] + (incl - v);
   for (int c = c0; c < c1; ++c) {
-    if (per <= 32 && !((acc_mask >> ((c - c0) & 31)) & 1u)) continue;
+    if (!((acc_mask >> (c - c0)) & 1u)) continue;
     const long long t = p_lo + c;
     double x1, x2, r2;
-    if (!mt_attempt(wbase + 4 * (long long)c, x1, x2, r2)) continue;
+    (void)mt_attempt(wbase + 4 * (long long)c, x1, x2, r2);  // (accepted: the bit says so; its numbers)
     if ((long long)p < a.pairs) {
       const double f = sqrt(-2.0 * mt_log_dd(r2) / r2);  // (division and square root are correctly rounded on the device too)
       const long long o = 2 * (long long)p;
@@ -431,6 +433,7 @@ struct RandnDev {
   int poly_count = 0;  // polynomials on the device (G_1 .. G_count)
   unsigned long long* d_counts = nullptr;
   uint32_t* d_words = nullptr;
+  uint32_t* d_masks = nullptr;
   int cap_S = 0;
   uint32_t* h_stage = nullptr;  // pinned, written by the kernels: end_key (624) | end_info (2 x 8 B) | end_vals (3 x 8 B) | total (8 B)
   uint32_t* hd_stage = nullptr;  // its device-side address
@@ -448,7 +451,7 @@ RandnDev* randn_of(vbmc_ctx* ctx) {
 void randn_dev_free(vbmc_ctx* ctx) {
   RandnDev* r = (RandnDev*)ctx->randn_dev;
   if (!r) return;
-  void* bufs[] = {r->d_key, r->d_win, r->d_taps, r->d_ntaps, r->d_counts, r->d_words};
+  void* bufs[] = {r->d_key, r->d_win, r->d_taps, r->d_ntaps, r->d_counts, r->d_words, r->d_masks};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (r->h_stage) (void)hipHostFree(r->h_stage);
@@ -529,11 +532,14 @@ int randn_device(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double*
   if (r->cap_S < S) {
     if (r->d_counts) HIP_TRY(ctx, hipFree(r->d_counts));
     if (r->d_words) HIP_TRY(ctx, hipFree(r->d_words));
+    if (r->d_masks) HIP_TRY(ctx, hipFree(r->d_masks));
     r->d_counts = nullptr;
     r->d_words = nullptr;
+    r->d_masks = nullptr;
     r->cap_S = 0;
     HIP_TRY(ctx, hipMalloc((void**)&r->d_counts, sizeof(unsigned long long) * ((size_t)N_PASS * S + 1)));
     HIP_TRY(ctx, hipMalloc((void**)&r->d_words, sizeof(uint32_t) * ((size_t)S * J_WORDS + 2 * MT_N)));
+    HIP_TRY(ctx, hipMalloc((void**)&r->d_masks, sizeof(uint32_t) * (size_t)N_PASS * S * NT));
     r->cap_S = S;
   }
   // hand-back block in pinned memory (nothing of an earlier call is in flight: every call ends with a wait for the stream)
@@ -552,6 +558,7 @@ int randn_device(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double*
   a.n_taps = r->d_ntaps;
   a.counts = r->d_counts;
   a.words = r->d_words;
+  a.masks = r->d_masks;
   a.S = S;
   a.pos0 = pos0;
   a.attempts = attempts;
