@@ -488,7 +488,7 @@ def test_armed_evaluation_on_a_shared_device(ctx):
 
 
 def test_armed_evaluation_soak(ctx):
-    """VBMC_SOAK_S seconds (default 60) of evaluations with seeds that repeat, jump and follow on, other
+    """VBMC_SOAK_S seconds (default 10) of evaluations with seeds that repeat, jump and follow on, other
     entry points, pauses and stream waits thrown in at random -- under a CPU hog: a busy process pinned
     to the SAME core as this one, so that this thread loses the CPU for milliseconds at arbitrary
     points of the call (between arming and use, between the age check and the go word, while it
@@ -512,7 +512,7 @@ def test_armed_evaluation_soak(ctx):
     rng = np.random.default_rng(0)
     NsK = 2 * 64 * 9
     ref = {}
-    soak_s = float(os.environ.get("VBMC_SOAK_S", "15"))  # (long soaks: set the variable; the suite's default keeps it short)
+    soak_s = float(os.environ.get("VBMC_SOAK_S", "10"))  # (long soaks: set the variable; the suite's default keeps it short)
     before = ctx.armed_stats()
     aff = os.sched_getaffinity(0)
     core = min(aff)
