@@ -44,9 +44,10 @@ constexpr int LDS_WORDS = TAP_OFF + 19968 / 2;                     // 31 216 wor
 constexpr int NT = 1024;
 constexpr int TAP_U = 16;                  // LDS reads in flight per thread in the jump
 constexpr int TAP_STRIDE = 19968;          // entries per polynomial: 19 937 rounded up to a multiple of TAP_U
-constexpr int TAP_PAD = WIN_WORDS;         // exponent whose window words are zeros (sm[1 + TAP_PAD + j], j < 624)
-static_assert(LDS_WORDS >= PASS_WORDS && TAP_OFF >= WIN_WORDS + MT_N + 1, "LDS plan");
-static_assert(TAP_STRIDE % TAP_U == 0 && TAP_PAD < 65536 && TAP_U == 16, "tap list layout");
+constexpr int TAP_PAD = WIN_WORDS;         // EVEN exponent whose window words are zeros (sm[TAP_PAD + j], j <= 625); TAP_PAD + 1: the odd one
+static_assert(LDS_WORDS >= PASS_WORDS && TAP_OFF >= WIN_WORDS + 1 + MT_N + 4 && (TAP_OFF % 4) == 0, "LDS plan");
+static_assert(TAP_STRIDE % TAP_U == 0 && TAP_PAD + 1 < 65536 && TAP_U == 16 && (TAP_PAD % 2) == 0, "tap list layout");
+static_assert(19937 + 2 * (TAP_U - 1) <= TAP_STRIDE, "both padded lists fit a polynomial's slot");
 
 __device__ __forceinline__ uint32_t mt_twist(uint32_t hi, uint32_t lo) {
   const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
@@ -132,8 +133,8 @@ __device__ __forceinline__ double mt_log_dd(double x) {
 struct RandnArgs {
   uint32_t* key;         // [624] the current block (device copy: written by mt_window_kernel from its argument)
   uint32_t* win;         // [WIN_WORDS]
-  const uint16_t* taps;  // [S - 1][TAP_STRIDE]: the set exponents of G_m, m = 1 .., padded with TAP_PAD
-  const int* n_taps;     // [S - 1]: entries used of each list (a multiple of TAP_U)
+  const uint16_t* taps;  // [S - 1][TAP_STRIDE]: the set exponents of G_m, m = 1 ..: the odd ones (padded with TAP_PAD + 1), then the even ones (TAP_PAD)
+  const int* n_taps;     // [S - 1][2]: entries of the odd and of the even list (multiples of TAP_U)
   unsigned long long* counts;  // [2 S + 1]: accepted attempts per half stream (m, pass), then (after the scan) exclusive prefix sums; [2 S] = total
   uint32_t* masks;       // [2 S][NT]: which of a thread's attempts of a half stream were accepted (bit c - c0), from the count pass
   uint32_t* words;       // [S J_WORDS + 624]: every stream's blocks as one sequence (word w of the stream sequence that starts at the key's word 0)
@@ -156,7 +157,7 @@ struct KeyArg {
   uint32_t k[MT_N];  // NumPy's current block, as a kernel argument (2 496 B)
 };
 __global__ __launch_bounds__(NT) void mt_window_kernel(RandnArgs a, KeyArg key) {
-  extern __shared__ uint32_t sm[];
+  extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
   for (int i = threadIdx.x; i < MT_N; i += NT) {
     sm[i] = key.k[i];
     a.key[i] = key.k[i];  // stream 0 starts from it (mt_stream_kernel, the next launch)
@@ -175,60 +176,88 @@ __device__ __forceinline__ void stream_start(const RandnArgs& a, int m, uint32_t
     return;
   }
   for (int i = tid; i < WIN_WORDS; i += NT) sm[i] = a.win[i];
-  for (int i = WIN_WORDS + tid; i < WIN_WORDS + MT_N + 1; i += NT) sm[i] = 0;  // what the padding taps read
+  for (int i = WIN_WORDS + tid; i < TAP_OFF; i += NT) sm[i] = 0;  // what the padding taps read
   __syncthreads();
-  // x_(m J + j) = XOR_{i : g_i} x_(1 + i + j), j < 624.  The polynomial comes as the list of its set exponents (16-bit,
-  // padded to a multiple of TAP_U with the exponent of a block of zeros) and is staged in LDS; per step a thread reads 16
-  // exponents (broadcast) and has 32 independent window reads in flight.  Measured on the way: walking the bits of the
-  // polynomial's words, one dependent read at a time: 400 us per jump; the list read from memory inside the loop: 230;
-  // from LDS, one word per thread on 10 waves: 150; two words per thread on 15 waves (below): ~100 -- the LDS-bandwidth
-  // floor of 6.2e6 four-byte reads per jump is 80.
-  uint32_t acc = 0;
-  const int n_tap = a.n_taps[m - 1];  // multiple of TAP_U
+  // x_(m J + j) = XOR_{i : g_i} x_(1 + i + j), j < 624.  The polynomial comes as the lists of its set exponents (16-bit,
+  // staged in LDS; per step a thread reads 16 of them, broadcast, and has 16 window reads in flight).
+  // Round 6: EIGHT-byte window reads.  Rounds 5's loop read one word per exponent and output word (two words j, j + 312
+  // per thread): 141 us per jump where the LDS-bandwidth floor of its 25 MB is 81 -- 97 500 ds_read_b32 per jump and SIMD
+  // group at ~3.5 cycles each: bound by the LDS instruction rate, not by its bytes.  A thread now owns two ADJACENT output
+  // words and reads them with one ds_read_b64, which wants an even word address: for an odd exponent e the pair
+  // (x_(1+e+j), x_(2+e+j)), j = 2 j2, is aligned and serves outputs (j, j + 1); for an even exponent the aligned pair is
+  // (x_(e+j), x_(1+e+j)) and serves outputs (j - 1, j) -- so the exponents come as two lists (odd: "A", even: "B", each
+  // padded to a multiple of 16 with an exponent of its own parity whose words are zeros), the B pairs are kept apart and
+  // shifted by one when the partial sums are put together, and a 313th thread of each group covers output 623 of the B
+  // pairs (its A pair, and output -1 of thread 0's B pair, fall outside and are dropped).
+  // (Measured on the way, round 5: walking the bits of the polynomial's words, one dependent read at a time: 400 us per
+  // jump; the list read from memory inside the loop: 230; from LDS, one word per thread on 10 waves: 150; two words per
+  // thread on 15 waves: 141.)
+  const int n_a = a.n_taps[2 * (m - 1)], n_b = a.n_taps[2 * (m - 1) + 1];  // multiples of TAP_U
   {
-    // the list into LDS first (40 KB; read from memory inside the loop, every step waited ~0.3 us for its 32 bytes)
+    // the lists into LDS first (40 KB; read from memory inside the loop, every step waited ~0.3 us for its 32 bytes)
     const uint32_t* tg = (const uint32_t*)(a.taps + (size_t)(m - 1) * TAP_STRIDE);
-    for (int i = tid; i < n_tap / 2; i += NT) sm[TAP_OFF + i] = tg[i];
+    for (int i = tid; i < (n_a + n_b) / 2; i += NT) sm[TAP_OFF + i] = tg[i];
   }
   __syncthreads();
-  // three groups of 312 threads, a third of the exponents each, two words (j, j + 312) per thread: 15 of the 16 waves
-  // read LDS (one word per thread over all exponents kept 10 waves busy at half the LDS rate)
-  constexpr int GRP = MT_N / 2, NGRP = 3;
-  const int grp = tid / GRP, j = tid - grp * GRP;
-  uint32_t acc1 = 0;
+  constexpr int GRP = MT_N / 2 + 1, NGRP = 3;  // three groups of 313 threads, a third of the steps each
+  static_assert(GRP * NGRP <= NT, "the jump's groups fit the workgroup");
+  const int grp = tid / GRP, j2 = tid - grp * GRP;
+  uint2 acc_a = make_uint2(0u, 0u), acc_b = make_uint2(0u, 0u);
   if (grp < NGRP) {
-    const uint32_t* base = sm + 1 + j;
     const uint4* tl = (const uint4*)(sm + TAP_OFF);
-    const int steps = n_tap / TAP_U;
-    for (int t = grp; t < steps; t += NGRP) {
-      const uint4 p0 = tl[2 * t], p1 = tl[2 * t + 1];  // 16 exponents, the same for every thread of the group (broadcast reads)
-      const uint32_t pw[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-      uint32_t v[TAP_U], w[TAP_U];
+    // list A (odd exponents): the pair at word 1 + e + 2 j2
+    {
+      const uint32_t* base = sm + 1 + 2 * j2;
+      const int steps = n_a / TAP_U;
+      for (int t = grp; t < steps; t += NGRP) {
+        const uint4 p0 = tl[2 * t], p1 = tl[2 * t + 1];  // 16 exponents, the same for every thread (broadcast reads)
+        const uint32_t pw[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        uint2 v[TAP_U];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const uint32_t* r0 = base + (pw[q] & 0xFFFFu);
-        const uint32_t* r1 = base + (pw[q] >> 16);
-        v[2 * q] = r0[0];
-        w[2 * q] = r0[GRP];
-        v[2 * q + 1] = r1[0];
-        w[2 * q + 1] = r1[GRP];
+        for (int q = 0; q < 8; ++q) {
+          v[2 * q] = *(const uint2*)(base + (pw[q] & 0xFFFFu));
+          v[2 * q + 1] = *(const uint2*)(base + (pw[q] >> 16));
+        }
+#pragma unroll
+        for (int q = 0; q < TAP_U; ++q) {
+          acc_a.x ^= v[q].x;
+          acc_a.y ^= v[q].y;
+        }
       }
+    }
+    // list B (even exponents), behind list A: the pair at word e + 2 j2
+    {
+      const uint32_t* base = sm + 2 * j2;
+      const int steps = n_b / TAP_U, t0 = n_a / TAP_U;
+      for (int t = grp; t < steps; t += NGRP) {
+        const uint4 p0 = tl[2 * (t0 + t)], p1 = tl[2 * (t0 + t) + 1];
+        const uint32_t pw[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        uint2 v[TAP_U];
 #pragma unroll
-      for (int q = 0; q < TAP_U; ++q) {
-        acc ^= v[q];
-        acc1 ^= w[q];
+        for (int q = 0; q < 8; ++q) {
+          v[2 * q] = *(const uint2*)(base + (pw[q] & 0xFFFFu));
+          v[2 * q + 1] = *(const uint2*)(base + (pw[q] >> 16));
+        }
+#pragma unroll
+        for (int q = 0; q < TAP_U; ++q) {
+          acc_b.x ^= v[q].x;
+          acc_b.y ^= v[q].y;
+        }
       }
     }
   }
-  __syncthreads();  // every read of the window is done: the partial sums go where the exponent list was
-  uint32_t* part = sm + TAP_OFF;
+  __syncthreads();  // every read of the window is done: the partial sums go where the exponent lists were
+  uint32_t* part_a = sm + TAP_OFF;                          // [NGRP][2 GRP]: outputs 2 j2, 2 j2 + 1
+  uint32_t* part_b = part_a + NGRP * 2 * GRP;               // [NGRP][2 GRP]: entry k = output k - 1
   if (grp < NGRP) {
-    part[grp * MT_N + j] = acc;
-    part[grp * MT_N + GRP + j] = acc1;
+    *(uint2*)(part_a + grp * 2 * GRP + 2 * j2) = acc_a;
+    *(uint2*)(part_b + grp * 2 * GRP + 2 * j2) = acc_b;
   }
   __syncthreads();
   if (tid < MT_N) {
-    const uint32_t x = part[tid] ^ part[MT_N + tid] ^ part[2 * MT_N + tid];
+    uint32_t x = 0;
+#pragma unroll
+    for (int g = 0; g < NGRP; ++g) x ^= part_a[g * 2 * GRP + tid] ^ part_b[g * 2 * GRP + tid + 1];
     sm[tid] = x;
   }
   __syncthreads();
@@ -261,7 +290,7 @@ __device__ __forceinline__ void pass_attempts(const RandnArgs& a, int m, int pas
 // (Measured and not kept, round 6: the jump, the recurrence on four-wave workgroups and the counts as three kernels --
 // 141 + 50 + 17.5 us against this kernel's 187.)
 __global__ __launch_bounds__(NT) void mt_stream_kernel(RandnArgs a) {
-  extern __shared__ uint32_t sm[];
+  extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
   __shared__ unsigned long long s_red[NT / 64];
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   long long t_lo, t_hi;
@@ -316,7 +345,7 @@ constexpr int NTV = 1024;
 constexpr int MAX_PER = (BLK_PER_PASS * (MT_N / 4) + 1 + NTV - 1) / NTV;  // attempts per thread and half stream: 7
 static_assert(NTV == NT && MAX_PER <= 32, "the count pass and the values pass cut a half stream's attempts the same way; a bit per attempt");
 __global__ __launch_bounds__(NTV) void mt_values_kernel(RandnArgs a) {
-  extern __shared__ uint32_t sm[];  // the half stream's words (+ the block behind them): PASS_WORDS
+  extern __shared__ __attribute__((aligned(16))) uint32_t sm[];  // the half stream's words (+ the block behind them): PASS_WORDS
   __shared__ unsigned long long s_red[NTV / 64];
   __shared__ unsigned long long s_scan[NTV / 64];
   __shared__ long long s_end_blk;
@@ -500,23 +529,27 @@ int randn_device(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double*
     if (!mtj::jump_polys((uint64_t)J_WORDS, want, nthreads, r->polys)) return vbmc_fail(ctx, VBMC_E_HIP, "randn: MT19937's characteristic polynomial was not found");
     // the polynomials as lists of their set exponents
     std::vector<uint16_t> taps((size_t)want * TAP_STRIDE, (uint16_t)TAP_PAD);
-    std::vector<int> ntaps(want);
+    std::vector<int> ntaps(2 * (size_t)want);
     for (int m = 0; m < want; ++m) {
       const uint32_t* g = r->polys.data() + (size_t)m * MT_N;
       uint16_t* tp = taps.data() + (size_t)m * TAP_STRIDE;
       int n = 0;
-      for (int i = 0; i < mtj::DEG; ++i)
-        if ((g[i >> 5] >> (i & 31)) & 1u) tp[n++] = (uint16_t)i;
-      ntaps[m] = (n + TAP_U - 1) / TAP_U * TAP_U;
+      for (int par = 1; par >= 0; --par) {  // the odd exponents first, then the even ones; each list padded with its own zero exponent
+        const int n0 = n;
+        for (int i = par; i < mtj::DEG; i += 2)
+          if ((g[i >> 5] >> (i & 31)) & 1u) tp[n++] = (uint16_t)i;
+        while ((n - n0) % TAP_U) tp[n++] = (uint16_t)(TAP_PAD + par);
+        ntaps[2 * (size_t)m + (1 - par)] = n - n0;
+      }
     }
     if (r->d_taps) HIP_TRY(ctx, hipFree(r->d_taps));
     if (r->d_ntaps) HIP_TRY(ctx, hipFree(r->d_ntaps));
     r->d_taps = nullptr;
     r->d_ntaps = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&r->d_taps, sizeof(uint16_t) * taps.size()));
-    HIP_TRY(ctx, hipMalloc((void**)&r->d_ntaps, sizeof(int) * (size_t)want));
+    HIP_TRY(ctx, hipMalloc((void**)&r->d_ntaps, sizeof(int) * 2 * (size_t)want));
     HIP_TRY(ctx, hipMemcpy(r->d_taps, taps.data(), sizeof(uint16_t) * taps.size(), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(r->d_ntaps, ntaps.data(), sizeof(int) * (size_t)want, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(r->d_ntaps, ntaps.data(), sizeof(int) * 2 * (size_t)want, hipMemcpyHostToDevice));
     r->poly_count = want;
   }
   if (!r->d_key) {
