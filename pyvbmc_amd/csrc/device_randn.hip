@@ -40,14 +40,15 @@ constexpr int J_WORDS = BLK_PER_STREAM * MT_N;                    // 49 920
 constexpr int WIN_WORDS = 33 * MT_N;                               // x_0 .. x_20591 (x_1 .. x_20560 are used)
 constexpr int PASS_WORDS = (BLK_PER_PASS + 1) * MT_N;              // 25 584 words = 102 KB: the blocks of a pass
 constexpr int TAP_OFF = 33 * MT_N + 640;                           // (words) the jump's exponent list behind the window and its zero block
-constexpr int LDS_WORDS = TAP_OFF + 19968 / 2;                     // 31 216 words = 125 KB
+constexpr int LDS_WORDS = TAP_OFF + 20032 / 2;                     // 31 248 words = 125 KB
 constexpr int NT = 1024;
 constexpr int TAP_U = 16;                  // LDS reads in flight per thread in the jump
-constexpr int TAP_STRIDE = 19968;          // entries per polynomial: 19 937 rounded up to a multiple of TAP_U
-constexpr int TAP_PAD = WIN_WORDS;         // EVEN exponent whose window words are zeros (sm[TAP_PAD + j], j <= 625); TAP_PAD + 1: the odd one
-static_assert(LDS_WORDS >= PASS_WORDS && TAP_OFF >= WIN_WORDS + 1 + MT_N + 4 && (TAP_OFF % 4) == 0, "LDS plan");
-static_assert(TAP_STRIDE % TAP_U == 0 && TAP_PAD + 1 < 65536 && TAP_U == 16 && (TAP_PAD % 2) == 0, "tap list layout");
-static_assert(19937 + 2 * (TAP_U - 1) <= TAP_STRIDE, "both padded lists fit a polynomial's slot");
+constexpr int TAP_STRIDE = 20032;          // entries per polynomial: 19 937 + four lists' padding, a multiple of TAP_U
+constexpr int TAP_PAD = WIN_WORDS;         // exponents TAP_PAD + 3 - c, c = 0 .. 3: class-c exponents whose window words are zeros
+static_assert(LDS_WORDS >= PASS_WORDS && TAP_OFF >= WIN_WORDS + 4 + MT_N + 8 && (TAP_OFF % 4) == 0, "LDS plan");
+static_assert(TAP_STRIDE % TAP_U == 0 && TAP_PAD + 3 < 65536 && TAP_U == 16 && (TAP_PAD % 4) == 0, "tap list layout");
+static_assert(19937 + 4 * (TAP_U - 1) <= TAP_STRIDE, "the four padded lists fit a polynomial's slot");
+static_assert(1024 + 4 * 6 * (MT_N / 4 + 1) * 4 + 4 <= WIN_WORDS, "the jump's partial sums fit over the window");
 
 __device__ __forceinline__ uint32_t mt_twist(uint32_t hi, uint32_t lo) {
   const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
@@ -133,8 +134,8 @@ __device__ __forceinline__ double mt_log_dd(double x) {
 struct RandnArgs {
   uint32_t* key;         // [624] the current block (device copy: written by mt_window_kernel from its argument)
   uint32_t* win;         // [WIN_WORDS]
-  const uint16_t* taps;  // [S - 1][TAP_STRIDE]: the set exponents of G_m, m = 1 ..: the odd ones (padded with TAP_PAD + 1), then the even ones (TAP_PAD)
-  const int* n_taps;     // [S - 1][2]: entries of the odd and of the even list (multiples of TAP_U)
+  const uint16_t* taps;  // [S - 1][TAP_STRIDE]: the set exponents e of G_m, m = 1 .., as four lists by c = (1 + e) mod 4, each padded with TAP_PAD + 3 - c
+  const int* n_taps;     // [S - 1][4]: entries of the four lists (multiples of TAP_U)
   unsigned long long* counts;  // [2 S + 1]: accepted attempts per half stream (m, pass), then (after the scan) exclusive prefix sums; [2 S] = total
   uint32_t* masks;       // [2 S][NT]: which of a thread's attempts of a half stream were accepted (bit c - c0), from the count pass
   uint32_t* words;       // [S J_WORDS + 624]: every stream's blocks as one sequence (word w of the stream sequence that starts at the key's word 0)
@@ -180,7 +181,7 @@ __device__ __forceinline__ void stream_start(const RandnArgs& a, int m, uint32_t
   __syncthreads();
   // x_(m J + j) = XOR_{i : g_i} x_(1 + i + j), j < 624.  The polynomial comes as the lists of its set exponents (16-bit,
   // staged in LDS; per step a thread reads 16 of them, broadcast, and has 16 window reads in flight).
-  // Round 6: EIGHT-byte window reads.  Rounds 5's loop read one word per exponent and output word (two words j, j + 312
+  // Round 6: wide window reads (first eight bytes: 141 -> 108 us per jump; then sixteen).  Rounds 5's loop read one word per exponent and output word (two words j, j + 312
   // per thread): 141 us per jump where the LDS-bandwidth floor of its 25 MB is 81 -- 97 500 ds_read_b32 per jump and SIMD
   // group at ~3.5 cycles each: bound by the LDS instruction rate, not by its bytes.  A thread now owns two ADJACENT output
   // words and reads them with one ds_read_b64, which wants an even word address: for an odd exponent e the pair
@@ -192,72 +193,67 @@ __device__ __forceinline__ void stream_start(const RandnArgs& a, int m, uint32_t
   // (Measured on the way, round 5: walking the bits of the polynomial's words, one dependent read at a time: 400 us per
   // jump; the list read from memory inside the loop: 230; from LDS, one word per thread on 10 waves: 150; two words per
   // thread on 15 waves: 141.)
-  const int n_a = a.n_taps[2 * (m - 1)], n_b = a.n_taps[2 * (m - 1) + 1];  // multiples of TAP_U
+  // (then sixteen-byte reads: four adjacent output words per thread, four lists by (1 + e) mod 4)
+  int n_c[4], off_c[4];
   {
+    int o = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      n_c[c] = a.n_taps[4 * (m - 1) + c];  // multiples of TAP_U
+      off_c[c] = o;
+      o += n_c[c];
+    }
     // the lists into LDS first (40 KB; read from memory inside the loop, every step waited ~0.3 us for its 32 bytes)
     const uint32_t* tg = (const uint32_t*)(a.taps + (size_t)(m - 1) * TAP_STRIDE);
-    for (int i = tid; i < (n_a + n_b) / 2; i += NT) sm[TAP_OFF + i] = tg[i];
+    for (int i = tid; i < o / 2; i += NT) sm[TAP_OFF + i] = tg[i];
   }
   __syncthreads();
-  constexpr int GRP = MT_N / 2 + 1, NGRP = 3;  // three groups of 313 threads, a third of the steps each
+  // Class c = (1 + e) mod 4: the aligned quad at word 1 + e - c + 4 j4 holds outputs 4 j4 - c .. 4 j4 - c + 3; j4 = 0 .. 156
+  // covers outputs 0 .. 623 for every c (what falls outside is dropped when the partial sums are put together).
+  constexpr int GRP = MT_N / 4 + 1, NGRP = 6;  // six groups of 157 threads, a sixth of every list's steps each
   static_assert(GRP * NGRP <= NT, "the jump's groups fit the workgroup");
-  const int grp = tid / GRP, j2 = tid - grp * GRP;
-  uint2 acc_a = make_uint2(0u, 0u), acc_b = make_uint2(0u, 0u);
+  const int grp = tid / GRP, j4 = tid - grp * GRP;
+  uint4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = make_uint4(0u, 0u, 0u, 0u);
   if (grp < NGRP) {
     const uint4* tl = (const uint4*)(sm + TAP_OFF);
-    // list A (odd exponents): the pair at word 1 + e + 2 j2
-    {
-      const uint32_t* base = sm + 1 + 2 * j2;
-      const int steps = n_a / TAP_U;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint32_t* base = sm + 1 - c + 4 * j4;  // + e: a multiple of four words for every exponent of the class
+      const int steps = n_c[c] / TAP_U, t0 = off_c[c] / TAP_U;
       for (int t = grp; t < steps; t += NGRP) {
-        const uint4 p0 = tl[2 * t], p1 = tl[2 * t + 1];  // 16 exponents, the same for every thread (broadcast reads)
+        const uint4 p0 = tl[2 * (t0 + t)], p1 = tl[2 * (t0 + t) + 1];  // 16 exponents, the same for every thread (broadcast reads)
         const uint32_t pw[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-        uint2 v[TAP_U];
+        uint4 v[TAP_U];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          v[2 * q] = *(const uint2*)(base + (pw[q] & 0xFFFFu));
-          v[2 * q + 1] = *(const uint2*)(base + (pw[q] >> 16));
+          v[2 * q] = *(const uint4*)(base + (pw[q] & 0xFFFFu));
+          v[2 * q + 1] = *(const uint4*)(base + (pw[q] >> 16));
         }
 #pragma unroll
         for (int q = 0; q < TAP_U; ++q) {
-          acc_a.x ^= v[q].x;
-          acc_a.y ^= v[q].y;
-        }
-      }
-    }
-    // list B (even exponents), behind list A: the pair at word e + 2 j2
-    {
-      const uint32_t* base = sm + 2 * j2;
-      const int steps = n_b / TAP_U, t0 = n_a / TAP_U;
-      for (int t = grp; t < steps; t += NGRP) {
-        const uint4 p0 = tl[2 * (t0 + t)], p1 = tl[2 * (t0 + t) + 1];
-        const uint32_t pw[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-        uint2 v[TAP_U];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          v[2 * q] = *(const uint2*)(base + (pw[q] & 0xFFFFu));
-          v[2 * q + 1] = *(const uint2*)(base + (pw[q] >> 16));
-        }
-#pragma unroll
-        for (int q = 0; q < TAP_U; ++q) {
-          acc_b.x ^= v[q].x;
-          acc_b.y ^= v[q].y;
+          acc[c].x ^= v[q].x;
+          acc[c].y ^= v[q].y;
+          acc[c].z ^= v[q].z;
+          acc[c].w ^= v[q].w;
         }
       }
     }
   }
-  __syncthreads();  // every read of the window is done: the partial sums go where the exponent lists were
-  uint32_t* part_a = sm + TAP_OFF;                          // [NGRP][2 GRP]: outputs 2 j2, 2 j2 + 1
-  uint32_t* part_b = part_a + NGRP * 2 * GRP;               // [NGRP][2 GRP]: entry k = output k - 1
+  __syncthreads();  // every read of the window is done: the partial sums go over it (behind the 624 words of the result)
+  uint32_t* part = sm + 1024;  // [4 classes][NGRP][4 GRP]: entry k of class c = output k - c
   if (grp < NGRP) {
-    *(uint2*)(part_a + grp * 2 * GRP + 2 * j2) = acc_a;
-    *(uint2*)(part_b + grp * 2 * GRP + 2 * j2) = acc_b;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *(uint4*)(part + ((c * NGRP + grp) * GRP + j4) * 4) = acc[c];
   }
   __syncthreads();
   if (tid < MT_N) {
     uint32_t x = 0;
 #pragma unroll
-    for (int g = 0; g < NGRP; ++g) x ^= part_a[g * 2 * GRP + tid] ^ part_b[g * 2 * GRP + tid + 1];
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int g = 0; g < NGRP; ++g) x ^= part[(c * NGRP + g) * GRP * 4 + tid + c];
     sm[tid] = x;
   }
   __syncthreads();
@@ -529,17 +525,17 @@ int randn_device(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double*
     if (!mtj::jump_polys((uint64_t)J_WORDS, want, nthreads, r->polys)) return vbmc_fail(ctx, VBMC_E_HIP, "randn: MT19937's characteristic polynomial was not found");
     // the polynomials as lists of their set exponents
     std::vector<uint16_t> taps((size_t)want * TAP_STRIDE, (uint16_t)TAP_PAD);
-    std::vector<int> ntaps(2 * (size_t)want);
+    std::vector<int> ntaps(4 * (size_t)want);
     for (int m = 0; m < want; ++m) {
       const uint32_t* g = r->polys.data() + (size_t)m * MT_N;
       uint16_t* tp = taps.data() + (size_t)m * TAP_STRIDE;
       int n = 0;
-      for (int par = 1; par >= 0; --par) {  // the odd exponents first, then the even ones; each list padded with its own zero exponent
+      for (int c = 0; c < 4; ++c) {  // class c: (1 + e) mod 4 == c, i.e. e = c - 1 (mod 4); each list padded with its own zero exponent
         const int n0 = n;
-        for (int i = par; i < mtj::DEG; i += 2)
+        for (int i = (c + 3) & 3; i < mtj::DEG; i += 4)
           if ((g[i >> 5] >> (i & 31)) & 1u) tp[n++] = (uint16_t)i;
-        while ((n - n0) % TAP_U) tp[n++] = (uint16_t)(TAP_PAD + par);
-        ntaps[2 * (size_t)m + (1 - par)] = n - n0;
+        while ((n - n0) % TAP_U) tp[n++] = (uint16_t)(TAP_PAD + ((c + 3) & 3));
+        ntaps[4 * (size_t)m + c] = n - n0;
       }
     }
     if (r->d_taps) HIP_TRY(ctx, hipFree(r->d_taps));
@@ -547,9 +543,9 @@ int randn_device(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double*
     r->d_taps = nullptr;
     r->d_ntaps = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&r->d_taps, sizeof(uint16_t) * taps.size()));
-    HIP_TRY(ctx, hipMalloc((void**)&r->d_ntaps, sizeof(int) * 2 * (size_t)want));
+    HIP_TRY(ctx, hipMalloc((void**)&r->d_ntaps, sizeof(int) * 4 * (size_t)want));
     HIP_TRY(ctx, hipMemcpy(r->d_taps, taps.data(), sizeof(uint16_t) * taps.size(), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(r->d_ntaps, ntaps.data(), sizeof(int) * 2 * (size_t)want, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(r->d_ntaps, ntaps.data(), sizeof(int) * 4 * (size_t)want, hipMemcpyHostToDevice));
     r->poly_count = want;
   }
   if (!r->d_key) {
