@@ -54,17 +54,17 @@ __device__ __forceinline__ uint32_t mt_twist(uint32_t hi, uint32_t lo) {
   const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
   return (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
 }
-// d = the block after s (both in LDS; all NT threads call it)
-__device__ __forceinline__ void mt_next_block_lds(const uint32_t* s, uint32_t* d) {
+// The recurrence on a buffer of consecutive words in LDS: x_n = x_(n-227) ^ twist(x_(n-624), x_(n-623)) for n in
+// [624, n_end) given x_0 .. x_623 -- 227 words per step (the nearest operand is 227 words back), one barrier per step:
+// 2.75 barriers per block where round 5's block-by-block form (three phases and the last word) had four.  All NT threads call it.
+__device__ __forceinline__ void mt_extend_lds(uint32_t* x, int n_end) {
+  constexpr int Q = MT_N - MT_M;
   const int i = threadIdx.x;
-  if (i < MT_N - MT_M) d[i] = s[i + MT_M] ^ mt_twist(s[i], s[i + 1]);
-  __syncthreads();
-  if (i >= MT_N - MT_M && i < 2 * (MT_N - MT_M)) d[i] = d[i - (MT_N - MT_M)] ^ mt_twist(s[i], s[i + 1]);
-  __syncthreads();
-  if (i >= 2 * (MT_N - MT_M) && i < MT_N - 1) d[i] = d[i - (MT_N - MT_M)] ^ mt_twist(s[i], s[i + 1]);
-  __syncthreads();
-  if (i == MT_N - 1) d[i] = d[MT_M - 1] ^ mt_twist(s[MT_N - 1], d[0]);
-  __syncthreads();
+  for (int n0 = MT_N; n0 < n_end; n0 += Q) {
+    const int n = n0 + i;
+    if (i < Q && n < n_end) x[n] = x[n - Q] ^ mt_twist(x[n - MT_N], x[n - MT_N + 1]);
+    __syncthreads();
+  }
 }
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
   y ^= y >> 11;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(NT) void mt_window_kernel(RandnArgs a, KeyArg key) 
     a.key[i] = key.k[i];  // stream 0 starts from it (mt_stream_kernel, the next launch)
   }
   __syncthreads();
-  for (int b = 1; b < WIN_WORDS / MT_N; ++b) mt_next_block_lds(sm + (b - 1) * MT_N, sm + b * MT_N);
+  mt_extend_lds(sm, WIN_WORDS);
   for (int i = threadIdx.x; i < WIN_WORDS; i += NT) a.win[i] = sm[i];
 }
 
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NT) void mt_stream_kernel(RandnArgs a) {
       for (int i = tid; i < MT_N; i += NT) sm[i] = sm[BLK_PER_PASS * MT_N + i];
       __syncthreads();
     }
-    for (int b = 1; b <= BLK_PER_PASS; ++b) mt_next_block_lds(sm + (b - 1) * MT_N, sm + b * MT_N);
+    mt_extend_lds(sm, (BLK_PER_PASS + 1) * MT_N);
     // the pass's own blocks to memory (the last stream's last pass: the block behind them too -- an attempt may end there)
     const long long w0 = (long long)m * J_WORDS + (long long)pass * BLK_PER_PASS * MT_N;
     {
