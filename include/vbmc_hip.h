@@ -315,6 +315,10 @@ int vbmc_mt19937_randn(uint32_t* key, int* pos, int* has_gauss, double* gauss, d
  * Reference: entropy/entmc_vbmc.py:64-68. */
 int vbmc_mt19937_randn_dev(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double* gauss, double* out,
                            int64_t n);
+/* *window_reused = 1 when the context's last device pass (vbmc_mt19937_randn_dev / vbmc_set_eps_numpy) found the 33 blocks
+ * behind its incoming state in the word sequence of the pass before -- a caller that keeps drawing from the stream where
+ * the last call left it -- and did not have to compute them (csrc/device_randn.hip). */
+int vbmc_randn_dev_info(const vbmc_ctx* ctx, int* window_reused);
 /* Host twins of that jump for the CPU tests: the MT19937 block that starts n_words (>= 1) words after key_in[0], by the
  * polynomial t^(n_words-1) mod the characteristic polynomial (found by Berlekamp-Massey, csrc/mt_jump.h); and the
  * polynomials t^(m stride - 1), m = 1 .. count, as [count][624] words. */

@@ -95,6 +95,7 @@ SIGNATURES = {
         C.c_int,
         [C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp, C.c_int64, C.c_int],
     ),
+    "vbmc_randn_dev_info": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "vbmc_mt19937_randn_dev": (
         C.c_int,
         [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp, C.c_int64],

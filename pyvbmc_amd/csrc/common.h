@@ -228,6 +228,7 @@ struct vbmc_ctx {
   bool host_bound = false;    // vbmc_ctx_create narrowed the calling thread's affinity to the device's NUMA node (ctx.hip)
   int host_cpus = 0;          // CPUs in that thread's affinity set after context creation (0: not looked at)
   void* randn_dev = nullptr;  // buffers of the device-side NumPy stream (device_randn.hip)
+  int randn_last_reused = 0;  // the last device pass found its window in the pass before (device_randn.hip)
   int opt_randn_dev = 1;      // vbmc_set_eps_numpy: the reference's stream generated on the device (0: on the host cores + PCIe)
 };
 int vbmc_live_contexts_on(int device);  // ctx.hip

@@ -309,7 +309,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "ws_front")) ctx->opt_ws_front = value < 0 ? 0 : value > 990 ? 990 : value;
   else if (!strcmp(key, "elbo_arm")) ctx->opt_elbo_arm = value < 0 ? 0 : value > 2 ? 2 : value;  // 1: only while this context is alone on its device; 2: always
   else if (!strcmp(key, "acq_poll")) ctx->opt_acq_poll = value != 0;
-  else if (!strcmp(key, "randn_device")) ctx->opt_randn_dev = value < 0 ? 0 : value > 2 ? 2 : value;  // vbmc_set_eps_numpy: the NumPy stream on the device (device_randn.hip); 0 = strict parity (host generator, values bit-identical to np.random.randn); 2 = test hook: the device pass reports its margin exceeded
+  else if (!strcmp(key, "randn_device")) ctx->opt_randn_dev = value < 0 ? 0 : value > 3 ? 3 : value;  // vbmc_set_eps_numpy: the NumPy stream on the device (device_randn.hip); 0 = strict parity (host generator, values bit-identical to np.random.randn); 2 = test hook: the device pass reports its margin exceeded; 3 = test hook: the window is always computed, never taken from the pass before
   else if (!strcmp(key, "adam_tail")) ctx->opt_adam_tail = value;  // the optimiser loop's two-launch iteration (adam.hip)
   else if (!strcmp(key, "adam_fused")) ctx->opt_adam_fused = value;  // 2: test hook, see FusedArgs::test_absent; 3: release / acquire flags (FusedArgs::rel_acq)
   else return vbmc_fail(ctx, VBMC_E_ARG, "vbmc_set_option: unknown key '%s'", key);

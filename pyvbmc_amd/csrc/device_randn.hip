@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 #include "mt_jump.h"
@@ -457,7 +458,15 @@ struct RandnDev {
   int* d_ntaps = nullptr;
   int poly_count = 0;  // polynomials on the device (G_1 .. G_count)
   unsigned long long* d_counts = nullptr;
-  uint32_t* d_words = nullptr;
+  // the streams' words of the last two calls, alternating: a call whose incoming block is the one the call before handed
+  // back finds its window -- the 33 blocks from there on -- in that call's sequence (the streams cover ~1 % more than a
+  // request consumes) and does not launch mt_window_kernel, the one sequential kernel of the pass (13.6 us)
+  uint32_t* d_words[2] = {nullptr, nullptr};
+  int cur = 0;               // the buffer the last successful call wrote
+  bool prev_valid = false;
+  long long prev_blk = 0;    // block of that sequence the handed-back key is
+  int prev_S = 0;
+  std::vector<uint32_t> prev_key;
   uint32_t* d_masks = nullptr;
   int cap_S = 0;
   uint32_t* h_stage = nullptr;  // pinned, written by the kernels: end_key (624) | end_info (2 x 8 B) | end_vals (3 x 8 B) | total (8 B)
@@ -476,7 +485,7 @@ RandnDev* randn_of(vbmc_ctx* ctx) {
 void randn_dev_free(vbmc_ctx* ctx) {
   RandnDev* r = (RandnDev*)ctx->randn_dev;
   if (!r) return;
-  void* bufs[] = {r->d_key, r->d_win, r->d_taps, r->d_ntaps, r->d_counts, r->d_words, r->d_masks};
+  void* bufs[] = {r->d_key, r->d_win, r->d_taps, r->d_ntaps, r->d_counts, r->d_words[0], r->d_words[1], r->d_masks};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (r->h_stage) (void)hipHostFree(r->h_stage);
@@ -560,14 +569,17 @@ int randn_device(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double*
   }
   if (r->cap_S < S) {
     if (r->d_counts) HIP_TRY(ctx, hipFree(r->d_counts));
-    if (r->d_words) HIP_TRY(ctx, hipFree(r->d_words));
+    for (int q = 0; q < 2; ++q) {
+      if (r->d_words[q]) HIP_TRY(ctx, hipFree(r->d_words[q]));
+      r->d_words[q] = nullptr;
+    }
     if (r->d_masks) HIP_TRY(ctx, hipFree(r->d_masks));
     r->d_counts = nullptr;
-    r->d_words = nullptr;
     r->d_masks = nullptr;
     r->cap_S = 0;
+    r->prev_valid = false;
     HIP_TRY(ctx, hipMalloc((void**)&r->d_counts, sizeof(unsigned long long) * ((size_t)N_PASS * S + 1)));
-    HIP_TRY(ctx, hipMalloc((void**)&r->d_words, sizeof(uint32_t) * ((size_t)S * J_WORDS + 2 * MT_N)));
+    for (int q = 0; q < 2; ++q) HIP_TRY(ctx, hipMalloc((void**)&r->d_words[q], sizeof(uint32_t) * ((size_t)S * J_WORDS + 2 * MT_N)));
     HIP_TRY(ctx, hipMalloc((void**)&r->d_masks, sizeof(uint32_t) * (size_t)N_PASS * S * NT));
     r->cap_S = S;
   }
@@ -578,15 +590,23 @@ int randn_device(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double*
   unsigned long long* h_total = (unsigned long long*)(h_vals + 3);
   h_info[0] = h_info[1] = 0;
   *h_total = 0;
-  KeyArg karg;
-  std::memcpy(karg.k, key, sizeof(uint32_t) * MT_N);
+  // the window: in the last call's sequence when this call continues where that one ended (see RandnDev), else computed
+  const bool reuse = r->prev_valid && ctx->opt_randn_dev != 3 /* test hook: never */ && r->prev_key.size() == (size_t)MT_N &&
+                     std::memcmp(key, r->prev_key.data(), sizeof(uint32_t) * MT_N) == 0 &&
+                     r->prev_blk + WIN_WORDS / MT_N <= (long long)r->prev_S * BLK_PER_STREAM + 1;
+  r->prev_valid = false;  // (until this call succeeds)
   RandnArgs a;
-  a.key = r->d_key;
-  a.win = r->d_win;
+  if (reuse) {
+    a.win = r->d_words[r->cur] + r->prev_blk * MT_N;
+    a.key = a.win;
+  } else {
+    a.key = r->d_key;
+    a.win = r->d_win;
+  }
   a.taps = r->d_taps;
   a.n_taps = r->d_ntaps;
   a.counts = r->d_counts;
-  a.words = r->d_words;
+  a.words = r->d_words[r->cur ^ 1];
   a.masks = r->d_masks;
   a.S = S;
   a.pos0 = pos0;
@@ -599,7 +619,12 @@ int randn_device(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double*
   a.end_vals = (double*)(a.end_info + 2);
   a.end_total = (unsigned long long*)(a.end_vals + 3);
   const size_t lds = sizeof(uint32_t) * LDS_WORDS;
-  hipLaunchKernelGGL(mt_window_kernel, dim3(1), dim3(NT), lds, sm, a, karg);
+  if (!reuse) {
+    KeyArg karg;
+    std::memcpy(karg.k, key, sizeof(uint32_t) * MT_N);
+    hipLaunchKernelGGL(mt_window_kernel, dim3(1), dim3(NT), lds, sm, a, karg);
+  }
+  ctx->randn_last_reused = reuse ? 1 : 0;
   hipLaunchKernelGGL(mt_stream_kernel, dim3(S), dim3(NT), lds, sm, a);
   hipLaunchKernelGGL(mt_scan_kernel, dim3(1), dim3(256), 0, sm, a);
   hipLaunchKernelGGL(mt_values_kernel, dim3(N_PASS * S), dim3(NTV), sizeof(uint32_t) * PASS_WORDS, sm, a);
@@ -615,6 +640,11 @@ int randn_device(vbmc_ctx* ctx, uint32_t* key, int* pos, int* has_gauss, double*
   const int64_t b = (w - 1) / MT_N;       // the block holding the last word read
   if (b > 0) std::memcpy(key, h_end_key, sizeof(uint32_t) * MT_N);
   *pos = (int)(w - b * MT_N);
+  r->cur ^= 1;  // this call's sequence: where the next call may find its window
+  r->prev_key.assign(key, key + MT_N);
+  r->prev_blk = b;
+  r->prev_S = S;
+  r->prev_valid = true;
   if (rest & 1) {
     // NumPy's cached second value, with the host's libm: bit-identical to what legacy_gauss would hold
     const double r2 = h_vals[2];
@@ -638,6 +668,13 @@ extern "C" int vbmc_mt19937_randn_dev(vbmc_ctx* ctx, uint32_t* key, int* pos, in
   rc = randn_device(ctx, key, pos, has_gauss, gauss, ctx->d_scratch, n);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpy(out, ctx->d_scratch, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  return VBMC_OK;
+}
+
+// whether the last device pass of this context took its window from the pass before (tests)
+extern "C" int vbmc_randn_dev_info(const vbmc_ctx* ctx, int* window_reused) {
+  if (!ctx || !window_reused) return VBMC_E_ARG;
+  *window_reused = ctx->randn_last_reused;
   return VBMC_OK;
 }
 

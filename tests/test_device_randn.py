@@ -129,6 +129,50 @@ def test_device_randn_matches_numpy_large(ctx):
 
 
 @pytest.mark.gpu
+def test_consecutive_requests_take_their_window_from_the_pass_before(ctx):
+    """Round 6: a request that continues the stream where the last one left it finds the 33 blocks behind its incoming
+    state in that pass's word sequence and skips the one sequential kernel (vbmc_randn_dev_info says so).  Values and
+    states as np.random.randn's through a chain of requests of different sizes, odd ones included (cached second value),
+    with the window computed afresh after a foreign draw and after a re-seed -- and the same chain with the reuse switched
+    off (option randn_device = 3) gives the same values bit for bit."""
+    def reused():
+        v = C.c_int(-1)
+        ctx.check(ctx._lib.vbmc_randn_dev_info(ctx._h, C.byref(v)))
+        return v.value
+
+    sizes = [300_000, 300_000, 70_001, 70_001, 1_000_000, 65_536]
+    chains = {}
+    for mode in (1, 3):
+        ctx.set_option("randn_device", mode)
+        np.random.seed(2024)
+        want_state = []
+        got, flags = [], []
+        for i, n in enumerate(sizes):
+            if i == 4:
+                np.random.randint(0, 2**32, size=5, dtype=np.uint32)  # somebody else draws: another position, same or next block
+            got.append(device_randn(ctx, n))
+            flags.append(reused())
+            want_state.append(np.random.get_state())
+        chains[mode] = (got, flags, want_state)
+    ctx.set_option("randn_device", 1)
+    np.random.seed(2024)
+    for i, n in enumerate(sizes):
+        if i == 4:
+            np.random.randint(0, 2**32, size=5, dtype=np.uint32)
+        want = np.random.randn(n)
+        s_want = np.random.get_state()
+        for mode in (1, 3):
+            s_got = chains[mode][2][i]
+            assert np.array_equal(s_got[1], s_want[1]) and s_got[2:] == s_want[2:], (mode, i)
+            assert ulp_diff(chains[mode][0][i], want).max() <= 4, (mode, i)
+        assert np.array_equal(chains[1][0][i], chains[3][0][i]), i  # with and without the reuse: the same bits
+    assert chains[3][1] == [0] * len(sizes)
+    # request 0 follows a re-seed (nothing to reuse); 1 .. 3 continue; 4 follows five foreign words -- still inside the block
+    # the last pass ended in or the next one, both in its sequence: the key decides, not the position; 5 continues
+    assert chains[1][1][0] == 0 and chains[1][1][1:4] == [1, 1, 1] and chains[1][1][5] == 1, chains[1][1]
+
+
+@pytest.mark.gpu
 def test_device_randn_at_block_boundaries(ctx):
     """Positions 620 .. 624 of the current block going in (attempts that straddle two blocks, a block that is used up)."""
     for pre_words in (620, 621, 622, 623, 624, 625, 1247, 1248):

@@ -30,3 +30,14 @@ for _ in range(n):
     ts.append(time.perf_counter() - t0)
 print("rng=numpy: %.3f ms per evaluation (median of %d; p10 %.3f p90 %.3f)  F %.10f" % (
     1e3 * np.median(ts), n, 1e3 * np.percentile(ts, 10), 1e3 * np.percentile(ts, 90), out[0]))
+# the entropy kernel's own duration in this path (HIP events on its dispatch), against the Philox path's
+ctx.set_timing(True)
+ms = {"numpy": [], "philox": []}
+for i in range(12):
+    _neg_elcbo(wl.theta.copy(), g, vp, 0.0, wl.NsK, True, False, bnd, rng="numpy")
+    ms["numpy"].append(ctx.last_kernel_ms(0))
+    _neg_elcbo(wl.theta.copy(), g, vp, 0.0, wl.NsK, True, False, bnd, rng="philox", seed=100 + i)
+    ms["philox"].append(ctx.last_kernel_ms(0))
+ctx.set_timing(False)
+print("entropy kernel by events: behind the NumPy stream %.2f us, with Philox draws %.2f us (alternating, medians)" % (
+    1e3 * np.median(ms["numpy"]), 1e3 * np.median(ms["philox"])))
