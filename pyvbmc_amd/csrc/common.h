@@ -401,6 +401,7 @@ struct PrepArgs {
   size_t mix_stride = 0, res_stride = 0;
   const double* X = nullptr;
   const double* XT = nullptr;  // [D][N]
+  int x_lds = 0;               // glj_block.h: the launch's dynamic LDS holds X^T behind the block's own arrays (glj_block_lds_x): staged once per workgroup
   const double* alpha = nullptr;
   const double* hyp = nullptr;
   double* res = nullptr;  // [S][K][1+2D]  (device or device-visible pinned host memory)

@@ -190,9 +190,17 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
   // items in the workgroup slots this launch's entropy parts leave free (entropy_args.h)
   if (a.gp_items > 0 && (span ? (int)blockIdx.x >= a.sp.n_parts() && (int)blockIdx.x < a.sp.n_parts() + a.gp_wgs : blockIdx.y == gridDim.y - 1)) {
     const int first = span ? (int)blockIdx.x - a.sp.n_parts() : (int)blockIdx.x, step = span ? a.gp_wgs : (int)gridDim.x;
-    for (int it = first; it < a.gp_items; it += step) {
-      glj_block(a.gp, it, dyn);
-      __syncthreads();
+    if (a.gp.x_lds) {  // X^T staged once for all of this workgroup's items (glj_block.h)
+      if (first < a.gp_items) glj_stage_x(a.gp, dyn);
+      for (int it = first; it < a.gp_items; it += step) {
+        glj_block<true>(a.gp, it, dyn);
+        __syncthreads();
+      }
+    } else {
+      for (int it = first; it < a.gp_items; it += step) {
+        glj_block<false>(a.gp, it, dyn);
+        __syncthreads();
+      }
     }
     return;
   }
@@ -630,7 +638,8 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
 }
 
 template <int DP, int KTMAX>
-void launch_one(hipStream_t st, const EntArgs& a, const double* d_table, hipEvent_t e0, hipEvent_t e1) {
+void launch_one(hipStream_t st, const EntArgs& a_in, const double* d_table, hipEvent_t e0, hipEvent_t e1) {
+  EntArgs a = a_in;
   const int K = a.ml.K;
   const int K4 = 4 * KTMAX;  // the table carries zero-density padding rows up to 4 * KTMAX (entropy_args.h)
   size_t lds = sizeof(double) * ((size_t)K4 + ws_epi_doubles(DP, KTMAX, a.want_grad != 0));
@@ -641,6 +650,15 @@ void launch_one(hipStream_t st, const EntArgs& a, const double* d_table, hipEven
   const dim3 block(WG);
   if (extra_row && sizeof(double) * (size_t)a.extra_lds > lds) lds = sizeof(double) * (size_t)a.extra_lds;
   if (a.gp_items > 0 && glj_block_lds(a.ml.D, a.gp.N) > lds) lds = glj_block_lds(a.ml.D, a.gp.N);
+  // the GP riders read X^T from LDS where that needs no more dynamic LDS than the launch has anyway (its occupancy is the
+  // entropy workgroups': config 3's 36 KB hold N = 400, D = 10)
+  {
+    static const bool x_lds_on = [] {
+      const char* e = getenv("VBMC_GLJ_X_LDS");  // measurement aid: 0 = X^T always from memory
+      return !(e && e[0] == '0');
+    }();
+    a.gp.x_lds = (x_lds_on && a.gp_items > 0 && glj_block_lds_x(a.ml.D, a.gp.N) <= lds) ? 1 : 0;
+  }
   int dev = 0;
   if (lds > 32 * 1024) (void)hipGetDevice(&dev);
   // (the raised dynamic-LDS limit is set once per instantiation and size)

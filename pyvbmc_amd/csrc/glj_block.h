@@ -13,8 +13,38 @@
 #include "fastmath.h"
 
 inline size_t glj_block_lds(int D, int N) { return sizeof(double) * ((size_t)2 * D + N + 4 + 1); }
+// Round 6: with X^T in LDS behind those arrays (PrepArgs::x_lds).  A block is a chain of memory latencies -- X^T is read
+// twice, in 5 + 8 dependent groups of loads at N = 800, D = 20 -- and a rider workgroup of the entropy launch works
+// through four to five items one after the other: staged ONCE per workgroup (all loads in flight) both passes of every
+// item read LDS.  What it buys is small (config 3: the GP word 1.5-2 us earlier, S = 8 step 99.2 -> 97.3 us, the two-launch
+// optimiser iteration 92.4 -> 91.6): beside two entropy waves per SIMD the riders are slowed by issue contention more than by
+// their loads.  Used where it needs no LDS the launch does not have anyway (the riders) or little (prep.hip).
+__host__ __device__ inline size_t glj_x_off(int D, int N) { return ((size_t)2 * D + N + 4 + 1 + 1) & ~(size_t)1; }  // doubles, 16-byte aligned
+inline size_t glj_block_lds_x(int D, int N) { return sizeof(double) * (glj_x_off(D, N) + (size_t)D * N); }
 
-// a.mix / a.res already advanced to this candidate; b = s * K + k
+// all 256 threads: X^T (D x N) into LDS behind a block's arrays; 32 loads in flight per thread and round
+__device__ __forceinline__ void glj_stage_x(const PrepArgs& a, double* lds) {
+  const int D = a.ml.D, n = D * a.N, tid = threadIdx.x;
+  double* sX = lds + glj_x_off(D, a.N);
+  constexpr int U = 32;
+  for (int base = 0; base < n; base += U * 256) {
+    double r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * 256 + tid;
+      r[u] = a.XT[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * 256 + tid;
+      if (i < n) sX[i] = r[u];
+    }
+  }
+  __syncthreads();
+}
+
+// a.mix / a.res already advanced to this candidate; b = s * K + k.  XL: X^T was staged in LDS (glj_stage_x).
+template <bool XL = false>
 __device__ __forceinline__ void glj_block(const PrepArgs& a, int b, double* lds) {
   const int D = a.ml.D, K = a.ml.K;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -25,6 +55,7 @@ __device__ __forceinline__ void glj_block(const PrepArgs& a, int b, double* lds)
   double* sZa = sMu + D;           // [N]
   double* sPart = sZa + N;         // [4]
   double* sMisc = sPart + 4;       // [1]
+  const double* XT = XL ? lds + glj_x_off(D, N) : a.XT;  // (compile-time: LDS or global addressing, never flat)
   const double* h = a.hyp + (size_t)s * a.P;
   const double sigk = a.mix[a.ml.o_sig + k];
   if (tid < 64) {
@@ -58,7 +89,7 @@ __device__ __forceinline__ void glj_block(const PrepArgs& a, int b, double* lds)
       double x[4][4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const double* col = a.XT + (size_t)min(d0 + u, D - 1) * N;
+        const double* col = XT + (size_t)min(d0 + u, D - 1) * N;
 #pragma unroll
         for (int p = 0; p < 4; ++p) x[p][u] = col[nn[p]];
       }
@@ -116,7 +147,7 @@ __device__ __forceinline__ void glj_block(const PrepArgs& a, int b, double* lds)
 #pragma unroll
         for (int u = 0; u < PS; ++u) {
           const int n = min(n0 + 16 * u, N - 1);
-          x[u] = a.XT[(size_t)d * N + n];
+          x[u] = XT[(size_t)d * N + n];
           za[u] = n0 + 16 * u < N ? sZa[n] : 0.0;
         }
 #pragma unroll

@@ -10,6 +10,8 @@
 //        z_n = exp(lnnf - 1/2 sum_d delta_nd^2),  delta_nd = (mu_dk - X_nd)/tau_dk,
 //        tau_dk = sqrt(sigma_k^2 lambda_d^2 + ell_d^2);  optionally Z[s][k][n] = z_n.
 //      The host turns these into G, dG (api_gp.hip: glj_finalize).  (Block body: glj_block.h.)
+#include <cstdlib>
+
 #include "common.h"
 #include "fastmath.h"
 #include "philox.h"
@@ -91,7 +93,12 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
 
 
   // ---- GP expected-log-joint block (s,k): glj_block.h ----
-  glj_block(a, blockIdx.x - a.n_table, lds);
+  if (a.x_lds) {
+    glj_stage_x(a, lds);
+    glj_block<true>(a, blockIdx.x - a.n_table, lds);
+  } else {
+    glj_block<false>(a, blockIdx.x - a.n_table, lds);
+  }
 }
 
 }  // namespace
@@ -103,15 +110,30 @@ extern "C" int vbmc_debug_prep_times(unsigned long long* out) {
 #endif
 int launch_prep(vbmc_ctx* ctx, const PrepArgs& a) { return launch_prep_on(ctx, ctx->stream, a); }
 
-int launch_prep_on(vbmc_ctx* ctx, hipStream_t stream, const PrepArgs& a) {
+int launch_prep_on(vbmc_ctx* ctx, hipStream_t stream, const PrepArgs& a_in) {
+  PrepArgs a = a_in;
   const int D = a.ml.D;
   const int gblocks = a.n_glj;
   const int grid = a.n_table + gblocks + a.gen.n_blocks + (a.mix_copy ? 1 : 0);
   if (grid <= 0) return 0;
   size_t lds = 0;
+  a.x_lds = 0;
   if (gblocks > 0) {
     lds = glj_block_lds(D, a.N);
     if (lds > 150 * 1024) return vbmc_fail(ctx, VBMC_E_UNSUP, "gp_log_joint: N=%d too large", a.N);
+    // X^T through LDS (glj_block.h) where it is small (<= 40 KB: N = 400 at D = 10) and the launch is only its few
+    // latency-bound blocks: the launch's dynamic LDS is the same for all of its workgroups, and a grid that also generates
+    // draws (~1e4 throughput blocks when no speculative generation hit) must keep many of them per CU.  (Measured at
+    // config 5's shape, 128 KB per block: the step 172.9 -> 174-177 us -- staging 100 x 128 KB costs more than the 13 us
+    // chain of dependent loads it replaces; not used there.)
+    static const bool x_lds_on = [] {
+      const char* e = getenv("VBMC_GLJ_X_LDS");  // measurement aid: 0 = X^T always from memory
+      return !(e && e[0] == '0');
+    }();
+    if (x_lds_on && a.gen.n_blocks == 0 && a.batch == 1 && glj_block_lds_x(D, a.N) <= 40 * 1024) {
+      a.x_lds = 1;
+      lds = glj_block_lds_x(D, a.N);
+    }
   }
   if (a.n_table > 0) {
     const size_t lt = sizeof(double) * (size_t)a.K4 * a.DP;
