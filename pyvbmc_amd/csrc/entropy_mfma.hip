@@ -70,6 +70,12 @@ __device__ __forceinline__ double sum_lk(double v) {
 // DP: D padded to a multiple of 4 (the products' depth / width); TDP: the padded D of the (j,k) table in
 // memory (prep.hip: its rows are [Delta (TDP) | c0 | a | w | wis2 | pad pad]) -- equal except for D = 9, 10,
 // whose table is 10 wide and whose products are 12 deep.
+#if defined(MFMA_TIMES) && VBMC_MFMA_DP == 20
+__device__ unsigned long long g_mfma_times[1024 * 4];  // per workgroup: start, table staged, batch loop end, reduction done
+#define MF_STAMP(i) do { if (threadIdx.x == 0) g_mfma_times[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define MF_STAMP(i) (void)0
+#endif
 template <int DP, int KTILES, int TDP = DP>
 __global__ __launch_bounds__(WG, 1) void entmc_mfma_kernel(EntArgs a, const double* __restrict__ T) {
   constexpr int TS = DP + 6, TTS = TDP + 6, NS = DP / 4, NT = (DP + 15) / 16, KP = 16 * KTILES;
@@ -98,16 +104,33 @@ __global__ __launch_bounds__(WG, 1) void entmc_mfma_kernel(EntArgs a, const doub
   const int li = lane & 15, lk = lane >> 4;
   const double sig_j = a.mix[a.ml.o_sig + j];
   const double sj2 = sig_j * sig_j, two_sj = 2.0 * sig_j;
+  MF_STAMP(0);
   {
     const double* Tj = T + (size_t)j * K4 * TTS;
-    for (int i = tid; i < KP * TS; i += WG) {
-      const int k = i / TS, c = i - k * TS;
-      // LDS row [Delta (DP, zero beyond TDP) | c0 | a | w | wis2 | pad pad]; beyond K4: a component of density exactly 0
-      const int cs = c < TDP ? c : c < DP ? -1 : TDP + (c - DP);
-      sT[i] = k < K4 ? (cs >= 0 ? Tj[(size_t)k * TTS + cs] : 0.0) : (c == DP ? -2000.0 : 0.0);
+    // (round 6: sixteen loads in flight per thread -- in-kernel stamps put this copy of 23 KB at 3.6 us per workgroup, one
+    // load waited for at a time, of the ~66 us a workgroup of config 5's launch lives)
+    constexpr int U = 16;
+    for (int base = 0; base < KP * TS; base += U * WG) {
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * WG + tid;
+        const int k = i / TS, c = i - k * TS;
+        // LDS row [Delta (DP, zero beyond TDP) | c0 | a | w | wis2 | pad pad]; beyond K4: a component of density exactly 0
+        const int cs = c < TDP ? c : c < DP ? -1 : TDP + (c - DP);
+        const bool ld = i < KP * TS && k < K4 && cs >= 0;
+        const double x = Tj[ld ? (size_t)k * TTS + cs : 0];
+        v[u] = ld ? x : (k >= K4 && c == DP ? -2000.0 : 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * WG + tid;
+        if (i < KP * TS) sT[i] = v[u];
+      }
     }
   }
   __syncthreads();
+  MF_STAMP(1);
   double a1[KTILES][NS];
 #pragma unroll
   for (int kt = 0; kt < KTILES; ++kt)
@@ -255,6 +278,7 @@ __global__ __launch_bounds__(WG, 1) void entmc_mfma_kernel(EntArgs a, const doub
     }
   }
 
+  MF_STAMP(2);
   // ---- workgroup reduction -> the partial row [Slog | mu (D) | sig | lam (D) | W (K)] ----
   {
     const double v = fm::wave_sum_dpp(slog);
@@ -278,6 +302,7 @@ __global__ __launch_bounds__(WG, 1) void entmc_mfma_kernel(EntArgs a, const doub
       if (li == 0) sWk[wave * KP + 16 * kt + lk + 4 * r] = v;
     }
   __syncthreads();
+  MF_STAMP(3);
   double* out = a.partial + ((int64_t)j * a.chunks + chunk) * a.stride;
   for (int t = tid; t < a.stride; t += WG) {
     double v = 0.0;
@@ -386,5 +411,11 @@ void launch_entmc_mfma(hipStream_t st, const EntArgs& a, int DP, const double* d
     case 24: launch_entmc_mfma_dp24(st, a, kt, d_table, e0, e1); break;
     default: launch_entmc_mfma_dp32(st, a, kt, d_table, e0, e1); break;
   }
+}
+#endif
+
+#if defined(MFMA_TIMES) && VBMC_MFMA_DP == 20
+extern "C" int vbmc_debug_mfma_times(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mfma_times), sizeof(unsigned long long) * n);
 }
 #endif
