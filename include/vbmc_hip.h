@@ -151,6 +151,9 @@ int vbmc_set_release_callback(vbmc_ctx* ctx, void (*fn)(void*), void* user);
  *   "entmc_mfma"   1 = shapes the FP64 matrix tile pads little and the wave-split kernel runs one wave per SIMD on
  *                  (D > 10 or K > 80, K within 12 below a multiple of 16: BASELINE config 5) take the matrix-pipe form
  *                  of the entropy kernel (default), 0 = the wave-split kernel everywhere
+ *   "gp_ship"      [VBMC_GP_SHIP]: 1 = in the host-driven step whose GP sums run in the prep launch in front of the matrix-pipe entropy
+ *                  kernel, their copy to pinned memory and their completion word are issued by a workgroup of the entropy
+ *                  launch (default: the prep launch then ends with the sums), 0 = by the prep launch's last GP block
  *   "acq_poll"     [VBMC_ACQ_POLL]: 1 = vbmc_acq_eval with at most 256 points has the CPU write the points into host-writable
  *                  device memory and polls a completion word for the results (default), 0 = copies + stream wait
  *   "adam_fused"   [VBMC_ADAM_FUSED]: 1 = vbmc_adam_run runs a batch of iterations as ONE launch where the shape allows

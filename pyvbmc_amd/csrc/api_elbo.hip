@@ -293,6 +293,17 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
         plan.a.gp_items = gp_tail.n_glj;
         ctx->gp_where = 2;
       }
+      if (mc && pa.n_glj > 0 && pa.done.flag != nullptr && ctx->opt_gp_ship && entmc_uses_mfma(ctx, plan)) {
+        // GP sums in the prep launch in front of the matrix-pipe kernel (config 5's shape): their hand-over to pinned memory
+        // and the word ride in the entropy launch (EntArgs::ship_*): the prep launch ends with the sums, not with the 6 us
+        // of its last block's PCIe copy
+        plan.a.ship_src = pa.res;
+        plan.a.ship_dst = pa.done.host_out;
+        plan.a.ship_n = pa.done.host_n;
+        plan.a.ship_flag = pa.done.flag;
+        plan.a.ship_seq = pa.done.seq;
+        pa.done = DoneSignal();  // plain stores to device memory, complete at the kernel boundary
+      }
       pa.mix = fg;
       pa.mix_copy = ctx->d_mix;
       pa.mix_copy_n = ctx->ml.total;

@@ -182,6 +182,7 @@ struct vbmc_ctx {
   int gp_where = 0;  // where the GP sums of the launches issued last run: 0 prep launch, 1 finish launch, 2 entropy launch
   // vbmc_set_option switches (defaults from the environment at context creation)
   int opt_entmc_valu = 0;   // 1: always the generic entropy kernel
+  int opt_gp_ship = 1;      // host-driven step: the prep launch's GP sums are shipped to the host by a workgroup of the matrix-pipe entropy launch (EntArgs::ship_*)
   int opt_entmc_mfma = 1;   // the matrix-pipe form of the entropy kernel where its shape applies (entropy_mfma.hip)
   int opt_elbo_pregen = 1;  // Philox draws generated ahead of the entropy kernel
   int opt_elbo_ahead = 1;   // ... and those of seed+1 speculatively behind the finish kernel

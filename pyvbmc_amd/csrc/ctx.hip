@@ -90,6 +90,8 @@ static void options_from_env(vbmc_ctx* c) {
   c->opt_predict_dma = !(e && e[0] == '0');
   e = getenv("VBMC_PREDICT_FUSED_FINISH");
   if (e) c->opt_predict_fused = atoi(e);
+  e = getenv("VBMC_GP_SHIP");
+  c->opt_gp_ship = !(e && e[0] == '0');
 }
 
 extern "C" {
@@ -299,6 +301,7 @@ int vbmc_set_option(vbmc_ctx* ctx, const char* key, int value) {
   spec_disarm(ctx);
   if (!strcmp(key, "entmc_kernel")) ctx->opt_entmc_valu = value == 1;
   else if (!strcmp(key, "entmc_mfma")) ctx->opt_entmc_mfma = value != 0;
+  else if (!strcmp(key, "gp_ship")) ctx->opt_gp_ship = value != 0;
   else if (!strcmp(key, "elbo_pregen")) ctx->opt_elbo_pregen = value != 0;
   else if (!strcmp(key, "elbo_ahead")) ctx->opt_elbo_ahead = value != 0;
   else if (!strcmp(key, "predict_dma")) ctx->opt_predict_dma = value != 0;

@@ -639,6 +639,10 @@ GenSlice entmc_ahead_slice(vbmc_ctx* ctx, const EntPlan& p) {
   return make_gen_slice(ctx->d_epsgen[other], K, D, a.row_count, a.n_half, a.row_begin, ah.seed, nullptr, 0.0, frac_end);
 }
 
+bool entmc_uses_mfma(const vbmc_ctx* ctx, const EntPlan& p) {
+  return p.ws && p.a.sp.cus == 0 && !entmc_small_applies(p.a, p.DP) && ctx->opt_entmc_mfma && entmc_mfma_applies(p.a, p.DP);
+}
+
 int entmc_launch_main(vbmc_ctx* ctx, const EntPlan& p) {
   const EntArgs& a = p.a;
   // timing: the wave-split launch carries the event pair on its own dispatch packet; the generic

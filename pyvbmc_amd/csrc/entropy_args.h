@@ -86,6 +86,16 @@ struct EntArgs {
   int gp_wgs = 0;     // span mode: workgroups of the GP row (blocks behind the entropy parts)
   // armed evaluation (common.h ArmedEval): every workgroup returns at once when *cancel == ~0
   const uint64_t* cancel = nullptr;
+  // matrix-pipe kernel in the host-driven step (round 6): the GP sums of the prep launch IN FRONT of this one lie in device
+  // memory (ship_src, complete at the kernel boundary).  The launch gets one more grid row, the last, whose first workgroup
+  // copies them to pinned memory (ship_dst) and publishes ship_seq to ship_flag -- the 32 KB over PCIe and its
+  // acknowledgement (6 us as the last GP block of the prep launch: between the go word and this kernel's start) then run
+  // beside the entropy workgroups, in one of the workgroup slots the grid leaves free.
+  const double* ship_src = nullptr;
+  double* ship_dst = nullptr;
+  int ship_n = 0;
+  uint64_t* ship_flag = nullptr;
+  uint64_t ship_seq = 0;
 };
 
 // register-array size (components per wave) the wave-split launcher picks, and the waves per SIMD
@@ -132,6 +142,8 @@ VBMC_WS_DPS(VBMC_DECL_WS)
 // matrix-pipe form for shapes the 16 x 16 x 4 tile pads little (entropy_mfma.hip: D = 20, K up to 112 -- BASELINE
 // config 5); same table, same partial rows
 bool entmc_mfma_applies(const EntArgs& a, int DP);
+struct vbmc_ctx;
+bool entmc_uses_mfma(const vbmc_ctx* ctx, const EntPlan& p);  // entmc_launch_main's choice for this plan (entropy.hip)
 void launch_entmc_mfma(hipStream_t st, const EntArgs& a, int DP, const double* d_table, hipEvent_t e0, hipEvent_t e1);
 
 // small sample counts: lane = component (entropy_small.hip); same table, same partial rows

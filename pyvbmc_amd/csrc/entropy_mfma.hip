@@ -76,6 +76,12 @@ __device__ unsigned long long g_mfma_times[1024 * 4];  // per workgroup: start, 
 #else
 #define MF_STAMP(i) (void)0
 #endif
+// (not inlined: the entropy workgroups' code is laid out and scheduled as without it)
+__device__ __noinline__ void ship_gp_sums(const double* src, double* dst, int n, uint64_t* flag, uint64_t seq) {
+  staged_copy_to_host(src, dst, n);
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 template <int DP, int KTILES, int TDP = DP>
 __global__ __launch_bounds__(WG, 1) void entmc_mfma_kernel(EntArgs a, const double* __restrict__ T) {
   constexpr int TS = DP + 6, TTS = TDP + 6, NS = DP / 4, NT = (DP + 15) / 16, KP = 16 * KTILES;
@@ -98,6 +104,11 @@ __global__ __launch_bounds__(WG, 1) void entmc_mfma_kernel(EntArgs a, const doub
     return;
   }
   if (a.cancel != nullptr && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ~(uint64_t)0) return;
+  if (__builtin_expect(a.ship_flag != nullptr && blockIdx.y == gridDim.y - 1, 0)) {
+    // the ship row (entropy_args.h): the prep launch's GP sums to pinned memory, then their word
+    if (blockIdx.x == 0) ship_gp_sums(a.ship_src, a.ship_dst, a.ship_n, a.ship_flag, a.ship_seq);
+    return;
+  }
   const int D = a.ml.D, K = a.ml.K, K4 = ws_table_rows(K);  // table rows per component (entropy_args.h)
   const int j = a.extra != nullptr ? blockIdx.y - 1 : blockIdx.y, chunk = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -336,7 +347,7 @@ void launch_mfma(hipStream_t st, const EntArgs& a, const double* d_table, hipEve
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_limit[dev & 63] = lds;
   }
-  hipExtLaunchKernelGGL(kern, dim3(a.chunks, a.ml.K + (extra_row ? 1 : 0)), dim3(WG), (std::uint32_t)lds, st, e0, e1, 0u, a,
+  hipExtLaunchKernelGGL(kern, dim3(a.chunks, a.ml.K + (extra_row ? 1 : 0) + (a.ship_flag != nullptr ? 1 : 0)), dim3(WG), (std::uint32_t)lds, st, e0, e1, 0u, a,
                         d_table);
 }
 

@@ -98,6 +98,9 @@ __device__ __forceinline__ double wave_sum(double v) { return fm::wave_sum_dpp(v
 // registers of 2 waves/SIMD; beyond that one wave per SIMD with the 512-register budget
 // (AGPRs as spill space) beats spilling to scratch memory.
 // (ws_min_waves: entropy_args.h -- the host uses the same rule to count free workgroup slots)
+// the smallest D this translation unit's kernels see (padded_d: D pads up to the next entry of VBMC_WS_DPS); glj_block.h
+// instantiates the one form of the GP block that range needs
+constexpr int ws_dmin(int dp) { return dp <= 12 ? dp - 1 : dp == 16 ? 13 : dp == 20 ? 17 : dp == 24 ? 21 : 25; }
 
 // End-of-workgroup reduction: every wave holds 1 + 2 DP + KT per-lane accumulators whose 64 lanes have to be added up.
 // Round 6 form: NQ DPP steps add each accumulator up inside groups of 2^NQ neighbouring lanes (independent across the
@@ -193,12 +196,12 @@ __global__ __launch_bounds__(WG, ws_min_waves(DP, KTMAX, GRAD)) void entmc_ws_ke
     if (a.gp.x_lds) {  // X^T staged once for all of this workgroup's items (glj_block.h)
       if (first < a.gp_items) glj_stage_x(a.gp, dyn);
       for (int it = first; it < a.gp_items; it += step) {
-        glj_block<true>(a.gp, it, dyn);
+        glj_block<true, DP, ws_dmin(DP), true>(a.gp, it, dyn);
         __syncthreads();
       }
     } else {
       for (int it = first; it < a.gp_items; it += step) {
-        glj_block<false>(a.gp, it, dyn);
+        glj_block<false, DP, ws_dmin(DP), true>(a.gp, it, dyn);
         __syncthreads();
       }
     }

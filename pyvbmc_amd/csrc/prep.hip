@@ -15,6 +15,10 @@
 #include "common.h"
 #include "fastmath.h"
 #include "philox.h"
+#ifdef PREP_TIMES
+__device__ unsigned long long g_glj_phase[8 * 1024];
+#define GLJ_T(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_glj_phase[8 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+#endif
 #include "glj_block.h"
 #include "ws_table.h"
 
@@ -27,8 +31,25 @@ __device__ __forceinline__ double wave_sum(double v) {
 #ifdef FIN_TIMES
 __device__ unsigned long long g_prep_times[2 + 64];  // [0] launch counter, [2 + n % 64] start of block 0 of launch n
 #endif
+#ifdef PREP_TIMES
+// measurement aid (tools/prep_times.py): start and end of every workgroup of the LAST prep launch, wall-clock ticks
+__device__ unsigned long long g_prep_blocks[2 * 1024];
+struct PrepStamp {
+  int b;
+  __device__ PrepStamp() : b((int)blockIdx.x) {
+    if (threadIdx.x == 0 && b < 1024 && blockIdx.y == 0) g_prep_blocks[2 * b] = wall_clock64();
+  }
+  __device__ ~PrepStamp() {
+    __syncthreads();
+    if (threadIdx.x == 0 && b < 1024 && blockIdx.y == 0) g_prep_blocks[2 * b + 1] = wall_clock64();
+  }
+};
+#endif
 __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
   extern __shared__ double lds[];
+#ifdef PREP_TIMES
+  PrepStamp stamp_;
+#endif
 #ifdef FIN_TIMES
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_prep_times[2 + (g_prep_times[0]++ & 63)] = wall_clock64();
 #endif
@@ -64,11 +85,24 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
   }
   if (a.mix_copy && blockIdx.x == gridDim.x - 1) {
     // ---- copy block: the pack for the launches behind this one (+ its checksum, DoneSignal) ----
+    // (sixteen loads in flight per thread and round: one load per round -- the compiler cannot move a load above the
+    // store in front of it -- made this block a chain of n / 256 memory latencies, 18 at K = 100, D = 20: it was the
+    // prep launch's duration there, 16 us in front of config 5's entropy kernel)
     uint64_t ck = 0;
-    for (int i = tid; i < a.mix_copy_n; i += 256) {
-      const double v = a.mix[i];
-      a.mix_copy[i] = v;
-      ck += pack_ck_term(v, (uint32_t)i);
+    constexpr int U = 16;
+    const int n = a.mix_copy_n;
+    for (int base = 0; base < n; base += U * 256) {
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = a.mix[min(base + u * 256 + tid, n - 1)];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * 256 + tid;
+        if (i < n) {
+          a.mix_copy[i] = v[u];
+          ck += pack_ck_term(v[u], (uint32_t)i);
+        }
+      }
     }
     if (a.ident_out) {
       __shared__ unsigned long long s_ck;
@@ -103,6 +137,14 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
 
 }  // namespace
 
+#ifdef PREP_TIMES
+extern "C" int vbmc_debug_prep_blocks(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prep_blocks), sizeof(unsigned long long) * 2048);
+}
+extern "C" int vbmc_debug_glj_phases(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_glj_phase), sizeof(unsigned long long) * 8192);
+}
+#endif
 #ifdef FIN_TIMES
 extern "C" int vbmc_debug_prep_times(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prep_times), sizeof(unsigned long long) * 66);

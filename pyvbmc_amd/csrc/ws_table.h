@@ -12,11 +12,28 @@ __device__ __forceinline__ void ws_table_row_block(const double* mix, const MixL
   const double* mup = mix + ml.o_mup;
   // all lanes on the (k, d) differences (coalesced row writes), then one lane per k on the tail
   double* sV2 = lds;  // [K4][DP] squared differences
-  for (int idx = tid; idx < K4 * DP; idx += 256) {
-    const int k = idx / DP, d = idx - k * DP;
-    const double v = (d < D && k < K) ? (mup[j * D + d] - mup[k * D + d]) : 0.0;
-    table[((size_t)j * K4 + k) * TS + d] = v;
-    sV2[idx] = v * v;
+  // (eight entries per thread and round, their loads requested together: one entry per round was a chain of K4 DP / 256
+  // memory latencies -- the loads cannot move above the stores in front of them --, eight at K = 100, D = 20)
+  constexpr int U = 8;
+  for (int base = 0; base < K4 * DP; base += U * 256) {
+    double vj[U], vk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * 256 + tid;
+      const int k = idx / DP, d = idx - k * DP;
+      vj[u] = mup[j * D + min(d, D - 1)];
+      vk[u] = mup[min(k, K - 1) * D + min(d, D - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * 256 + tid;
+      const int k = idx / DP, d = idx - k * DP;
+      if (idx < K4 * DP) {
+        const double v = (d < D && k < K) ? (vj[u] - vk[u]) : 0.0;
+        table[((size_t)j * K4 + k) * TS + d] = v;
+        sV2[idx] = v * v;
+      }
+    }
   }
   __syncthreads();
   for (int k = tid; k < K4; k += 256) {
