@@ -338,6 +338,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
       if (can_poll) {
         if (ahead_ok) ahead_gen = entmc_ahead_slice(ctx, plan);
         done.cnt = ctx->d_done_cnt;
+        done.sub = ctx->d_done_sub;
         done.flag = ctx->hd_done;
         done.seq = seq_out;
         done.host_out = raw_out;
@@ -417,6 +418,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
         __builtin_ia32_sfence();
         HIP_TRY(ctx, stream_wait(ctx));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_done_cnt, 0, sizeof(int) * 16, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_done_sub, 0, sizeof(int) * 16 * 64, ctx->stream));
         ctx->gen_cur = sp.gen_cur_before;
         ctx->ahead.valid = sp.ahead_before_valid;
         ctx->ahead.seed = sp.ahead_before_seed;
@@ -603,6 +605,7 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   auto redo_unarmed = [&](const char* why) -> int {
     HIP_TRY(ctx, stream_wait(ctx));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_done_cnt, 0, sizeof(int) * 16, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_done_sub, 0, sizeof(int) * 16 * 64, ctx->stream));
     ctx->ahead.valid = false;
     if (ctx->ident_retry) return vbmc_fail(ctx, VBMC_E_HIP, "neg_elcbo: %s, twice in a row", why);
     ctx->ident_retry = true;

@@ -151,6 +151,7 @@ struct vbmc_ctx {
   uint64_t* h_done = nullptr;   // pinned, device-visible
   uint64_t* hd_done = nullptr;  // its device-side address
   int* d_done_cnt = nullptr;    // result waves finished so far (reset by the last one)
+  int* d_done_sub = nullptr;    // 16 sub-counters of the finish launch, 64 ints apart (DoneSignal::sub)
   uint64_t done_seq = 0;
 
   // resident antithetic half draws: [K][eps_rows][D]
@@ -293,6 +294,10 @@ static inline int raw_len(int D, int K) { return 1 + D * K + 2 * K + D; }
 // completion signalling of entmc_finish_kernel (all null/0: none)
 struct DoneSignal {
   int* cnt = nullptr;        // device counter of finished result waves
+  // optional, entmc_finish_kernel: sixteen sub-counters, 256 B apart.  One word takes ~88 atomic increments per us, and at
+  // K = 100, D = 20 the reduction has 556 workgroups that arrive together: 6 us of the 14 between the entropy kernel and the
+  // completion word.  From 256 workgroups on, workgroup b counts on sub-counter b % 16 and the last of each on `cnt`.
+  int* sub = nullptr;
   uint64_t* flag = nullptr;  // device-visible pinned word that receives `seq` when all are done
   uint64_t seq = 0;
   // Staged hand-over (optional): the kernel's result pointer is then DEVICE memory, and the last

@@ -211,6 +211,8 @@ int vbmc_ctx_create(int device_id, vbmc_ctx** out) {
   }
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_done_cnt, 64);
   if (e == hipSuccess) e = hipMemset(ctx->d_done_cnt, 0, 64);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_done_sub, 16 * 64 * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(ctx->d_done_sub, 0, 16 * 64 * sizeof(int));
   if (e != hipSuccess) {
     int rc = vbmc_fail(nullptr, VBMC_E_HIP, "context setup failed: %s", hipGetErrorString(e));
     delete ctx;
@@ -253,6 +255,7 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx) {
     if (b) (void)hipFree(b);
   if (ctx->h_done) (void)hipHostFree(ctx->h_done);
   if (ctx->d_done_cnt) (void)hipFree(ctx->d_done_cnt);
+  if (ctx->d_done_sub) (void)hipFree(ctx->d_done_sub);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->h_eps) (void)hipHostFree(ctx->h_eps);
   if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);

@@ -134,7 +134,19 @@ __device__ __forceinline__ void entmc_finish_body(const double* __restrict__ par
   __syncthreads();
   if (threadIdx.x == 0) {
     const int n_main = (n + 3) / 4;
-    s_last = __hip_atomic_fetch_add(done.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_main - 1;
+    if (done.sub != nullptr && n_main >= 256) {  // (DoneSignal::sub: one word takes ~88 increments per us)
+      constexpr int NS = 16;
+      const int g = (int)blockIdx.x % NS, n_g = (n_main - g + NS - 1) / NS;
+      int* sc = done.sub + g * 64;
+      bool last = false;
+      if (__hip_atomic_fetch_add(sc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_g - 1) {
+        __hip_atomic_store(sc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = __hip_atomic_fetch_add(done.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NS - 1;
+      }
+      s_last = last;
+    } else {
+      s_last = __hip_atomic_fetch_add(done.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_main - 1;
+    }
   }
   __syncthreads();
   if (!s_last) return;

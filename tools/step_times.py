@@ -2,7 +2,8 @@
 """GPU-clock timeline of consecutive host-driven evaluations without a tracer: prep start / end,
 finish start / publish / end (library with prep.hip and entropy.hip built with -DFIN_TIMES), read
 back after each call WITHOUT synchronising in between (the stamps of the call before last).
-    tools/build_times_variant.sh && VBMC_HIP_LIB=$PWD/variants/libvbmc_st.so python tools/step_times.py [config]"""
+    tools/build_times_variant.sh && VBMC_HIP_LIB=$PWD/variants/libvbmc_st.so python tools/step_times.py [config [Ns_total]]
+(Ns_total: the samples of ONE GPU's share -- bench.py's config 5 runs 4e6 / 8)"""
 import ctypes as C
 import sys
 import time
@@ -19,7 +20,7 @@ from pyvbmc_amd.variational_optimization import _neg_elcbo  # noqa: E402
 ctx = _lib.Context(0)
 _lib.set_default_context(ctx)
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-wl = synthetic.make_workload(cfg, S=1)
+wl = synthetic.make_workload(cfg, S=1, Ns_total=int(float(sys.argv[2])) if len(sys.argv) > 2 else None)
 gp = gpm.GP(wl.D, gpm.SquaredExponential(), gpm.NegativeQuadratic(),
             gpm.GaussianNoise(constant_add=True, user_provided_add=wl.s2 is not None))
 gp.update(X_new=wl.X, y_new=wl.y, s2_new=wl.s2, hyp=wl.hyp)
