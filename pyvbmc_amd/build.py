@@ -43,6 +43,10 @@ FLAGS = [
     "-ffp-contract=off",  # explicit fma() only: keep the arithmetic reproducible
     "-Wall",
     "-Wno-unused-function",
+    # a kernel that misses its __launch_bounds__ occupancy ("failed to meet occupancy target": one more register array in a
+    # rider path once cost the headline entropy kernel its second wave per SIMD, silently) or a "#pragma unroll" the
+    # compiler does not honour fails the build
+    "-Werror=pass-failed",
 ]
 
 

@@ -45,7 +45,7 @@ template <bool LDS>
 __global__ __launch_bounds__(256) void adam_pre_kernel(AdamDev a) {
   extern __shared__ double sh[];
   __shared__ double red[16];
-  adam_pre_body<LDS>(a, sh, red, a.pre);
+  adam_pre_body<LDS, false, 8>(a, sh, red, a.pre);
 }
 
 // ---------------------------------------------------------------------------
@@ -84,8 +84,18 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamDev a, int do_step, 
     if (o_w && tid < K) rw = raw[f_w + tid];  // K <= 256 per pass below
   }
   if (LDS) {
-    const int cnt = L.o_hyp();  // theta | aux
-    for (int i = tid; i < cnt; i += 256) sh[i] = a.state[i];
+    const int cnt = L.o_hyp();  // theta | aux: eight loads in flight per thread and round
+    constexpr int UC = 8;
+    for (int base = 0; base < cnt; base += 256 * UC) {
+      double r[UC];
+#pragma unroll
+      for (int u = 0; u < UC; ++u) r[u] = a.state[min(base + u * 256 + tid, cnt - 1)];
+#pragma unroll
+      for (int u = 0; u < UC; ++u) {
+        const int i = base + u * 256 + tid;
+        if (i < cnt) sh[i] = r[u];
+      }
+    }
   }
   // which accumulator entry / Jacobian scale belongs to theta index i
   auto raw_index = [&](int i) -> int {

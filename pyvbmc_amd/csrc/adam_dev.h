@@ -110,7 +110,10 @@ static __device__ __forceinline__ double wave_sum(double v) {
 // either at run time makes the compiler emit flat_* instructions, several times slower on LDS).
 // PRELOADED (with LDS): sh already holds the state prefix (the fused loop, adam_fused.hip, keeps it there
 // across iterations); pre_out: where the result goes (a.pre, or that loop's LDS copy).
-template <bool LDS, bool PRELOADED = false>
+// UB: soft-bound pairs requested together per thread (1 inside the wave-split entropy kernel, whose two-waves-per-SIMD builds
+// have no registers to spare: eight there cost the HEADLINE kernel its second wave -- 272 registers, "failed to meet
+// occupancy target"; 8 in the matrix-pipe kernel and the stand-alone launch)
+template <bool LDS, bool PRELOADED = false, int UB = 1>
 static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red, double* pre_out) {
   const int D = a.D, K = a.K, S = a.S, tid = threadIdx.x, n = a.n_theta;
   const int lane = tid & 63, wave = tid >> 6;
@@ -203,32 +206,46 @@ static __device__ void adam_pre_body(const AdamDev& a, double* sh, double* red, 
   double loss = 0.0;
   if (a.has_bnd) {
     const int n_mu = o_mu ? D * K : 0, n_sc = (o_sg || o_lm) ? D * K : 0;
-    for (int i = tid; i < a.n_bnd; i += 256) {
-      double x;
-      if (i < n_mu) {
-        x = theta[i];
-      } else if (i < n_mu + n_sc) {
-        const int q = i - n_mu, k = q / D, d = q - k * D;  // ravel('F') of the (D,K) array
-        const double ls = o_sg ? theta[p_sg + k] : log(sg[k]);
-        const double ll = o_lm ? theta[p_lm + d] : log(lm[d]);
-        x = ll + ls;
-      } else {
-        x = theta[p_w + (i - n_mu - n_sc)];
+    // (UB > 1: the bounds of UB entries per thread are requested together: one pair per round makes this loop a chain of
+    // n_bnd / 256 memory latencies -- sixteen at K = 100, D = 20, where this workgroup IS its launch)
+    for (int b0 = 0; b0 < a.n_bnd; b0 += 256 * UB) {
+      double lbv[UB], ubv[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int ic = min(b0 + u * 256 + tid, a.n_bnd - 1);
+        lbv[u] = bnd_lb[ic];
+        ubv[u] = bnd_ub[ic];
       }
-      const double lb = bnd_lb[i], ub = bnd_ub[i];
-      const double ell = (ub - lb) * a.tol_con;
-      double g = 0.0;
-      if (x < lb) {
-        const double t = (lb - x) / ell;
-        loss += 0.5 * t * t;
-        g = (x - lb) / (ell * ell);
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int i = b0 + u * 256 + tid;
+        if (i >= a.n_bnd) continue;
+        double x;
+        if (i < n_mu) {
+          x = theta[i];
+        } else if (i < n_mu + n_sc) {
+          const int q = i - n_mu, k = q / D, d = q - k * D;  // ravel('F') of the (D,K) array
+          const double ls = o_sg ? theta[p_sg + k] : log(sg[k]);
+          const double ll = o_lm ? theta[p_lm + d] : log(lm[d]);
+          x = ll + ls;
+        } else {
+          x = theta[p_w + (i - n_mu - n_sc)];
+        }
+        const double lb = lbv[u], ub = ubv[u];
+        const double ell = (ub - lb) * a.tol_con;
+        double g = 0.0;
+        if (x < lb) {
+          const double t = (lb - x) / ell;
+          loss += 0.5 * t * t;
+          g = (x - lb) / (ell * ell);
+        }
+        if (x > ub) {
+          const double t = (x - ub) / ell;
+          loss += 0.5 * t * t;
+          g = (x - ub) / (ell * ell);
+        }
+        dL[i] = g;
       }
-      if (x > ub) {
-        const double t = (x - ub) / ell;
-        loss += 0.5 * t * t;
-        g = (x - ub) / (ell * ell);
-      }
-      dL[i] = g;
     }
   }
   __syncthreads();

@@ -98,8 +98,8 @@ __global__ __launch_bounds__(WG, 1) void entmc_mfma_kernel(EntArgs a, const doub
   if (a.extra != nullptr && blockIdx.y == 0) {
     if (blockIdx.x == 0) {
       const adam_dev::AdamDev& pa = *(const adam_dev::AdamDev*)a.extra;
-      if (a.extra_lds > 0) adam_dev::adam_pre_body<true>(pa, dyn, &sLam[0][0], pa.pre);
-      else adam_dev::adam_pre_body<false>(pa, nullptr, &sLam[0][0], pa.pre);
+      if (a.extra_lds > 0) adam_dev::adam_pre_body<true, false, 8>(pa, dyn, &sLam[0][0], pa.pre);
+      else adam_dev::adam_pre_body<false, false, 8>(pa, nullptr, &sLam[0][0], pa.pre);
     }
     return;
   }

@@ -347,3 +347,39 @@ def test_empty_row_slice_contributes_zero(ctx):
     _, _, a = entmc_vbmc(vp, wl.NsK, (True,) * 4, True, rng="philox", seed=3, return_raw=True, rows=(0, h // 3))
     _, _, b = entmc_vbmc(vp, wl.NsK, (True,) * 4, True, rng="philox", seed=3, return_raw=True, rows=(h // 3, h - h // 3))
     assert rel_err(a + b, full) < 1e-13
+
+
+@pytest.mark.parametrize("D,N", [(1, 3), (2, 255), (4, 1025), (5, 256), (8, 1100), (9, 257), (10, 513), (12, 700),
+                                 (13, 300), (16, 515), (17, 511), (20, 800), (20, 1030), (21, 257), (24, 520),
+                                 (25, 130), (32, 300)])
+def test_gp_block_forms(ctx, D, N):
+    """The GP expected-log-joint block (csrc/glj_block.h) in every build of its one-pass form (D <= 24: thread = point,
+    P points per thread and round, the 1 + 2D sums in registers) and in the two-pass form (D > 24), with point counts
+    around one and several rounds of 256 P points: value + gradient, value only, and the variance path (which takes the
+    z_n from the same block) against the oracle; then the same sums through the fused objective's placements (prep
+    launch, riders of the entropy launch)."""
+    from pyvbmc_amd.variational_optimization import _gp_log_joint, _neg_elcbo
+
+    K = 3
+    wl, wd = case(D, K, N, 64, cfg=3, S=2)
+    vp, gp = objects(wd, ctx)
+    mix, ogp = oracle_mix(wd), oracle_gp(wd)
+    G, dG, _, _, _ = _gp_log_joint(vp, gp, True, True, True, False, False)
+    Go, dGo, _, _, _ = gp_ref.gp_log_joint(mix, ogp, True, True, True, False, False)
+    assert abs(G - Go) <= 1e-10 * max(1.0, abs(Go)) and rel_err(dG, dGo) < 1e-9
+    G0 = _gp_log_joint(vp, gp, False, True, True, False, False)[0]
+    assert abs(G0 - Go) <= 1e-10 * max(1.0, abs(Go))
+    r = _gp_log_joint(vp, gp, False, True, True, True, True)
+    ro = gp_ref.gp_log_joint(mix, ogp, False, True, True, True, True)
+    scale = max(1.0, float(np.max(np.abs(ro[6]))))
+    assert np.max(np.abs(r[6] - ro[6])) <= 1e-9 * scale  # J_sjk
+    eps = synthetic.draw_eps_half(K, D, 64, 3)
+    bnd = synthetic.default_theta_bnd(wl)
+    F = _neg_elcbo(wl.theta.copy(), gp, vp, 0.0, 64, True, False, bnd, eps_half=eps)
+    Fo = elbo_ref.neg_elcbo(wl.theta.copy(), ogp, oracle_mix(wd), 0.0, 64, True, False, bnd, eps_half=eps)
+    assert abs(F[0] - Fo[0]) <= 1e-10 * max(1.0, abs(Fo[0])) and rel_err(F[1], Fo[1]) < 1e-8
+    assert abs(F[2] - Fo[2]) <= 1e-10 * max(1.0, abs(Fo[2]))
+    # Philox draws: the polled step (GP sums as riders of the entropy launch or in the prep launch, armed or not)
+    for seed in (5, 6, 7):
+        Fp = _neg_elcbo(wl.theta.copy(), gp, vp, 0.0, 64, True, False, bnd, rng="philox", seed=seed)
+        assert abs(Fp[2] - Fo[2]) <= 1e-10 * max(1.0, abs(Fo[2]))  # G does not depend on the draws

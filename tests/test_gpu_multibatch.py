@@ -309,6 +309,56 @@ def test_config5_share_on_one_gpu(ctx, ws_mode):
     assert abs(got["mfma"][0] - got["ws"][0]) <= 1e-13 * abs(Ho) and rel_err(got["mfma"][1], got["ws"][1]) < 1e-11
 
 
+def test_config5_step_ship_row_and_sub_counters(ctx):
+    """Config 5's host-driven step (matrix-pipe entropy kernel, GP sums in the prep launch): with `gp_ship` the GP sums'
+    copy to pinned memory and their word are issued by the last grid row of the ENTROPY launch instead of the prep launch's
+    last GP block, and the finish launch's 556 workgroups count on sixteen sub-counters (DoneSignal::sub).  Consecutive
+    seeds (armed from the second evaluation on), `gp_ship` and `elbo_arm` on and off: bit-identical F, dF, G, H; G and the
+    soft-bound loss against the oracle."""
+    from pyvbmc_amd.variational_optimization import _neg_elcbo
+
+    wl = synthetic.make_workload(5, Ns_total=100 * 2 * 64 * 4)
+    D, K, NsK = wl.D, wl.K, wl.NsK
+    g = dict(D=D, K=K, mu=wl.mu, sigma=wl.sigma, lambd=wl.lambd, w=wl.w, eta=wl.eta, X=wl.X, y=wl.y,
+             s2=wl.s2 if wl.s2 is not None else np.zeros(0))
+    gp = make_gp(g, ctx, wl.hyp)
+    bnd = synthetic.default_theta_bnd(wl)
+    rng = np.random.default_rng(11)
+    th0 = make_vp(g, ctx).get_parameters()
+    thetas = [th0 + 0.02 * rng.standard_normal(th0.size) for _ in range(5)]
+
+    def run(ship, arm):
+        out = []
+        ctx.set_option("gp_ship", ship)
+        ctx.set_option("elbo_arm", arm)
+        try:
+            vp = make_vp(g, ctx)
+            for i, th in enumerate(thetas):
+                F, dF, G, H, _ = _neg_elcbo(th.copy(), gp, vp, 0.0, NsK, True, False, bnd, 0.0, False, rng="philox", seed=40 + i)
+                assert ctx.last_entmc_plan()["kernel"] == "mfma", ctx.last_entmc_plan()
+                out.append((F, dF.copy(), G, H))
+        finally:
+            ctx.set_option("gp_ship", 1)
+            ctx.set_option("elbo_arm", 1)
+        return out
+
+    base = run(1, 1)
+    for ship, arm in ((0, 1), (1, 0), (0, 0), (1, 1)):
+        for (F, dF, G, H), (F0, dF0, G0, H0) in zip(run(ship, arm), base):
+            assert F == F0 and G == G0 and H == H0 and np.array_equal(dF, dF0), (ship, arm)
+    from oracle import elbo_ref, gp_ref  # noqa: F401
+
+    vp = make_vp(g, ctx)
+    vp.set_parameters(thetas[-1].copy())
+    mix = oracle_mix(dict(mu=vp.mu, sigma=vp.sigma.ravel(), lambd=vp.lambd.ravel(), w=vp.w.ravel(), eta=vp.eta.ravel()))
+    ogp = oracle_gp(dict(g, hyp=wl.hyp))
+    eps = philox_ref.eps_half(K, NsK // 2, D, 40 + len(thetas) - 1)
+    Fo, dFo, Go, Ho, _ = elbo_ref.neg_elcbo(thetas[-1].copy(), ogp, mix, 0.0, NsK, True, False, bnd, eps_half=eps)
+    F, dF, G, H = base[-1]
+    assert abs(G - Go) <= 1e-10 * max(1.0, abs(Go)) and abs(H - Ho) <= 1e-10 * max(1.0, abs(Ho))
+    assert abs(F - Fo) <= 1e-10 * max(1.0, abs(Fo)) and rel_err(dF, dFo) < 1e-9
+
+
 @pytest.mark.parametrize("S", [1, 3])
 def test_step_option_combinations_bit_identical(ctx, S):
     """The host-driven step's launch plan depends on a handful of switches (include/vbmc_hip.h, vbmc_set_option:
