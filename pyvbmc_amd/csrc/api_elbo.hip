@@ -339,6 +339,10 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
         if (ahead_ok) ahead_gen = entmc_ahead_slice(ctx, plan);
         done.cnt = ctx->d_done_cnt;
         done.sub = ctx->d_done_sub;
+        {
+          static const int sub_min = [] { const char* e = getenv("VBMC_FIN_SUB_MIN"); return e ? atoi(e) : 256; }();  // measurement aid
+          done.sub_min = sub_min;
+        }
         done.flag = ctx->hd_done;
         done.seq = seq_out;
         done.host_out = raw_out;

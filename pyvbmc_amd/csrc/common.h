@@ -298,6 +298,7 @@ struct DoneSignal {
   // K = 100, D = 20 the reduction has 556 workgroups that arrive together: 6 us of the 14 between the entropy kernel and the
   // completion word.  From 256 workgroups on, workgroup b counts on sub-counter b % 16 and the last of each on `cnt`.
   int* sub = nullptr;
+  int sub_min = 256;         // workgroups from which the sub-counters are used
   uint64_t* flag = nullptr;  // device-visible pinned word that receives `seq` when all are done
   uint64_t seq = 0;
   // Staged hand-over (optional): the kernel's result pointer is then DEVICE memory, and the last

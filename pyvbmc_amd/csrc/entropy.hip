@@ -494,6 +494,7 @@ int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
       return e ? atoi(e) : 0;
     }();
     int WS_GP_SLOTS = 10;
+    constexpr int WS_GP_PER = 5;  // GP items per rider slot
     int gp_wgs = 0;
     bool gp_here = false;
     if (gp_per_slot > 0) {
@@ -508,11 +509,16 @@ int entmc_plan(vbmc_ctx* ctx, int64_t ns_per_comp, int eps_mode, uint64_t seed, 
         gp_wgs = 0;
       }
     } else {
+      static const int per_env = [] {
+        const char* e = getenv("VBMC_WS_GP_PER");  // measurement aid: items per slot
+        return e ? atoi(e) : 0;
+      }();
+      const int per = per_env > 0 ? per_env : WS_GP_PER;
       if (slots_env > 0) WS_GP_SLOTS = slots_env;
-      else if (gp_items > 50 && gp_items <= 500) WS_GP_SLOTS = (gp_items + 4) / 5;
+      else if (gp_items > 10 * per && gp_items <= 100 * per) WS_GP_SLOTS = (gp_items + per - 1) / per;
       if (WS_GP_SLOTS > cus / 2) WS_GP_SLOTS = cus / 2;
-      gp_wgs = gp_items > 0 ? std::min(WS_GP_SLOTS, (gp_items + 4) / 5) : 0;
-      gp_here = waves == 2 && gp_wgs > 0 && gp_items <= 6 * WS_GP_SLOTS;
+      gp_wgs = gp_items > 0 ? std::min(WS_GP_SLOTS, (gp_items + per - 1) / per) : 0;
+      gp_here = waves == 2 && gp_wgs > 0 && gp_items <= (per + 1) * WS_GP_SLOTS;
     }
     sp.pb = waves == 2 ? cus - WS_GP_SLOTS : 0;
     if (sp.pb == 0) sp.front = 1000;

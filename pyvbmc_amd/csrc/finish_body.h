@@ -134,7 +134,7 @@ __device__ __forceinline__ void entmc_finish_body(const double* __restrict__ par
   __syncthreads();
   if (threadIdx.x == 0) {
     const int n_main = (n + 3) / 4;
-    if (done.sub != nullptr && n_main >= 256) {  // (DoneSignal::sub: one word takes ~88 increments per us)
+    if (done.sub != nullptr && n_main >= done.sub_min) {  // (DoneSignal::sub: one word takes ~88 increments per us)
       constexpr int NS = 16;
       const int g = (int)blockIdx.x % NS, n_g = (n_main - g + NS - 1) / NS;
       int* sc = done.sub + g * 64;

@@ -94,9 +94,13 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
     for (int base = 0; base < n; base += U * 256) {
       double v[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = a.mix[min(base + u * 256 + tid, n - 1)];
+      for (int u = 0; u < U; ++u) {
+        if (base + u * 256 >= n) break;  // (wave-uniform)
+        v[u] = a.mix[min(base + u * 256 + tid, n - 1)];
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
+        if (base + u * 256 >= n) break;
         const int i = base + u * 256 + tid;
         if (i < n) {
           a.mix_copy[i] = v[u];

@@ -17,8 +17,11 @@ __device__ __forceinline__ void ws_table_row_block(const double* mix, const MixL
   constexpr int U = 8;
   for (int base = 0; base < K4 * DP; base += U * 256) {
     double vj[U], vk[U];
+    // (slices wholly past the end are skipped by a wave-uniform test: a small table -- K = 50, D = 10: two entries per
+    // thread -- must not pay eight entries' index arithmetic; this block is on the optimiser loop's chain too)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      if (base + u * 256 >= K4 * DP) break;
       const int idx = base + u * 256 + tid;
       const int k = idx / DP, d = idx - k * DP;
       vj[u] = mup[j * D + min(d, D - 1)];
@@ -26,6 +29,7 @@ __device__ __forceinline__ void ws_table_row_block(const double* mix, const MixL
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      if (base + u * 256 >= K4 * DP) break;
       const int idx = base + u * 256 + tid;
       const int k = idx / DP, d = idx - k * DP;
       if (idx < K4 * DP) {
