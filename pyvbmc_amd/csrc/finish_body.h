@@ -45,35 +45,39 @@ __device__ __forceinline__ void entmc_finish_body(const double* __restrict__ par
   const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (t >= n && !done.flag) return;  // (with a completion word every wave of the block meets at the barrier below)
   double v = 0.0;
-  // v = step(v, coef(i), partial[at(i)]) for i = lane, lane + 64, ... < total, in that order -- with the
-  // loads of four steps issued together (indices clamped, coefficients zeroed past the end, which
-  // leaves v unchanged): a wave's 8 steps at K * chunks = 500 cost two memory latencies instead of
-  // eight, and this reduction is on the path between the entropy kernel and the completion word
-  // (32-bit element offsets: the launcher refuses a partial block of 2^31 elements or more)
+  // Every long sum here runs over (row, chunk) pairs -- row = a component (k for the mean's Delta part, j elsewhere) --
+  // with a coefficient that depends on the row alone.  Lane = row (row + 64, ... beyond 64 components), the chunks in an
+  // inner loop with twelve loads in flight (eleven chunks at config 3: one round): the coefficient (up to three loads) is formed once per row and there is no
+  // index arithmetic per term.  (Rounds 4-6 flattened the pairs over the lanes: a division and a remainder by run-time
+  // divisors and three coefficient loads per TERM -- ~600 instructions per lane at K = 50, eleven chunks, and four
+  // dependent rounds of them at K = 100, twenty chunks -- on the path between the entropy kernel and the completion word.)
+  // Fixed order: bit-reproducible.  (32-bit element offsets: the launcher refuses a partial block of 2^31 elements or more)
 #ifndef FIN_FOLD_U
-#define FIN_FOLD_U 10
+#define FIN_FOLD_U 12
 #endif
   constexpr int FOLD_U = FIN_FOLD_U;
-  auto fold = [&](double acc, int total, auto&& coef, auto&& at, auto&& step) {
-    for (int b = 0; b < total; b += FOLD_U * 64) {
-      double c[FOLD_U], x[FOLD_U];
+  auto fold = [&](double acc, int rows, auto&& coef, auto&& base, auto&& step) {
+    for (int r0 = 0; r0 < rows; r0 += 64) {
+      const int r = r0 + lane;
+      const int rc = min(r, rows - 1);
+      const double c = r < rows ? coef(rc) : 0.0;  // (0 leaves acc unchanged)
+      const unsigned b = base(rc);
+      for (int c0 = 0; c0 < chunks; c0 += FOLD_U) {
+        double x[FOLD_U];
 #pragma unroll
-      for (int u = 0; u < FOLD_U; ++u) {
-        const int i = b + 64 * u + lane;
-        const int ic = min(i, total - 1);
-        x[u] = partial[at(ic)];
-        c[u] = coef(ic);
-        if (i >= total) c[u] = 0.0;
+        for (int u = 0; u < FOLD_U; ++u) x[u] = partial[b + (unsigned)(min(c0 + u, chunks - 1) * stride)];
+#pragma unroll
+        for (int u = 0; u < FOLD_U; ++u)
+          if (c0 + u < chunks) acc = step(acc, c, x[u]);
       }
-#pragma unroll
-      for (int u = 0; u < FOLD_U; ++u) acc = step(acc, c[u], x[u]);
     }
     return acc;
   };
   const auto add_prod = [](double a, double c, double x) { return a + c * x; };
+  const unsigned jstride = (unsigned)(chunks * stride);  // elements between two components' first partial rows
   if (t >= n) {
   } else if (t == 0) {
-    v = fold(0.0, K * chunks, [&](int i) { return w[i / chunks]; }, [&](int i) { return (unsigned)(i * stride); },
+    v = fold(0.0, K, [&](int j) { return w[j]; }, [&](int j) { return (unsigned)j * jstride; },
              [](double a, double c, double x) { return a - c * x; });
     v = wave_sum(v) * inv_ns;
   } else if (want_grad) {
@@ -86,11 +90,10 @@ __device__ __forceinline__ void entmc_finish_body(const double* __restrict__ par
         //   sum_k w_k/sigma_k^2 (mu'_jd - mu'_kd) W_jk   (entropy_ws.hip, pass 2)
         const double* mup = mix + ml.o_mup;
         const double* is2 = mix + ml.o_is2;
-        // lanes run over k within one partial row (coalesced), then over the chunks
+        // lanes run over k within one partial row (coalesced), the chunks in the inner loop
         const double mjd = mup[j * D + d];
-        v = fold(v, K * chunks,
-                 [&](int i) { const int k = i % K; return w[k] * is2[k] * (mjd - mup[k * D + d]); },
-                 [&](int i) { const int c = i / K, k = i - c * K; return (unsigned)((j * chunks + c) * stride + 2 + 2 * D + k); },
+        v = fold(v, K, [&](int k) { return w[k] * is2[k] * (mjd - mup[k * D + d]); },
+                 [&](int k) { return (unsigned)j * jstride + (unsigned)(2 + 2 * D + k); },
                  [](double a, double c, double x) { return fma(c, x, a); });
       }
       v = wave_sum(v) * w[j] * inv_ns * ilam[d];
@@ -98,15 +101,15 @@ __device__ __forceinline__ void entmc_finish_body(const double* __restrict__ par
       for (int c = lane; c < chunks; c += 64) v += partial[((int64_t)u * chunks + c) * stride + 1 + D];
       v = wave_sum(v) * w[u] * inv_ns;
     } else if ((u -= K) < D) {
-      v = fold(0.0, K * chunks, [&](int i) { const int j = i / chunks; return w[j] * sig[j]; },
-               [&](int i) { return (unsigned)(i * stride + 2 + D + u); }, add_prod);
+      v = fold(0.0, K, [&](int j) { return w[j] * sig[j]; },
+               [&](int j) { return (unsigned)j * jstride + (unsigned)(2 + D + u); }, add_prod);
       v = wave_sum(v) * inv_ns * ilam[u];
     } else {
       u -= D;
       double sl = 0.0;
       for (int c = lane; c < chunks; c += 64) sl += partial[((int64_t)u * chunks + c) * stride];
-      double s = fold(0.0, K * chunks, [&](int i) { return w[i / chunks]; },
-                      [&](int i) { return (unsigned)(i * stride + 2 + 2 * D + u); }, add_prod);
+      double s = fold(0.0, K, [&](int j) { return w[j]; },
+                      [&](int j) { return (unsigned)j * jstride + (unsigned)(2 + 2 * D + u); }, add_prod);
       s = wave_sum(s);
       sl = wave_sum(sl);
       v = -inv_ns * (sl + s);

@@ -214,6 +214,7 @@ __device__ __forceinline__ void glj_sums_1p(const PrepArgs& a, int s, int k, dou
   auto request = [&](int base) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
+      if (p > 0 && base + 256 * p >= N) break;  // (wave-uniform: a small N pays for the point slots it fills)
       const int n = base + 256 * p + tid;
       // (a wave-uniform base and a 32-bit byte offset per lane: the scalar-base form of the load, one offset register per
       // point instead of an address pair per load)
@@ -244,6 +245,7 @@ __device__ __forceinline__ void glj_sums_1p(const PrepArgs& a, int s, int k, dou
     const double* qItau = sItau + zoff;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
+      if (p > 0 && base + 256 * p >= N) break;
       const int n = base + 256 * p + tid;
       double d2 = 0.0;
 #pragma unroll

@@ -634,14 +634,22 @@ def test_result_blocks_identify_themselves(ctx):
             out.append((F, dF.copy(), G, H))
         return out
 
+    # (a host thread that loses the CPU between two evaluations makes an armed evaluation late: the library recovers by
+    # repeating it, which is one more check -- and possibly one more mismatch -- than the undisturbed run has; the
+    # counters say how often that happened)
+    def disturbed(a, b):
+        return (b["late"] - a["late"]) + (b["lost"] - a["lost"])
+
     s0 = ctx.armed_stats()
     base = run(12)
     s1 = ctx.armed_stats()
-    assert s1["ident_checked"] - s0["ident_checked"] == 12 and s1["ident_bad"] == s0["ident_bad"]
-    assert s1["hits"] - s0["hits"] >= 8  # consecutive seeds: the evaluations after the first are armed ones
+    x1 = disturbed(s0, s1)
+    assert 12 <= s1["ident_checked"] - s0["ident_checked"] <= 12 + 2 * x1 and s1["ident_bad"] - s0["ident_bad"] <= x1, (s0, s1)
+    assert s1["hits"] - s0["hits"] >= 8 - 2 * x1, (s0, s1)  # consecutive seeds: the evaluations after the first are armed ones
     got = run(12, hook_at=(0, 5, 6))
     s2 = ctx.armed_stats()
-    assert s2["ident_bad"] - s1["ident_bad"] == 3
+    x2 = disturbed(s1, s2)
+    assert 3 <= s2["ident_bad"] - s1["ident_bad"] <= 3 + x2, (s1, s2)
     for (F, dF, G, H), (F0, dF0, G0, H0) in zip(got, base):
         assert F == F0 and G == G0 and H == H0 and np.array_equal(dF, dF0)
     # the multi-batch shape of the bench too (GP sums in the entropy launch's free slots)
@@ -651,7 +659,8 @@ def test_result_blocks_identify_themselves(ctx):
             s3 = ctx.armed_stats()
             r = run(3)
             s4 = ctx.armed_stats()
-            assert (s4["ident_checked"] - s3["ident_checked"] == 3) == bool(mb)  # the upload-kernel path has no copy block
+            n_chk = s4["ident_checked"] - s3["ident_checked"]
+            assert (3 <= n_chk <= 3 + 2 * disturbed(s3, s4)) if mb else n_chk == 0, (s3, s4)  # the upload-kernel path has no copy block
             for (F, dF, G, H), (F0, dF0, G0, H0) in zip(r, base):
                 assert F == F0 and np.array_equal(dF, dF0)
         finally:
