@@ -109,12 +109,19 @@ __global__ __launch_bounds__(256) void elbo_prep_kernel(PrepArgs a) {
       }
     }
     if (a.ident_out) {
-      __shared__ unsigned long long s_ck;
-      if (tid == 0) s_ck = 0;
+      // (sixteen LDS words, sixteen threads each: 256 atomic additions to ONE word are executed one after the other --
+      // ~0.8 us of this block, which is the longest of the prep launch at config 3; integer sums: any order gives the same bits)
+      __shared__ unsigned long long s_ck[16];
+      if (tid < 16) s_ck[tid] = 0;
       __syncthreads();
-      atomicAdd(&s_ck, (unsigned long long)ck);
+      atomicAdd(&s_ck[tid & 15], (unsigned long long)ck);
       __syncthreads();
-      if (tid == 0) *a.ident_out = s_ck;
+      if (tid == 0) {
+        unsigned long long t = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += s_ck[i];
+        *a.ident_out = t;
+      }
     }
     return;
   }

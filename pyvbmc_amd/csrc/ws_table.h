@@ -14,6 +14,11 @@ __device__ __forceinline__ void ws_table_row_block(const double* mix, const MixL
   double* sV2 = lds;  // [K4][DP] squared differences
   // (eight entries per thread and round, their loads requested together: one entry per round was a chain of K4 DP / 256
   // memory latencies -- the loads cannot move above the stores in front of them --, eight at K = 100, D = 20)
+  // (the per-component constants of the row's tail are requested here as well, in front of the barrier: behind it they
+  // were a second memory latency of this block -- and the block is the prep launch, between the host's go word and the
+  // entropy kernel)
+  const int kt = min(tid, K - 1);
+  const double t_is2 = mix[ml.o_is2 + kt], t_w = mix[ml.o_w + kt], t_lrc = mix[ml.o_lrc + kt];
   constexpr int U = 8;
   for (int base = 0; base < K4 * DP; base += U * 256) {
     double vj[U], vk[U];
@@ -45,10 +50,11 @@ __device__ __forceinline__ void ws_table_row_block(const double* mix, const MixL
     double s = 0.0;
     for (int d = 0; d < DP; ++d) s += sV2[k * DP + d];
     if (k < K) {
-      const double is2 = mix[ml.o_is2 + k];
-      const double w = mix[ml.o_w + k];
+      const bool pre = k == tid;  // (the first pass: K4 <= 256 in every build, so the only one)
+      const double is2 = pre ? t_is2 : mix[ml.o_is2 + k];
+      const double w = pre ? t_w : mix[ml.o_w + k];
       const double ak = -0.5 * 0x1.71547652b82fep+0 * is2;  // -log2(e) / (2 sigma_k^2)
-      row[DP + 0] = fma(ak, s, mix[ml.o_lrc + k]);          // log2 density of component k at mu_j
+      row[DP + 0] = fma(ak, s, pre ? t_lrc : mix[ml.o_lrc + k]);  // log2 density of component k at mu_j
       row[DP + 1] = ak;
       row[DP + 2] = w;
       row[DP + 3] = w * is2;

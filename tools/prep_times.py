@@ -37,21 +37,25 @@ for i in range(30):
     t = np.array(buf, dtype=np.int64).reshape(-1, 2)
     if i < 25:
         continue
-    used = t[:, 1] > 0
-    t0 = t[used, 0].min()
+    marks = ctx.last_step_marks()
+    gp_in_prep = marks["gp_sums_in"] == "prep launch"
+    n_gp = S * K if gp_in_prep else 0
+    nb = K + n_gp + 1  # this launch's blocks (later entries are other launches' -- the stamps are not cleared)
+    t0 = t[:nb, 0].min()
+
     def span(lo, hi, name):
         r = t[lo:hi]
-        r = r[r[:, 1] > 0]
         if len(r) == 0:
             return
         print("  %-10s %3d blocks: first start %5.2f, last start %5.2f, longest %5.2f, last end %5.2f us"
               % (name, len(r), (r[:, 0].min() - t0) / 100.0, (r[:, 0].max() - t0) / 100.0,
                  (r[:, 1] - r[:, 0]).max() / 100.0, (r[:, 1].max() - t0) / 100.0))
-    print("evaluation %d, plan %s" % (i, ctx.last_entmc_plan()))
-    n_used = int(used.sum())
+    print("evaluation %d, plan %s, GP sums in the %s" % (i, ctx.last_entmc_plan(), "prep launch" if gp_in_prep else "entropy launch"))
     span(0, K, "table")
-    span(K, n_used - 1, "rest")
-    span(n_used - 1, n_used, "last(copy)")
+    span(K, K + n_gp, "GP")
+    span(nb - 1, nb, "copy")
+    if not gp_in_prep:
+        continue
     ph = (C.c_ulonglong * 8192)()
     assert lib.vbmc_debug_glj_phases(ph) == 0
     q = np.array(ph, dtype=np.int64).reshape(-1, 8)[K:2 * K]  # the GP blocks of an S = 1 launch
