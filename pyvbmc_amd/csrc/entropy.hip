@@ -214,6 +214,14 @@ __global__ __launch_bounds__(256) void entmc_finish_kernel(const double* __restr
 extern "C" int vbmc_debug_fin_times(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_times), sizeof(unsigned long long) * (4 + 3 * 64));
 }
+extern "C" int vbmc_debug_fin_phases(unsigned long long* out, int reset) {
+  const int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_x), sizeof(unsigned long long) * 8);
+  if (reset) {
+    unsigned long long z[8] = {~0ull, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_x), z, sizeof(z));
+  }
+  return rc;
+}
 namespace {
 #endif
 

@@ -13,6 +13,13 @@
 // `raw` may be device memory or device-visible pinned host memory.
 #ifdef FIN_TIMES_HERE
 __device__ unsigned long long g_fin_times[4 + 3 * 64];  // [3] launch counter; per launch n % 64: start of block 0, publish, latest end
+// phases of the LAST finish launch (tools/fin_phases.py): [0] earliest block start, [1] latest "sum formed", [2] latest
+// "result store acknowledged", [3] the counting block knows it is last, [4] its staged copy is acknowledged, [5] flag stored,
+// [6] latest start of a reduction block
+__device__ unsigned long long g_fin_x[8];
+#define FIN_X_MAX(i) do { if ((threadIdx.x & 63) == 0) atomicMax(&g_fin_x[i], wall_clock64()); } while (0)
+#else
+#define FIN_X_MAX(i) (void)0
 #endif
 // (the body of entmc_finish_kernel, entropy.hip; also the first blocks of the optimiser loop's tail launch, adam.hip)
 __device__ __forceinline__ void entmc_finish_body(const double* __restrict__ partial, int chunks, int stride,
@@ -37,6 +44,12 @@ __device__ __forceinline__ void entmc_finish_body(const double* __restrict__ par
       return;
     }
   }
+#ifdef FIN_TIMES_HERE
+  if (threadIdx.x == 0) {
+    atomicMin(&g_fin_x[0], wall_clock64());
+    atomicMax(&g_fin_x[6], wall_clock64());
+  }
+#endif
   const double* w = mix + ml.o_w;
   const double* sig = mix + ml.o_sig;
   const double* ilam = mix + ml.o_ilam;
@@ -115,6 +128,7 @@ __device__ __forceinline__ void entmc_finish_body(const double* __restrict__ par
       v = -inv_ns * (sl + s);
     }
   }
+  FIN_X_MAX(1);
   if (!done.flag) {
     if (lane == 0) raw[t] = v;
     return;
@@ -133,6 +147,7 @@ __device__ __forceinline__ void entmc_finish_body(const double* __restrict__ par
     else __hip_atomic_store(raw + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   }
+  FIN_X_MAX(2);
   __shared__ int s_last;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -153,6 +168,9 @@ __device__ __forceinline__ void entmc_finish_body(const double* __restrict__ par
   }
   __syncthreads();
   if (!s_last) return;
+#ifdef FIN_TIMES_HERE
+  if (threadIdx.x == 0) g_fin_x[3] = wall_clock64();
+#endif
   if (done.ident_dst && threadIdx.x == 255) {  // what this result block was computed from (DoneSignal)
     __hip_atomic_store(done.ident_dst, *done.ident_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(done.ident_dst + 1, done.ident_seed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -163,10 +181,14 @@ __device__ __forceinline__ void entmc_finish_body(const double* __restrict__ par
   }
   if (staged || done.ident_dst) __syncthreads();
   if (threadIdx.x == 0) {
+#ifdef FIN_TIMES_HERE
+    g_fin_x[4] = wall_clock64();
+#endif
     __hip_atomic_store(done.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (dev) __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef FIN_TIMES_HERE
+    g_fin_x[5] = wall_clock64();
     g_fin_times[1] = wall_clock64();
     const unsigned long long slot = g_fin_times[3]++ & 63;
     g_fin_times[4 + 3 * slot] = g_fin_times[0];
