@@ -212,6 +212,12 @@ __device__ __forceinline__ void glj_sums_1p(const PrepArgs& a, int s, int k, dou
   const double* al = a.alpha + (size_t)s * N;
   double x[P][DP], av[P];
   auto request = [&](int base) {
+    // (the DP column bases are formed anew per request -- opaque copy of the pointer --: carried from the first request to
+    // the later rounds' they are 2 DP scalar registers held across the block, and inside the wave-split entropy kernel,
+    // whose registers are allotted over all of its code, that put 25 reloads of spilled scalar registers into pass 2 of
+    // the BATCH loop: tools/ws_hot_blocks.py)
+    const double* XTq = XT;
+    if constexpr (!XL) asm volatile("" : "+s"(XTq));
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       if (p > 0 && base + 256 * p >= N) break;  // (wave-uniform: a small N pays for the point slots it fills)
@@ -221,7 +227,7 @@ __device__ __forceinline__ void glj_sums_1p(const PrepArgs& a, int s, int k, dou
       const unsigned off = (unsigned)min(n, N - 1) * 8u;
 #pragma unroll
       for (int d = 0; d < DP; ++d) {
-        const char* col = (const char*)(XT + (size_t)min(d, D - 1) * N);
+        const char* col = (const char*)(XTq + (size_t)min(d, D - 1) * N);
         x[p][d] = *(const double*)(col + off);
       }
       av[p] = *(const double*)((const char*)al + off);
@@ -344,7 +350,7 @@ __device__ __forceinline__ void glj_block(const PrepArgs& a, int b, double* lds)
   }
   if constexpr (DMAX > 8 && DMIN <= 12) {
     if (DMIN > 8 || D > 8) {
-      glj_sums_1p<12, 2, XL>(a, s, k, lds, put);
+      glj_sums_1p<12, LEAN ? 1 : 2, XL>(a, s, k, lds, put);
       goto tail;
     }
   }
