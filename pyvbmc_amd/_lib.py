@@ -60,6 +60,25 @@ class ElboOpts(C.Structure):
     ]
 
 
+class ElboCall(C.Structure):
+    """vbmc_elbo_call: vbmc_neg_elcbo's arguments in one block (a foreign call converts every argument on every call)."""
+
+    _fields_ = [
+        ("theta", _dp),
+        ("n_theta", C.c_int),
+        ("opts", C.POINTER(ElboOpts)),
+        ("F", _dp),
+        ("dF", _dp),
+        ("G", _dp),
+        ("H", _dp),
+        ("mu_KxD", _dp),
+        ("sigma_K", _dp),
+        ("lambd_D", _dp),
+        ("w_K", _dp),
+        ("eta_K", _dp),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/vbmc_hip.h declares
 SIGNATURES = {
     "vbmc_abi_version": (C.c_int, []),
@@ -128,6 +147,7 @@ SIGNATURES = {
         C.c_int,
         [_vp, _dp, C.c_int, C.POINTER(ElboOpts), _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     ),
+    "vbmc_neg_elcbo_call": (C.c_int, [_vp, C.POINTER(ElboCall)]),
     "vbmc_neg_elcbo_batch": (
         C.c_int,
         [_vp, _dp, C.c_int, C.c_int, C.POINTER(ElboOpts), _dp, _dp, _dp],

@@ -723,6 +723,12 @@ extern "C" int vbmc_neg_elcbo(vbmc_ctx* ctx, double* theta, int n_theta,
   return gp_changed ? VBMC_W_GP_CHANGED : VBMC_OK;
 }
 
+extern "C" int vbmc_neg_elcbo_call(vbmc_ctx* ctx, const vbmc_elbo_call* c) {
+  if (!c) return VBMC_E_ARG;
+  return vbmc_neg_elcbo(ctx, c->theta, c->n_theta, c->opts, c->F, c->dF, c->G, c->H, c->mu_KxD, c->sigma_K, c->lambd_D, c->w_K,
+                        c->eta_K);
+}
+
 extern "C" int vbmc_armed_stats(const vbmc_ctx* ctx, uint64_t out[6]) {
   if (!ctx || !out) return VBMC_E_ARG;
   const vbmc_ctx::ArmedEval& sp = ctx->spec;
